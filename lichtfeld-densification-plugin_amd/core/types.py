@@ -1,0 +1,91 @@
+"""Boundary types of the dense-initialisation path.
+
+``DensePipelineConfig`` keeps the 18 fields of the upstream dataclass with the same names, order and
+defaults (upstream core/config.py:7-26) so that the GUI panel / CLI can construct it unchanged, and
+adds MI355X-specific knobs *after* them (all defaulted, so positional construction still works).
+``CameraRecord`` keeps upstream's per-camera record (core/camera_models.py:10-28): f32 intrinsics and
+world-to-camera pose, the projection ``P = K [R|t]`` and the centre ``C = -R^T t``.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Optional
+
+import numpy as np
+
+TRIANGULATION_MODES = ("sampled", "dense")
+
+
+@dataclasses.dataclass
+class DensePipelineConfig:
+    output_path: str
+    roma_setting: str = "fast"
+    roi_only_selected: bool = False
+    num_refs: float = 0.8
+    nns_per_ref: int = 3
+    matches_per_ref: int = 10000
+    certainty_thresh: float = 0.20
+    reproj_thresh: float = 0.8
+    sampson_thresh: float = 5.0
+    min_parallax_deg: float = 0.5
+    max_points: int = 0
+    no_filter: bool = False
+    use_masks: bool = True
+    voxel_size: float = 0.0
+    seed: int = 0
+    viz_interval: int = 3
+    prefetch_packages: int = 8
+    pack_workers: int = 4
+    # ---- extensions of this implementation (not present upstream) --------------------------
+    # "sampled": upstream behaviour - coverage sampling picks ~0.85*M+tiles cells per reference and
+    #            only those are triangulated.  "dense": every grid cell goes through the fused kernel.
+    triangulation_mode: str = "sampled"
+    # references whose RoMa outputs are kept resident and triangulated by ONE kernel launch
+    refs_per_launch: int = 1
+    # per-reference RNG stream (seed ^ uid) instead of upstream's single process-global stream;
+    # forced on when references are sharded over several GPUs (results then do not depend on
+    # the shard count).
+    per_reference_rng: bool = False
+
+    def __post_init__(self) -> None:
+        if self.triangulation_mode not in TRIANGULATION_MODES:
+            raise ValueError(f"triangulation_mode must be one of {TRIANGULATION_MODES}, "
+                             f"got {self.triangulation_mode!r}")
+        if int(self.refs_per_launch) < 1:
+            raise ValueError("refs_per_launch must be >= 1")
+
+
+@dataclasses.dataclass
+class CameraRecord:
+    uid: int
+    image_path: str
+    width: int
+    height: int
+    K: np.ndarray
+    R: np.ndarray
+    t: np.ndarray
+    P: np.ndarray
+    C: np.ndarray
+    mask_path: Optional[str] = None
+
+    def flat_pose(self) -> np.ndarray:
+        """Row-major 4x4 world-to-camera matrix as a 16-vector (f64), the feature used for
+        k-centres reference selection and nearest-neighbour lookup (upstream
+        core/camera_models.py:23-28)."""
+        pose = np.eye(4)
+        pose[:3, :3] = self.R
+        pose[:3, 3] = np.asarray(self.t).reshape(3)
+        return pose.reshape(-1)
+
+    @staticmethod
+    def from_krt(uid: int, K, R, t, width: int, height: int, image_path: str = "",
+                 mask_path: Optional[str] = None) -> "CameraRecord":
+        """Build a record the way both upstream entry points do (densify.py:59-88,215-245):
+        f32 ``K,R,t``; ``P = K @ [R|t]`` and ``C = -R^T t`` evaluated in f32."""
+        K = np.asarray(K, np.float32).reshape(3, 3)
+        R = np.asarray(R, np.float32).reshape(3, 3)
+        t = np.asarray(t, np.float32).reshape(3, 1)
+        P = K @ np.concatenate([R, t], axis=1)
+        C = (-R.T @ t).reshape(3)
+        return CameraRecord(uid=int(uid), image_path=image_path, width=int(width), height=int(height),
+                            K=K, R=R, t=t, P=P, C=C, mask_path=mask_path)

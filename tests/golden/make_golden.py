@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by running the UPSTREAM code (development container only).
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Imports the upstream plugin modules from /root/reference through ``ref_import.load_reference`` (stub
+host modules, nothing copied), drives them with seeded synthetic inputs and stores inputs + outputs.
+The fixtures are data only.  NumPy / torch versions and the CPU capability used are recorded because
+LAPACK rounding, ``argsort`` tie order and torch's f32 sum order may differ between builds.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+from ref_import import load_reference  # noqa: E402
+import lichtfeld_densification_plugin_amd as lfd  # noqa: E402
+from lichtfeld_densification_plugin_amd import synthetic  # noqa: E402
+
+ns = load_reference()
+G = ns.geometry
+VERSIONS = json.dumps({"numpy": np.__version__, "torch": torch.__version__,
+                       "cpu_capability": torch.backends.cpu.get_cpu_capability()})
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, versions=np.array(VERSIONS), **arrays)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def cam_arrays(cams):
+    return dict(
+        cam_K=np.stack([c.K for c in cams]).astype(np.float32), cam_R=np.stack([c.R for c in cams]).astype(np.float32),
+        cam_t=np.stack([c.t.reshape(3) for c in cams]).astype(np.float32), cam_P=np.stack([c.P for c in cams]).astype(np.float32),
+        cam_C=np.stack([c.C for c in cams]).astype(np.float32), cam_wh=np.array([[c.width, c.height] for c in cams], np.int32),
+        cam_uid=np.array([c.uid for c in cams], np.int64))
+
+
+# ---------------------------------------------------------------------------------------------
+# G1: geometry known-answer vectors
+# ---------------------------------------------------------------------------------------------
+def g1_geometry():
+    cams = synthetic.ring_cameras(24, seed=3)
+    # near-degenerate partner: almost the same centre as camera 0 (tiny baseline)
+    c0 = cams[0]
+    tiny = lfd.CameraRecord.from_krt(99, c0.K, c0.R, c0.t.reshape(3) + np.array([1e-3, 0, 0], np.float32),
+                                     c0.width, c0.height)
+    pairs = [(cams[0], cams[1]), (cams[0], cams[3]), (cams[5], cams[4]), (cams[0], tiny), (cams[2], cams[14])]
+    rng = np.random.RandomState(11)
+    out = {}
+    for pi, (ca, cb) in enumerate(pairs):
+        n = 257
+        # true 3-D points in front of camera a, projected into both, plus pixel noise
+        Xw = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.5, 1.5, n), rng.uniform(-0.2, 0.6, n)], 1)
+        def proj(c, X):
+            p = (c.P.astype(np.float64) @ np.concatenate([X, np.ones((len(X), 1))], 1).T).T
+            return (p[:, :2] / p[:, 2:3])
+        uv1 = (proj(ca, Xw) + rng.normal(0, 0.4, (n, 2))).astype(np.float32)
+        uv2 = (proj(cb, Xw) + rng.normal(0, 0.4, (n, 2))).astype(np.float32)
+        uv2[::17] += rng.normal(0, 30.0, uv2[::17].shape).astype(np.float32)     # gross outliers
+        F = G.fundamental_from_world2cam(ca.K, ca.R, ca.t, cb.K, cb.R, cb.t)
+        se = G.sampson_error(F, uv1, uv2)
+        with np.errstate(all="ignore"):
+            X = G.dlt_triangulate_batch(ca.P, cb.P, uv1, uv2)
+            X1 = G.dlt_triangulate_batch(ca.P, cb.P, uv1[:1], uv2[:1])
+            e1 = G.reprojection_errors(ca.P, X, uv1)
+            e2 = G.reprojection_errors(cb.P, X, uv2)
+            ch1 = G.cheirality_mask(ca.P, X)
+            ch2 = G.cheirality_mask(cb.P, X)
+            par = G.parallax_mask(ca.C, cb.C, X, min_deg=0.5)
+        pre = f"p{pi}_"
+        out.update({pre + "camA": np.int64(pi), pre + "uv1": uv1, pre + "uv2": uv2, pre + "F": F, pre + "sampson": se,
+                    pre + "X": X, pre + "X_single": X1, pre + "err1": e1, pre + "err2": e2,
+                    pre + "cheir1": ch1, pre + "cheir2": ch2, pre + "parallax": par})
+        out.update({pre + k: v for k, v in cam_arrays([ca, cb]).items()})
+    out["n_pairs"] = np.int64(len(pairs))
+    # points behind the camera / w ~ 0
+    ca, cb = cams[0], cams[1]
+    uv1 = np.array([[100.0, 100.0], [648.5, 420.0], [5000.0, -3000.0]], np.float32)
+    uv2 = np.array([[1200.0, 800.0], [648.5, 420.0], [-4000.0, 9000.0]], np.float32)
+    with np.errstate(all="ignore"):
+        X = G.dlt_triangulate_batch(ca.P, cb.P, uv1, uv2)
+        out["odd_uv1"], out["odd_uv2"], out["odd_X"] = uv1, uv2, X
+        out["odd_err1"] = G.reprojection_errors(ca.P, X, uv1)
+        out["odd_cheir1"] = G.cheirality_mask(ca.P, X)
+        out["odd_cheir2"] = G.cheirality_mask(cb.P, X)
+    save("g1_geometry.npz", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+# G2: select_samples_with_coverage
+# ---------------------------------------------------------------------------------------------
+def tiefree_cert(h, w, seed):
+    """Distinct f32 values strictly inside (0.2, 0.9): no ties under the floor/cap clamps."""
+    rs = np.random.RandomState(seed)
+    perm = rs.permutation(h * w).astype(np.float64)
+    return (0.2 + 0.7 * (perm + 0.5) / (h * w)).astype(np.float32).reshape(h, w)
+
+
+def g2_selection():
+    out = {}
+    cases = [(64, 64, 1000, 0), (64, 64, 3000, 1), (80, 96, 1500, 2), (320, 320, 10000, 0), (512, 512, 10000, 0)]
+    meta = []
+    for ci, (h, w, M, seed) in enumerate(cases):
+        cert = tiefree_cert(h, w, 100 + ci)
+        for no_filter in (False, True):
+            np.random.seed(seed)
+            sel = ns.sampling.select_samples_with_coverage(torch.from_numpy(cert.copy()), M, cap=0.9, border=2,
+                                                           tiles=24, no_filter=no_filter)
+            pos = int(np.random.get_state()[2])
+            nxt = np.random.random_sample(2)          # the next two doubles of the stream
+            key = f"c{ci}_{'nf' if no_filter else 'f'}_"
+            out[key + "sel"] = np.asarray(sel, np.int64)
+            out[key + "mt_pos"] = np.int64(pos)
+            out[key + "next_doubles"] = nxt
+        if h * w <= 96 * 96:
+            out[f"c{ci}_cert"] = cert
+        out[f"c{ci}_cert_sha256"] = np.array(hashlib.sha256(cert.tobytes()).hexdigest())
+        meta.append([h, w, M, seed, 100 + ci])
+    out["cases"] = np.array(meta, np.int64)
+    # a case with massive ties (floor + cap) - only order-insensitive facts are pinned for it
+    rs = np.random.RandomState(5)
+    cert = rs.beta(2, 2, size=(64, 64)).astype(np.float32)
+    cert = np.maximum(cert, np.float32(0.2))
+    np.random.seed(3)
+    sel = ns.sampling.select_samples_with_coverage(torch.from_numpy(cert.copy()), 1200, cap=0.9, border=2, tiles=24,
+                                                   no_filter=False)
+    out["ties_cert"], out["ties_sel"] = cert, np.asarray(sel, np.int64)
+    # more draws requested than non-zero weights: upstream's np.random.choice raises ValueError
+    # (the pipeline logs it per reference and skips the reference, core/pipeline.py:874-879)
+    try:
+        np.random.seed(0)
+        ns.sampling.select_samples_with_coverage(torch.from_numpy(tiefree_cert(64, 64, 1)), 10000)
+        out["too_many_raises"] = np.int64(0)
+    except ValueError as exc:
+        out["too_many_raises"] = np.int64(1)
+        out["too_many_msg"] = np.array(str(exc))
+    # all-zero weights -> empty
+    z = ns.sampling.select_samples_with_coverage(torch.zeros(16, 16), 100)
+    out["zero_sel"] = np.asarray(z, np.int64)
+    save("g2_selection.npz", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+# G3: _collect_reference_matches (prologue) + _triangulate_ref
+# ---------------------------------------------------------------------------------------------
+class FakeMatcher:
+    """Duck-typed stand-in for RomaMatcher: returns the prepared (warp HxWx4, cert HxW) tensors."""
+    sample_thresh = 0.9
+
+    def __init__(self, w_match, h_match, table):
+        self.w_resized, self.h_resized = w_match, h_match
+        self.table = table
+        self.calls = 0
+
+    def match_grids_batch(self, imA, imB_list):
+        res = self.table[self.calls]
+        self.calls += 1
+        assert len(res) == len(imB_list)
+        return [(w.clone(), c.clone()) for (w, c) in res]
+
+    def close(self):
+        pass
+
+
+def run_upstream_reference(cams, ref, nbrs, sref, cfg, mask_a=None, masks_b=None, seed=0):
+    """Drive upstream _collect_reference_matches + _triangulate_ref on one reference."""
+    P = ns.pipeline
+    lookup = P._build_camera_lookup(cams)
+    ids = [c.uid for c in cams]
+    packed = P._PackedReferenceBatch(
+        ref_id=ids[ref], ref_path=cams[ref].image_path, imA_np=sref.image.numpy(), maskA_np=mask_a,
+        wA_cam=cams[ref].width, hA_cam=cams[ref].height, nn_ids=[ids[n] for n in nbrs],
+        nn_masks=list(masks_b) if masks_b is not None else [None] * len(nbrs),
+        nn_arrays=[np.zeros_like(sref.image.numpy()) for _ in nbrs])
+    table = [[(sref.warp[j], sref.cert[j]) for j in range(len(nbrs))]]
+    fm = FakeMatcher(sref.w_match, sref.h_match, table)
+    matched, _ = P._collect_reference_matches(packed, fm, cfg, 0, None)
+    ctx = P._TriangulationContext(cameras=lookup, config=cfg, matcher_sample_cap=fm.sample_thresh,
+                                  w_match=sref.w_match, h_match=sref.h_match)
+    captured = {}
+    orig = P.select_samples_with_coverage
+
+    def spy(*a, **kw):
+        r = orig(*a, **kw)
+        captured["sel"] = np.asarray(r, np.int64).copy()
+        return r
+
+    P.select_samples_with_coverage = spy
+    try:
+        np.random.seed(seed)
+        with np.errstate(all="ignore"):
+            tri = P._triangulate_ref(matched, ctx, collect_debug_matches=True)
+    finally:
+        P.select_samples_with_coverage = orig
+    post_cert = np.stack([c.numpy() for c in matched.cert_list_cpu])
+    return tri, captured.get("sel", np.zeros(0, np.int64)), post_cert
+
+
+def g3_triangulate():
+    cams = synthetic.ring_cameras(40, seed=1)
+    Cfg = ns.config.DensePipelineConfig
+    cases = [
+        # name, H, W, w_match, h_match, ref, k, cfg kwargs, synth kwargs, masks
+        ("a_filter_k3", 64, 64, 64, 64, 0, 3, dict(matches_per_ref=1500), dict(noise_px=0.35, outlier_frac=0.08), False),
+        ("b_nofilter_k1", 48, 48, 48, 48, 3, 1, dict(matches_per_ref=600, no_filter=True), dict(noise_px=0.3), False),
+        ("c_rect_k3", 56, 72, 72, 56, 5, 3, dict(matches_per_ref=1200, reproj_thresh=1.5), dict(noise_px=0.6, outlier_frac=0.05), False),
+        ("d_hires_k2", 96, 96, 64, 64, 7, 2, dict(matches_per_ref=2000), dict(noise_px=0.3), False),
+        ("e_masks_k3", 64, 64, 64, 64, 9, 3, dict(matches_per_ref=1500), dict(noise_px=0.3, outlier_frac=0.03), True),
+        ("f_nosampson_k4", 64, 64, 64, 64, 11, 4, dict(matches_per_ref=1500, sampson_thresh=0.0, min_parallax_deg=0.0),
+         dict(noise_px=0.5, outlier_frac=0.05), False),
+    ]
+    out = cam_arrays(cams)
+    names = []
+    for (name, H, W, wm, hm, ref, k, ckw, skw, use_masks) in cases:
+        nbrs = synthetic.ring_neighbours(len(cams), ref, k)
+        if name == "a_filter_k3":
+            nbrs = [nbrs[0], nbrs[1], ref + 12]            # one wide-baseline neighbour
+        sref = synthetic.synth_reference(cams, ref, nbrs, H, W, wm, hm, channels=4, seed=21, cert_mode="tiefree",
+                                         **skw)
+        cfg = Cfg(output_path="/tmp/x.ply", **ckw)
+        mask_a = masks_b = None
+        if use_masks:
+            yy, xx = np.mgrid[0:hm, 0:wm]
+            mask_a = ((xx - 20) ** 2 + (yy - 30) ** 2 > 12 ** 2).astype(np.uint8)
+            masks_b = [((xx + 2 * j) % 16 > 2).astype(np.uint8) if j != 1 else None for j in range(k)]
+        tri, sel, post_cert = run_upstream_reference(cams, ref, nbrs, sref, cfg, mask_a, masks_b, seed=7)
+        ids = [c.uid for c in cams]
+        pre = name + "_"
+        out[pre + "warp"] = sref.warp.numpy()
+        out[pre + "cert"] = sref.cert.numpy()
+        out[pre + "image"] = sref.image.numpy()
+        out[pre + "post_cert"] = post_cert
+        out[pre + "sel"] = sel
+        out[pre + "dims"] = np.array([H, W, wm, hm, ref, k], np.int64)
+        out[pre + "nbrs"] = np.array(nbrs, np.int64)
+        out[pre + "cfg"] = np.array(json.dumps({f: getattr(cfg, f) for f in (
+            "matches_per_ref", "certainty_thresh", "reproj_thresh", "sampson_thresh", "min_parallax_deg", "no_filter")}))
+        if mask_a is not None:
+            out[pre + "mask_a"] = mask_a
+            for j, m in enumerate(masks_b):
+                if m is not None:
+                    out[pre + f"mask_b{j}"] = m
+        if tri is None:
+            out[pre + "none"] = np.int64(1)
+        else:
+            out[pre + "xyz"], out[pre + "rgb"], out[pre + "err"] = tri.xyz, tri.rgb, tri.err
+            order = [ids.index(n) for n in tri.debug_matches_by_nbr.keys()]
+            out[pre + "seg_nbr_cam"] = np.array(order, np.int64)
+            out[pre + "seg_count"] = np.array([v.shape[0] for v in tri.debug_matches_by_nbr.values()], np.int64)
+            out[pre + "dbg_matches"] = np.concatenate(list(tri.debug_matches_by_nbr.values()), 0)
+            out[pre + "dbg_cert"] = np.concatenate(list(tri.debug_cert_by_nbr.values()), 0)
+            print(f"  {name}: sel={sel.size} survivors={tri.xyz.shape[0]} segs={out[pre + 'seg_count'].tolist()}")
+        names.append(name)
+    out["names"] = np.array(names)
+    save("g3_triangulate.npz", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+# G5: writers
+# ---------------------------------------------------------------------------------------------
+def g5_writers():
+    rs = np.random.RandomState(2)
+    xyz = rs.normal(0, 3, (5, 3)).astype(np.float32)
+    rgb = np.array([[0.0, 1.0, 0.5], [0.0019607844, 0.49803922, 0.5019608], [2.5 / 255, 3.5 / 255, 254.5 / 255],
+                    [1.2, -0.3, 0.999], [0.25, 0.75, 0.1]], np.float32)
+    err = rs.uniform(0, 1, 5).astype(np.float32)
+    u8 = ns.image_utils.to_uint8_rgb(rgb)
+    with tempfile.TemporaryDirectory() as d:
+        p1, p2 = os.path.join(d, "a.ply"), os.path.join(d, "a.bin")
+        ns.writers.write_ply(p1, xyz, u8)
+        ns.writers.write_points3D_bin(p2, xyz, u8, err)
+        ply = np.frombuffer(open(p1, "rb").read(), np.uint8)
+        pbin = np.frombuffer(open(p2, "rb").read(), np.uint8)
+    save("g5_writers.npz", xyz=xyz, rgb=rgb, err=err, rgb_u8=u8, ply=ply, points3d_bin=pbin)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5"]
+    for w in which:
+        {"g1": g1_geometry, "g2": g2_selection, "g3": g3_triangulate, "g5": g5_writers}[w]()
