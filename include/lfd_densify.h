@@ -1,0 +1,143 @@
+/*
+ * lfd_densify.h -- C ABI of the MI355X-native dense-initialisation hot path.
+ *
+ * The upstream plugin (shadygm/Lichtfeld-Densification-Plugin) has no FFI: its boundary is a set of
+ * Python call signatures inside one interpreter.  This header is the C-ABI a maintainer would bind
+ * (ctypes / cffi / pybind) to replace, per reference view, the CPU stage
+ *
+ *     core/pipeline.py:405-442   _collect_reference_matches epilogue (certainty floor, masks, D2H)
+ *     core/pipeline.py:602-780   _triangulate_ref
+ *     core/geometry.py:53-141    skew / DLT / reprojection / cheirality / parallax / F / Sampson
+ *     core/sampling.py:8-53      select_samples_with_coverage        (lfd_select_*: see below)
+ *     core/writers.py:15-46      write_ply / write_points3D_bin      (lfd_pack_*)
+ *
+ * with hand-written HIP kernels for gfx950.  All tensor arguments are raw DEVICE pointers unless the
+ * comment says "host"; nothing here depends on torch.  Every function returns LFD_OK (0) or an
+ * error code and records a message retrievable with lfd_last_error(); nothing aborts.  A context is
+ * bound to one HIP device and one stream; use one context per thread (no hidden globals).
+ *
+ * There is no CPU implementation behind this interface: every entry point that computes needs a
+ * GPU and fails with LFD_ERR_HIP when none is present.
+ */
+#ifndef LFD_DENSIFY_H
+#define LFD_DENSIFY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFD_ABI_VERSION 1
+#define LFD_MAX_SLOTS 16 /* neighbours per reference handled by one launch */
+
+enum lfd_status {
+    LFD_OK = 0,
+    LFD_ERR_INVALID = 1,  /* bad argument */
+    LFD_ERR_HIP = 2,      /* HIP runtime error / no device */
+    LFD_ERR_CAPACITY = 3, /* output buffers too small (counts are still valid) */
+    LFD_ERR_STATE = 4     /* call order (e.g. cameras not uploaded) */
+};
+
+typedef struct lfd_context lfd_context;
+
+/* Thresholds of DensePipelineConfig that reach the kernels (core/config.py:7-26).  Comparison
+ * dtypes follow upstream: Sampson f64 `<`, reprojection f32 `<=`, depth f32 `> 0`, parallax f32 `>=`. */
+typedef struct lfd_params {
+    double sampson_thresh;  /* px^2; <= 0 disables the Sampson gate (core/pipeline.py:708)          */
+    float certainty_thresh; /* FLOOR applied to certainty, not a reject (core/pipeline.py:407)       */
+    float sample_cap;       /* RomaMatcher.sample_thresh = 0.9 (core/matcher.py:92)                  */
+    float reproj_thresh;    /* px (core/pipeline.py:745)                                             */
+    float min_parallax_deg; /* degrees; <= 0 disables (core/pipeline.py:748)                         */
+    int32_t no_filter;      /* keep every finite point (core/pipeline.py:739-743)                    */
+    int32_t reserved;
+} lfd_params;
+
+/* One launch = n_refs reference views, each with up to k neighbour slots (slots [0, n_slots[r]) are
+ * valid, in the order upstream's `nn_ids` lists the loaded neighbours).  Arrays marked "host" are
+ * host arrays whose ELEMENTS are device pointers. */
+typedef struct lfd_batch {
+    int32_t n_refs;
+    int32_t k;                    /* slot stride of the per-slot arrays, 1..LFD_MAX_SLOTS            */
+    int32_t H, W;                 /* RoMa output grid                                                */
+    int32_t w_match, h_match;     /* matcher.w_resized / h_resized (pixel conversion, image, masks)  */
+    int32_t warp_channels;        /* 4: [xA,yA,xB,yB] as upstream's matcher emits; 2: [xB,yB] only   */
+    int32_t reserved;
+    const int32_t* ref_cam;       /* host [n_refs]      index into the uploaded camera table         */
+    const int32_t* n_slots;       /* host [n_refs]      valid slots of each reference (<= k)         */
+    const int32_t* nbr_cam;       /* host [n_refs*k]    camera index of every slot                   */
+    const float* const* cert;     /* host [n_refs*k] -> device f32 [H*W]   raw certainty (pre-floor) */
+    const float* const* warp;     /* host [n_refs*k] -> device f32 [H*W*warp_channels], normalised   */
+    const uint8_t* const* image;  /* host [n_refs]   -> device u8 [h_match*w_match*3] (RGB, resized) */
+    const uint8_t* const* mask_a; /* NULL, or host [n_refs]   -> device u8 {0,1} [h_match*w_match] or NULL */
+    const uint8_t* const* mask_b; /* NULL, or host [n_refs*k] -> device u8 {0,1} [h_match*w_match] or NULL */
+    const float* axis_x;          /* device f32 [W]: A-grid x of column j (torch.linspace(-1+1/W,1-1/W,W)); */
+    const float* axis_y;          /* device f32 [H]; both NULL -> lfd_identity_axis() values. Used when warp_channels==2 */
+} lfd_batch;
+
+/* Survivors.  Capacity is in points.  cell / slot are optional (NULL to skip). */
+typedef struct lfd_points {
+    float* xyz;     /* [capacity*3]                                                                  */
+    float* rgb;     /* [capacity*3]  f32 in [0,1] (quantised only by the writers, as upstream)       */
+    float* err;     /* [capacity]    max reprojection error of the two views, px                     */
+    int32_t* cell;  /* [capacity]    flat grid index y*W+x                                            */
+    uint8_t* slot;  /* [capacity]    neighbour slot that won the arg-max                              */
+    int64_t capacity;
+} lfd_points;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int lfd_abi_version(void);
+int lfd_create(int device_index, void* hip_stream, lfd_context** out);
+void lfd_destroy(lfd_context* ctx);
+int lfd_set_stream(lfd_context* ctx, void* hip_stream);
+const char* lfd_last_error(const lfd_context* ctx); /* ctx may be NULL: last creation error */
+
+/* Camera table, all host f32 row-major as upstream's CameraRecord holds them
+ * (core/camera_models.py:10-28): K[n][9] R[n][9] t[n][3] P[n][12] C[n][3], wh[n][2] = width,height. */
+int lfd_upload_cameras(lfd_context* ctx, int32_t n, const float* K, const float* R, const float* t,
+                       const float* P, const float* C, const int32_t* wh);
+
+/* ---- the hot path ------------------------------------------------------------------------------ */
+/* P1+F1: certainty floor, masks, per-cell arg-max over the neighbours (first maximum wins).
+ * best_cert: device f32 [n_refs*H*W]; best_slot: device u8 [n_refs*H*W] or NULL. */
+int lfd_aggregate(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params,
+                  float* best_cert, uint8_t* best_slot);
+
+/* Fused dense kernel: every grid cell -> floor/masks/arg-max -> Sampson -> DLT -> reprojection,
+ * cheirality, parallax -> colour -> ordered compaction.  Survivors are emitted per reference in
+ * raster order.  ref_offsets: device i64 [n_refs+1] (exclusive prefix of survivors per reference;
+ * last = total); seg_counts: device i32 [n_refs*k] survivors per (reference, slot) or NULL. */
+int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params,
+                          const lfd_points* out, int64_t* ref_offsets, int32_t* seg_counts);
+
+/* Upstream-equivalent mode: only the selected cells (sel_idx: device i64, concatenated per
+ * reference; sel_offsets: host i64 [n_refs+1]) are triangulated, and survivors are emitted in
+ * upstream's order: per reference, neighbour groups in order of first appearance while scanning
+ * sel_idx, members in sel_idx order (core/pipeline.py:685-780).  seg_order: device i32 [n_refs*k]
+ * or NULL: the slot of the g-th group (or -1). */
+int lfd_triangulate_indexed(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params,
+                            const int64_t* sel_idx, const int64_t* sel_offsets, const lfd_points* out,
+                            int64_t* ref_offsets, int32_t* seg_counts, int32_t* seg_order);
+
+/* ---- host-side helpers (no GPU needed; used by the CPU test-suite) -------------------------------- */
+/* A-grid axis used when axis_x/axis_y are NULL: start + step*j below the midpoint,
+ * end - step*(n-1-j) from it on, f32 (the per-element form of torch.linspace, core/matcher.py:132-133). */
+int lfd_identity_axis(int32_t n, float* out_host);
+/* Largest f32 d with degrees(acosf(d)) >= min_deg: the kernels test `dot <= d` instead of calling
+ * acos per cell (core/geometry.py:113-119). */
+float lfd_parallax_dot_threshold(float min_deg);
+/* F (f32, row-major 9) for one camera pair, the same routine the kernels run in their prologue
+ * (core/geometry.py:122-130). */
+int lfd_host_fundamental(const float* K1, const float* R1, const float* t1, const float* K2,
+                         const float* R2, const float* t2, float* F_out);
+/* One correspondence through the per-cell routine on the HOST build of the same source (debug /
+ * CPU unit tests of the arithmetic; not a fallback: no batch entry point uses it).
+ * cam1/cam2: K[9] R[9] t[3] P[12] C[3] w h (as floats, 38 values).  out: x y z r g b err keep. */
+int lfd_host_eval_correspondence(const float* cam1, const float* cam2, float xa_norm, float ya_norm,
+                                 float xb_norm, float yb_norm, int32_t w_match, int32_t h_match,
+                                 const lfd_params* params, float* out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFD_DENSIFY_H */

@@ -1,0 +1,364 @@
+"""ctypes binding of the C-ABI in ``include/lfd_densify.h`` (the HIP library is the only backend).
+
+Torch is used for what it is good at here - owning device memory and streams; every tensor is
+handed to the library as a raw device pointer.  If ``liblfd_densify.so`` is missing or no GPU is
+present the constructors raise: there is deliberately no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .types import CameraRecord, DensePipelineConfig
+
+LFD_MAX_SLOTS = 16
+_LIB_NAME = "liblfd_densify.so"
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class HipBackendError(RuntimeError):
+    """Raised for any non-zero status of the HIP library (message from ``lfd_last_error``)."""
+
+
+class lfd_params(C.Structure):
+    _fields_ = [("sampson_thresh", C.c_double), ("certainty_thresh", C.c_float), ("sample_cap", C.c_float),
+                ("reproj_thresh", C.c_float), ("min_parallax_deg", C.c_float), ("no_filter", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class lfd_batch(C.Structure):
+    _fields_ = [("n_refs", C.c_int32), ("k", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("w_match", C.c_int32), ("h_match", C.c_int32), ("warp_channels", C.c_int32), ("reserved", C.c_int32),
+                ("ref_cam", C.POINTER(C.c_int32)), ("n_slots", C.POINTER(C.c_int32)), ("nbr_cam", C.POINTER(C.c_int32)),
+                ("cert", C.POINTER(C.c_void_p)), ("warp", C.POINTER(C.c_void_p)), ("image", C.POINTER(C.c_void_p)),
+                ("mask_a", C.POINTER(C.c_void_p)), ("mask_b", C.POINTER(C.c_void_p)),
+                ("axis_x", C.c_void_p), ("axis_y", C.c_void_p)]
+
+
+class lfd_points(C.Structure):
+    _fields_ = [("xyz", C.c_void_p), ("rgb", C.c_void_p), ("err", C.c_void_p), ("cell", C.c_void_p),
+                ("slot", C.c_void_p), ("capacity", C.c_int64)]
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return os.path.join(_PKG_DIR, _LIB_NAME)
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree HIP library and declare its prototypes (works without a GPU: the host
+    helpers and symbol table are usable, every compute entry point then returns LFD_ERR_HIP)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise HipBackendError(
+            f"{path} not found: build it with `python {os.path.join(_PKG_DIR, 'csrc', 'build.py')}` "
+            "(hipcc, --offload-arch=gfx950). There is no CPU fallback for the dense-initialisation path.")
+    lib = C.CDLL(path)
+    ctxp = C.c_void_p
+    lib.lfd_abi_version.restype = C.c_int
+    lib.lfd_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(ctxp)]
+    lib.lfd_destroy.argtypes = [ctxp]
+    lib.lfd_destroy.restype = None
+    lib.lfd_set_stream.argtypes = [ctxp, C.c_void_p]
+    lib.lfd_last_error.argtypes = [ctxp]
+    lib.lfd_last_error.restype = C.c_char_p
+    fptr = C.POINTER(C.c_float)
+    lib.lfd_upload_cameras.argtypes = [ctxp, C.c_int32, fptr, fptr, fptr, fptr, fptr, C.POINTER(C.c_int32)]
+    lib.lfd_aggregate.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p, C.c_void_p]
+    lib.lfd_triangulate_dense.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.POINTER(lfd_points),
+                                          C.c_void_p, C.c_void_p]
+    lib.lfd_triangulate_indexed.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p,
+                                            C.POINTER(C.c_int64), C.POINTER(lfd_points), C.c_void_p, C.c_void_p,
+                                            C.c_void_p]
+    lib.lfd_identity_axis.argtypes = [C.c_int32, fptr]
+    lib.lfd_parallax_dot_threshold.argtypes = [C.c_float]
+    lib.lfd_parallax_dot_threshold.restype = C.c_float
+    lib.lfd_host_fundamental.argtypes = [fptr] * 7
+    lib.lfd_host_eval_correspondence.argtypes = [fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                                 C.c_int32, C.POINTER(lfd_params), fptr]
+    for name in ("lfd_create", "lfd_set_stream", "lfd_upload_cameras", "lfd_aggregate", "lfd_triangulate_dense",
+                 "lfd_triangulate_indexed", "lfd_identity_axis", "lfd_host_fundamental",
+                 "lfd_host_eval_correspondence"):
+        getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def make_params(config: DensePipelineConfig, sample_cap: float = 0.9) -> lfd_params:
+    return lfd_params(sampson_thresh=float(config.sampson_thresh), certainty_thresh=float(config.certainty_thresh),
+                      sample_cap=float(sample_cap), reproj_thresh=float(config.reproj_thresh),
+                      min_parallax_deg=float(config.min_parallax_deg), no_filter=1 if config.no_filter else 0,
+                      reserved=0)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, np.float32))
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+# ---- host helpers (usable without a GPU) --------------------------------------------------------
+def identity_axis(n: int) -> np.ndarray:
+    out = np.empty(n, np.float32)
+    rc = load_library().lfd_identity_axis(n, _fp(out))
+    if rc != 0:
+        raise HipBackendError("lfd_identity_axis failed")
+    return out
+
+
+def parallax_dot_threshold(min_deg: float) -> float:
+    return float(load_library().lfd_parallax_dot_threshold(C.c_float(min_deg)))
+
+
+def host_fundamental(K1, R1, t1, K2, R2, t2) -> np.ndarray:
+    a = [_f32(x).reshape(-1) for x in (K1, R1, t1, K2, R2, t2)]
+    out = np.empty(9, np.float32)
+    rc = load_library().lfd_host_fundamental(*[_fp(x) for x in a], _fp(out))
+    if rc != 0:
+        raise HipBackendError("lfd_host_fundamental failed")
+    return out.reshape(3, 3)
+
+
+def pack_camera(cam: CameraRecord) -> np.ndarray:
+    return np.concatenate([_f32(cam.K).reshape(-1), _f32(cam.R).reshape(-1), _f32(cam.t).reshape(-1),
+                           _f32(cam.P).reshape(-1), _f32(cam.C).reshape(-1),
+                           np.array([cam.width, cam.height], np.float32)]).astype(np.float32)
+
+
+def host_eval_correspondence(cam1: CameraRecord, cam2: CameraRecord, xa, ya, xb, yb, w_match, h_match,
+                             params: lfd_params) -> np.ndarray:
+    """The per-cell routine (host build of the kernels' source) on one correspondence: a debugging /
+    unit-test aid, not a code path of the pipeline.  Returns [x,y,z,_,_,_,err,keep]."""
+    out = np.zeros(8, np.float32)
+    c1, c2 = pack_camera(cam1), pack_camera(cam2)
+    rc = load_library().lfd_host_eval_correspondence(_fp(c1), _fp(c2), C.c_float(xa), C.c_float(ya), C.c_float(xb),
+                                                     C.c_float(yb), int(w_match), int(h_match), C.byref(params), _fp(out))
+    if rc != 0:
+        raise HipBackendError("lfd_host_eval_correspondence failed")
+    return out
+
+
+# ---- device path ---------------------------------------------------------------------------------
+@dataclasses.dataclass
+class ReferenceInputs:
+    """Device-resident inputs of one reference view (what RoMa produced for it)."""
+    ref_cam: int                              # index into the uploaded camera table
+    nbr_cams: List[int]                       # one per neighbour slot
+    cert: List[torch.Tensor]                  # per slot (H,W) f32, raw certainty
+    warp: List[torch.Tensor]                  # per slot (H,W,2|4) f32
+    image: torch.Tensor                       # (h_match,w_match,3) u8
+    mask_a: Optional[torch.Tensor] = None     # (h_match,w_match) u8 {0,1}
+    mask_b: Optional[List[Optional[torch.Tensor]]] = None
+
+
+@dataclasses.dataclass
+class TriangulationOutput:
+    xyz: torch.Tensor            # (n,3) f32
+    rgb: torch.Tensor            # (n,3) f32 in [0,1]
+    err: torch.Tensor            # (n,)  f32
+    cell: Optional[torch.Tensor]  # (n,) i32
+    slot: Optional[torch.Tensor]  # (n,) u8
+    ref_offsets: np.ndarray      # (n_refs+1,) i64 host
+    seg_counts: np.ndarray       # (n_refs,k) i32 host
+    seg_order: Optional[np.ndarray] = None   # indexed mode: slot of the g-th emitted group, -1 = none
+
+    @property
+    def count(self) -> int:
+        return int(self.ref_offsets[-1])
+
+
+class PreparedBatch:
+    """ctypes view of a list of ReferenceInputs; keeps the tensors alive."""
+
+    def __init__(self, refs: Sequence[ReferenceInputs], w_match: int, h_match: int,
+                 axes: Optional[Sequence[torch.Tensor]] = None):
+        if not refs:
+            raise ValueError("empty batch")
+        self.refs = list(refs)
+        n = len(self.refs)
+        k = max(len(r.cert) for r in self.refs)
+        if k < 1 or k > LFD_MAX_SLOTS:
+            raise ValueError(f"neighbour slots per reference must be in [1,{LFD_MAX_SLOTS}]")
+        H, W = self.refs[0].cert[0].shape
+        ch = int(self.refs[0].warp[0].shape[-1])
+        dev = self.refs[0].cert[0].device
+        self.n_refs, self.k, self.H, self.W, self.channels, self.device = n, k, int(H), int(W), ch, dev
+        self.ref_cam = (C.c_int32 * n)(*[int(r.ref_cam) for r in self.refs])
+        self.n_slots = (C.c_int32 * n)(*[len(r.cert) for r in self.refs])
+        self.nbr_cam = (C.c_int32 * (n * k))()
+        self.cert = (C.c_void_p * (n * k))()
+        self.warp = (C.c_void_p * (n * k))()
+        self.image = (C.c_void_p * n)()
+        any_ma = any(r.mask_a is not None for r in self.refs)
+        any_mb = any(r.mask_b is not None and any(m is not None for m in r.mask_b) for r in self.refs)
+        self.mask_a = (C.c_void_p * n)() if any_ma else None
+        self.mask_b = (C.c_void_p * (n * k))() if any_mb else None
+        self._keep = []
+        for i, r in enumerate(self.refs):
+            if not (len(r.cert) == len(r.warp) == len(r.nbr_cams)):
+                raise ValueError("cert / warp / nbr_cams length mismatch")
+            img = self._chk(r.image, torch.uint8, (h_match, w_match, 3), "image")
+            self.image[i] = img.data_ptr()
+            if r.mask_a is not None:
+                self.mask_a[i] = self._chk(r.mask_a, torch.uint8, (h_match, w_match), "mask_a").data_ptr()
+            for j in range(len(r.cert)):
+                s = i * k + j
+                self.nbr_cam[s] = int(r.nbr_cams[j])
+                self.cert[s] = self._chk(r.cert[j], torch.float32, (H, W), "cert").data_ptr()
+                self.warp[s] = self._chk(r.warp[j], torch.float32, (H, W, ch), "warp").data_ptr()
+                if r.mask_b is not None and r.mask_b[j] is not None:
+                    self.mask_b[s] = self._chk(r.mask_b[j], torch.uint8, (h_match, w_match), "mask_b").data_ptr()
+        self.axes = None
+        if axes is not None:
+            ax = self._chk(axes[0], torch.float32, (W,), "axis_x")
+            ay = self._chk(axes[1], torch.float32, (H,), "axis_y")
+            self.axes = (ax, ay)
+        vp = C.POINTER(C.c_void_p)
+        self.c = lfd_batch(
+            n_refs=n, k=k, H=int(H), W=int(W), w_match=int(w_match), h_match=int(h_match), warp_channels=ch, reserved=0,
+            ref_cam=C.cast(self.ref_cam, C.POINTER(C.c_int32)), n_slots=C.cast(self.n_slots, C.POINTER(C.c_int32)),
+            nbr_cam=C.cast(self.nbr_cam, C.POINTER(C.c_int32)), cert=C.cast(self.cert, vp), warp=C.cast(self.warp, vp),
+            image=C.cast(self.image, vp), mask_a=C.cast(self.mask_a, vp) if self.mask_a is not None else None,
+            mask_b=C.cast(self.mask_b, vp) if self.mask_b is not None else None,
+            axis_x=self.axes[0].data_ptr() if self.axes else None, axis_y=self.axes[1].data_ptr() if self.axes else None)
+
+    def _chk(self, t: torch.Tensor, dtype, shape, what: str) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise ValueError(f"{what} must be a device tensor (the HIP path consumes RoMa's outputs in place)")
+        if t.dtype != dtype or tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{what}: expected {dtype} {tuple(shape)}, got {t.dtype} {tuple(t.shape)}")
+        if not t.is_contiguous():
+            t = t.contiguous()
+        self._keep.append(t)
+        return t
+
+
+class OutputBuffers:
+    """Caller-owned survivor buffers (device).  Allocate once, reuse across launches."""
+
+    def __init__(self, capacity: int, n_refs: int, k: int, device, with_cell: bool = True):
+        self.capacity = int(capacity)
+        cap = max(self.capacity, 1)
+        self.xyz = torch.empty((cap, 3), dtype=torch.float32, device=device)
+        self.rgb = torch.empty((cap, 3), dtype=torch.float32, device=device)
+        self.err = torch.empty((cap,), dtype=torch.float32, device=device)
+        self.cell = torch.empty((cap,), dtype=torch.int32, device=device) if with_cell else None
+        self.slot = torch.empty((cap,), dtype=torch.uint8, device=device) if with_cell else None
+        self.ref_offsets = torch.zeros((n_refs + 1,), dtype=torch.int64, device=device)
+        self.seg_counts = torch.zeros((n_refs, k), dtype=torch.int32, device=device)
+        self.seg_order = torch.full((n_refs, k), -1, dtype=torch.int32, device=device)
+        self.c = lfd_points(xyz=self.xyz.data_ptr(), rgb=self.rgb.data_ptr(), err=self.err.data_ptr(),
+                            cell=self.cell.data_ptr() if with_cell else None,
+                            slot=self.slot.data_ptr() if with_cell else None, capacity=self.capacity)
+
+    def collect(self, indexed: bool = False) -> TriangulationOutput:
+        """Synchronise and trim to the number of survivors."""
+        offs = self.ref_offsets.cpu().numpy()
+        n = int(offs[-1])
+        if n > self.capacity:
+            raise HipBackendError(f"output capacity {self.capacity} too small for {n} survivors")
+        return TriangulationOutput(
+            xyz=self.xyz[:n], rgb=self.rgb[:n], err=self.err[:n],
+            cell=self.cell[:n] if self.cell is not None else None, slot=self.slot[:n] if self.slot is not None else None,
+            ref_offsets=offs, seg_counts=self.seg_counts.cpu().numpy(),
+            seg_order=self.seg_order.cpu().numpy() if indexed else None)
+
+
+class HipDensifier:
+    """One context = one GPU + one stream (``torch.cuda.current_stream`` of the device at creation,
+    unless a stream is given).  Not thread-safe: use one per thread, as the C-ABI requires."""
+
+    def __init__(self, device: Optional[torch.device] = None, stream: Optional[torch.cuda.Stream] = None):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        if not torch.cuda.is_available():
+            raise HipBackendError("no GPU visible: the dense-initialisation hot path has no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise HipBackendError(f"HipDensifier needs a cuda (HIP) device, got {self.device}")
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        rc = self._lib.lfd_create(index, C.c_void_p(self.stream.cuda_stream), C.byref(self._ctx))
+        if rc != 0:
+            raise HipBackendError(f"lfd_create failed ({rc}): {self._lib.lfd_last_error(None).decode()}")
+        self.n_cams = 0
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.lfd_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise HipBackendError(f"{what} failed ({rc}): {self._lib.lfd_last_error(self._ctx).decode()}")
+
+    def upload_cameras(self, cams: Sequence[CameraRecord]) -> None:
+        K = _f32(np.stack([np.asarray(c.K, np.float32).reshape(9) for c in cams]))
+        R = _f32(np.stack([np.asarray(c.R, np.float32).reshape(9) for c in cams]))
+        t = _f32(np.stack([np.asarray(c.t, np.float32).reshape(3) for c in cams]))
+        P = _f32(np.stack([np.asarray(c.P, np.float32).reshape(12) for c in cams]))
+        Cc = _f32(np.stack([np.asarray(c.C, np.float32).reshape(3) for c in cams]))
+        wh = np.ascontiguousarray(np.array([[c.width, c.height] for c in cams], np.int32))
+        self._check(self._lib.lfd_upload_cameras(self._ctx, len(cams), _fp(K), _fp(R), _fp(t), _fp(P), _fp(Cc),
+                                                 wh.ctypes.data_as(C.POINTER(C.c_int32))), "lfd_upload_cameras")
+        self.n_cams = len(cams)
+
+    # -- launches (asynchronous on self.stream) -------------------------------------------------------
+    def launch_aggregate(self, batch: PreparedBatch, params: lfd_params, best_cert: torch.Tensor,
+                         best_slot: Optional[torch.Tensor]) -> None:
+        self._check(self._lib.lfd_aggregate(self._ctx, C.byref(batch.c), C.byref(params), best_cert.data_ptr(),
+                                            best_slot.data_ptr() if best_slot is not None else None), "lfd_aggregate")
+
+    def launch_dense(self, batch: PreparedBatch, params: lfd_params, out: OutputBuffers) -> None:
+        self._check(self._lib.lfd_triangulate_dense(self._ctx, C.byref(batch.c), C.byref(params), C.byref(out.c),
+                                                    out.ref_offsets.data_ptr(), out.seg_counts.data_ptr()),
+                    "lfd_triangulate_dense")
+
+    def launch_indexed(self, batch: PreparedBatch, params: lfd_params, sel_idx: torch.Tensor,
+                       sel_offsets: Sequence[int], out: OutputBuffers) -> None:
+        if sel_idx.dtype != torch.int64 or not sel_idx.is_cuda or not sel_idx.is_contiguous():
+            raise ValueError("sel_idx must be a contiguous int64 device tensor")
+        offs = (C.c_int64 * (batch.n_refs + 1))(*[int(v) for v in sel_offsets])
+        self._check(self._lib.lfd_triangulate_indexed(self._ctx, C.byref(batch.c), C.byref(params), sel_idx.data_ptr(),
+                                                      offs, C.byref(out.c), out.ref_offsets.data_ptr(),
+                                                      out.seg_counts.data_ptr(), out.seg_order.data_ptr()),
+                    "lfd_triangulate_indexed")
+
+    # -- convenience wrappers (synchronising) -------------------------------------------------------------
+    def aggregate(self, batch: PreparedBatch, params: lfd_params):
+        best = torch.empty((batch.n_refs, batch.H, batch.W), dtype=torch.float32, device=self.device)
+        slot = torch.empty((batch.n_refs, batch.H, batch.W), dtype=torch.uint8, device=self.device)
+        self.launch_aggregate(batch, params, best, slot)
+        return best, slot
+
+    def triangulate_dense(self, batch: PreparedBatch, params: lfd_params, capacity: Optional[int] = None,
+                          with_cell: bool = True) -> TriangulationOutput:
+        cap = batch.n_refs * batch.H * batch.W if capacity is None else int(capacity)
+        out = OutputBuffers(cap, batch.n_refs, batch.k, self.device, with_cell)
+        self.launch_dense(batch, params, out)
+        return out.collect()
+
+    def triangulate_indexed(self, batch: PreparedBatch, params: lfd_params, sel_idx: torch.Tensor,
+                            sel_offsets: Sequence[int], with_cell: bool = True) -> TriangulationOutput:
+        out = OutputBuffers(int(sel_offsets[-1]), batch.n_refs, batch.k, self.device, with_cell)
+        self.launch_indexed(batch, params, sel_idx, sel_offsets, out)
+        return out.collect(indexed=True)

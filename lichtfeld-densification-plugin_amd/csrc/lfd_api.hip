@@ -1,0 +1,451 @@
+// Host side of the C-ABI declared in include/lfd_densify.h: context, tables, launches.
+// No compute happens on the host here except the tiny helpers the header lists as host-side.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lfd_densify.h"
+#include "lfd_device.hpp"
+
+extern "C" __global__ void lfd_aggregate_kernel(LfdLaunch L, float* best_cert, uint8_t* best_slot);
+extern "C" __global__ void lfd_dense_kernel(LfdLaunch L);
+extern "C" __global__ void lfd_indexed_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets,
+                                              float* scratch, uint8_t* codes, int32_t* seg_order);
+
+namespace {
+
+std::string g_create_error;
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct lfd_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // camera table
+    DeviceBuffer cams;
+    int32_t n_cams = 0;
+    // descriptor tables: refs | slots | sel_offsets, staged through pinned memory
+    DeviceBuffer desc;
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    hipEvent_t pinned_free = nullptr;
+    bool pinned_in_flight = false;
+    std::vector<unsigned char> desc_cache;   // what the device table currently holds
+    // look-back workspace: [0] u64 ticket counter, [1..] tile states
+    DeviceBuffer ws;
+    unsigned long long tickets_issued = 0;   // host mirror of the device ticket counter
+    unsigned epoch = 0;
+    // default A-grid axes
+    DeviceBuffer axes;
+    int axes_w = 0, axes_h = 0;
+    // indexed-mode scratch
+    DeviceBuffer scratch, codes;
+};
+
+namespace {
+
+int fail(lfd_context* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define LFD_HIP(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail((ctx), LFD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+int ensure(lfd_context* ctx, DeviceBuffer& b, size_t bytes, bool zero = false) {
+    if (b.bytes >= bytes && b.ptr) return LFD_OK;
+    if (b.ptr) {
+        LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        LFD_HIP(ctx, hipFree(b.ptr));
+        b.ptr = nullptr; b.bytes = 0;
+    }
+    size_t want = std::max<size_t>(bytes, 256);
+    want = (want + 255) & ~size_t(255);
+    LFD_HIP(ctx, hipMalloc(&b.ptr, want));
+    b.bytes = want;
+    if (zero) LFD_HIP(ctx, hipMemsetAsync(b.ptr, 0, want, ctx->stream));
+    return LFD_OK;
+}
+
+int validate_batch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (!b || !p) return fail(ctx, LFD_ERR_INVALID, "null batch/params");
+    if (ctx->n_cams <= 0) return fail(ctx, LFD_ERR_STATE, "lfd_upload_cameras must be called first");
+    if (b->n_refs <= 0) return fail(ctx, LFD_ERR_INVALID, "n_refs must be > 0");
+    if (b->k <= 0 || b->k > LFD_MAX_SLOTS) return fail(ctx, LFD_ERR_INVALID, "k must be in [1, LFD_MAX_SLOTS]");
+    if (b->H <= 0 || b->W <= 0 || b->w_match <= 1 || b->h_match <= 1) return fail(ctx, LFD_ERR_INVALID, "bad grid / match size");
+    if ((long long)b->H * b->W > 0x7fffffffLL) return fail(ctx, LFD_ERR_INVALID, "grid too large");
+    if (b->warp_channels != 2 && b->warp_channels != 4) return fail(ctx, LFD_ERR_INVALID, "warp_channels must be 2 or 4");
+    if (!b->ref_cam || !b->n_slots || !b->nbr_cam || !b->cert || !b->warp || !b->image)
+        return fail(ctx, LFD_ERR_INVALID, "null table in batch");
+    if ((b->axis_x == nullptr) != (b->axis_y == nullptr)) return fail(ctx, LFD_ERR_INVALID, "axis_x and axis_y must both be given or both be null");
+    for (int r = 0; r < b->n_refs; ++r) {
+        if (b->ref_cam[r] < 0 || b->ref_cam[r] >= ctx->n_cams) return fail(ctx, LFD_ERR_INVALID, "ref_cam out of range");
+        if (b->n_slots[r] < 1 || b->n_slots[r] > b->k) return fail(ctx, LFD_ERR_INVALID, "n_slots must be in [1, k]");
+        if (!b->image[r]) return fail(ctx, LFD_ERR_INVALID, "null image pointer");
+        for (int j = 0; j < b->n_slots[r]; ++j) {
+            const size_t s = (size_t)r * b->k + j;
+            if (b->nbr_cam[s] < 0 || b->nbr_cam[s] >= ctx->n_cams) return fail(ctx, LFD_ERR_INVALID, "nbr_cam out of range");
+            if (!b->cert[s] || !b->warp[s]) return fail(ctx, LFD_ERR_INVALID, "null cert/warp pointer in a valid slot");
+            if ((reinterpret_cast<uintptr_t>(b->cert[s]) & 15u) || (reinterpret_cast<uintptr_t>(b->warp[s]) & 15u))
+                return fail(ctx, LFD_ERR_INVALID, "cert/warp planes must be 16-byte aligned");
+        }
+    }
+    return LFD_OK;
+}
+
+// Build refs|slots|extra into one blob, upload only when it differs from what the device holds.
+int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, size_t n_extra,
+                  const LfdRefDesc** d_refs, const LfdSlotDesc** d_slots, const long long** d_extra) {
+    const size_t nr = (size_t)b->n_refs, ns = nr * (size_t)b->k;
+    const size_t off_slots = (nr * sizeof(LfdRefDesc) + 15) & ~size_t(15);
+    const size_t off_extra = (off_slots + ns * sizeof(LfdSlotDesc) + 15) & ~size_t(15);
+    const size_t total = off_extra + n_extra * sizeof(long long);
+    std::vector<unsigned char> blob(total, 0);
+    LfdRefDesc* refs = reinterpret_cast<LfdRefDesc*>(blob.data());
+    LfdSlotDesc* slots = reinterpret_cast<LfdSlotDesc*>(blob.data() + off_slots);
+    for (size_t r = 0; r < nr; ++r) {
+        refs[r].image = b->image[r];
+        refs[r].mask_a = b->mask_a ? b->mask_a[r] : nullptr;
+        refs[r].cam = b->ref_cam[r];
+        refs[r].n_slots = b->n_slots[r];
+        for (int j = 0; j < b->k; ++j) {
+            LfdSlotDesc& s = slots[r * b->k + j];
+            const bool valid = j < b->n_slots[r];
+            s.cert = valid ? b->cert[r * b->k + j] : nullptr;
+            s.warp = valid ? b->warp[r * b->k + j] : nullptr;
+            s.mask_b = (valid && b->mask_b) ? b->mask_b[r * b->k + j] : nullptr;
+            s.cam = valid ? b->nbr_cam[r * b->k + j] : 0;
+            s.pad = 0;
+        }
+    }
+    if (n_extra) std::memcpy(blob.data() + off_extra, extra, n_extra * sizeof(long long));
+    int rc = ensure(ctx, ctx->desc, total);
+    if (rc != LFD_OK) return rc;
+    if (blob != ctx->desc_cache) {
+        if (ctx->pinned_bytes < total) {
+            if (ctx->pinned_in_flight) { LFD_HIP(ctx, hipEventSynchronize(ctx->pinned_free)); ctx->pinned_in_flight = false; }
+            if (ctx->pinned) LFD_HIP(ctx, hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_bytes = std::max<size_t>(total * 2, 1 << 16);
+            LFD_HIP(ctx, hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
+        }
+        if (ctx->pinned_in_flight) { LFD_HIP(ctx, hipEventSynchronize(ctx->pinned_free)); ctx->pinned_in_flight = false; }
+        std::memcpy(ctx->pinned, blob.data(), total);
+        LFD_HIP(ctx, hipMemcpyAsync(ctx->desc.ptr, ctx->pinned, total, hipMemcpyHostToDevice, ctx->stream));
+        LFD_HIP(ctx, hipEventRecord(ctx->pinned_free, ctx->stream));
+        ctx->pinned_in_flight = true;
+        ctx->desc_cache.swap(blob);
+    }
+    *d_refs = reinterpret_cast<const LfdRefDesc*>(ctx->desc.ptr);
+    *d_slots = reinterpret_cast<const LfdSlotDesc*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_slots);
+    if (d_extra) *d_extra = reinterpret_cast<const long long*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_extra);
+    return LFD_OK;
+}
+
+int default_axes(lfd_context* ctx, int W, int H, const float** ax, const float** ay) {
+    if (ctx->axes_w != W || ctx->axes_h != H || !ctx->axes.ptr) {
+        int rc = ensure(ctx, ctx->axes, sizeof(float) * (size_t)(W + H));
+        if (rc != LFD_OK) return rc;
+        std::vector<float> host((size_t)W + H);
+        lfd_identity_axis(W, host.data());
+        lfd_identity_axis(H, host.data() + W);
+        LFD_HIP(ctx, hipMemcpyAsync(ctx->axes.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->axes_w = W; ctx->axes_h = H;
+    }
+    *ax = static_cast<const float*>(ctx->axes.ptr);
+    *ay = *ax + W;
+    return LFD_OK;
+}
+
+void fill_kernel_params(const lfd_batch* b, const lfd_params* p, LfdKernelParams& kp) {
+    kp.sampson_thresh = p->sampson_thresh;
+    kp.certainty_thresh = p->certainty_thresh;
+    kp.reproj_thresh = p->reproj_thresh;
+    kp.no_filter = p->no_filter ? 1 : 0;
+    kp.use_sampson = (!p->no_filter && p->sampson_thresh > 0.0) ? 1 : 0;
+    kp.use_parallax = (!p->no_filter && p->min_parallax_deg > 0.0f) ? 1 : 0;
+    kp.dot_thresh = kp.use_parallax ? lfd_parallax_dot_threshold(p->min_parallax_deg) : 2.0f;
+    kp.wm1 = (float)(b->w_match - 1);
+    kp.hm1 = (float)(b->h_match - 1);
+}
+
+int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, const long long* extra, size_t n_extra,
+                   LfdLaunch& L, const long long** d_extra) {
+    int rc = validate_batch(ctx, b, p);
+    if (rc != LFD_OK) return rc;
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    std::memset(&L, 0, sizeof(L));
+    rc = upload_tables(ctx, b, extra, n_extra, &L.refs, &L.slots, d_extra);
+    if (rc != LFD_OK) return rc;
+    L.cams = static_cast<const LfdCam*>(ctx->cams.ptr);
+    if (b->axis_x) { L.axis_x = b->axis_x; L.axis_y = b->axis_y; }
+    else {
+        rc = default_axes(ctx, b->W, b->H, &L.axis_x, &L.axis_y);
+        if (rc != LFD_OK) return rc;
+    }
+    L.n_refs = b->n_refs; L.k = b->k; L.H = b->H; L.W = b->W;
+    L.w_match = b->w_match; L.h_match = b->h_match; L.warp_channels = b->warp_channels;
+    const long long HW = (long long)b->H * b->W;
+    const int tile = LFD_DENSE_BLOCK * LFD_DENSE_CPT;
+    L.tiles_per_ref = (int)((HW + tile - 1) / tile);
+    L.mask_sx = (float)b->w_match / (float)b->W;
+    L.mask_sy = (float)b->h_match / (float)b->H;
+    fill_kernel_params(b, p, L.kp);
+    return LFD_OK;
+}
+
+// ticket counter + tile states.  Tickets are never reset: each launch is given the value the
+// counter holds when it starts; tile-state words carry a launch epoch, so stale words of earlier
+// launches read as "empty" and no per-launch memset is needed.
+int prepare_lookback(lfd_context* ctx, size_t n_tiles, LfdLaunch& L) {
+    const size_t need = 16 + n_tiles * sizeof(unsigned long long);
+    const bool fresh = ctx->ws.bytes < need || !ctx->ws.ptr;
+    int rc = ensure(ctx, ctx->ws, need, true);
+    if (rc != LFD_OK) return rc;
+    if (fresh) { ctx->tickets_issued = 0; ctx->epoch = 0; }
+    ctx->epoch = (ctx->epoch + 1) & LFD_EPOCH_MASK;
+    if (ctx->epoch == 0) {   // epoch wrapped: clear stale words once
+        LFD_HIP(ctx, hipMemsetAsync(static_cast<unsigned char*>(ctx->ws.ptr) + 16, 0, ctx->ws.bytes - 16, ctx->stream));
+        ctx->epoch = 1;
+    }
+    L.ticket = static_cast<unsigned long long*>(ctx->ws.ptr);
+    L.tile_state = static_cast<unsigned long long*>(ctx->ws.ptr) + 2;
+    L.ticket_base = ctx->tickets_issued;
+    L.epoch = ctx->epoch;
+    ctx->tickets_issued += n_tiles;
+    return LFD_OK;
+}
+
+int check_points(lfd_context* ctx, const lfd_points* out, const long long* ref_offsets) {
+    if (!out || !out->xyz || !out->rgb || !out->err) return fail(ctx, LFD_ERR_INVALID, "null output buffers");
+    if (out->capacity < 0) return fail(ctx, LFD_ERR_INVALID, "negative capacity");
+    if (!ref_offsets) return fail(ctx, LFD_ERR_INVALID, "ref_offsets is required");
+    return LFD_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int lfd_abi_version(void) { return LFD_ABI_VERSION; }
+
+const char* lfd_last_error(const lfd_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int lfd_create(int device_index, void* hip_stream, lfd_context** out) {
+    if (!out) return fail(nullptr, LFD_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, LFD_ERR_HIP, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device_index < 0 || device_index >= n) return fail(nullptr, LFD_ERR_INVALID, "device index out of range");
+    lfd_context* ctx = new lfd_context();
+    ctx->device = device_index;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    e = hipSetDevice(device_index);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pinned_free, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        std::string m = std::string("context init: ") + hipGetErrorString(e);
+        delete ctx;
+        return fail(nullptr, LFD_ERR_HIP, m);
+    }
+    *out = ctx;
+    return LFD_OK;
+}
+
+void lfd_destroy(lfd_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->scratch, &ctx->codes})
+        if (b->ptr) (void)hipFree(b->ptr);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pinned_free) (void)hipEventDestroy(ctx->pinned_free);
+    delete ctx;
+}
+
+int lfd_set_stream(lfd_context* ctx, void* hip_stream) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return LFD_OK;
+}
+
+int lfd_upload_cameras(lfd_context* ctx, int32_t n, const float* K, const float* R, const float* t, const float* P,
+                       const float* C, const int32_t* wh) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (n <= 0 || !K || !R || !t || !P || !C || !wh) return fail(ctx, LFD_ERR_INVALID, "bad camera arrays");
+    std::vector<LfdCam> cams((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        LfdCam& c = cams[i];
+        std::memcpy(c.K, K + (size_t)i * 9, sizeof(c.K));
+        std::memcpy(c.R, R + (size_t)i * 9, sizeof(c.R));
+        std::memcpy(c.t, t + (size_t)i * 3, sizeof(c.t));
+        std::memcpy(c.P, P + (size_t)i * 12, sizeof(c.P));
+        std::memcpy(c.C, C + (size_t)i * 3, sizeof(c.C));
+        c.w = wh[i * 2 + 0]; c.h = wh[i * 2 + 1];
+        c.pad[0] = c.pad[1] = 0;
+        if (c.w <= 0 || c.h <= 0) return fail(ctx, LFD_ERR_INVALID, "camera width/height must be positive");
+    }
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, ctx->cams, cams.size() * sizeof(LfdCam));
+    if (rc != LFD_OK) return rc;
+    LFD_HIP(ctx, hipMemcpyAsync(ctx->cams.ptr, cams.data(), cams.size() * sizeof(LfdCam), hipMemcpyHostToDevice, ctx->stream));
+    LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_cams = n;
+    return LFD_OK;
+}
+
+int lfd_aggregate(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, float* best_cert, uint8_t* best_slot) {
+    LfdLaunch L;
+    int rc = prepare_launch(ctx, batch, params, nullptr, 0, L, nullptr);
+    if (rc != LFD_OK) return rc;
+    if (!best_cert) return fail(ctx, LFD_ERR_INVALID, "best_cert is null");
+    const long long HW = (long long)batch->H * batch->W;
+    const int per_block = 256 * 4;
+    int gx = (int)std::min<long long>((HW + per_block - 1) / per_block, 2048);
+    dim3 grid((unsigned)gx, (unsigned)batch->n_refs, 1);
+    hipLaunchKernelGGL(lfd_aggregate_kernel, grid, dim3(256), 0, ctx->stream, L, best_cert, best_slot);
+    LFD_HIP(ctx, hipGetLastError());
+    return LFD_OK;
+}
+
+int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, const lfd_points* out,
+                          int64_t* ref_offsets, int32_t* seg_counts) {
+    LfdLaunch L;
+    int rc = prepare_launch(ctx, batch, params, nullptr, 0, L, nullptr);
+    if (rc != LFD_OK) return rc;
+    rc = check_points(ctx, out, reinterpret_cast<long long*>(ref_offsets));
+    if (rc != LFD_OK) return rc;
+    const size_t n_tiles = (size_t)batch->n_refs * (size_t)L.tiles_per_ref;
+    if (n_tiles > 0x7fffffffu) return fail(ctx, LFD_ERR_INVALID, "too many tiles in one launch");
+    rc = prepare_lookback(ctx, n_tiles, L);
+    if (rc != LFD_OK) return rc;
+    L.xyz = out->xyz; L.rgb = out->rgb; L.err = out->err; L.cell = out->cell; L.slot = out->slot;
+    L.capacity = out->capacity;
+    L.ref_offsets = reinterpret_cast<long long*>(ref_offsets);
+    L.seg_counts = seg_counts;
+    if (seg_counts) LFD_HIP(ctx, hipMemsetAsync(seg_counts, 0, sizeof(int32_t) * (size_t)batch->n_refs * batch->k, ctx->stream));
+    hipLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)n_tiles), dim3(LFD_DENSE_BLOCK), 0, ctx->stream, L);
+    LFD_HIP(ctx, hipGetLastError());
+    return LFD_OK;
+}
+
+int lfd_triangulate_indexed(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, const int64_t* sel_idx,
+                            const int64_t* sel_offsets, const lfd_points* out, int64_t* ref_offsets, int32_t* seg_counts,
+                            int32_t* seg_order) {
+    if (ctx && (!sel_idx || !sel_offsets)) return fail(ctx, LFD_ERR_INVALID, "sel_idx / sel_offsets are required");
+    if (ctx && batch && batch->n_refs > 0) {
+        if (sel_offsets[0] != 0) return fail(ctx, LFD_ERR_INVALID, "sel_offsets[0] must be 0");
+        for (int r = 0; r < batch->n_refs; ++r)
+            if (sel_offsets[r + 1] < sel_offsets[r]) return fail(ctx, LFD_ERR_INVALID, "sel_offsets must be non-decreasing");
+    }
+    LfdLaunch L;
+    const long long* d_off = nullptr;
+    int rc = prepare_launch(ctx, batch, params, reinterpret_cast<const long long*>(sel_offsets),
+                            batch ? (size_t)std::max(batch->n_refs, 0) + 1 : 0, L, &d_off);
+    if (rc != LFD_OK) return rc;
+    rc = check_points(ctx, out, reinterpret_cast<long long*>(ref_offsets));
+    if (rc != LFD_OK) return rc;
+    const size_t n_sel = (size_t)sel_offsets[batch->n_refs];
+    rc = prepare_lookback(ctx, (size_t)batch->n_refs, L);
+    if (rc != LFD_OK) return rc;
+    rc = ensure(ctx, ctx->scratch, std::max<size_t>(n_sel, 1) * 8 * sizeof(float));
+    if (rc != LFD_OK) return rc;
+    rc = ensure(ctx, ctx->codes, std::max<size_t>(n_sel, 1));
+    if (rc != LFD_OK) return rc;
+    L.xyz = out->xyz; L.rgb = out->rgb; L.err = out->err; L.cell = out->cell; L.slot = out->slot;
+    L.capacity = out->capacity;
+    L.ref_offsets = reinterpret_cast<long long*>(ref_offsets);
+    L.seg_counts = seg_counts;
+    hipLaunchKernelGGL(lfd_indexed_kernel, dim3((unsigned)batch->n_refs), dim3(LFD_INDEXED_BLOCK), 0, ctx->stream, L,
+                       reinterpret_cast<const long long*>(sel_idx), d_off, static_cast<float*>(ctx->scratch.ptr),
+                       static_cast<uint8_t*>(ctx->codes.ptr), seg_order);
+    LFD_HIP(ctx, hipGetLastError());
+    return LFD_OK;
+}
+
+// ---- host-side helpers -----------------------------------------------------------------------
+int lfd_identity_axis(int32_t n, float* out) {
+    if (n <= 0 || !out) return LFD_ERR_INVALID;
+    const float start = (float)(-1.0 + 1.0 / (double)n);
+    const float end = (float)(1.0 - 1.0 / (double)n);
+    if (n == 1) { out[0] = start; return LFD_OK; }
+    const float step = (end - start) / (float)(n - 1);
+    const int half = n / 2;
+    for (int j = 0; j < n; ++j) {
+        if (j < half) { const float m = step * (float)j; out[j] = start + m; }
+        else { const float m = step * (float)(n - 1 - j); out[j] = end - m; }
+    }
+    return LFD_OK;
+}
+
+float lfd_parallax_dot_threshold(float min_deg) {
+    // ang(d) = (float)acosf(clip(d)) * (180/pi as f32) is non-increasing in d; find the largest f32 d
+    // in [-1, 1] with ang(d) >= min_deg by bisection over the ordered f32 bit patterns.
+    const float k = 57.295776f;   // 180.0f / NPY_PIf, the constant np.degrees uses for f32
+    auto ok = [&](float d) { return acosf(d) * k >= min_deg; };
+    if (!ok(-1.0f)) return -2.0f;             // nothing passes (min_deg > 180)
+    if (ok(1.0f)) return 1.0f;                // everything in range passes (min_deg <= 0)
+    auto key = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i >= 0 ? (int64_t)i : -(int64_t)(i & 0x7fffffff); };
+    auto unkey = [](int64_t kx) { int32_t i = kx >= 0 ? (int32_t)kx : (int32_t)(0x80000000u | (uint32_t)(-kx)); float f; std::memcpy(&f, &i, 4); return f; };
+    int64_t lo = key(-1.0f), hi = key(1.0f);   // ok(lo) true, ok(hi) false
+    while (hi - lo > 1) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (ok(unkey(mid))) lo = mid; else hi = mid;
+    }
+    return unkey(lo);
+}
+
+int lfd_host_fundamental(const float* K1, const float* R1, const float* t1, const float* K2, const float* R2,
+                         const float* t2, float* F_out) {
+    if (!K1 || !R1 || !t1 || !K2 || !R2 || !t2 || !F_out) return LFD_ERR_INVALID;
+    lfd_fundamental(K1, R1, t1, K2, R2, t2, F_out);
+    return LFD_OK;
+}
+
+static void unpack_cam(const float* v, LfdCam& c) {
+    std::memcpy(c.K, v, 9 * 4); std::memcpy(c.R, v + 9, 9 * 4); std::memcpy(c.t, v + 18, 3 * 4);
+    std::memcpy(c.P, v + 21, 12 * 4); std::memcpy(c.C, v + 33, 3 * 4);
+    c.w = (int32_t)v[36]; c.h = (int32_t)v[37]; c.pad[0] = c.pad[1] = 0;
+}
+
+int lfd_host_eval_correspondence(const float* cam1, const float* cam2, float xa_norm, float ya_norm, float xb_norm,
+                                 float yb_norm, int32_t w_match, int32_t h_match, const lfd_params* params, float* out8) {
+    if (!cam1 || !cam2 || !params || !out8 || w_match <= 1 || h_match <= 1) return LFD_ERR_INVALID;
+    LfdCam a, b;
+    unpack_cam(cam1, a); unpack_cam(cam2, b);
+    LfdRefConst rc; LfdPairConst pc;
+    lfd_make_ref_const(a, w_match, h_match, rc);
+    lfd_make_pair_const(a, b, 1, w_match, h_match, pc);
+    lfd_batch bb; std::memset(&bb, 0, sizeof(bb));
+    bb.w_match = w_match; bb.h_match = h_match;
+    LfdKernelParams kp;
+    fill_kernel_params(&bb, params, kp);
+    LfdCellResult res;
+    lfd_eval_correspondence(rc, pc, xa_norm, ya_norm, xb_norm, yb_norm, kp, res);
+    out8[0] = res.x; out8[1] = res.y; out8[2] = res.z; out8[3] = 0.0f; out8[4] = 0.0f; out8[5] = 0.0f;
+    out8[6] = res.err; out8[7] = (float)res.keep;
+    return LFD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// Structures shared between the host API (lfd_api.hip) and the kernels (lfd_kernels.hip).
+#pragma once
+
+#include <stdint.h>
+
+#include "lfd_geometry.hpp"
+
+#ifndef LFD_MAX_SLOTS
+#define LFD_MAX_SLOTS 16
+#endif
+
+#define LFD_DENSE_BLOCK 256     // threads per workgroup of the fused dense kernel (4 waves)
+#define LFD_DENSE_CPT 4         // consecutive grid cells per thread (one 16-byte certainty load per slot)
+#define LFD_INDEXED_BLOCK 1024  // one workgroup (16 waves) per reference in the indexed kernel
+
+#define LFD_EPOCH_BITS 22
+#define LFD_EPOCH_MASK ((1u << LFD_EPOCH_BITS) - 1u)
+#define LFD_VALUE_BITS 40     // survivors-so-far fits 40 bits (1e12 points)
+
+struct LfdRefDesc {             // one per reference of a launch (device table)
+    const uint8_t* image;       // u8 [h_match][w_match][3]
+    const uint8_t* mask_a;      // u8 {0,1} [h_match][w_match] or null
+    int32_t cam;                // row of the camera table
+    int32_t n_slots;            // valid neighbour slots
+};
+
+struct LfdSlotDesc {            // one per (reference, slot)
+    const float* cert;          // f32 [H*W]
+    const float* warp;          // f32 [H*W*C]
+    const uint8_t* mask_b;      // u8 {0,1} [h_match][w_match] or null
+    int32_t cam;
+    int32_t pad;
+};
+
+struct LfdLaunch {              // kernel argument, passed by value
+    const LfdCam* cams;
+    const LfdRefDesc* refs;
+    const LfdSlotDesc* slots;
+    const float* axis_x;        // [W]
+    const float* axis_y;        // [H]
+    int32_t n_refs, k, H, W, w_match, h_match, warp_channels, tiles_per_ref;
+    float mask_sx, mask_sy;     // (float)w_match/(float)W, (float)h_match/(float)H  (nearest resize)
+    LfdKernelParams kp;
+    // outputs
+    float* xyz;
+    float* rgb;
+    float* err;
+    int32_t* cell;
+    uint8_t* slot;
+    long long capacity;
+    long long* ref_offsets;
+    int32_t* seg_counts;
+    // look-back workspace.  The ticket counter is never reset (ticket_base = its value at launch)
+    // and tile-state words carry the launch epoch, so nothing is memset between launches.
+    unsigned long long* tile_state;
+    unsigned long long* ticket;
+    unsigned long long ticket_base;
+    unsigned int epoch;
+    unsigned int pad0;
+};
