@@ -528,6 +528,22 @@ def triangulate_dense(cert_list, warp_list, img_a, cam_a, cams_b, w_match, h_mat
     }
 
 
+def _reproj_noise(P, X) -> np.ndarray:
+    """First-order bound on the f32 rounding noise of one view's reprojection error, in pixels: the
+    three dot products of ``X @ P.T`` each carry ~eps32 * sum|terms| of absolute error and the
+    division by the depth amplifies the depth's share by |u|/z.  For an ordinary cell this is ~1e-4 px;
+    for a point that almost lies in the neighbour's principal plane (z -> 0, |u| ~ 1e5 px) it reaches
+    a pixel, i.e. upstream's own error value is then not reproducible by ANY other evaluation order."""
+    eps = np.float64(np.finfo(np.float32).eps)
+    Xd = np.abs(X.astype(np.float64))
+    Pd = np.abs(P.astype(np.float64))
+    mag = Xd @ Pd.T                                    # sum of |terms| per row
+    pr = X.astype(np.float64) @ P.astype(np.float64).T
+    z = np.maximum(np.abs(pr[:, 2]), 1e-30)
+    uv = np.hypot(pr[:, 0], pr[:, 1]) / z
+    return (4.0 * eps * ((mag[:, 0] + mag[:, 1]) / z + mag[:, 2] / z * uv)).astype(np.float32)
+
+
 def cell_diagnostics(cells: np.ndarray, best_k: np.ndarray, agg: np.ndarray, cam_a: OracleCamera,
                      cams_b: Sequence[OracleCamera], w_match: int, h_match: int,
                      axes=None) -> Dict[str, np.ndarray]:
@@ -547,6 +563,7 @@ def cell_diagnostics(cells: np.ndarray, best_k: np.ndarray, agg: np.ndarray, cam
     z2 = np.full(n, np.nan, np.float32)
     ang = np.full(n, np.nan, np.float32)
     sv_gap = np.full(n, np.nan, np.float32)
+    noise = np.full(n, np.nan, np.float32)
     sel = agg[cells]
     xA = match_pixels(sel[:, 0], w_match)
     yA = match_pixels(sel[:, 1], h_match)
@@ -569,8 +586,10 @@ def cell_diagnostics(cells: np.ndarray, best_k: np.ndarray, agg: np.ndarray, cam
             err[pos] = np.maximum(reprojection_error(cam_a.P, X, uvA), reprojection_error(cb.P, X, uvB))
             z1[pos] = (cam_a.P @ X.T)[2, :]
             z2[pos] = (cb.P @ X.T)[2, :]
+            noise[pos] = np.maximum(_reproj_noise(cam_a.P, X), _reproj_noise(cb.P, X))
             ang[pos] = parallax_angle_deg(cam_a.C, cb.C, X)
-    return {"sampson": se, "err": err, "z1": z1, "z2": z2, "parallax_deg": ang, "sv_ratio": sv_gap}
+    return {"sampson": se, "err": err, "z1": z1, "z2": z2, "parallax_deg": ang, "sv_ratio": sv_gap,
+            "err_noise": noise}
 
 
 # --------------------------------------------------------------------------------------------

@@ -52,7 +52,7 @@ def guard_band_ok(diag, params, eps_sampson=1e-6, eps_err=2e-3, eps_par=5e-3, ep
         if params.sampson_thresh > 0:
             ok &= np.abs(diag["sampson"] - params.sampson_thresh) > eps_sampson * max(1.0, params.sampson_thresh)
         passed_s = (diag["sampson"] < params.sampson_thresh) if params.sampson_thresh > 0 else np.ones_like(ok)
-        near = np.abs(diag["err"] - np.float32(params.reproj_thresh)) <= eps_err
+        near = np.abs(diag["err"] - np.float32(params.reproj_thresh)) <= eps_err + 4.0 * diag["err_noise"]
         near |= np.abs(diag["z1"]) <= eps_z_rel * np.maximum(1.0, np.abs(diag["z1"]))
         near |= np.abs(diag["z2"]) <= eps_z_rel * np.maximum(1.0, np.abs(diag["z2"]))
         if params.min_parallax_deg > 0:

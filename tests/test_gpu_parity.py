@@ -6,7 +6,8 @@ Tolerances (stated once, used everywhere):
     decision variables are farther than a guard band from their thresholds (upstream's f32 LAPACK SVD
     carries ~1e-4 px of noise in the reprojection error; a cell inside the band may legitimately flip).
     The golden fixtures contain no in-band cell, so their counts must match exactly.
-  * xyz: relative 1e-5 (+1e-6 abs);  err: 1e-3 px absolute;  rgb: 1/(255*4) absolute.
+  * xyz: relative 1e-5 (+1e-6 abs);  err: 1e-3 px absolute (+1e-5 relative, + 4x the oracle's bound on
+    upstream's own f32 rounding noise for that point);  rgb: 1/(255*4) absolute.
 """
 import numpy as np
 import pytest
@@ -19,7 +20,7 @@ from helpers import g3_case, guard_band_ok, oracle_cams, orc
 
 pytestmark = pytest.mark.gpu
 
-XYZ_RTOL, XYZ_ATOL, ERR_ATOL, RGB_ATOL = 1e-5, 1e-6, 1e-3, 1.0 / 255.0 / 4.0
+XYZ_RTOL, XYZ_ATOL, ERR_ATOL, ERR_RTOL, RGB_ATOL = 1e-5, 1e-6, 1e-3, 1e-5, 1.0 / 255.0 / 4.0
 
 
 @pytest.fixture(scope="module")
@@ -54,10 +55,24 @@ def _ref_inputs(case, dev, channels=4):
         mask_a=torch.from_numpy(case["mask_a"]).to(dev) if case["mask_a"] is not None else None, mask_b=mb)
 
 
-def _assert_values(out_xyz, out_rgb, out_err, xyz, rgb, err):
+def _assert_values(out_xyz, out_rgb, out_err, xyz, rgb, err, err_noise=None):
+    """err_noise: the oracle's per-point bound on upstream's own f32 rounding noise in the error
+    (orc._reproj_noise): ~1e-4 px normally, up to a pixel for points almost in a camera's principal
+    plane, where the f32 reference value itself is not reproducible by any other evaluation order."""
     np.testing.assert_allclose(out_xyz, xyz, rtol=XYZ_RTOL, atol=XYZ_ATOL)
-    np.testing.assert_allclose(out_err, err, rtol=0, atol=ERR_ATOL)
+    tol = ERR_ATOL + ERR_RTOL * np.abs(err.astype(np.float64))      # rtol matters only for no_filter garbage (err ~ 1e14)
+    if err_noise is not None:
+        tol = tol + 4.0 * np.asarray(err_noise, np.float64)
+    bad = np.abs(out_err.astype(np.float64) - err.astype(np.float64)) > tol
+    assert not bad.any(), (f"{int(bad.sum())} reprojection errors differ by more than the tolerance: "
+                           f"{out_err[bad][:5]} vs {err[bad][:5]}")
     np.testing.assert_allclose(out_rgb, rgb, rtol=0, atol=RGB_ATOL)
+
+
+def _noise_for(cells, case_or_inputs, ocams_a, ocams_b, wm, hm, cert_list, warp_list, params, axes=None, masks=(None, None)):
+    with np.errstate(all="ignore"):
+        _, bk, agg = orc.prepare_reference(cert_list, warp_list, params, masks[0], masks[1])
+        return orc.cell_diagnostics(cells, bk, agg, ocams_a, ocams_b, wm, hm, axes=axes)["err_noise"]
 
 
 G3_NAMES = ["a_filter_k3", "b_nofilter_k1", "c_rect_k3", "d_hires_k2", "e_masks_k3", "f_nosampson_k4"]
@@ -77,10 +92,14 @@ def test_indexed_matches_upstream_golden(g3, dev, name):
     order = [int(s) for s in out.seg_order[0] if s >= 0]
     assert [case["nbrs"][s] for s in order] == [int(v) for v in case["seg_nbr_cam"]]
     assert [int(out.seg_counts[0, s]) for s in order] == [int(v) for v in case["seg_count"]]
-    _assert_values(out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy(), case["xyz"], case["rgb"], case["err"])
-    # cell / slot bookkeeping agrees with the oracle's segments
     cert_list = [case["cert"][j] for j in range(case["k"])]
     warp_list = [case["warp"][j] for j in range(case["k"])]
+    noise = _noise_for(out.cell.cpu().numpy().astype(np.int64), case, ocams[case["ref"]], [ocams[n] for n in case["nbrs"]],
+                       case["w_match"], case["h_match"], cert_list, warp_list, case["params"],
+                       masks=(case["mask_a"], case["masks_b"]))
+    _assert_values(out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy(), case["xyz"], case["rgb"],
+                   case["err"], noise)
+    # cell / slot bookkeeping agrees with the oracle's segments
     with np.errstate(all="ignore"):
         res, _ = orc.triangulate_reference(cert_list, warp_list, case["image"], ocams[case["ref"]],
                                            [ocams[n] for n in case["nbrs"]], case["w_match"], case["h_match"],
@@ -104,7 +123,13 @@ def test_indexed_two_channel_warp_with_explicit_axes(g3, dev, name):
     sel = torch.from_numpy(case["sel"]).to(dev)
     out = dens.triangulate_indexed(batch, hb.make_params(_config(case["params"])), sel, [0, sel.numel()])
     assert out.count == case["xyz"].shape[0]
-    _assert_values(out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy(), case["xyz"], case["rgb"], case["err"])
+    cert_list = [case["cert"][j] for j in range(case["k"])]
+    warp_list = [case["warp"][j] for j in range(case["k"])]
+    noise = _noise_for(out.cell.cpu().numpy().astype(np.int64), case, ocams[case["ref"]], [ocams[n] for n in case["nbrs"]],
+                       case["w_match"], case["h_match"], cert_list, warp_list, case["params"],
+                       masks=(case["mask_a"], case["masks_b"]))
+    _assert_values(out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy(), case["xyz"], case["rgb"],
+                   case["err"], noise)
     dens.close()
 
 
@@ -182,7 +207,8 @@ def test_dense_matches_oracle(dev, H, W, wm, hm, channels, no_filter):
             both &= diag["sv_ratio"] < 0.2
         pos_h = np.searchsorted(my_cell, np.nonzero(both)[0]) + lo
         pos_o = np.searchsorted(d["cell"], np.nonzero(both)[0])
-        _assert_values(xyz[pos_h], rgb[pos_h], err[pos_h], d["xyz"][pos_o], d["rgb"][pos_o], d["err"][pos_o])
+        _assert_values(xyz[pos_h], rgb[pos_h], err[pos_h], d["xyz"][pos_o], d["rgb"][pos_o], d["err"][pos_o],
+                       diag["err_noise"][np.nonzero(both)[0]])
     assert n_band < 0.01 * 3 * H * W
     dens.close()
 
@@ -262,7 +288,11 @@ def test_dense_full_size_properties(dev):
     common = np.intersect1d(cell[lo:hi], d["cell"])
     ph = np.searchsorted(cell[lo:hi], common) + lo
     po = np.searchsorted(d["cell"], common)
-    _assert_values(out.xyz.cpu().numpy()[ph], out.rgb.cpu().numpy()[ph], err[ph], d["xyz"][po], d["rgb"][po], d["err"][po])
+    with np.errstate(all="ignore"):
+        diag = orc.cell_diagnostics(common, d["best_k"], np.stack([s.warp[j].numpy() for j in range(3)])[
+            d["best_k"].reshape(-1), np.arange(H * W) // W, np.arange(H * W) % W], ca, cbs, 512, 512, axes=axes_np)
+    _assert_values(out.xyz.cpu().numpy()[ph], out.rgb.cpu().numpy()[ph], err[ph], d["xyz"][po], d["rgb"][po], d["err"][po],
+                   diag["err_noise"])
     dens.close()
 
 
@@ -290,9 +320,14 @@ def test_indexed_batch_of_references_and_empty_selection(dev):
     np.testing.assert_array_equal(np.diff(out.ref_offsets), [e.count for e in expect])
     assert expect[1].count == 0 and expect[0].count > 100
     np.testing.assert_array_equal(out.cell.cpu().numpy(), np.concatenate([e.cell for e in expect]))
+    noises = []
+    for s, e in zip(srefs, expect):
+        k = len(s.nbr_indices)
+        noises.append(_noise_for(e.cell, None, _oracle_cam(cams[s.ref_index]), [_oracle_cam(cams[n]) for n in s.nbr_indices],
+                                 64, 64, [s.cert[j].numpy() for j in range(k)], [s.warp[j].numpy() for j in range(k)], params))
     _assert_values(out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy(),
                    np.concatenate([e.xyz for e in expect]), np.concatenate([e.rgb for e in expect]),
-                   np.concatenate([e.err for e in expect]))
+                   np.concatenate([e.err for e in expect]), np.concatenate(noises))
     dens.close()
 
 
