@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the dense-initialisation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the fused HIP kernel (certainty floor -> arg-max over neighbours -> Sampson
+-> DLT -> reprojection / cheirality / parallax -> colour -> ordered compaction) over one batch of
+synthetic RoMa outputs that is already resident in HBM: R reference views x k neighbours at the
+`fast` preset's 512x512 grid (MipNeRF360 `garden` geometry: 185 cameras on a ring, 1297x840 images),
+default filter thresholds.  Metric: triangulated (surviving) points per second, whole job.
+
+For N > 1 the references are dealt round-robin to the ranks (one process per GPU, no data-path
+collective inside the timed region: the path shards by reference view) and the survivors are
+all-gathered once after the timed region as a correctness check of the multi-GPU path.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description) with two extra objects:
+`roofline` (HBM roofline of the fused kernel, measured live with HIP events) and `cpu_baseline` (the
+NumPy oracle = a faithful port of the upstream CPU path, timed on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import lichtfeld_densification_plugin_amd as lfd  # noqa: E402
+from lichtfeld_densification_plugin_amd import synthetic  # noqa: E402
+from lichtfeld_densification_plugin_amd.core import hip_backend as hb  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--refs", type=int, default=64, help="reference views resident per GPU (per launch)")
+    ap.add_argument("--k", type=int, default=3, help="neighbours per reference (GUI default 3)")
+    ap.add_argument("--preset", default="fast", choices=sorted(synthetic.ROMA_PRESETS))
+    ap.add_argument("--noise-px", type=float, default=0.5)
+    ap.add_argument("--outliers", type=float, default=0.05)
+    ap.add_argument("--cpu-sample-refs", type=int, default=2, help="references timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch from a rocprofv3 --pmc run of this same command (profiles/)")
+    return ap.parse_args()
+
+
+def build_workload(args, rank, world, dev):
+    """Global reference list dealt round-robin; this rank generates and keeps only its share."""
+    h_lr, w_lr, H, W = synthetic.ROMA_PRESETS[args.preset]
+    n_cams = 185
+    cams = synthetic.ring_cameras(n_cams, seed=0)
+    total_refs = args.refs * world
+    ref_ids = [(i * 3) % n_cams for i in range(total_refs)]          # spread over the ring
+    mine = [i for i in range(total_refs) if i % world == rank]
+    refs, srefs = [], []
+    for gi in mine:
+        ref = ref_ids[gi]
+        nbrs = synthetic.ring_neighbours(n_cams, ref, args.k)
+        s = synthetic.synth_reference(cams, ref, nbrs, H, W, w_lr, h_lr, noise_px=args.noise_px,
+                                      outlier_frac=args.outliers, channels=2, seed=1000 + gi, cert_mode="smooth",
+                                      device=dev)
+        srefs.append(s)
+        refs.append(hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=[s.cert[j] for j in range(args.k)],
+                                       warp=[s.warp[j] for j in range(args.k)], image=s.image))
+    return cams, refs, srefs, (H, W, w_lr, h_lr), mine
+
+
+def cpu_baseline(args, cams, srefs, dims, cfg):
+    """The oracle (NumPy restatement of upstream's CPU path: same LAPACK batched f32 SVD, same dtype
+    ladder) on every cell of a few references of this very workload, single-threaded."""
+    if args.cpu_sample_refs <= 0:
+        return None
+    from oracle import densify_oracle as orc     # checker / baseline only
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:                              # pragma: no cover
+        threadpool_limits = None
+    H, W, wm, hm = dims
+    params = orc.OracleParams(certainty_thresh=cfg.certainty_thresh, reproj_thresh=cfg.reproj_thresh,
+                              sampson_thresh=cfg.sampson_thresh, min_parallax_deg=cfg.min_parallax_deg)
+    axes = (orc.identity_axis_scalar(W), orc.identity_axis_scalar(H))
+
+    def oc(c):
+        return orc.OracleCamera(K=c.K, R=c.R, t=c.t, P=c.P, C=c.C, width=c.width, height=c.height)
+
+    sample = srefs[:args.cpu_sample_refs]
+    host = [([s.cert[j].cpu().numpy() for j in range(args.k)], [s.warp[j].cpu().numpy() for j in range(args.k)],
+             s.image.cpu().numpy(), oc(cams[s.ref_index]), [oc(cams[n]) for n in s.nbr_indices]) for s in sample]
+    pts = 0
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        for certs, warps, img, ca, cbs in host:
+            pts += orc.triangulate_dense(certs, warps, img, ca, cbs, wm, hm, params, axes=axes)["xyz"].shape[0]
+    dt = time.perf_counter() - t0
+    if ctx is not None:
+        ctx.restore_original_limits() if hasattr(ctx, "restore_original_limits") else None
+    return {"value": pts / dt, "unit": "points/s", "cores": 1, "kind": "port",
+            "sample": f"{len(sample)} reference views x {args.k} neighbours x {H}x{W} cells of this workload "
+                      f"({pts} survivors in {dt:.1f} s, NumPy oracle, BLAS threads limited to 1)",
+            "pairs_per_s": len(sample) * args.k / dt}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cams, refs, srefs, dims, mine = build_workload(args, rank, world, dev)
+    H, W, wm, hm = dims
+    cfg = lfd.DensePipelineConfig(output_path="", roma_setting=args.preset, nns_per_ref=args.k)   # GUI defaults
+    params = hb.make_params(cfg)
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    batch = hb.PreparedBatch(refs, wm, hm)
+    out = hb.OutputBuffers(len(refs) * H * W, len(refs), args.k, dev, with_cell=True)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        dens.launch_dense(batch, params, out)
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()                      # same stream the kernel is launched on (torch's current stream)
+        dens.launch_dense(batch, params, out)
+        b.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    res = out.collect()
+    n_pts = res.count
+
+    stats = torch.tensor([elapsed, float(n_pts), kernel_ms], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0].item())
+        total_pts = float(tsum[1].item())
+        # the one exchange step of the path: ordered all-gather of the survivors (outside the timed region)
+        from lichtfeld_densification_plugin_amd.core import distributed as lfd_dist
+        gathered = lfd_dist.all_gather_points(res.xyz, res.rgb, res.err, dist)
+        assert gathered[0].shape[0] == int(total_pts), (gathered[0].shape, total_pts)
+    else:
+        total_pts = float(n_pts)
+
+    if rank == 0:
+        cells = len(refs) * H * W
+        s_frac = n_pts / cells
+        bytes_per_cell = 4 * args.k + 11 + 28 * s_frac
+        algo_bytes = cells * bytes_per_cell
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        value = total_pts * args.steps / elapsed
+        line = {
+            "metric": "triangulated points/sec (dense fused filter+triangulate kernel), MipNeRF360 garden @fast",
+            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (+f64 Sampson/DLT solve)", "data": "synthetic",
+            "config": {"workload": f"garden-like ring of 185 cameras 1297x840, `{args.preset}` grid {H}x{W}, "
+                                   f"{args.refs} reference views x {args.k} neighbours resident per GPU, "
+                                   f"default thresholds (certainty 0.2 / sampson 5.0 / reproj 0.8 / parallax 0.5 deg), "
+                                   f"noise {args.noise_px} px, {args.outliers:.0%} outliers",
+                       "mode": "dense", "refs_per_gpu": args.refs, "neighbours": args.k, "grid": [H, W],
+                       "sharding": f"references round-robin over {world} rank(s)"},
+            "pairs_per_s": args.refs * world * args.k * args.steps / elapsed,
+            "cells_per_s": cells * world * args.steps / elapsed,
+            "survivor_fraction": s_frac,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": args.traffic_bytes,
+                         "kernel": "lfd_dense_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_cell": bytes_per_cell},
+        }
+        base = cpu_baseline(args, cams, srefs, dims, cfg)
+        if base is not None:
+            line["cpu_baseline"] = base
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    dens.close()
+
+
+if __name__ == "__main__":
+    main()

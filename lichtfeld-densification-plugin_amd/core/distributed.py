@@ -1,0 +1,93 @@
+"""Multi-GPU sharding of the dense-initialisation path (one process per GPU, torch.distributed).
+
+The path shards by REFERENCE VIEW: the arg-max across neighbours couples the k pairs of one
+reference, nothing couples two references.  References are dealt round-robin to the
+ranks, every rank runs the whole per-reference path on its share with no collective, and there is
+exactly one exchange step at the end: a variable-length all-gather of the survivors
+(28 B per point: xyz f32x3, rgb f32x3, err f32) over RCCL/xGMI.  Payloads are small (<= tens of MB
+per rank), so the exchange is two collectives - counts, then one padded all-gather - rather than a
+chain of point-to-point sends.
+
+The upstream plugin has no multi-GPU code; the ordering rule below is this implementation's:
+the gathered sequence is ordered by position in the global reference list, so 1-GPU and N-GPU runs
+produce the same sequence.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def shard_references(n_refs: int, rank: int, world: int) -> List[int]:
+    """Positions (in the global reference list) owned by ``rank``: round-robin, which balances the
+    k-centres ordering of the list."""
+    return list(range(rank, n_refs, world))
+
+
+def _pack(xyz: torch.Tensor, rgb: torch.Tensor, err: torch.Tensor, rows: int) -> torch.Tensor:
+    buf = torch.zeros((rows, 7), dtype=torch.float32, device=xyz.device)
+    n = xyz.shape[0]
+    if n:
+        buf[:n, 0:3] = xyz
+        buf[:n, 3:6] = rgb
+        buf[:n, 6] = err
+    return buf
+
+
+def all_gather_points(xyz: torch.Tensor, rgb: torch.Tensor, err: torch.Tensor, dist, group=None
+                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, List[int]]:
+    """Concatenate every rank's survivors in rank order.  Returns (xyz, rgb, err, counts)."""
+    world = dist.get_world_size(group)
+    dev = xyz.device
+    n_local = torch.tensor([xyz.shape[0]], dtype=torch.int64, device=dev)
+    counts_t = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts_t, n_local, group=group)
+    counts = [int(c.item()) for c in counts_t]
+    rows = max(max(counts), 1)
+    mine = _pack(xyz, rgb, err, rows)
+    bufs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine, group=group)
+    cat = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0) if sum(counts) else mine[:0]
+    return cat[:, 0:3].contiguous(), cat[:, 3:6].contiguous(), cat[:, 6].contiguous(), counts
+
+
+def all_gather_by_reference(xyz: torch.Tensor, rgb: torch.Tensor, err: torch.Tensor,
+                            ref_counts: Sequence[int], n_refs_global: int, dist, group=None
+                            ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, np.ndarray]:
+    """All-gather and restore the global reference order.
+
+    ``ref_counts[i]`` = survivors of the i-th LOCAL reference (global position ``rank + i*world``),
+    local points being stored reference after reference.  Returns the points ordered by global
+    reference position and the per-reference counts ``(n_refs_global,)``."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = xyz.device
+    per_rank = (n_refs_global + world - 1) // world
+    local = torch.zeros(per_rank, dtype=torch.int64, device=dev)
+    expected = len(shard_references(n_refs_global, rank, world))
+    if len(ref_counts) != expected:
+        raise ValueError(f"rank {rank} owns {expected} references, got {len(ref_counts)} counts")
+    if len(ref_counts):
+        local[:len(ref_counts)] = torch.as_tensor(list(ref_counts), dtype=torch.int64, device=dev)
+    if int(local.sum().item()) != xyz.shape[0]:
+        raise ValueError("ref_counts do not add up to the number of local points")
+    tables = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(tables, local, group=group)
+    table = torch.stack(tables, 0).cpu().numpy()                  # [world, per_rank]
+    gx, gc, ge, counts = all_gather_points(xyz, rgb, err, dist, group)
+    rank_base = np.concatenate([[0], np.cumsum(counts)])[:-1]
+    within = np.concatenate([np.zeros((world, 1), np.int64), np.cumsum(table, axis=1)], axis=1)
+    pieces, global_counts = [], np.zeros(n_refs_global, np.int64)
+    for g in range(n_refs_global):
+        r, i = g % world, g // world
+        lo = rank_base[r] + within[r, i]
+        hi = rank_base[r] + within[r, i + 1]
+        global_counts[g] = hi - lo
+        if hi > lo:
+            pieces.append(torch.arange(lo, hi, device=dev))
+    if pieces:
+        order = torch.cat(pieces)
+        gx, gc, ge = gx[order], gc[order], ge[order]
+    return gx, gc, ge, global_counts
