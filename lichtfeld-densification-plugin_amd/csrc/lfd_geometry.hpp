@@ -142,11 +142,12 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
 // ---- smallest right singular vector of a 4x4 matrix, f64 ---------------------------------------
 // adj(A) = det(A) A^-1, so G = adj(A) adj(A)^T = det(A)^2 (A^T A)^-1 has the right singular vectors
 // of A as eigenvectors with eigenvalues prod_{j!=i} sigma_j^2: the wanted vector v4 dominates by the
-// factor (sigma_3/sigma_4)^2.  Repeated squaring of the trace-normalised G (each squaring squares
-// that factor) converges to v4 v4^T; for a trace-1 PSD matrix trace(G^2) = 1 exactly when rank 1, so
-// 1 - trace(G^2) ~ 2*lambda_2/lambda_1 is the stopping test.  No pivoting, no division except the
-// normalisations, and (unlike eig(A^T A)) the conditioning is that of A, not of A^T A: the entries of
-// A are f32, so all 2x2 minors are differences of exact f64 products.
+// factor (sigma_3/sigma_4)^2.  Repeated squaring of G (each squaring squares that factor) converges
+// to a multiple of v4 v4^T; for a PSD matrix trace(G^2) = trace(G)^2 exactly when rank 1, so
+// trace(G)^2 - trace(G^2) <= tol * trace(G)^2  (~ 2*lambda_2/lambda_1 <= tol) is the stopping test.
+// No pivoting and no division: G is rescaled by an exact power of two before each squaring.  Unlike
+// eig(A^T A) the conditioning is that of A, not of A^T A: the entries of A are f32, so every 2x2
+// minor is the difference of two EXACT f64 products (fma below changes nothing there).
 #ifndef LFD_NULLVEC_TOL
 #define LFD_NULLVEC_TOL 2e-9
 #endif
@@ -154,43 +155,63 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
 #define LFD_NULLVEC_MAXIT 6
 #endif
 
-LFD_HD int lfd_null_vector(const float* Af, double* v) {
+LFD_HD double lfd_pow2_inv_scale(double t) {
+    // 2^-e with t = m * 2^e, m in [0.5, 1): exact rescaling to keep the squarings inside f64 range.
+    // t <= 0, Inf or NaN give 1.0 (the caller's tests then fail and the cell is rejected downstream).
+    if (!(t > 0.0) || !(t < 1.7976931348623157e308)) return 1.0;
+    int e;
+    (void)frexp(t, &e);
+    return ldexp(1.0, -e);
+}
+
+// c[4]: un-normalised dominant column (a multiple of the null vector); returns squarings used.
+LFD_HD int lfd_null_vector(const float* Af, double* c) {
     double a[16];
     for (int i = 0; i < 16; ++i) a[i] = (double)Af[i];
 #define A_(i, j) a[(i) * 4 + (j)]
-    const double s0 = A_(0, 0) * A_(1, 1) - A_(1, 0) * A_(0, 1);
-    const double s1 = A_(0, 0) * A_(1, 2) - A_(1, 0) * A_(0, 2);
-    const double s2 = A_(0, 0) * A_(1, 3) - A_(1, 0) * A_(0, 3);
-    const double s3 = A_(0, 1) * A_(1, 2) - A_(1, 1) * A_(0, 2);
-    const double s4 = A_(0, 1) * A_(1, 3) - A_(1, 1) * A_(0, 3);
-    const double s5 = A_(0, 2) * A_(1, 3) - A_(1, 2) * A_(0, 3);
-    const double c5 = A_(2, 2) * A_(3, 3) - A_(3, 2) * A_(2, 3);
-    const double c4 = A_(2, 1) * A_(3, 3) - A_(3, 1) * A_(2, 3);
-    const double c3 = A_(2, 1) * A_(3, 2) - A_(3, 1) * A_(2, 2);
-    const double c2 = A_(2, 0) * A_(3, 3) - A_(3, 0) * A_(2, 3);
-    const double c1 = A_(2, 0) * A_(3, 2) - A_(3, 0) * A_(2, 2);
-    const double c0 = A_(2, 0) * A_(3, 1) - A_(3, 0) * A_(2, 1);
+#define MINOR(p, q, r, s) fma(p, q, -((r) * (s)))      /* p*q - r*s, single rounding (products exact) */
+    const double s0 = MINOR(A_(0, 0), A_(1, 1), A_(1, 0), A_(0, 1));
+    const double s1 = MINOR(A_(0, 0), A_(1, 2), A_(1, 0), A_(0, 2));
+    const double s2 = MINOR(A_(0, 0), A_(1, 3), A_(1, 0), A_(0, 3));
+    const double s3 = MINOR(A_(0, 1), A_(1, 2), A_(1, 1), A_(0, 2));
+    const double s4 = MINOR(A_(0, 1), A_(1, 3), A_(1, 1), A_(0, 3));
+    const double s5 = MINOR(A_(0, 2), A_(1, 3), A_(1, 2), A_(0, 3));
+    const double c5 = MINOR(A_(2, 2), A_(3, 3), A_(3, 2), A_(2, 3));
+    const double c4 = MINOR(A_(2, 1), A_(3, 3), A_(3, 1), A_(2, 3));
+    const double c3 = MINOR(A_(2, 1), A_(3, 2), A_(3, 1), A_(2, 2));
+    const double c2 = MINOR(A_(2, 0), A_(3, 3), A_(3, 0), A_(2, 3));
+    const double c1 = MINOR(A_(2, 0), A_(3, 2), A_(3, 0), A_(2, 2));
+    const double c0 = MINOR(A_(2, 0), A_(3, 1), A_(3, 0), A_(2, 1));
+#undef MINOR
+    // adjugate, each entry x*u - y*v + z*w as fma(z, w, fma(-y, v, x*u))
+#define ADJ(x, u, y, v, z, w) fma(z, w, fma(-(y), v, (x) * (u)))
     double J[16];
-    J[0] = (A_(1, 1) * c5 - A_(1, 2) * c4) + A_(1, 3) * c3;
-    J[1] = (A_(0, 2) * c4 - A_(0, 1) * c5) - A_(0, 3) * c3;
-    J[2] = (A_(3, 1) * s5 - A_(3, 2) * s4) + A_(3, 3) * s3;
-    J[3] = (A_(2, 2) * s4 - A_(2, 1) * s5) - A_(2, 3) * s3;
-    J[4] = (A_(1, 2) * c2 - A_(1, 0) * c5) - A_(1, 3) * c1;
-    J[5] = (A_(0, 0) * c5 - A_(0, 2) * c2) + A_(0, 3) * c1;
-    J[6] = (A_(3, 2) * s2 - A_(3, 0) * s5) - A_(3, 3) * s1;
-    J[7] = (A_(2, 0) * s5 - A_(2, 2) * s2) + A_(2, 3) * s1;
-    J[8] = (A_(1, 0) * c4 - A_(1, 1) * c2) + A_(1, 3) * c0;
-    J[9] = (A_(0, 1) * c2 - A_(0, 0) * c4) - A_(0, 3) * c0;
-    J[10] = (A_(3, 0) * s4 - A_(3, 1) * s2) + A_(3, 3) * s0;
-    J[11] = (A_(2, 1) * s2 - A_(2, 0) * s4) - A_(2, 3) * s0;
-    J[12] = (A_(1, 1) * c1 - A_(1, 0) * c3) - A_(1, 2) * c0;
-    J[13] = (A_(0, 0) * c3 - A_(0, 1) * c1) + A_(0, 2) * c0;
-    J[14] = (A_(3, 1) * s1 - A_(3, 0) * s3) - A_(3, 2) * s0;
-    J[15] = (A_(2, 0) * s3 - A_(2, 1) * s1) + A_(2, 2) * s0;
+    J[0] = ADJ(A_(1, 1), c5, A_(1, 2), c4, A_(1, 3), c3);
+    J[1] = -ADJ(A_(0, 1), c5, A_(0, 2), c4, A_(0, 3), c3);
+    J[2] = ADJ(A_(3, 1), s5, A_(3, 2), s4, A_(3, 3), s3);
+    J[3] = -ADJ(A_(2, 1), s5, A_(2, 2), s4, A_(2, 3), s3);
+    J[4] = -ADJ(A_(1, 0), c5, A_(1, 2), c2, A_(1, 3), c1);
+    J[5] = ADJ(A_(0, 0), c5, A_(0, 2), c2, A_(0, 3), c1);
+    J[6] = -ADJ(A_(3, 0), s5, A_(3, 2), s2, A_(3, 3), s1);
+    J[7] = ADJ(A_(2, 0), s5, A_(2, 2), s2, A_(2, 3), s1);
+    J[8] = ADJ(A_(1, 0), c4, A_(1, 1), c2, A_(1, 3), c0);
+    J[9] = -ADJ(A_(0, 0), c4, A_(0, 1), c2, A_(0, 3), c0);
+    J[10] = ADJ(A_(3, 0), s4, A_(3, 1), s2, A_(3, 3), s0);
+    J[11] = -ADJ(A_(2, 0), s4, A_(2, 1), s2, A_(2, 3), s0);
+    J[12] = -ADJ(A_(1, 0), c3, A_(1, 1), c1, A_(1, 2), c0);
+    J[13] = ADJ(A_(0, 0), c3, A_(0, 1), c1, A_(0, 2), c0);
+    J[14] = -ADJ(A_(3, 0), s3, A_(3, 1), s1, A_(3, 2), s0);
+    J[15] = ADJ(A_(2, 0), s3, A_(2, 1), s1, A_(2, 2), s0);
+#undef ADJ
 #undef A_
     // G = J J^T (symmetric, upper triangle g00 g01 g02 g03 g11 g12 g13 g22 g23 g33)
-    double g00 = 0, g01 = 0, g02 = 0, g03 = 0, g11 = 0, g12 = 0, g13 = 0, g22 = 0, g23 = 0, g33 = 0;
-    for (int r = 0; r < 4; ++r) {
+    double g00, g01, g02, g03, g11, g12, g13, g22, g23, g33;
+    {
+        const double j0 = J[0], j1 = J[4], j2 = J[8], j3 = J[12];
+        g00 = j0 * j0; g01 = j0 * j1; g02 = j0 * j2; g03 = j0 * j3;
+        g11 = j1 * j1; g12 = j1 * j2; g13 = j1 * j3; g22 = j2 * j2; g23 = j2 * j3; g33 = j3 * j3;
+    }
+    for (int r = 1; r < 4; ++r) {
         const double j0 = J[0 + r], j1 = J[4 + r], j2 = J[8 + r], j3 = J[12 + r];
         g00 = fma(j0, j0, g00); g01 = fma(j0, j1, g01); g02 = fma(j0, j2, g02); g03 = fma(j0, j3, g03);
         g11 = fma(j1, j1, g11); g12 = fma(j1, j2, g12); g13 = fma(j1, j3, g13);
@@ -199,8 +220,9 @@ LFD_HD int lfd_null_vector(const float* Af, double* v) {
     double tr = (g00 + g11) + (g22 + g33);
     int it = 0;
     for (; it < LFD_NULLVEC_MAXIT; ++it) {
-        const double s = 1.0 / tr;
+        const double s = lfd_pow2_inv_scale(tr);
         g00 *= s; g01 *= s; g02 *= s; g03 *= s; g11 *= s; g12 *= s; g13 *= s; g22 *= s; g23 *= s; g33 *= s;
+        const double t1 = tr * s;
         const double h00 = fma(g03, g03, fma(g02, g02, fma(g01, g01, g00 * g00)));
         const double h01 = fma(g03, g13, fma(g02, g12, fma(g01, g11, g00 * g01)));
         const double h02 = fma(g03, g23, fma(g02, g22, fma(g01, g12, g00 * g02)));
@@ -213,17 +235,23 @@ LFD_HD int lfd_null_vector(const float* Af, double* v) {
         const double h33 = fma(g33, g33, fma(g23, g23, fma(g13, g13, g03 * g03)));
         g00 = h00; g01 = h01; g02 = h02; g03 = h03; g11 = h11; g12 = h12; g13 = h13; g22 = h22; g23 = h23; g33 = h33;
         tr = (g00 + g11) + (g22 + g33);
-        if (!((1.0 - tr) > LFD_NULLVEC_TOL)) { ++it; break; }   // also leaves on NaN
+        const double t2 = t1 * t1;
+        if (!((t2 - tr) > LFD_NULLVEC_TOL * t2)) { ++it; break; }   // rank 1 reached (also leaves on NaN)
     }
     // dominant column = column of the largest diagonal entry
-    double c0v = g00, c1v = g01, c2v = g02, c3v = g03, best = g00;
-    if (g11 > best) { best = g11; c0v = g01; c1v = g11; c2v = g12; c3v = g13; }
-    if (g22 > best) { best = g22; c0v = g02; c1v = g12; c2v = g22; c3v = g23; }
-    if (g33 > best) { best = g33; c0v = g03; c1v = g13; c2v = g23; c3v = g33; }
-    const double n2 = (c0v * c0v + c1v * c1v) + (c2v * c2v + c3v * c3v);
-    const double inv = 1.0 / sqrt(n2);
-    v[0] = c0v * inv; v[1] = c1v * inv; v[2] = c2v * inv; v[3] = c3v * inv;
+    double best = g00;
+    c[0] = g00; c[1] = g01; c[2] = g02; c[3] = g03;
+    if (g11 > best) { best = g11; c[0] = g01; c[1] = g11; c[2] = g12; c[3] = g13; }
+    if (g22 > best) { best = g22; c[0] = g02; c[1] = g12; c[2] = g22; c[3] = g23; }
+    if (g33 > best) { best = g33; c[0] = g03; c[1] = g13; c[2] = g23; c[3] = g33; }
     return it;
+}
+
+// a / b for f64 with ONE division shared by several numerators: r = RN(1/b); q = RN(a*r);
+// q' = RN(q + (a - b*q)*r) is the correctly rounded quotient (Markstein), i.e. bit-identical to a/b.
+LFD_HD double lfd_div_by_recip(double a, double b, double r) {
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
 }
 
 // ---- one correspondence -------------------------------------------------------------------------
@@ -268,8 +296,9 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
         const double ft1 = fma(F[4], y2, F[1] * x2) + F[7];
         const double num = (x2 * fx0 + y2 * fx1) + fx2;
         const double den = (((fx0 * fx0 + fx1 * fx1) + ft0 * ft0) + ft1 * ft1) + 1e-12;
-        const double se = (num * num) / den;
-        if (!(se < kp.sampson_thresh)) return;
+        // se = num^2/den < thresh  <=>  num^2 < thresh*den  (den > 0); differs from the division only
+        // within one f64 ulp of the threshold, and NaN still rejects
+        if (!((num * num) < kp.sampson_thresh * den)) return;
     }
 
     float A[16];              // DLT rows, f32, multiply then subtract (core/geometry.py:72-75)
@@ -279,11 +308,23 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
         A[8 + c] = ub * pc.P[8 + c] - pc.P[0 + c];
         A[12 + c] = vb * pc.P[8 + c] - pc.P[4 + c];
     }
-    double v[4];
-    lfd_null_vector(A, v);
-    double w = v[3];
-    if (fabs(w) < 1e-12) w = 1e-12;       // sign is lost on purpose (core/geometry.py:86)
-    const float X0 = (float)(v[0] / w), X1 = (float)(v[1] / w), X2 = (float)(v[2] / w), X3 = (float)(v[3] / w);
+    double c[4];
+    lfd_null_vector(A, c);
+    // upstream: Xh = unit null vector, w = (|Xh[3]| < 1e-12 ? 1e-12 : Xh[3]), X = Xh / w
+    // (core/geometry.py:84-87).  |c3|/|c| < 1e-12 is tested on squares; the common branch divides by
+    // c3 directly (X3 == 1), the guard branch normalises first (sign is lost on purpose).
+    const double n2 = (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+    float X0, X1, X2, X3;
+    if (c[3] * c[3] < 1e-24 * n2) {
+        const double inv = 1.0 / (sqrt(n2) * 1e-12);
+        X0 = (float)(c[0] * inv); X1 = (float)(c[1] * inv); X2 = (float)(c[2] * inv); X3 = (float)(c[3] * inv);
+    } else {
+        const double r = 1.0 / c[3];
+        X0 = (float)lfd_div_by_recip(c[0], c[3], r);
+        X1 = (float)lfd_div_by_recip(c[1], c[3], r);
+        X2 = (float)lfd_div_by_recip(c[2], c[3], r);
+        X3 = 1.0f;
+    }
 
     float z1, z2;
     const float e1 = lfd_reproj(rc.P, X0, X1, X2, X3, ua, va, z1);
@@ -336,7 +377,7 @@ LFD_HD void lfd_bilinear_rgb(const uint8_t* img, int wi, int hi, float xa_px, fl
     for (int c = 0; c < 3; ++c) {
         const double s = (((double)(float)pa[c] * wa + (double)(float)pb[c] * wb) + (double)(float)pcx[c] * wc) +
                          (double)(float)pd[c] * wd;
-        rgb[c] = (float)(s / 255.0);
+        rgb[c] = (float)lfd_div_by_recip(s, 255.0, 1.0 / 255.0);   // == s / 255.0, correctly rounded
     }
 }
 
