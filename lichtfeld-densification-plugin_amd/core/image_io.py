@@ -1,0 +1,73 @@
+"""Host image I/O for the pipeline driver (upstream core/image_utils.py:12-91).
+
+Same decoding rules as upstream so that the colours sampled by the kernel come from the same
+pixels: RGB via PIL, resized to the matcher resolution with ``Image.BILINEAR``; masks converted to
+"L", resized with ``Image.NEAREST`` and thresholded at ``> 0.5`` of full scale (1 = keep)."""
+from __future__ import annotations
+
+import os
+from functools import lru_cache
+from typing import Tuple
+
+import numpy as np
+
+
+def image_dir(scene_root: str, preferred: str) -> str:
+    first = os.path.join(scene_root, preferred)
+    if os.path.isdir(first):
+        return first
+    for name in ("images_4", "images_2", "images_8", "images"):
+        cand = os.path.join(scene_root, name)
+        if os.path.isdir(cand):
+            return cand
+    raise FileNotFoundError("Could not locate an images directory under scene_root.")
+
+
+def find_image(root: str, name: str) -> str:
+    for cand in (os.path.join(root, name), os.path.join(root, os.path.basename(name))):
+        if os.path.isfile(cand):
+            return cand
+    raise FileNotFoundError(f"Image '{name}' not found under {root}")
+
+
+def to_uint8_rgb(rgb01: np.ndarray) -> np.ndarray:
+    """[0,1] floats -> u8 with NumPy's round-half-to-even, clipped (upstream core/image_utils.py:24-26)."""
+    return np.clip(np.round(np.asarray(rgb01) * 255.0), 0, 255).astype(np.uint8)
+
+
+@lru_cache(maxsize=4096)
+def load_rgb_u8(path: str, size: Tuple[int, int]) -> np.ndarray:
+    """(h, w, 3) u8 array of ``path`` resized to ``size=(w, h)``."""
+    from PIL import Image
+    im = Image.open(path).convert("RGB")
+    if im.size != tuple(size):
+        im = im.resize(tuple(size), Image.BILINEAR)
+    arr = np.asarray(im, dtype=np.uint8)
+    arr.setflags(write=False)
+    return arr
+
+
+@lru_cache(maxsize=4096)
+def load_mask01(path: str, size: Tuple[int, int], invert: bool = False, threshold: float = 0.5) -> np.ndarray:
+    """(h, w) u8 {0,1} mask, 1 = keep."""
+    from PIL import Image
+    if not os.path.isfile(path):
+        raise FileNotFoundError(path)
+    im = Image.open(path).convert("L")
+    if im.size != tuple(size):
+        im = im.resize(tuple(size), Image.NEAREST)
+    keep = (np.asarray(im, dtype=np.uint8).astype(np.float32) / 255.0) > float(threshold)
+    if invert:
+        keep = ~keep
+    out = keep.astype(np.uint8)
+    out.setflags(write=False)
+    return out
+
+
+def black_out(rgb: np.ndarray, mask01: np.ndarray) -> np.ndarray:
+    """Masked pixels become black before matching (upstream core/image_utils.py:69-82)."""
+    if mask01.ndim != 2 or mask01.shape != rgb.shape[:2]:
+        raise ValueError(f"mask shape {mask01.shape} must match image shape {rgb.shape[:2]}")
+    out = np.array(rgb, dtype=np.uint8, copy=True)
+    out[mask01 == 0] = 0
+    return out

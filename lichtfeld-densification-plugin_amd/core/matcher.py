@@ -1,0 +1,157 @@
+"""RoMa-v2 producer of the hot path's inputs (upstream core/matcher.py:74-211).
+
+RoMa-v2 itself is a third-party model (DINOv3 ViT-L/16 + match transformer + DPT head + conv
+refiners) and runs unmodified on PyTorch-ROCm; it is not re-implemented here.  This wrapper keeps
+upstream's interface - ``w_resized / h_resized / sample_thresh / match_grids_batch / close`` - with
+two MI355X-side differences: the outputs STAY on the GPU (the HIP kernels read them in place, there
+is no device-to-host copy), and the warp can be handed over as the 2-channel ``warp_AB`` together
+with the A-grid axes instead of being concatenated with a materialised identity grid.
+"""
+from __future__ import annotations
+
+import gc
+import os
+import sys
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .hostlog import log
+
+ROMA_WEIGHTS_FILE = "romav2.pt"
+
+# name -> (H_lr, W_lr, H_hr, W_hr, bidirectional); "high" is the plugin's own preset
+# (upstream core/matcher.py:82-87), the others are RoMaV2.apply_setting presets
+PLUGIN_PRESETS = {"high": (640, 640, 960, 960, True)}
+
+
+def romav2_cached_weights_paths() -> List[str]:
+    roots: List[str] = []
+    try:
+        roots.append(os.path.join(torch.hub.get_dir(), "checkpoints"))
+    except Exception:
+        pass
+    if os.getenv("TORCH_HOME"):
+        roots.append(os.path.join(os.path.expanduser(os.environ["TORCH_HOME"]), "hub", "checkpoints"))
+    roots.append(os.path.join(os.path.expanduser(os.getenv("XDG_CACHE_HOME", "~/.cache")), "torch", "hub", "checkpoints"))
+    seen, out = set(), []
+    for r in roots:
+        key = os.path.normcase(os.path.normpath(r))
+        if key not in seen:
+            seen.add(key)
+            out.append(os.path.join(r, ROMA_WEIGHTS_FILE))
+    return out
+
+
+def has_cached_romav2_weights() -> bool:
+    return any(os.path.isfile(p) for p in romav2_cached_weights_paths())
+
+
+def _import_romav2():
+    try:
+        from romav2 import RoMaV2
+        return RoMaV2
+    except Exception:
+        pass
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cand in (os.path.join(here, "RoMaV2", "src"), os.path.join(os.path.dirname(here), "RoMaV2", "src")):
+        if os.path.isdir(cand) and cand not in sys.path:
+            sys.path.insert(0, cand)
+    try:
+        from romav2 import RoMaV2
+        return RoMaV2
+    except Exception as exc:
+        raise RuntimeError(
+            "RoMa-v2 (package `romav2`) is not importable. Install it (PyTorch-ROCm build) or vendor it under "
+            "RoMaV2/src next to this package; the dense-initialisation kernels only consume its outputs.") from exc
+
+
+class RomaMatcher:
+    """Dense matcher with the reference image's features cached across its neighbours."""
+
+    def __init__(self, device: str = "cuda", mode: str = "outdoor", setting: str = "fast", two_channel: bool = True):
+        del mode
+        RoMaV2 = _import_romav2()
+        self.device = torch.device(device)
+        torch.set_float32_matmul_precision("highest")
+        self.model = RoMaV2(RoMaV2.Cfg(compile=False))
+        if setting in PLUGIN_PRESETS:
+            h_lr, w_lr, h_hr, w_hr, bidir = PLUGIN_PRESETS[setting]
+            self.model.H_lr, self.model.W_lr, self.model.H_hr, self.model.W_hr = h_lr, w_lr, h_hr, w_hr
+            self.model.bidirectional = bidir
+        else:
+            self.model.apply_setting(setting)
+        self.model.to(self.device).eval()
+        self.sample_thresh = 0.9
+        self.w_resized, self.h_resized = int(self.model.W_lr), int(self.model.H_lr)
+        self.two_channel = bool(two_channel)
+        self._axes: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
+        log.info(f"RoMaV2 initialized (setting={setting}, H_lr={self.model.H_lr}, W_lr={self.model.W_lr}, device={device})")
+
+    def reference_axes(self, H: int, W: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The A-grid exactly as upstream builds it (core/matcher.py:132-135), as two 1-D axes."""
+        key = (int(H), int(W))
+        if key not in self._axes:
+            self._axes[key] = (torch.linspace(-1 + 1 / W, 1 - 1 / W, W, device=self.device),
+                               torch.linspace(-1 + 1 / H, 1 - 1 / H, H, device=self.device))
+        return self._axes[key]
+
+    @torch.inference_mode()
+    def match_grids_batch(self, imA, imB_list: Sequence) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+        if self.model is None:
+            raise RuntimeError("RoMaV2 model has been released; create a new matcher before matching.")
+        if not imB_list:
+            return []
+        torch.set_float32_matmul_precision("highest")
+        model = self.model
+        img_a = model._load_image(imA)
+        kw = dict(mode="bicubic", align_corners=False, antialias=True)
+        a_lr = F.interpolate(img_a, size=(int(model.H_lr), int(model.W_lr)), **kw)
+        a_hr = None
+        if model.H_hr is not None and model.W_hr is not None:
+            a_hr = F.interpolate(img_a, size=(int(model.H_hr), int(model.W_hr)), **kw)
+        feats_a = model.f(a_lr)                    # DINOv3 features of the reference: once per reference
+        out: List[Tuple[torch.Tensor, torch.Tensor]] = []
+        for im_b in imB_list:
+            pred = model.match_from_features(f_list_A=feats_a, img_A_lr=a_lr, imB=im_b, img_A_hr=a_hr)
+            warp_ab = pred["warp_AB"][0]
+            cert = pred["overlap_AB"][0].squeeze(-1).contiguous()
+            H, W = cert.shape
+            if self.two_channel:
+                out.append((warp_ab.contiguous(), cert))
+            else:
+                ax, ay = self.reference_axes(H, W)
+                grid = torch.stack([ax.view(1, W).expand(H, W), ay.view(H, 1).expand(H, W)], dim=-1)
+                out.append((torch.cat([grid, warp_ab], dim=-1).contiguous(), cert))
+        return out
+
+    def match_grids(self, imA, imB):
+        res = self.match_grids_batch(imA, [imB])
+        if not res:
+            raise RuntimeError("RoMaV2 returned no matches for the requested pair.")
+        return res[0]
+
+    def close(self) -> None:
+        model = getattr(self, "model", None)
+        if model is None:
+            return
+        try:
+            model.to("cpu")
+        except Exception:
+            pass
+        self.model = None
+        self._axes.clear()
+        gc.collect()
+        if torch.cuda.is_available():
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            torch.cuda.empty_cache()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,506 @@
+"""Dense-initialisation pipeline driver with the per-reference hot path on the GPU.
+
+Drop-in for upstream ``core/pipeline.py::run_dense_pipeline`` (:783-928): same signature, same
+callbacks, same result type, same exceptions.  What changes is where the work happens:
+
+    upstream                                     here
+    --------------------------------------       ----------------------------------------------
+    RoMa outputs copied to the host, sync        stay on the GPU, consumed in place
+    _collect_reference_matches epilogue (CPU)    folded into the HIP kernels (floor, masks)
+    _triangulate_ref (torch-CPU + NumPy)         lfd_aggregate + lfd_triangulate_indexed  ("sampled")
+                                                 or lfd_triangulate_dense                 ("dense")
+    4 pack threads, completion order             ordered prefetch (results do not depend on timing)
+
+Two triangulation modes (``DensePipelineConfig.triangulation_mode``):
+  * "sampled" (default) reproduces upstream: coverage sampling picks ~0.85*M + <=625 cells per
+    reference from the aggregated certainty, those cells are triangulated and emitted in upstream's
+    per-neighbour group order.  With ``per_reference_rng=False`` and one GPU the legacy NumPy stream
+    is consumed exactly as upstream consumes it (one stream, reference after reference).
+  * "dense" sends every grid cell through the fused kernel (survivors in raster order per reference).
+
+Multi-GPU: when ``torch.distributed`` is initialised with world_size > 1 the reference list is dealt
+round-robin to the ranks and the survivors are all-gathered in reference order at the end
+(core/distributed.py); sampling then uses one RNG stream per reference.
+"""
+from __future__ import annotations
+
+import dataclasses
+import gc
+import os
+import time
+from concurrent.futures import Future, ThreadPoolExecutor
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import distributed as lfd_dist
+from . import hip_backend as hb
+from .debug_viz import MatchDebugState, MatchPreview
+from .hostlog import log
+from .image_io import black_out, load_mask01, load_rgb_u8, to_uint8_rgb
+from .matcher import RomaMatcher, has_cached_romav2_weights, romav2_cached_weights_paths
+from .sampling import select_samples_with_coverage
+from .types import CameraRecord, DensePipelineConfig
+from .writers import ensure_dir, write_ply
+
+_DEBUG_PREVIEW_INTERVAL = 3      # upstream core/pipeline.py:34
+_PREVIEW_MAX_MATCHES = 10000     # upstream core/pipeline.py:50
+
+
+@dataclasses.dataclass
+class PipelineResult:
+    xyz: np.ndarray                 # (N,3) f32
+    rgb: np.ndarray                 # (N,3) f32 in [0,1]
+    err: np.ndarray                 # (N,)  f32
+    elapsed_seconds: float
+    pairs_processed: int            # upstream's name; counts REFERENCES that produced points
+    # extras (not present upstream)
+    pairs_matched: int = 0          # actual (reference, neighbour) pairs matched
+    points_per_reference: Optional[np.ndarray] = None
+
+
+class PipelineCancelled(RuntimeError):
+    """Raised when a running dense pipeline is cancelled."""
+
+
+@dataclasses.dataclass
+class _PackedReference:
+    position: int                   # position in refs_local
+    ref_index: int                  # index into camera_records
+    ref_uid: int
+    image: np.ndarray               # (h,w,3) u8, masked pixels blacked out
+    mask_a: Optional[np.ndarray]
+    nbr_indices: List[int]
+    nbr_images: List[np.ndarray]
+    nbr_masks: List[Optional[np.ndarray]]
+
+
+def _cancelled(cb: Optional[Callable[[], bool]]) -> bool:
+    if cb is None:
+        return False
+    try:
+        return bool(cb())
+    except Exception as exc:
+        log.warn(f"Cancellation callback failed: {exc}")
+        return False
+
+
+def _raise_if_cancelled(cb) -> None:
+    if _cancelled(cb):
+        raise PipelineCancelled("Cancelled")
+
+
+def _estimate_total_pairs(refs_local, nn_table, uids, nns_per_ref) -> int:
+    return sum(sum(1 for n in nn_table[r][:nns_per_ref] if uids[n] != uids[r]) for r in refs_local)
+
+
+def _pack_reference(position: int, ref_index: int, cams: Sequence[CameraRecord], nn_table, nns_per_ref: int,
+                    size_wh: Tuple[int, int], cancel) -> Optional[_PackedReference]:
+    """Load and pre-process one reference and its neighbours (upstream core/pipeline.py:132-227)."""
+    if _cancelled(cancel):
+        return None
+    cam = cams[ref_index]
+    try:
+        img_a = load_rgb_u8(cam.image_path, size_wh)
+    except Exception as exc:
+        log.warn(f"Failed to load reference {cam.image_path}: {exc}")
+        return None
+    mask_a = None
+    if getattr(cam, "mask_path", None):
+        try:
+            mask_a = load_mask01(cam.mask_path, size_wh)
+            img_a = black_out(img_a, mask_a)
+        except Exception as exc:
+            log.warn(f"Failed to load/apply mask for reference {cam.uid}: {exc}")
+            mask_a = None
+    local = nn_table[ref_index][:nns_per_ref]
+    if len(local) == 0:
+        return None
+    nbr_indices, nbr_images, nbr_masks = [], [], []
+    for n in local:
+        n = int(n)
+        if _cancelled(cancel):
+            return None
+        nb = cams[n]
+        if nb.uid == cam.uid:
+            continue
+        try:
+            img_b = load_rgb_u8(nb.image_path, size_wh)
+            mask_b = None
+            if getattr(nb, "mask_path", None):
+                try:
+                    mask_b = load_mask01(nb.mask_path, size_wh)
+                    img_b = black_out(img_b, mask_b)
+                except Exception as exc:
+                    log.warn(f"Failed to load/apply mask for neighbor {nb.uid}: {exc}")
+                    mask_b = None
+            nbr_indices.append(n)
+            nbr_images.append(np.asarray(img_b, dtype=np.uint8))
+            nbr_masks.append(mask_b)
+        except Exception as exc:
+            log.warn(f"Failed to load neighbor {nb.uid}: {exc}")
+    if not nbr_images:
+        return None
+    return _PackedReference(position=position, ref_index=ref_index, ref_uid=int(cam.uid),
+                            image=np.asarray(img_a, dtype=np.uint8), mask_a=mask_a, nbr_indices=nbr_indices,
+                            nbr_images=nbr_images, nbr_masks=nbr_masks)
+
+
+class _OrderedPrefetcher:
+    """Bounded look-ahead over an indexable job list; results come back in submission order, so the
+    order references are consumed in (and therefore the RNG stream and the output order) does not
+    depend on thread timing - unlike upstream's completion-ordered pool
+    (core/threaded_dataloader.py:190-222)."""
+
+    def __init__(self, jobs: Sequence[Callable[[], object]], workers: int, window: int):
+        self._jobs = list(jobs)
+        self._pool = ThreadPoolExecutor(max_workers=max(1, int(workers)), thread_name_prefix="lfd-pack")
+        self._window = max(1, int(window))
+        self._futures: Dict[int, Future] = {}
+        self._next_submit = 0
+        self._next_yield = 0
+        self._closed = False
+
+    def _fill(self) -> None:
+        while self._next_submit < len(self._jobs) and self._next_submit - self._next_yield < self._window:
+            self._futures[self._next_submit] = self._pool.submit(self._jobs[self._next_submit])
+            self._next_submit += 1
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._closed or self._next_yield >= len(self._jobs):
+            raise StopIteration
+        self._fill()
+        fut = self._futures.pop(self._next_yield)
+        self._next_yield += 1
+        res = fut.result()
+        self._fill()
+        return res
+
+    def close(self) -> None:
+        if self._closed:
+            return
+        self._closed = True
+        for f in self._futures.values():
+            f.cancel()
+        self._pool.shutdown(wait=True, cancel_futures=True)
+
+
+def _as_device_maps(results, dev) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    warps, certs = [], []
+    for warp, cert in results:
+        warps.append(torch.as_tensor(warp).detach().to(dev, torch.float32).contiguous())
+        certs.append(torch.as_tensor(cert).detach().to(dev, torch.float32).contiguous())
+    return warps, certs
+
+
+def _reference_rng(seed: int, uid: int) -> np.random.RandomState:
+    return np.random.RandomState((int(seed) * 1000003 + int(uid) * 7919 + 12345) & 0xFFFFFFFF)
+
+
+def _build_preview(packed: _PackedReference, slot: int, cams, matches: np.ndarray, cert_norm: np.ndarray,
+                   pair_index: int, total_pairs: int) -> Optional[MatchPreview]:
+    if matches.size == 0:
+        return None
+    total = int(matches.shape[0])
+    nbr = cams[packed.nbr_indices[slot]]
+    if matches.shape[0] > _PREVIEW_MAX_MATCHES:
+        seed = ((int(packed.ref_uid) & 0xFFFFFFFF) * 73856093) ^ ((int(nbr.uid) & 0xFFFFFFFF) * 19349663)
+        pick = np.random.default_rng(seed & 0xFFFFFFFF).choice(matches.shape[0], size=_PREVIEW_MAX_MATCHES, replace=False)
+        matches, cert_norm = matches[pick], cert_norm[pick]
+    return MatchPreview(ref_id=packed.ref_uid, nbr_id=int(nbr.uid),
+                        ref_label=os.path.basename(cams[packed.ref_index].image_path),
+                        nbr_label=os.path.basename(nbr.image_path), left_image=packed.image,
+                        right_image=packed.nbr_images[slot], matches=matches.astype(np.float32, copy=False),
+                        cert_norm=cert_norm.astype(np.float32, copy=False), match_count=total,
+                        pair_index=int(pair_index), total_pairs=int(total_pairs))
+
+
+class _HotPath:
+    """Per-run GPU state: context, camera table, and the two ways of triangulating a reference."""
+
+    def __init__(self, cams: Sequence[CameraRecord], config: DensePipelineConfig, sample_cap: float, w_match: int,
+                 h_match: int, dev: torch.device, densifier: Optional[hb.HipDensifier]):
+        self.dev = dev
+        self.config = config
+        self.sample_cap = float(sample_cap)
+        self.w_match, self.h_match = int(w_match), int(h_match)
+        self.dens = densifier if densifier is not None else hb.HipDensifier(dev)
+        self._own = densifier is None
+        self.dens.upload_cameras(cams)
+        self.params = hb.make_params(config, sample_cap)
+
+    def close(self) -> None:
+        if self._own:
+            self.dens.close()
+
+    def inputs(self, packed: _PackedReference, warps, certs) -> hb.ReferenceInputs:
+        dev = self.dev
+        use_masks = packed.mask_a is not None or any(m is not None for m in packed.nbr_masks)
+        mask_b = None
+        if use_masks:
+            mask_b = [torch.from_numpy(np.ascontiguousarray(m)).to(dev) if m is not None else None
+                      for m in packed.nbr_masks]
+        return hb.ReferenceInputs(
+            ref_cam=packed.ref_index, nbr_cams=list(packed.nbr_indices), cert=certs, warp=warps,
+            image=torch.from_numpy(np.ascontiguousarray(packed.image)).to(dev),
+            mask_a=torch.from_numpy(np.ascontiguousarray(packed.mask_a)).to(dev) if packed.mask_a is not None else None,
+            mask_b=mask_b)
+
+    def sampled(self, ref: hb.ReferenceInputs, axes, rng) -> Tuple[Optional[hb.TriangulationOutput], Optional[torch.Tensor]]:
+        """aggregate (GPU) -> coverage sampling (host stage, see core/sampling.py) -> indexed kernel (GPU)."""
+        batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes)
+        best, _ = self.dens.aggregate(batch, self.params)
+        sel = select_samples_with_coverage(best[0], self.config.matches_per_ref, cap=self.sample_cap, border=2,
+                                           tiles=24, no_filter=self.config.no_filter, rng=rng)
+        if sel.size == 0:
+            return None, best[0]
+        sel_t = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int64)).to(self.dev)
+        out = self.dens.triangulate_indexed(batch, self.params, sel_t, [0, int(sel.size)])
+        return (out if out.count else None), best[0]
+
+    def dense(self, refs: List[hb.ReferenceInputs], axes) -> hb.TriangulationOutput:
+        batch = hb.PreparedBatch(refs, self.w_match, self.h_match, axes=axes)
+        return self.dens.triangulate_dense(batch, self.params)
+
+    def debug_matches(self, ref: hb.ReferenceInputs, out_cell: torch.Tensor, out_slot: torch.Tensor, axes,
+                      best_cert: Optional[torch.Tensor]):
+        """Per neighbour slot: clipped [xA,yA,xB,yB] in match pixels + certainty/cap of the survivors
+        (upstream core/pipeline.py:761-769), gathered on the GPU from the maps the kernel consumed."""
+        res = {}
+        H, W = ref.cert[0].shape
+        wm1, hm1 = float(self.w_match - 1), float(self.h_match - 1)
+        cells = out_cell.long()
+        for j in range(len(ref.cert)):
+            sel = cells[out_slot == j]
+            if sel.numel() == 0:
+                continue
+            wp = ref.warp[j].reshape(H * W, -1)[sel]
+            if wp.shape[1] == 4:
+                xan, yan, xbn, ybn = wp[:, 0], wp[:, 1], wp[:, 2], wp[:, 3]
+            else:
+                ax, ay = axes if axes is not None else (torch.from_numpy(hb.identity_axis(W)).to(self.dev),
+                                                        torch.from_numpy(hb.identity_axis(H)).to(self.dev))
+                xan, yan, xbn, ybn = ax[sel % W], ay[sel // W], wp[:, 0], wp[:, 1]
+            m = torch.stack([((xan + 1.0) * 0.5 * wm1).clamp(0.0, wm1), ((yan + 1.0) * 0.5 * hm1).clamp(0.0, hm1),
+                             ((xbn + 1.0) * 0.5 * wm1).clamp(0.0, wm1), ((ybn + 1.0) * 0.5 * hm1).clamp(0.0, hm1)], dim=1)
+            denom = self.sample_cap if self.sample_cap > 1e-6 else 1.0
+            if best_cert is not None:
+                cn = (best_cert.reshape(-1)[sel] / denom).clamp(0.0, 1.0)
+            else:
+                cn = torch.ones(sel.numel(), device=self.dev)
+            res[j] = (m.cpu().numpy().astype(np.float32), cn.cpu().numpy().astype(np.float32))
+        return res
+
+
+def run_dense_pipeline(
+    camera_records: List[CameraRecord],
+    refs_local: List[int],
+    nn_table: np.ndarray,
+    config: DensePipelineConfig,
+    progress_callback: Optional[Callable[[float, str], None]] = None,
+    on_sequential_viz: Optional[Callable[[str], None]] = None,
+    debug_state: Optional[MatchDebugState] = None,
+    cancel_requested: Optional[Callable[[], bool]] = None,
+    *,
+    matcher=None,
+    densifier: Optional[hb.HipDensifier] = None,
+    device: Optional[torch.device] = None,
+) -> PipelineResult:
+    """See module docstring.  ``matcher`` / ``densifier`` / ``device`` are injection points for
+    tests and for callers that keep a warm model; by default a RomaMatcher is created (and released)
+    per run exactly like upstream."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+
+    uids = [c.uid for c in camera_records]
+    total_pairs_est = _estimate_total_pairs(refs_local, nn_table, uids, config.nns_per_ref)
+    if debug_state:
+        debug_state.set_total_pairs(total_pairs_est)
+    viz_interval = config.viz_interval
+    intermediate_base = None
+    if on_sequential_viz and viz_interval > 0:
+        ensure_dir(config.output_path)
+        intermediate_base = os.path.splitext(config.output_path)[0] + "_intermediate"
+
+    if not torch.cuda.is_available():
+        raise hb.HipBackendError("no GPU visible: the dense-initialisation hot path has no CPU fallback")
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    per_ref_rng = bool(config.per_reference_rng) or world > 1
+    stream_rng = np.random.RandomState(int(config.seed))     # upstream: np.random.seed(config.seed), global stream
+    my_positions = lfd_dist.shard_references(len(refs_local), rank, world)
+
+    xyz_parts: List[np.ndarray] = []
+    rgb_parts: List[np.ndarray] = []
+    err_parts: List[np.ndarray] = []
+    counts_local = [0] * len(my_positions)
+    refs_with_points = 0
+    pair_counter = 0
+    t0 = time.time()
+    own_matcher = matcher is None
+    prefetch: Optional[_OrderedPrefetcher] = None
+    hot: Optional[_HotPath] = None
+
+    try:
+        cached = has_cached_romav2_weights() if own_matcher else True
+        msg = "Initializing RoMa v2 model..." if cached else "Installing model weights..."
+        if progress_callback is not None:
+            progress_callback(10.0, msg)
+        log.info(msg)
+        if not cached:
+            log.info("RoMaV2 weights not found in cache; expected cache paths: " + ", ".join(romav2_cached_weights_paths()))
+        if own_matcher:
+            matcher = RomaMatcher(device=str(dev), mode="outdoor", setting=config.roma_setting)
+            if not cached and progress_callback is not None:
+                progress_callback(10.0, "RoMa v2 model installation complete. Starting matching...")
+        _raise_if_cancelled(cancel_requested)
+
+        w_match, h_match = int(matcher.w_resized), int(matcher.h_resized)
+        hot = _HotPath(camera_records, config, float(matcher.sample_thresh), w_match, h_match, dev, densifier)
+        jobs = [(lambda p=p: _pack_reference(p, refs_local[p], camera_records, nn_table, config.nns_per_ref,
+                                             (w_match, h_match), cancel_requested)) for p in my_positions]
+        prefetch = _OrderedPrefetcher(jobs, workers=int(getattr(config, "pack_workers", 4)),
+                                      window=int(getattr(config, "prefetch_packages", 8)))
+        total_refs = len(my_positions)
+        pending: List[Tuple[int, _PackedReference, hb.ReferenceInputs, object]] = []   # dense mode batching
+
+        def emit(local_i: int, packed: _PackedReference, xyz, rgb, err, dbg) -> None:
+            nonlocal refs_with_points
+            xyz_parts.append(xyz)
+            rgb_parts.append(rgb)
+            err_parts.append(err)
+            counts_local[local_i] = int(xyz.shape[0])
+            refs_with_points += 1
+            if dbg is not None and debug_state is not None:
+                total_val = total_pairs_est if total_pairs_est > 0 else max(pair_counter, 1)
+                for slot, (m, cn) in dbg["matches"].items():
+                    _raise_if_cancelled(cancel_requested)
+                    pair_idx = dbg["pair_index"][slot]
+                    show = (not debug_state.is_auto_step()) or _DEBUG_PREVIEW_INTERVAL <= 0 or pair_idx % _DEBUG_PREVIEW_INTERVAL == 1
+                    if not show:
+                        continue
+                    try:
+                        pv = _build_preview(packed, slot, camera_records, m, cn, pair_idx, total_val)
+                        if pv:
+                            debug_state.submit_preview(pv)
+                    except Exception as exc:
+                        log.warn(f"Debug preview failed: {exc}")
+            if on_sequential_viz and viz_interval > 0 and intermediate_base and refs_with_points % viz_interval == 0:
+                _raise_if_cancelled(cancel_requested)
+                try:
+                    path = f"{intermediate_base}_{refs_with_points}.ply"
+                    write_ply(path, np.concatenate(xyz_parts, 0), to_uint8_rgb(np.concatenate(rgb_parts, 0)))
+                    log.debug(f"Live update: {sum(p.shape[0] for p in xyz_parts):,} points after {refs_with_points} refs")
+                    on_sequential_viz(path)
+                except Exception as exc:
+                    log.warn(f"Failed to emit intermediate PLY: {exc}")
+
+        def flush_dense() -> None:
+            if not pending:
+                return
+            axes = pending[0][3]
+            try:
+                out = hot.dense([p[2] for p in pending], axes)
+            except Exception as ex:
+                log.error(f"Triangulation error for refs {[p[1].ref_uid for p in pending]}: {ex}")
+                pending.clear()
+                return
+            offs = out.ref_offsets
+            xyz, rgb, err = out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy()
+            for bi, (local_i, packed, ref, _axes) in enumerate(pending):
+                lo, hi = int(offs[bi]), int(offs[bi + 1])
+                if hi > lo:
+                    emit(local_i, packed, xyz[lo:hi], rgb[lo:hi], err[lo:hi], None)
+            pending.clear()
+
+        for local_i, packed in enumerate(prefetch):
+            _raise_if_cancelled(cancel_requested)
+            if progress_callback is not None:
+                done = local_i + 1
+                progress_callback(10.0 + (float(done - 1) / max(1, total_refs)) * 80.0,
+                                  f"Matching {done}/{total_refs} | {done / max(0.001, time.time() - t0):.1f} it/s")
+            if packed is None:
+                continue
+            _raise_if_cancelled(cancel_requested)
+            from PIL import Image
+            results = matcher.match_grids_batch(Image.fromarray(np.ascontiguousarray(packed.image)),
+                                                [Image.fromarray(np.ascontiguousarray(a)) for a in packed.nbr_images])
+            _raise_if_cancelled(cancel_requested)
+            if not results:
+                continue
+            first_pair = pair_counter + 1
+            pair_counter += len(results)
+            warps, certs = _as_device_maps(results, dev)
+            H, W = certs[0].shape
+            axes = None
+            if warps[0].shape[-1] == 2:
+                ax = getattr(matcher, "reference_axes", None)
+                if callable(ax):
+                    a0, a1 = ax(H, W)
+                    axes = (torch.as_tensor(a0).to(dev, torch.float32).contiguous(), torch.as_tensor(a1).to(dev, torch.float32).contiguous())
+            ref = hot.inputs(packed, warps, certs)
+            want_debug = debug_state is not None and debug_state.is_enabled()
+
+            if config.triangulation_mode == "dense":
+                pending.append((local_i, packed, ref, axes))
+                if len(pending) >= int(config.refs_per_launch):
+                    flush_dense()
+                continue
+
+            try:
+                rng = _reference_rng(config.seed, packed.ref_uid) if per_ref_rng else stream_rng
+                out, best = hot.sampled(ref, axes, rng)
+            except Exception as ex:
+                log.error(f"Triangulation error for ref {packed.ref_uid}: {ex}")
+                out = None
+            if out is None:
+                continue
+            dbg = None
+            if want_debug:
+                dbg = {"matches": hot.debug_matches(ref, out.cell, out.slot, axes, best),
+                       "pair_index": {j: first_pair + j for j in range(len(certs))}}
+            emit(local_i, packed, out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy(), dbg)
+        flush_dense()
+    finally:
+        if prefetch is not None:
+            prefetch.close()
+        if own_matcher and matcher is not None:
+            try:
+                matcher.close()
+            except Exception as exc:
+                log.warn(f"Matcher cleanup failed: {exc}")
+        if hot is not None:
+            hot.close()
+        if debug_state:
+            debug_state.release_waiters()
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+
+    _raise_if_cancelled(cancel_requested)
+    if progress_callback:
+        progress_callback(90.0, "Finalizing triangulation...")
+
+    if xyz_parts:
+        xyz, rgb, err = np.concatenate(xyz_parts, 0), np.concatenate(rgb_parts, 0), np.concatenate(err_parts, 0)
+    else:
+        xyz, rgb, err = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0,), np.float32)
+    counts = np.asarray(counts_local, np.int64)
+    if world > 1:       # the one exchange step: ordered all-gather of the survivors over RCCL
+        gx, gc_, ge, counts = lfd_dist.all_gather_by_reference(
+            torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev), torch.from_numpy(err).to(dev),
+            counts_local, len(refs_local), dist)
+        xyz, rgb, err = gx.cpu().numpy(), gc_.cpu().numpy(), ge.cpu().numpy()
+        t = torch.tensor([refs_with_points, pair_counter], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        refs_with_points, pair_counter = int(t[0].item()), int(t[1].item())
+
+    if xyz.shape[0] == 0:
+        raise RuntimeError("No points triangulated. Try adjusting parameters.")
+    return PipelineResult(xyz=xyz, rgb=rgb, err=err, elapsed_seconds=time.time() - t0,
+                          pairs_processed=refs_with_points, pairs_matched=pair_counter, points_per_reference=counts)

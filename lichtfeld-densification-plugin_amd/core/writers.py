@@ -1,0 +1,101 @@
+"""Point-cloud writers (upstream core/writers.py:15-46), byte-identical output, vectorised.
+
+Upstream packs every point with ``struct.pack`` in a Python loop (0.25-0.38 M points/s); here a
+structured NumPy array with the same field layout is written in one call."""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+
+_PLY_REC = np.dtype([("xyz", "<f4", 3), ("rgb", "u1", 3)])                       # 15 bytes
+_BIN_REC = np.dtype([("id", "<u8"), ("xyz", "<f8", 3), ("rgb", "u1", 3), ("err", "<f8")])   # 43 bytes
+
+
+def ensure_dir(path: str) -> None:
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+
+
+def ply_header(n: int) -> bytes:
+    return ("ply\nformat binary_little_endian 1.0\n"
+            f"element vertex {int(n)}\n"
+            "property float x\nproperty float y\nproperty float z\n"
+            "property uchar red\nproperty uchar green\nproperty uchar blue\n"
+            "end_header\n").encode("ascii")
+
+
+def ply_records(xyz: np.ndarray, rgb_uint8: np.ndarray) -> np.ndarray:
+    n = int(xyz.shape[0])
+    rec = np.empty(n, dtype=_PLY_REC)
+    rec["xyz"] = np.asarray(xyz, dtype=np.float32).reshape(n, 3)
+    rec["rgb"] = np.asarray(rgb_uint8, dtype=np.uint8).reshape(n, 3)
+    return rec
+
+
+def write_ply(path_out: str, xyz: np.ndarray, rgb_uint8: np.ndarray) -> None:
+    """Binary little-endian PLY: x y z (f32) + red green blue (u8)."""
+    with open(path_out, "wb") as f:
+        f.write(ply_header(xyz.shape[0]))
+        ply_records(xyz, rgb_uint8).tofile(f)
+
+
+def write_points3D_bin(path_out: str, xyz: np.ndarray, rgb_uint8: np.ndarray,
+                       errors: Optional[np.ndarray] = None) -> None:
+    """Upstream's COLMAP-like ``points3D.bin``: u64 count, then per point u64 id (1-based), xyz f64,
+    rgb u8, error f64 - and no track-length field, exactly as upstream writes it."""
+    n = int(xyz.shape[0])
+    rec = np.empty(n, dtype=_BIN_REC)
+    rec["id"] = np.arange(1, n + 1, dtype=np.uint64)
+    rec["xyz"] = np.asarray(xyz).reshape(n, 3).astype(np.float64)
+    rec["rgb"] = np.asarray(rgb_uint8, dtype=np.uint8).reshape(n, 3)
+    rec["err"] = 0.0 if errors is None else np.asarray(errors).reshape(n).astype(np.float64)
+    with open(path_out, "wb") as f:
+        f.write(np.uint64(n).tobytes())
+        rec.tofile(f)
+
+
+class StreamedPlyWriter:
+    """Append survivor segments as they complete; the vertex count in the header is patched on close
+    (the header is padded so its length does not depend on the count)."""
+
+    _COUNT_WIDTH = 12
+
+    def __init__(self, path_out: str):
+        ensure_dir(path_out)
+        self._f = open(path_out, "wb")
+        self._n = 0
+        head = ply_header(0).decode("ascii")
+        self._prefix = "ply\nformat binary_little_endian 1.0\n"
+        self._rest = head.split("element vertex 0\n", 1)[1]
+        self._f.write(self._header_bytes(0))
+
+    def _header_bytes(self, n: int) -> bytes:
+        # PLY allows comment lines: pad with one so the data offset is fixed
+        count = str(int(n))
+        pad = "x" * (self._COUNT_WIDTH - len(count))
+        return (self._prefix + f"comment {pad}\n" + f"element vertex {count}\n" + self._rest).encode("ascii")
+
+    def append(self, xyz: np.ndarray, rgb_uint8: np.ndarray) -> None:
+        ply_records(xyz, rgb_uint8).tofile(self._f)
+        self._n += int(xyz.shape[0])
+
+    @property
+    def count(self) -> int:
+        return self._n
+
+    def close(self) -> None:
+        if self._f is None:
+            return
+        self._f.seek(0)
+        self._f.write(self._header_bytes(self._n))
+        self._f.close()
+        self._f = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Entry points of the dense-initialisation pass (upstream densify.py:148-420).
+
+``dense_init`` (COLMAP scene on disk / CLI), ``dense_init_from_lfs`` (camera nodes handed over by
+LichtFeld Studio's GUI job) and ``build_argparser`` keep upstream's signatures, flags, return codes
+and progress milestones; the body is host glue around ``core.pipeline.run_dense_pipeline`` whose
+per-reference hot path runs on the GPU.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .core.hostlog import log
+from .core.image_io import find_image, image_dir, to_uint8_rgb
+from .core.pipeline import PipelineCancelled, run_dense_pipeline
+from .core.selection import nearest_neighbors, select_cameras_by_visibility, select_cameras_kcenters
+from .core.types import CameraRecord, DensePipelineConfig, TRIANGULATION_MODES
+from .core.writers import write_ply, write_points3D_bin
+
+
+# ---- COLMAP -> CameraRecord (upstream core/geometry.py:10-50, densify.py:53-88) ----------------------
+def K_from_camera(cam) -> np.ndarray:
+    """3x3 f32 intrinsics from a pycolmap camera: (fx, fy, cx, cy) by model family; distortion
+    parameters are ignored exactly as upstream ignores them."""
+    model = str(cam.model.name).upper()
+    p = np.asarray(cam.params, dtype=np.float32)
+    if ("PINHOLE" in model and "SIMPLE" not in model) or "OPENCV" in model or "FISHEYE" in model:
+        fx, fy, cx, cy = p[0], p[1], p[2], p[3]
+    elif "SIMPLE_PINHOLE" in model or "SIMPLE_RADIAL" in model or model == "RADIAL":
+        fx = fy = p[0]
+        cx, cy = p[1], p[2]
+    else:
+        fx = fy = p[0]
+        cx = p[1] if len(p) > 1 else cam.width / 2
+        cy = p[2] if len(p) > 2 else cam.height / 2
+    K = np.eye(3, dtype=np.float32)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = fx, fy, cx, cy
+    return K
+
+
+def pose_world2cam(im) -> Tuple[np.ndarray, np.ndarray]:
+    if hasattr(im, "cam_from_world"):
+        cfw = im.cam_from_world
+        cfw = cfw() if callable(cfw) else cfw
+        R = np.asarray(cfw.rotation.matrix(), dtype=np.float32)
+        t = np.asarray(cfw.translation, dtype=np.float32).reshape(3, 1)
+    else:
+        R = im.qvec.to_rotation_matrix()
+        t = np.asarray(im.tvec, dtype=np.float32).reshape(3, 1)
+    return R, t
+
+
+def load_reconstruction(sparse_dir: str):
+    import pycolmap
+    rec = pycolmap.Reconstruction(sparse_dir)
+    return rec, rec.cameras, rec.images
+
+
+def camera_records_from_colmap(cams: Dict, imgs: Dict, images_dir: str) -> Tuple[List[CameraRecord], List[int]]:
+    records: List[CameraRecord] = []
+    img_ids = sorted(imgs.keys())
+    for iid in img_ids:
+        im = imgs[iid]
+        cam = cams[im.camera_id]
+        R, t = pose_world2cam(im)
+        rec = CameraRecord.from_krt(iid, K_from_camera(cam), R, t, cam.width, cam.height,
+                                    image_path=find_image(images_dir, im.name))
+        records.append(rec)
+    return records, img_ids
+
+
+def extract_cameras_from_lfs(camera_nodes) -> List[CameraRecord]:
+    """Scene camera nodes -> records; the principal point is assumed at the image centre
+    (upstream densify.py:215-245)."""
+    records: List[CameraRecord] = []
+    for node in camera_nodes:
+        if not getattr(node, "has_camera", False):
+            continue
+        w, h = node.camera_width, node.camera_height
+        K = np.array([[node.camera_focal_x, 0.0, w / 2.0], [0.0, node.camera_focal_y, h / 2.0], [0.0, 0.0, 1.0]],
+                     dtype=np.float32)
+        rec = CameraRecord.from_krt(node.camera_uid, K, node.camera_R, node.camera_T, w, h, image_path=node.image_path,
+                                    mask_path=(node.mask_path if getattr(node, "has_mask", False) else None))
+        records.append(rec)
+    return records
+
+
+# ---- post-processing ------------------------------------------------------------------------------
+def _flat_pose_stack(records: List[CameraRecord]) -> np.ndarray:
+    return np.stack([c.flat_pose() for c in records], axis=0)
+
+
+def _num_refs(fraction_or_count: float, n: int) -> int:
+    return int(round(fraction_or_count * n)) if fraction_or_count <= 1.0 else int(fraction_or_count)
+
+
+def _effective_neighbor_count(requested: int, camera_count: int) -> int:
+    if camera_count <= 1:
+        return 0
+    return max(1, min(int(requested), camera_count - 1))
+
+
+def _apply_point_cap(xyz, rgb, err, max_points: int, seed: int):
+    if max_points > 0 and xyz.shape[0] > max_points:
+        keep = np.random.default_rng(seed).choice(xyz.shape[0], size=max_points, replace=False)
+        return xyz[keep], rgb[keep], err[keep]
+    return xyz, rgb, err
+
+
+def _voxel_downsample(xyz: np.ndarray, rgb: np.ndarray, voxel_size: float) -> Tuple[np.ndarray, np.ndarray]:
+    """One averaged point (and colour) per occupied voxel.  Uses Open3D when installed (upstream
+    densify.py:29-50); otherwise an equivalent NumPy voxel-grid average (voxel order then follows the
+    sorted voxel index instead of Open3D's hash order)."""
+    col = rgb[:, :3].astype(np.float64) / (255.0 if rgb.size and rgb.max() > 1.0 else 1.0)
+    try:
+        import open3d as o3d
+        pcd = o3d.geometry.PointCloud()
+        pcd.points = o3d.utility.Vector3dVector(xyz.astype(np.float64))
+        pcd.colors = o3d.utility.Vector3dVector(col)
+        down = pcd.voxel_down_sample(voxel_size=float(voxel_size))
+        return np.asarray(down.points, dtype=np.float32), np.asarray(down.colors, dtype=np.float32)
+    except ImportError:
+        pts = xyz.astype(np.float64)
+        origin = pts.min(axis=0) - 0.5 * voxel_size
+        key = np.floor((pts - origin) / float(voxel_size)).astype(np.int64)
+        _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+        inv = inv.reshape(-1)
+        p = np.zeros((cnt.size, 3))
+        c = np.zeros((cnt.size, 3))
+        np.add.at(p, inv, pts)
+        np.add.at(c, inv, col)
+        return (p / cnt[:, None]).astype(np.float32), (c / cnt[:, None]).astype(np.float32)
+
+
+def _write_output(path: str, xyz, rgb, err) -> None:
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    rgb8 = to_uint8_rgb(rgb)
+    if path.lower().endswith(".ply"):
+        write_ply(path, xyz, rgb8)
+    else:
+        write_points3D_bin(path, xyz, rgb8, err)
+
+
+def _was_cancelled(cb) -> bool:
+    if cb is None:
+        return False
+    try:
+        return bool(cb())
+    except Exception as exc:
+        log.warn(f"Cancellation callback failed: {exc}")
+        return False
+
+
+# ---- entry points ------------------------------------------------------------------------------------
+def dense_init(args, progress_callback: Optional[Callable[[float, str], None]] = None, debug_state=None,
+               cancel_requested: Optional[Callable[[], bool]] = None) -> int:
+    """CLI / COLMAP entry point.  Returns 0 on success, 2 when cancelled; raises on error."""
+    scene_root = os.path.abspath(args.scene_root)
+    sparse_dir = os.path.join(scene_root, "sparse", "0")
+    images_dir = image_dir(scene_root, args.images_subdir)
+    rec, cams, imgs = load_reconstruction(sparse_dir)
+    records, img_ids = camera_records_from_colmap(cams, imgs, images_dir)
+    flat = _flat_pose_stack(records)
+    want = max(1, _num_refs(args.num_refs, len(img_ids)))
+    try:
+        by_id = {iid: i for i, iid in enumerate(img_ids)}
+        refs_local = [by_id[r] for r in select_cameras_by_visibility(rec, want) if r in by_id]
+    except Exception as exc:
+        log.warn(f"Visibility-based selection failed: {exc}")
+        refs_local = select_cameras_kcenters(flat, want)
+    nn_table = nearest_neighbors(flat, max(1, args.nns_per_ref))
+
+    config = DensePipelineConfig(
+        output_path=os.path.join(sparse_dir, args.out_name), roma_setting=args.roma_setting, num_refs=args.num_refs,
+        nns_per_ref=args.nns_per_ref, matches_per_ref=args.matches_per_ref, certainty_thresh=args.certainty_thresh,
+        reproj_thresh=args.reproj_thresh, sampson_thresh=args.sampson_thresh, min_parallax_deg=args.min_parallax_deg,
+        max_points=args.max_points, no_filter=args.no_filter, seed=args.seed, viz_interval=0,
+        prefetch_packages=args.prefetch_packages, pack_workers=args.pack_workers,
+        triangulation_mode=getattr(args, "triangulation_mode", "sampled"),
+        refs_per_launch=getattr(args, "refs_per_launch", 1))
+    try:
+        result = run_dense_pipeline(records, refs_local, nn_table, config, progress_callback=progress_callback,
+                                    on_sequential_viz=None, debug_state=debug_state, cancel_requested=cancel_requested)
+    except PipelineCancelled:
+        if progress_callback:
+            progress_callback(0.0, "Cancelled")
+        return 2
+    if _was_cancelled(cancel_requested):
+        if progress_callback:
+            progress_callback(0.0, "Cancelled")
+        return 2
+    xyz, rgb, err = _apply_point_cap(result.xyz, result.rgb, result.err, args.max_points, args.seed)
+    if progress_callback:
+        progress_callback(95.0, "Writing output...")
+    _write_output(config.output_path, xyz, rgb, err)
+    log.info(f"Dense reconstruction finished: {xyz.shape[0]:,} points -> {config.output_path}")
+    if progress_callback:
+        progress_callback(100.0, f"Done! {xyz.shape[0]:,} points")
+    return 0
+
+
+def dense_init_from_lfs(camera_nodes, config: DensePipelineConfig,
+                        progress_callback: Optional[Callable[[float, str], None]] = None,
+                        on_sequential_viz: Optional[Callable[[str], None]] = None, debug_state=None,
+                        cancel_requested: Optional[Callable[[], bool]] = None, **pipeline_kwargs
+                        ) -> Tuple[int, Optional[str]]:
+    """GUI entry point.  Returns ``(0, output_path)``, ``(1, message)`` or ``(2, "Cancelled")``."""
+    if progress_callback:
+        progress_callback(2.0, "Extracting camera data from scene...")
+    records = extract_cameras_from_lfs(camera_nodes)
+    if not config.use_masks:
+        for r in records:
+            r.mask_path = None
+    if len(records) < 2:
+        return 1, "Need at least 2 cameras for dense initialization"
+    flat = _flat_pose_stack(records)
+    refs_local = select_cameras_kcenters(flat, max(1, _num_refs(config.num_refs, len(records))))
+    nns = _effective_neighbor_count(config.nns_per_ref, len(records))
+    if nns < 1:
+        return 1, "Need at least 2 cameras for dense initialization"
+    if nns != int(config.nns_per_ref):
+        log.info(f"Clamping neighbors per reference from {config.nns_per_ref} to {nns} for {len(records)} ROI cameras")
+    nn_table = nearest_neighbors(flat, nns)
+    log.info(f"Prepared {len(records)} cameras (refs={len(refs_local)})")
+    try:
+        result = run_dense_pipeline(records, refs_local, nn_table, config, progress_callback=progress_callback,
+                                    on_sequential_viz=on_sequential_viz, debug_state=debug_state,
+                                    cancel_requested=cancel_requested, **pipeline_kwargs)
+    except PipelineCancelled:
+        return 2, "Cancelled"
+    except RuntimeError as exc:
+        return 1, str(exc)
+    if _was_cancelled(cancel_requested):
+        return 2, "Cancelled"
+    xyz, rgb, err = _apply_point_cap(result.xyz, result.rgb, result.err, config.max_points, config.seed)
+    if config.voxel_size > 0.0:
+        if progress_callback:
+            progress_callback(93.0, "Applying distance filter...")
+        xyz, rgb = _voxel_downsample(xyz, rgb, config.voxel_size)
+        log.info(f"Distance filter ({config.voxel_size:.4f}): {xyz.shape[0]:,} points remaining")
+    if progress_callback:
+        progress_callback(95.0, "Writing output PLY...")
+    d = os.path.dirname(config.output_path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    write_ply(config.output_path, xyz, to_uint8_rgb(rgb))
+    log.info(f"Dense point cloud saved to {config.output_path} ({xyz.shape[0]:,} points)")
+    if progress_callback:
+        progress_callback(100.0, f"Done! {xyz.shape[0]:,} points")
+    return 0, config.output_path
+
+
+def build_argparser() -> argparse.ArgumentParser:
+    """Upstream's CLI flags and defaults (densify.py:318-415) plus the two launch-shape extensions."""
+    ap = argparse.ArgumentParser("Dense COLMAP initializer (RoMa v2 matching + fused HIP filter/triangulate on MI355X)")
+    ap.add_argument("--scene_root", type=str, required=True, help="Path containing images*/ and sparse/0/")
+    ap.add_argument("--images_subdir", type=str, default="images_2", help="Which images dir to read under scene_root")
+    ap.add_argument("--out_name", type=str, default="points3D_dense.ply", help="Output filename under sparse/0/")
+    ap.add_argument("--roma_setting", type=str, default="fast", choices=["precise", "high", "base", "fast", "turbo"],
+                    help="RoMaV2 quality/speed setting")
+    ap.add_argument("--roma_model", type=str, default="outdoor", choices=["outdoor", "indoor"],
+                    help="Legacy flag for compatibility (RoMaV2 is unified)")
+    ap.add_argument("--num_refs", type=float, default=0.75, help="Fraction (<=1) or count (>1) of frames to use as references")
+    ap.add_argument("--nns_per_ref", type=int, default=4, help="Nearest neighbors per reference (3-5 is robust)")
+    ap.add_argument("--matches_per_ref", type=int, default=12000, help="Samples per ref after aggregation")
+    ap.add_argument("--certainty_thresh", type=float, default=0.20, help="Min certainty floor before selection")
+    ap.add_argument("--reproj_thresh", type=float, default=1.5, help="Max reprojection error (px)")
+    ap.add_argument("--sampson_thresh", type=float, default=5.0, help="Max Sampson error (px^2) pre-triangulation (<=0 disables)")
+    ap.add_argument("--min_parallax_deg", type=float, default=0.5, help="Min parallax angle in degrees")
+    ap.add_argument("--no_filter", action="store_true", help="Disable geometric filtering (debug only)")
+    ap.add_argument("--max_points", type=int, default=0, help="Optional cap on total points (0 = unlimited)")
+    ap.add_argument("--prefetch_packages", type=int, default=8, help="Reference packages prefetched ahead of the GPU")
+    ap.add_argument("--pack_workers", type=int, default=4, help="Threads used to load/resize images")
+    ap.add_argument("--seed", type=int, default=0, help="Random seed")
+    ap.add_argument("--triangulation_mode", type=str, default="sampled", choices=list(TRIANGULATION_MODES),
+                    help="sampled = upstream behaviour; dense = every grid cell through the fused kernel")
+    ap.add_argument("--refs_per_launch", type=int, default=1, help="dense mode: references triangulated per kernel launch")
+    return ap
+
+
+if __name__ == "__main__":
+    raise SystemExit(dense_init(build_argparser().parse_args()))

@@ -37,3 +37,13 @@ def g3():
 @pytest.fixture(scope="session")
 def g5():
     return load_golden("g5_writers.npz")
+
+
+@pytest.fixture(scope="session")
+def g4():
+    return load_golden("g4_pipeline.npz")
+
+
+@pytest.fixture(scope="session")
+def g6():
+    return load_golden("g6_selection_tables.npz")

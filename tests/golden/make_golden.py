@@ -287,7 +287,75 @@ def g5_writers():
     save("g5_writers.npz", xyz=xyz, rgb=rgb, err=err, rgb_u8=u8, ply=ply, points3d_bin=pbin)
 
 
+# ---------------------------------------------------------------------------------------------
+# G4: run_dense_pipeline end to end with a fake matcher (3 references, pack_workers=1)
+# ---------------------------------------------------------------------------------------------
+def g4_pipeline():
+    from PIL import Image
+    P = ns.pipeline
+    n_cams, wm, hm, H, W = 6, 64, 64, 64, 64
+    cams = synthetic.ring_cameras(n_cams, seed=4, arc=0.9)          # partial arc: every pair overlaps
+    refs_local = [0, 2, 5]
+    nn_table = ns.selection.nearest_neighbors(np.stack([c.flat_pose() for c in cams]), 2)
+    out = cam_arrays(cams)
+    with tempfile.TemporaryDirectory() as d:
+        images = []
+        for i, c in enumerate(cams):
+            img = synthetic.synth_image(hm, wm, 300 + i).numpy()
+            c.image_path = os.path.join(d, f"im{i:02d}.png")
+            Image.fromarray(img).save(c.image_path)
+            images.append(img)
+        table, sref_store = [], {}
+        for r in refs_local:
+            nbrs = [int(n) for n in nn_table[r][:2]]
+            s = synthetic.synth_reference(cams, r, nbrs, H, W, wm, hm, noise_px=0.4, outlier_frac=0.05, channels=4,
+                                          seed=31, cert_mode="tiefree")
+            table.append([(s.warp[j], s.cert[j]) for j in range(len(nbrs))])
+            sref_store[r] = s
+        for mode_name, cfg_kw in (("filter", dict(matches_per_ref=1200)), ("nofilter", dict(matches_per_ref=500, no_filter=True))):
+            fm = FakeMatcher(wm, hm, table)
+            P.RomaMatcher = lambda device="cpu", mode="outdoor", setting="fast", _fm=fm: _fm
+            P.has_cached_romav2_weights = lambda: True
+            cfg = ns.config.DensePipelineConfig(output_path=os.path.join(d, "out", "dense.ply"), roma_setting="fast",
+                                                nns_per_ref=2, seed=5, viz_interval=2, pack_workers=1, **cfg_kw)
+            progress, viz = [], []
+            with np.errstate(all="ignore"):
+                res = P.run_dense_pipeline(cams, refs_local, nn_table, cfg, progress_callback=lambda p, m: progress.append((p, m)),
+                                           on_sequential_viz=lambda path: viz.append(os.path.basename(path)))
+            pre = mode_name + "_"
+            out[pre + "xyz"], out[pre + "rgb"], out[pre + "err"] = res.xyz, res.rgb, res.err
+            out[pre + "pairs_processed"] = np.int64(res.pairs_processed)
+            out[pre + "progress_pct"] = np.array([p for p, _ in progress], np.float64)
+            out[pre + "progress_msg"] = np.array([m.split(" | ")[0] for _, m in progress])
+            out[pre + "viz_files"] = np.array(viz)
+            out[pre + "cfg"] = np.array(json.dumps(cfg_kw))
+            print(f"  g4 {mode_name}: {res.xyz.shape[0]} points, refs={res.pairs_processed}, viz={viz}")
+        out["images"] = np.stack(images)
+        out["refs_local"] = np.array(refs_local, np.int64)
+        out["nn_table"] = np.asarray(nn_table, np.int64)
+        for r in refs_local:
+            out[f"ref{r}_warp"] = sref_store[r].warp.numpy()
+            out[f"ref{r}_cert"] = sref_store[r].cert.numpy()
+    save("g4_pipeline.npz", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+# G6: camera selection / neighbour table
+# ---------------------------------------------------------------------------------------------
+def g6_selection_tables():
+    cams = synthetic.ring_cameras(185, seed=0)
+    flat = np.stack([c.flat_pose() for c in cams])
+    out = {"flat_poses": flat}
+    for k in (3, 4, 8):
+        out[f"nn_k{k}"] = np.asarray(ns.selection.nearest_neighbors(flat, k), np.int64)
+    for k in (1, 56, 148):
+        out[f"kcenters_{k}"] = np.asarray(ns.selection.select_cameras_kcenters(flat, k), np.int64)
+    out["nn_two"] = np.asarray(ns.selection.nearest_neighbors(flat[:2], 5), np.int64)
+    save("g6_selection_tables.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     for w in which:
-        {"g1": g1_geometry, "g2": g2_selection, "g3": g3_triangulate, "g5": g5_writers}[w]()
+        {"g1": g1_geometry, "g2": g2_selection, "g3": g3_triangulate, "g4": g4_pipeline, "g5": g5_writers,
+         "g6": g6_selection_tables}[w]()

@@ -1,0 +1,105 @@
+"""End-to-end: this package's run_dense_pipeline (HIP hot path) against the result upstream's
+run_dense_pipeline produced on the same cameras / images / matcher outputs (tests/golden/g4)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lichtfeld_densification_plugin_amd as lfd
+from lichtfeld_densification_plugin_amd.core import pipeline as pl
+from lichtfeld_densification_plugin_amd.core.debug_viz import MatchDebugState
+from helpers import oracle_cams
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeMatcher:
+    sample_thresh = 0.9
+
+    def __init__(self, w, h, table, two_channel=False):
+        self.w_resized, self.h_resized, self.table, self.calls, self.two = w, h, table, 0, two_channel
+        self.closed = False
+
+    def match_grids_batch(self, imA, imB_list):
+        res = self.table[self.calls]
+        self.calls += 1
+        assert len(res) == len(imB_list)
+        return [((w[..., 2:4].contiguous() if self.two else w), c) for w, c in res]
+
+    def reference_axes(self, H, W):
+        w0 = self.table[0][0][0]
+        return w0[0, :, 0].contiguous(), w0[:, 0, 1].contiguous()
+
+    def close(self):
+        self.closed = True
+
+
+def _scene(g4, tmp_path):
+    from PIL import Image
+    ocams = oracle_cams(g4)
+    cams = []
+    for i, c in enumerate(ocams):
+        path = os.path.join(tmp_path, f"im{i:02d}.png")
+        Image.fromarray(g4["images"][i]).save(path)
+        cams.append(lfd.CameraRecord(uid=int(g4["cam_uid"][i]), image_path=path, width=c.width, height=c.height,
+                                     K=c.K, R=c.R, t=c.t, P=c.P, C=c.C))
+    refs = [int(r) for r in g4["refs_local"]]
+    table = [[(torch.from_numpy(g4[f"ref{r}_warp"][j]), torch.from_numpy(g4[f"ref{r}_cert"][j])) for j in range(2)] for r in refs]
+    return cams, refs, g4["nn_table"], table
+
+
+@pytest.mark.parametrize("mode,two_channel", [("filter", False), ("nofilter", False), ("filter", True)])
+def test_pipeline_matches_upstream_run(g4, tmp_path, mode, two_channel):
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+    kw = json.loads(str(g4[mode + "_cfg"]))
+    cfg = lfd.DensePipelineConfig(output_path=os.path.join(str(tmp_path), "out", "dense.ply"), roma_setting="fast",
+                                  nns_per_ref=2, seed=5, viz_interval=2, pack_workers=1, **kw)
+    fm = FakeMatcher(64, 64, table, two_channel)
+    progress, viz = [], []
+    res = pl.run_dense_pipeline(cams, refs, nn, cfg, progress_callback=lambda p, m: progress.append((p, m)),
+                                on_sequential_viz=lambda p: viz.append(os.path.basename(p)), matcher=fm)
+    assert res.xyz.shape == g4[mode + "_xyz"].shape          # identical survivor count
+    assert res.pairs_processed == int(g4[mode + "_pairs_processed"]) and res.pairs_matched == 6
+    np.testing.assert_allclose(res.xyz, g4[mode + "_xyz"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(res.rgb, g4[mode + "_rgb"], rtol=0, atol=1.0 / 255 / 4)
+    if mode == "filter":
+        np.testing.assert_allclose(res.err, g4[mode + "_err"], rtol=1e-5, atol=2e-3)
+    np.testing.assert_array_equal([p for p, _ in progress], g4[mode + "_progress_pct"])
+    assert [m.split(" | ")[0] for _, m in progress] == [str(m) for m in g4[mode + "_progress_msg"]]
+    assert viz == [str(v) for v in g4[mode + "_viz_files"]]
+    assert not fm.closed                                       # an injected matcher is the caller's to close
+    assert res.xyz.dtype == np.float32 and res.rgb.dtype == np.float32 and res.err.dtype == np.float32
+
+
+def test_pipeline_dense_mode_cancel_and_debug(g4, tmp_path):
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+    cfg = lfd.DensePipelineConfig(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=2, seed=5, viz_interval=0,
+                                  triangulation_mode="dense", refs_per_launch=2)
+    res = pl.run_dense_pipeline(cams, refs, nn, cfg, matcher=FakeMatcher(64, 64, table))
+    assert res.pairs_processed == 3 and res.xyz.shape[0] > 3 * 1000
+    assert res.points_per_reference.sum() == res.xyz.shape[0]
+    # cancellation between references
+    calls = {"n": 0}
+
+    def cancel():
+        calls["n"] += 1
+        return calls["n"] > 6
+
+    with pytest.raises(pl.PipelineCancelled):
+        pl.run_dense_pipeline(cams, refs, nn, cfg, matcher=FakeMatcher(64, 64, table), cancel_requested=cancel)
+    # debug previews carry survivors in match pixels
+    st = MatchDebugState()
+    st.set_enabled(True)
+    cfg2 = lfd.DensePipelineConfig(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=2, seed=5, viz_interval=0,
+                                   matches_per_ref=1200)
+    pl.run_dense_pipeline(cams, refs, nn, cfg2, matcher=FakeMatcher(64, 64, table), debug_state=st)
+    pv = st.latest()
+    assert pv is not None and pv.matches.shape[1] == 4 and pv.matches.min() >= 0 and pv.matches.max() <= 63
+    assert pv.cert_norm.min() >= 0 and pv.cert_norm.max() <= 1 and pv.total_pairs == 6
+    # nothing survives -> upstream's RuntimeError text
+    cfg3 = lfd.DensePipelineConfig(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=2, reproj_thresh=1e-9,
+                                   matches_per_ref=1200)
+    with pytest.raises(RuntimeError, match="No points triangulated. Try adjusting parameters."):
+        pl.run_dense_pipeline(cams, refs, nn, cfg3, matcher=FakeMatcher(64, 64, table))

@@ -1,0 +1,182 @@
+"""CPU tests of the host-side mirror of upstream's interface: boundary types, sampling stage,
+writers, camera selection, entry-point plumbing (no GPU needed)."""
+import dataclasses
+import hashlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lichtfeld_densification_plugin_amd as lfd
+from lichtfeld_densification_plugin_amd import densify
+from lichtfeld_densification_plugin_amd.core import sampling, selection, writers
+from lichtfeld_densification_plugin_amd.core.config import DensePipelineConfig
+from lichtfeld_densification_plugin_amd.core.camera_models import CameraRecord
+from lichtfeld_densification_plugin_amd.core.debug_viz import MatchDebugState, MatchPreview
+from lichtfeld_densification_plugin_amd.core.image_io import to_uint8_rgb
+from helpers import orc
+
+
+UPSTREAM_FIELDS = [("output_path", None), ("roma_setting", "fast"), ("roi_only_selected", False), ("num_refs", 0.8),
+                   ("nns_per_ref", 3), ("matches_per_ref", 10000), ("certainty_thresh", 0.20), ("reproj_thresh", 0.8),
+                   ("sampson_thresh", 5.0), ("min_parallax_deg", 0.5), ("max_points", 0), ("no_filter", False),
+                   ("use_masks", True), ("voxel_size", 0.0), ("seed", 0), ("viz_interval", 3), ("prefetch_packages", 8),
+                   ("pack_workers", 4)]
+
+
+def test_config_keeps_upstream_fields_in_order():
+    fields = dataclasses.fields(DensePipelineConfig)
+    assert [f.name for f in fields[:18]] == [n for n, _ in UPSTREAM_FIELDS]
+    for f, (_, default) in zip(fields[1:18], UPSTREAM_FIELDS[1:]):
+        assert f.default == default
+    cfg = DensePipelineConfig("/tmp/x.ply", "turbo", False, 0.5, 2)       # positional construction still works
+    assert cfg.roma_setting == "turbo" and cfg.nns_per_ref == 2 and cfg.triangulation_mode == "sampled"
+    with pytest.raises(ValueError):
+        DensePipelineConfig("/tmp/x.ply", triangulation_mode="bogus")
+
+
+def test_camera_record_flat_pose_and_derived():
+    K = np.array([[900, 0, 640], [0, 905, 360], [0, 0, 1]], np.float32)
+    R = np.eye(3, dtype=np.float32)[[1, 2, 0]]
+    t = np.array([0.5, -1.0, 2.0], np.float32)
+    c = CameraRecord.from_krt(7, K, R, t, 1280, 720)
+    T = c.flat_pose().reshape(4, 4)
+    np.testing.assert_array_equal(T[:3, :3], R)
+    np.testing.assert_array_equal(T[:3, 3], t)
+    np.testing.assert_array_equal(c.P, K @ np.concatenate([R, t.reshape(3, 1)], 1))
+    np.testing.assert_allclose(c.C, -R.T @ t, atol=1e-6)
+    assert c.P.dtype == np.float32 and c.C.shape == (3,)
+
+
+def _tiefree(h, w, seed):
+    rs = np.random.RandomState(seed)
+    perm = rs.permutation(h * w).astype(np.float64)
+    return (0.2 + 0.7 * (perm + 0.5) / (h * w)).astype(np.float32).reshape(h, w)
+
+
+def test_sampling_stage_matches_upstream_golden(g2):
+    for ci, (h, w, M, seed, cseed) in enumerate(g2["cases"]):
+        cert = _tiefree(int(h), int(w), int(cseed))
+        for no_filter in (False, True):
+            key = f"c{ci}_{'nf' if no_filter else 'f'}_"
+            rng = np.random.RandomState(int(seed))
+            sel = sampling.select_samples_with_coverage(torch.from_numpy(cert), int(M), no_filter=no_filter, rng=rng)
+            np.testing.assert_array_equal(sel, g2[key + "sel"])
+            assert int(rng.get_state()[2]) == int(g2[key + "mt_pos"])
+            # the process-global stream gives the same answer (upstream's way of calling it)
+            np.random.seed(int(seed))
+            sel2 = sampling.select_samples_with_coverage(cert, int(M), no_filter=no_filter)
+            np.testing.assert_array_equal(sel2, sel)
+    assert sampling.select_samples_with_coverage(np.zeros((16, 16), np.float32), 100).size == 0
+    with pytest.raises(ValueError):
+        sampling.select_samples_with_coverage(_tiefree(64, 64, 1), 10000, rng=np.random.RandomState(0))
+
+
+def test_sampling_coverage_pass_equals_the_walk_on_tied_maps(g2):
+    """Floor/cap clamps create massive ties; the vectorised first-occurrence pass must equal upstream's
+    sequential walk for whatever order argsort yields."""
+    cert = g2["ties_cert"]
+    sel = sampling.select_samples_with_coverage(cert, 1200, rng=np.random.RandomState(3))
+    ref = orc.select_samples(cert, 1200, rng=np.random.RandomState(3))
+    np.testing.assert_array_equal(sel, ref)
+
+
+def test_writers_byte_exact(g5, tmp_path):
+    u8 = to_uint8_rgb(g5["rgb"])
+    np.testing.assert_array_equal(u8, g5["rgb_u8"])
+    p1, p2 = tmp_path / "a.ply", tmp_path / "a.bin"
+    writers.write_ply(str(p1), g5["xyz"], u8)
+    writers.write_points3D_bin(str(p2), g5["xyz"], u8, g5["err"])
+    assert p1.read_bytes() == g5["ply"].tobytes()
+    assert p2.read_bytes() == g5["points3d_bin"].tobytes()
+    writers.write_points3D_bin(str(p2), g5["xyz"], u8, None)
+    assert len(p2.read_bytes()) == 8 + 43 * 5
+
+
+def test_streamed_ply_writer_is_a_valid_ply_with_the_same_payload(g5, tmp_path):
+    u8 = g5["rgb_u8"]
+    path = tmp_path / "s.ply"
+    with writers.StreamedPlyWriter(str(path)) as w:
+        w.append(g5["xyz"][:2], u8[:2])
+        w.append(g5["xyz"][2:], u8[2:])
+        assert w.count == 5
+    raw = path.read_bytes()
+    head, body = raw.split(b"end_header\n", 1)
+    assert b"element vertex 5\n" in head and head.startswith(b"ply\nformat binary_little_endian 1.0\n")
+    assert body == g5["ply"].tobytes().split(b"end_header\n", 1)[1]
+
+
+def test_selection_tables_match_upstream(g6):
+    flat = g6["flat_poses"]
+    for k in (3, 4, 8):
+        np.testing.assert_array_equal(selection.nearest_neighbors(flat, k), g6[f"nn_k{k}"])
+    for k in (1, 56, 148):
+        np.testing.assert_array_equal(selection.select_cameras_kcenters(flat, k), g6[f"kcenters_{k}"])
+    np.testing.assert_array_equal(selection.nearest_neighbors(flat[:2], 5), g6["nn_two"])
+    assert selection.nearest_neighbors(flat[:1], 3).shape == (1, 0)
+
+
+def test_argparser_has_upstream_flags_and_defaults():
+    a = densify.build_argparser().parse_args(["--scene_root", "/x"])
+    assert (a.images_subdir, a.out_name, a.roma_setting, a.num_refs, a.nns_per_ref, a.matches_per_ref) == \
+        ("images_2", "points3D_dense.ply", "fast", 0.75, 4, 12000)
+    assert (a.certainty_thresh, a.reproj_thresh, a.sampson_thresh, a.min_parallax_deg) == (0.20, 1.5, 5.0, 0.5)
+    assert (a.no_filter, a.max_points, a.prefetch_packages, a.pack_workers, a.seed) == (False, 0, 8, 4, 0)
+    assert a.triangulation_mode == "sampled"
+    with pytest.raises(SystemExit):
+        densify.build_argparser().parse_args(["--scene_root", "/x", "--roma_setting", "ultra"])
+
+
+class _Node:
+    def __init__(self, uid, R, T, w=640, h=480, has_camera=True):
+        self.has_camera, self.camera_uid = has_camera, uid
+        self.camera_width, self.camera_height = w, h
+        self.camera_focal_x, self.camera_focal_y = 500.0, 505.0
+        self.camera_R, self.camera_T = R, T
+        self.image_path, self.has_mask, self.mask_path = f"/nowhere/{uid}.png", False, None
+
+
+def test_dense_init_from_lfs_argument_checks():
+    cfg = DensePipelineConfig(output_path="/tmp/out.ply")
+    code, msg = densify.dense_init_from_lfs([_Node(1, np.eye(3), np.zeros(3))], cfg)
+    assert (code, msg) == (1, "Need at least 2 cameras for dense initialization")
+    recs = densify.extract_cameras_from_lfs([_Node(1, np.eye(3), np.zeros(3)), _Node(2, np.eye(3), np.ones(3), has_camera=False)])
+    assert len(recs) == 1 and recs[0].K[0, 2] == 320.0 and recs[0].K[1, 2] == 240.0
+
+
+def test_point_cap_and_voxel_filter():
+    rs = np.random.RandomState(0)
+    xyz = rs.uniform(0, 1, (500, 3)).astype(np.float32)
+    rgb = rs.uniform(0, 1, (500, 3)).astype(np.float32)
+    err = rs.uniform(0, 1, 500).astype(np.float32)
+    a, b, c = densify._apply_point_cap(xyz, rgb, err, 100, 3)
+    keep = np.random.default_rng(3).choice(500, size=100, replace=False)
+    np.testing.assert_array_equal(a, xyz[keep])
+    assert densify._apply_point_cap(xyz, rgb, err, 0, 3)[0] is xyz
+    vx, vc = densify._voxel_downsample(xyz, rgb, 0.25)
+    assert 1 <= vx.shape[0] <= 125 and vx.dtype == np.float32 and vc.min() >= 0 and vc.max() <= 1
+    np.testing.assert_allclose(vx.mean(0), xyz.mean(0), atol=0.1)
+
+
+def test_debug_state_blocks_until_stepped():
+    import threading
+    st = MatchDebugState()
+    pv = MatchPreview(1, 2, "a", "b", np.zeros((2, 2, 3), np.uint8), np.zeros((2, 2, 3), np.uint8),
+                      np.zeros((1, 4), np.float32), np.zeros(1, np.float32), 1, 1, 1)
+    st.submit_preview(pv)
+    assert st.latest() is None                       # disabled: dropped
+    st.set_enabled(True)
+    st.set_auto_step(False)
+    done = threading.Event()
+    th = threading.Thread(target=lambda: (st.submit_preview(pv), done.set()))
+    th.start()
+    assert not done.wait(0.2)
+    st.step_once()
+    assert done.wait(2.0)
+    th.join()
+    assert st.latest() is pv and st.visible_match_indices(5) == [0, 1, 2, 3, 4]
+    st.set_single_match_mode(True)
+    st.next_match(5)
+    assert st.visible_match_indices(5) == [1]
