@@ -242,12 +242,12 @@ class _HotPath:
         use_masks = packed.mask_a is not None or any(m is not None for m in packed.nbr_masks)
         mask_b = None
         if use_masks:
-            mask_b = [torch.from_numpy(np.ascontiguousarray(m)).to(dev) if m is not None else None
+            mask_b = [torch.from_numpy(np.array(m, dtype=np.uint8, copy=True)).to(dev) if m is not None else None
                       for m in packed.nbr_masks]
         return hb.ReferenceInputs(
             ref_cam=packed.ref_index, nbr_cams=list(packed.nbr_indices), cert=certs, warp=warps,
-            image=torch.from_numpy(np.ascontiguousarray(packed.image)).to(dev),
-            mask_a=torch.from_numpy(np.ascontiguousarray(packed.mask_a)).to(dev) if packed.mask_a is not None else None,
+            image=torch.from_numpy(np.array(packed.image, dtype=np.uint8, copy=True)).to(dev),
+            mask_a=torch.from_numpy(np.array(packed.mask_a, dtype=np.uint8, copy=True)).to(dev) if packed.mask_a is not None else None,
             mask_b=mask_b)
 
     def sampled(self, ref: hb.ReferenceInputs, axes, rng) -> Tuple[Optional[hb.TriangulationOutput], Optional[torch.Tensor]]:

@@ -14,6 +14,7 @@
 
 extern "C" __global__ void lfd_aggregate_kernel(LfdLaunch L, float* best_cert, uint8_t* best_slot);
 extern "C" __global__ void lfd_dense_kernel(LfdLaunch L);
+extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* ref_out, LfdPairConst* pair_out);
 extern "C" __global__ void lfd_indexed_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets,
                                               float* scratch, uint8_t* codes, int32_t* seg_order);
 
@@ -49,6 +50,10 @@ struct lfd_context {
     // default A-grid axes
     DeviceBuffer axes;
     int axes_w = 0, axes_h = 0;
+    // per-pair constants of the current batch (valid while the descriptor tables are unchanged)
+    DeviceBuffer consts;
+    bool consts_valid = false;
+    int consts_wm = 0, consts_hm = 0;
     // indexed-mode scratch
     DeviceBuffer scratch, codes;
 };
@@ -151,6 +156,7 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
         LFD_HIP(ctx, hipEventRecord(ctx->pinned_free, ctx->stream));
         ctx->pinned_in_flight = true;
         ctx->desc_cache.swap(blob);
+        ctx->consts_valid = false;
     }
     *d_refs = reinterpret_cast<const LfdRefDesc*>(ctx->desc.ptr);
     *d_slots = reinterpret_cast<const LfdSlotDesc*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_slots);
@@ -208,6 +214,24 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
     L.mask_sx = (float)b->w_match / (float)b->W;
     L.mask_sy = (float)b->h_match / (float)b->H;
     fill_kernel_params(b, p, L.kp);
+    // per-pair constants: (re)derive when the batch tables, the cameras or the match size changed
+    const size_t ref_bytes = ((size_t)b->n_refs * sizeof(LfdRefConst) + 15) & ~size_t(15);
+    const size_t need = ref_bytes + (size_t)b->n_refs * b->k * sizeof(LfdPairConst);
+    if (ctx->consts.bytes < need) ctx->consts_valid = false;
+    rc = ensure(ctx, ctx->consts, need);
+    if (rc != LFD_OK) return rc;
+    LfdRefConst* d_rc = static_cast<LfdRefConst*>(ctx->consts.ptr);
+    LfdPairConst* d_pc = reinterpret_cast<LfdPairConst*>(static_cast<unsigned char*>(ctx->consts.ptr) + ref_bytes);
+    L.ref_const = d_rc;
+    L.pair_const = d_pc;
+    if (!ctx->consts_valid || ctx->consts_wm != b->w_match || ctx->consts_hm != b->h_match) {
+        const int n = b->n_refs * b->k + b->n_refs;
+        hipLaunchKernelGGL(lfd_pair_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, L, d_rc, d_pc);
+        LFD_HIP(ctx, hipGetLastError());
+        ctx->consts_valid = true;
+        ctx->consts_wm = b->w_match;
+        ctx->consts_hm = b->h_match;
+    }
     return LFD_OK;
 }
 
@@ -275,7 +299,7 @@ void lfd_destroy(lfd_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->scratch, &ctx->codes})
+    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_free) (void)hipEventDestroy(ctx->pinned_free);
@@ -312,6 +336,7 @@ int lfd_upload_cameras(lfd_context* ctx, int32_t n, const float* K, const float*
     LFD_HIP(ctx, hipMemcpyAsync(ctx->cams.ptr, cams.data(), cams.size() * sizeof(LfdCam), hipMemcpyHostToDevice, ctx->stream));
     LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_cams = n;
+    ctx->consts_valid = false;
     return LFD_OK;
 }
 

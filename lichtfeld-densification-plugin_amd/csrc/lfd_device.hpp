@@ -36,6 +36,8 @@ struct LfdLaunch {              // kernel argument, passed by value
     const LfdCam* cams;
     const LfdRefDesc* refs;
     const LfdSlotDesc* slots;
+    const LfdRefConst* ref_const;    // [n_refs]    written by lfd_pair_setup_kernel
+    const LfdPairConst* pair_const;  // [n_refs*k]
     const float* axis_x;        // [W]
     const float* axis_y;        // [H]
     int32_t n_refs, k, H, W, w_match, h_match, warp_channels, tiles_per_ref;

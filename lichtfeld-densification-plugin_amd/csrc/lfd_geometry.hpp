@@ -149,7 +149,7 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
 // eig(A^T A) the conditioning is that of A, not of A^T A: the entries of A are f32, so every 2x2
 // minor is the difference of two EXACT f64 products (fma below changes nothing there).
 #ifndef LFD_NULLVEC_TOL
-#define LFD_NULLVEC_TOL 2e-9
+#define LFD_NULLVEC_TOL 2e-8
 #endif
 #ifndef LFD_NULLVEC_MAXIT
 #define LFD_NULLVEC_MAXIT 6
@@ -218,11 +218,15 @@ LFD_HD int lfd_null_vector(const float* Af, double* c) {
         g22 = fma(j2, j2, g22); g23 = fma(j2, j3, g23); g33 = fma(j3, j3, g33);
     }
     double tr = (g00 + g11) + (g22 + g33);
-    int it = 0;
-    for (; it < LFD_NULLVEC_MAXIT; ++it) {
+    {   // one exact power-of-two rescale to trace in [0.5, 1): six squarings then stay far inside the
+        // f64 range (trace(G^2) is between trace(G)^2/4 and trace(G)^2), so the loop needs no rescaling
         const double s = lfd_pow2_inv_scale(tr);
         g00 *= s; g01 *= s; g02 *= s; g03 *= s; g11 *= s; g12 *= s; g13 *= s; g22 *= s; g23 *= s; g33 *= s;
-        const double t1 = tr * s;
+        tr *= s;
+    }
+    int it = 0;
+    for (; it < LFD_NULLVEC_MAXIT; ++it) {
+        const double t1 = tr;
         const double h00 = fma(g03, g03, fma(g02, g02, fma(g01, g01, g00 * g00)));
         const double h01 = fma(g03, g13, fma(g02, g12, fma(g01, g11, g00 * g01)));
         const double h02 = fma(g03, g23, fma(g02, g22, fma(g01, g12, g00 * g02)));

@@ -106,9 +106,18 @@ __device__ __forceinline__ void block_prologue(const LfdLaunch& L, int r, BlockS
     if (tid == 0) S.ref = L.refs[r];
     if (tid < L.k) S.slot[tid] = L.slots[(size_t)r * L.k + tid];
     __syncthreads();
+    // per-pair constants (P, C, pixel scales, F) were derived once per batch by lfd_pair_setup_kernel;
+    // stage this reference's rows in LDS with coalesced dword copies
     const int ns = S.ref.n_slots;
-    if (tid < ns) lfd_make_pair_const(L.cams[S.ref.cam], L.cams[S.slot[tid].cam], S.slot[tid].cam, L.w_match, L.h_match, S.pc[tid]);
-    if (tid == 64) lfd_make_ref_const(L.cams[S.ref.cam], L.w_match, L.h_match, S.rc);
+    {
+        const unsigned* src = reinterpret_cast<const unsigned*>(L.pair_const + (size_t)r * L.k);
+        unsigned* dst = reinterpret_cast<unsigned*>(S.pc);
+        const int nw = ns * (int)(sizeof(LfdPairConst) / 4);
+        for (int i = tid; i < nw; i += (int)blockDim.x) dst[i] = src[i];
+        const unsigned* rsrc = reinterpret_cast<const unsigned*>(L.ref_const + r);
+        unsigned* rdst = reinterpret_cast<unsigned*>(&S.rc);
+        if (tid < (int)(sizeof(LfdRefConst) / 4)) rdst[tid] = rsrc[tid];
+    }
     __syncthreads();
 }
 
@@ -168,6 +177,23 @@ __device__ __forceinline__ void cell_coords(const LfdLaunch& L, const BlockShare
 }  // namespace
 
 // =================================================================================================
+// F5: per-(reference, neighbour) constants, once per batch (skipped when the batch is unchanged)
+// =================================================================================================
+extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* __restrict__ ref_out,
+                                                 LfdPairConst* __restrict__ pair_out) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int n_pairs = L.n_refs * L.k;
+    if (i < n_pairs) {
+        const int r = i / L.k, j = i - r * L.k;
+        if (j < L.refs[r].n_slots)
+            lfd_make_pair_const(L.cams[L.refs[r].cam], L.cams[L.slots[i].cam], L.slots[i].cam, L.w_match, L.h_match, pair_out[i]);
+    } else if (i < n_pairs + L.n_refs) {
+        const int r = i - n_pairs;
+        lfd_make_ref_const(L.cams[L.refs[r].cam], L.w_match, L.h_match, ref_out[r]);
+    }
+}
+
+// =================================================================================================
 // P1 + F1: aggregate
 // =================================================================================================
 extern "C" __global__ void __launch_bounds__(256) lfd_aggregate_kernel(LfdLaunch L, float* __restrict__ best_cert,
@@ -216,7 +242,7 @@ extern "C" __global__ void __launch_bounds__(256) lfd_aggregate_kernel(LfdLaunch
 // =================================================================================================
 // fused dense kernel
 // =================================================================================================
-extern "C" __global__ void __launch_bounds__(kBlock) lfd_dense_kernel(LfdLaunch L) {
+extern "C" __global__ void __launch_bounds__(kBlock, 3) lfd_dense_kernel(LfdLaunch L) {
     __shared__ BlockShared S;
     __shared__ unsigned s_ticket;
     __shared__ unsigned s_wave_cnt[kBlock / 64];
@@ -273,7 +299,7 @@ extern "C" __global__ void __launch_bounds__(kBlock) lfd_dense_kernel(LfdLaunch 
     // ---- stage 3: per-correspondence geometry ---------------------------------------------------
     float ox[kCpt], oy[kCpt], oz[kCpt], oe[kCpt], opx[kCpt], opy[kCpt];
     unsigned keep_bits = 0;
-#pragma unroll 1
+#pragma unroll
     for (int e = 0; e < kCpt; ++e) {
         LfdCellResult res;
         res.keep = 0; res.x = res.y = res.z = res.err = res.xa_px = res.ya_px = 0.0f;
@@ -320,7 +346,7 @@ extern "C" __global__ void __launch_bounds__(kBlock) lfd_dense_kernel(LfdLaunch 
     // ---- stage 5: colour for survivors + write --------------------------------------------------------
     long long pos = (long long)s_tile_excl + wave_off + (incl - my_cnt);
     const float sx_img = 1.0f, sy_img = 1.0f;   // the image handed over is already at match resolution
-#pragma unroll 1
+#pragma unroll
     for (int e = 0; e < kCpt; ++e) {
         if (!((keep_bits >> e) & 1u)) continue;
         if (pos < L.capacity) {
