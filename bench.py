@@ -148,13 +148,22 @@ def main():
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
+    host_t = []
     for a, b in ev:
         a.record()                      # same stream the kernel is launched on (torch's current stream)
         dens.launch_dense(batch, params, out)
         b.record()
+        host_t.append(time.perf_counter() - t0)
+    t_enq = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if os.environ.get("LFD_BENCH_DEBUG"):
+        print(f"[rank {rank}] enqueue done at {t_enq * 1e3:.2f} ms, first 5 host stamps {[round(x * 1e3, 2) for x in host_t[:5]]}", file=sys.stderr)
+    per_launch = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms = float(np.mean(per_launch))
+    if os.environ.get("LFD_BENCH_DEBUG"):
+        print(f"[rank {rank}] per-launch ms: min {min(per_launch):.3f} max {max(per_launch):.3f} mean {kernel_ms:.3f}; "
+              f"wall {elapsed * 1e3:.2f} ms for {args.steps} steps", file=sys.stderr)
     res = out.collect()
     n_pts = res.count
 

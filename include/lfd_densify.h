@@ -119,6 +119,10 @@ int lfd_triangulate_indexed(lfd_context* ctx, const lfd_batch* batch, const lfd_
                             const int64_t* sel_idx, const int64_t* sel_offsets, const lfd_points* out,
                             int64_t* ref_offsets, int32_t* seg_counts, int32_t* seg_order);
 
+/* Synchronise the context's stream and report whether the last launches completed normally.
+ * *status_out = 0, or 1 when a bounded look-back spin gave up (results invalid; returns LFD_ERR_HIP). */
+int lfd_launch_status(lfd_context* ctx, int32_t* status_out);
+
 /* ---- host-side helpers (no GPU needed; used by the CPU test-suite) -------------------------------- */
 /* A-grid axis used when axis_x/axis_y are NULL: start + step*j below the midpoint,
  * end - step*(n-1-j) from it on, f32 (the per-element form of torch.linspace, core/matcher.py:132-133). */

@@ -49,7 +49,8 @@ _lib = None
 
 
 def library_path() -> str:
-    return os.path.join(_PKG_DIR, _LIB_NAME)
+    """In-tree library; ``LFD_DENSIFY_LIB`` overrides it (used to A/B kernel builds while profiling)."""
+    return os.environ.get("LFD_DENSIFY_LIB") or os.path.join(_PKG_DIR, _LIB_NAME)
 
 
 def load_library() -> C.CDLL:
@@ -80,6 +81,7 @@ def load_library() -> C.CDLL:
     lib.lfd_triangulate_indexed.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p,
                                             C.POINTER(C.c_int64), C.POINTER(lfd_points), C.c_void_p, C.c_void_p,
                                             C.c_void_p]
+    lib.lfd_launch_status.argtypes = [ctxp, C.POINTER(C.c_int32)]
     lib.lfd_identity_axis.argtypes = [C.c_int32, fptr]
     lib.lfd_parallax_dot_threshold.argtypes = [C.c_float]
     lib.lfd_parallax_dot_threshold.restype = C.c_float
@@ -87,7 +89,7 @@ def load_library() -> C.CDLL:
     lib.lfd_host_eval_correspondence.argtypes = [fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                                  C.c_int32, C.POINTER(lfd_params), fptr]
     for name in ("lfd_create", "lfd_set_stream", "lfd_upload_cameras", "lfd_aggregate", "lfd_triangulate_dense",
-                 "lfd_triangulate_indexed", "lfd_identity_axis", "lfd_host_fundamental",
+                 "lfd_triangulate_indexed", "lfd_launch_status", "lfd_identity_axis", "lfd_host_fundamental",
                  "lfd_host_eval_correspondence"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
@@ -322,6 +324,11 @@ class HipDensifier:
                                                  wh.ctypes.data_as(C.POINTER(C.c_int32))), "lfd_upload_cameras")
         self.n_cams = len(cams)
 
+    def check_launches(self) -> None:
+        """Synchronise and raise if a kernel reported a look-back timeout."""
+        st = C.c_int32(0)
+        self._check(self._lib.lfd_launch_status(self._ctx, C.byref(st)), "lfd_launch_status")
+
     # -- launches (asynchronous on self.stream) -------------------------------------------------------
     def launch_aggregate(self, batch: PreparedBatch, params: lfd_params, best_cert: torch.Tensor,
                          best_slot: Optional[torch.Tensor]) -> None:
@@ -355,10 +362,12 @@ class HipDensifier:
         cap = batch.n_refs * batch.H * batch.W if capacity is None else int(capacity)
         out = OutputBuffers(cap, batch.n_refs, batch.k, self.device, with_cell)
         self.launch_dense(batch, params, out)
+        self.check_launches()
         return out.collect()
 
     def triangulate_indexed(self, batch: PreparedBatch, params: lfd_params, sel_idx: torch.Tensor,
                             sel_offsets: Sequence[int], with_cell: bool = True) -> TriangulationOutput:
         out = OutputBuffers(int(sel_offsets[-1]), batch.n_refs, batch.k, self.device, with_cell)
         self.launch_indexed(batch, params, sel_idx, sel_offsets, out)
+        self.check_launches()
         return out.collect(indexed=True)

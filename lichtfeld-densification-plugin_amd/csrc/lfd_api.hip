@@ -47,6 +47,8 @@ struct lfd_context {
     DeviceBuffer ws;
     unsigned long long tickets_issued = 0;   // host mirror of the device ticket counter
     unsigned epoch = 0;
+    int n_cus = 0;                 // compute units of the device
+    int dense_blocks_per_cu = 0;   // resident lfd_dense_kernel workgroups per CU (persistent grid size)
     // default A-grid axes
     DeviceBuffer axes;
     int axes_w = 0, axes_h = 0;
@@ -238,7 +240,8 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
 // ticket counter + tile states.  Tickets are never reset: each launch is given the value the
 // counter holds when it starts; tile-state words carry a launch epoch, so stale words of earlier
 // launches read as "empty" and no per-launch memset is needed.
-int prepare_lookback(lfd_context* ctx, size_t n_tiles, LfdLaunch& L) {
+// workspace: [0] u64 ticket counter, [8] u32 launch status, [16..] tile states
+int prepare_lookback(lfd_context* ctx, size_t n_tiles, size_t n_tickets, LfdLaunch& L) {
     const size_t need = 16 + n_tiles * sizeof(unsigned long long);
     const bool fresh = ctx->ws.bytes < need || !ctx->ws.ptr;
     int rc = ensure(ctx, ctx->ws, need, true);
@@ -251,9 +254,10 @@ int prepare_lookback(lfd_context* ctx, size_t n_tiles, LfdLaunch& L) {
     }
     L.ticket = static_cast<unsigned long long*>(ctx->ws.ptr);
     L.tile_state = static_cast<unsigned long long*>(ctx->ws.ptr) + 2;
+    L.status = reinterpret_cast<unsigned int*>(static_cast<unsigned char*>(ctx->ws.ptr) + 8);
     L.ticket_base = ctx->tickets_issued;
     L.epoch = ctx->epoch;
-    ctx->tickets_issued += n_tiles;
+    ctx->tickets_issued += n_tickets;
     return LFD_OK;
 }
 
@@ -285,6 +289,7 @@ int lfd_create(int device_index, void* hip_stream, lfd_context** out) {
     ctx->device = device_index;
     ctx->stream = static_cast<hipStream_t>(hip_stream);
     e = hipSetDevice(device_index);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device_index);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pinned_free, hipEventDisableTiming);
     if (e != hipSuccess) {
         std::string m = std::string("context init: ") + hipGetErrorString(e);
@@ -311,6 +316,22 @@ int lfd_set_stream(lfd_context* ctx, void* hip_stream) {
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return LFD_OK;
+}
+
+int lfd_launch_status(lfd_context* ctx, int32_t* status_out) {
+    if (!ctx || !status_out) return fail(ctx, LFD_ERR_INVALID, "null argument");
+    *status_out = 0;
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->ws.ptr) return LFD_OK;
+    unsigned int st = 0;
+    LFD_HIP(ctx, hipMemcpy(&st, static_cast<unsigned char*>(ctx->ws.ptr) + 8, sizeof(st), hipMemcpyDeviceToHost));
+    if (st != 0) {
+        LFD_HIP(ctx, hipMemset(static_cast<unsigned char*>(ctx->ws.ptr) + 8, 0, sizeof(st)));
+        *status_out = (int32_t)st;
+        return fail(ctx, LFD_ERR_HIP, "a look-back spin timed out (workgroups of the persistent grid were not co-resident); results of the last launch are invalid");
+    }
     return LFD_OK;
 }
 
@@ -363,14 +384,15 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
     if (rc != LFD_OK) return rc;
     const size_t n_tiles = (size_t)batch->n_refs * (size_t)L.tiles_per_ref;
     if (n_tiles > 0x7fffffffu) return fail(ctx, LFD_ERR_INVALID, "too many tiles in one launch");
-    rc = prepare_lookback(ctx, n_tiles, L);
+    const size_t grid = n_tiles;              // one workgroup per tile, numbered by ticket
+    rc = prepare_lookback(ctx, n_tiles, grid, L);
     if (rc != LFD_OK) return rc;
     L.xyz = out->xyz; L.rgb = out->rgb; L.err = out->err; L.cell = out->cell; L.slot = out->slot;
     L.capacity = out->capacity;
     L.ref_offsets = reinterpret_cast<long long*>(ref_offsets);
     L.seg_counts = seg_counts;
     if (seg_counts) LFD_HIP(ctx, hipMemsetAsync(seg_counts, 0, sizeof(int32_t) * (size_t)batch->n_refs * batch->k, ctx->stream));
-    hipLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)n_tiles), dim3(LFD_DENSE_BLOCK), 0, ctx->stream, L);
+    hipLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), 0, ctx->stream, L);
     LFD_HIP(ctx, hipGetLastError());
     return LFD_OK;
 }
@@ -392,7 +414,7 @@ int lfd_triangulate_indexed(lfd_context* ctx, const lfd_batch* batch, const lfd_
     rc = check_points(ctx, out, reinterpret_cast<long long*>(ref_offsets));
     if (rc != LFD_OK) return rc;
     const size_t n_sel = (size_t)sel_offsets[batch->n_refs];
-    rc = prepare_lookback(ctx, (size_t)batch->n_refs, L);
+    rc = prepare_lookback(ctx, (size_t)batch->n_refs, (size_t)batch->n_refs, L);
     if (rc != LFD_OK) return rc;
     rc = ensure(ctx, ctx->scratch, std::max<size_t>(n_sel, 1) * 8 * sizeof(float));
     if (rc != LFD_OK) return rc;

@@ -11,11 +11,17 @@
 
 #define LFD_DENSE_BLOCK 256     // threads per workgroup of the fused dense kernel (4 waves)
 #define LFD_DENSE_CPT 4         // consecutive grid cells per thread (one 16-byte certainty load per slot)
+#ifndef LFD_DENSE_WAVES_PER_SIMD
+#define LFD_DENSE_WAVES_PER_SIMD 4       // register budget of the fused kernel: 512/4 -> <=128 VGPRs
+#endif
+#define LFD_DENSE_MAX_BLOCKS_PER_CU LFD_DENSE_WAVES_PER_SIMD   // persistent grid = CUs x min(occupancy, this)
 #define LFD_INDEXED_BLOCK 1024  // one workgroup (16 waves) per reference in the indexed kernel
 
 #define LFD_EPOCH_BITS 22
 #define LFD_EPOCH_MASK ((1u << LFD_EPOCH_BITS) - 1u)
 #define LFD_VALUE_BITS 40     // survivors-so-far fits 40 bits (1e12 points)
+#define LFD_SPIN_LIMIT (1u << 24)   // ~ seconds of polling: a look-back that starves reports instead of hanging
+#define LFD_LAUNCH_TIMEOUT 1u
 
 struct LfdRefDesc {             // one per reference of a launch (device table)
     const uint8_t* image;       // u8 [h_match][w_match][3]
@@ -59,4 +65,5 @@ struct LfdLaunch {              // kernel argument, passed by value
     unsigned long long ticket_base;
     unsigned int epoch;
     unsigned int pad0;
+    unsigned int* status;         // 0 = ok, LFD_LAUNCH_TIMEOUT if a look-back spin gave up
 };

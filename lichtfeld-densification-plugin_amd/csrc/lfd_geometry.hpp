@@ -313,7 +313,11 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
         A[12 + c] = vb * pc.P[8 + c] - pc.P[4 + c];
     }
     double c[4];
+#if defined(LFD_ABLATE_SOLVER)
+    c[0] = A[0]; c[1] = A[5]; c[2] = A[10]; c[3] = A[15];
+#else
     lfd_null_vector(A, c);
+#endif
     // upstream: Xh = unit null vector, w = (|Xh[3]| < 1e-12 ? 1e-12 : Xh[3]), X = Xh / w
     // (core/geometry.py:84-87).  |c3|/|c| < 1e-12 is tested on squares; the common branch divides by
     // c3 directly (X3 == 1), the guard branch normalises first (sign is lost on purpose).

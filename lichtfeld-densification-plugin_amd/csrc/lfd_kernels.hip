@@ -58,8 +58,11 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 // lane returns the same value.  Each tile publishes ONE 8-byte word {status,value} with a relaxed
 // agent-scope store (the data is the flag, so no fence is needed); predecessors are guaranteed to
 // be running because tickets are handed out by an atomic counter.
-__device__ u64 lookback_exclusive(u64* state, unsigned epoch, unsigned tile, u64 my_total) {
+__device__ u64 lookback_exclusive(const LfdLaunch& L, unsigned tile, u64 my_total) {
+    u64* state = L.tile_state;
+    const unsigned epoch = L.epoch;
     const int lane = lane_id();
+    unsigned spins = 0;
     if (tile == 0) {
         if (lane == 0) state_store(state, pack_state(kStPrefix, epoch, my_total));
         return 0;
@@ -73,6 +76,10 @@ __device__ u64 lookback_exclusive(u64* state, unsigned epoch, unsigned tile, u64
         if (j >= 0) {
             s = state_load(state + j);
             while (__any(state_status(s, epoch) == kStEmpty)) {
+                if (++spins > LFD_SPIN_LIMIT) {          // never hang the GPU: report and bail out
+                    if (lane == 0) atomicExch(L.status, LFD_LAUNCH_TIMEOUT);
+                    return 0;
+                }
                 __builtin_amdgcn_s_sleep(1);
                 if (state_status(s, epoch) == kStEmpty) s = state_load(state + j);
             }
@@ -242,8 +249,52 @@ extern "C" __global__ void __launch_bounds__(256) lfd_aggregate_kernel(LfdLaunch
 // =================================================================================================
 // fused dense kernel
 // =================================================================================================
-extern "C" __global__ void __launch_bounds__(kBlock, 3) lfd_dense_kernel(LfdLaunch L) {
+// One 1024-cell tile per workgroup; tiles are numbered by an atomic ticket so that every tile a
+// workgroup can wait for in the look-back belongs to a workgroup that is already running.  (A
+// persistent-grid variant - one ticket per workgroup, tiles b, b+G, ... - was measured slower: with
+// only a few resident workgroups per CU their phases line up and the look-back / barrier bubbles are
+// no longer covered by other workgroups' arithmetic.)  The spin is bounded and reports
+// LFD_LAUNCH_TIMEOUT instead of hanging.
+//
+// A thread owns 4 consecutive cells.  Their inputs, and later their outputs, are parked in the
+// thread's own LDS slots, so the geometry loop carries no per-cell register arrays; survivors are
+// then copied out through an order map with coalesced 16-byte stores.
+struct DenseStage {                // per-tile results, indexed by the cell's slot inside the tile
+    float xyz[3 * kTile];
+    float rgb[3 * kTile];
+    float err[kTile];
+    unsigned short order[kTile];   // order[i] = tile slot of the i-th survivor (raster order)
+    unsigned char slot[kTile];
+};
+
+// copy n records of `width` floats each (gathered through stage.order) to g, coalesced; g is only
+// 4-byte aligned (it starts at an arbitrary survivor index): peel to 16 bytes, then float4 stores
+template <int WIDTH>
+__device__ __forceinline__ void copy_out_gather(float* __restrict__ g, const float* __restrict__ l,
+                                                const unsigned short* __restrict__ order, int n, int tid) {
+    const int total = n * WIDTH;
+    auto fetch = [&](int t) -> float {
+        const int i = (WIDTH == 1) ? t : t / WIDTH;
+        const int c = (WIDTH == 1) ? 0 : t - i * WIDTH;
+        return l[(int)order[i] * WIDTH + c];
+    };
+    const int mis = (int)((reinterpret_cast<uintptr_t>(g) >> 2) & 3u);
+    int head = (4 - mis) & 3;
+    if (head > total) head = total;
+    if (tid < head) g[tid] = fetch(tid);
+    const int nvec = (total - head) >> 2;
+    float4* g4 = reinterpret_cast<float4*>(g + head);
+    for (int i = tid; i < nvec; i += kBlock) {
+        const int t = head + 4 * i;
+        g4[i] = make_float4(fetch(t), fetch(t + 1), fetch(t + 2), fetch(t + 3));
+    }
+    const int done = head + 4 * nvec;
+    if (tid < total - done) g[done + tid] = fetch(done + tid);
+}
+
+extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_kernel(LfdLaunch L) {
     __shared__ BlockShared S;
+    __shared__ DenseStage stage;
     __shared__ unsigned s_ticket;
     __shared__ unsigned s_wave_cnt[kBlock / 64];
     __shared__ unsigned s_slot_cnt[LFD_MAX_SLOTS];
@@ -252,113 +303,145 @@ extern "C" __global__ void __launch_bounds__(kBlock, 3) lfd_dense_kernel(LfdLaun
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ticket = (unsigned)(atomicAdd(L.ticket, 1ull) - L.ticket_base);
-    if (tid < LFD_MAX_SLOTS) s_slot_cnt[tid] = 0;
     __syncthreads();
-    const unsigned ticket = s_ticket;
-    const int r = (int)(ticket / (unsigned)L.tiles_per_ref);
-    const int tile_in_ref = (int)(ticket - (unsigned)r * (unsigned)L.tiles_per_ref);
-    block_prologue(L, r, S);
-
+    const unsigned tile = s_ticket;
+    const unsigned n_tiles = (unsigned)L.n_refs * (unsigned)L.tiles_per_ref;
     const int HW = L.H * L.W;
-    const int ns = S.ref.n_slots;
-    const int cell0 = tile_in_ref * kTile + tid * kCpt;
-    bool any_mask = S.ref.mask_a != nullptr;
-    for (int j = 0; j < ns; ++j) any_mask |= (S.slot[j].mask_b != nullptr);
+    {
+        const int r = (int)(tile / (unsigned)L.tiles_per_ref);
+        const int tile_in_ref = (int)(tile - (unsigned)r * (unsigned)L.tiles_per_ref);
+        if (tid < LFD_MAX_SLOTS) s_slot_cnt[tid] = 0;
+        block_prologue(L, r, S);                 // ends with a barrier (also covers s_slot_cnt)
+        const int ns = S.ref.n_slots;
+        bool any_mask = S.ref.mask_a != nullptr;
+        for (int j = 0; j < ns; ++j) any_mask |= (S.slot[j].mask_b != nullptr);
+        const int tile_cell0 = tile_in_ref * kTile;
+        const int cell0 = tile_cell0 + tid * kCpt;
 
-    // ---- stage 1: certainty floor + arg-max over the neighbour slots (coalesced 16-B loads) -----
-    int bj[kCpt];
-    if (!any_mask && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW) {
-        const float th = L.kp.certainty_thresh;
-        float4 best = *reinterpret_cast<const float4*>(S.slot[0].cert + cell0);
-        best.x = lfd_cert_floor(best.x, th); best.y = lfd_cert_floor(best.y, th);
-        best.z = lfd_cert_floor(best.z, th); best.w = lfd_cert_floor(best.w, th);
-        bj[0] = bj[1] = bj[2] = bj[3] = 0;
-        for (int j = 1; j < ns; ++j) {
-            const float4 c = *reinterpret_cast<const float4*>(S.slot[j].cert + cell0);
-            argmax_step(lfd_cert_floor(c.x, th), j, best.x, bj[0]);
-            argmax_step(lfd_cert_floor(c.y, th), j, best.y, bj[1]);
-            argmax_step(lfd_cert_floor(c.z, th), j, best.z, bj[2]);
-            argmax_step(lfd_cert_floor(c.w, th), j, best.w, bj[3]);
+        // ---- stage 1: certainty floor + arg-max over the neighbour slots (coalesced 16-B loads) -----
+        int bj[kCpt];
+        if (!any_mask && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW) {
+            const float th = L.kp.certainty_thresh;
+            float4 best = *reinterpret_cast<const float4*>(S.slot[0].cert + cell0);
+            best.x = lfd_cert_floor(best.x, th); best.y = lfd_cert_floor(best.y, th);
+            best.z = lfd_cert_floor(best.z, th); best.w = lfd_cert_floor(best.w, th);
+            bj[0] = bj[1] = bj[2] = bj[3] = 0;
+            for (int j = 1; j < ns; ++j) {
+                const float4 c = *reinterpret_cast<const float4*>(S.slot[j].cert + cell0);
+                argmax_step(lfd_cert_floor(c.x, th), j, best.x, bj[0]);
+                argmax_step(lfd_cert_floor(c.y, th), j, best.y, bj[1]);
+                argmax_step(lfd_cert_floor(c.z, th), j, best.z, bj[2]);
+                argmax_step(lfd_cert_floor(c.w, th), j, best.w, bj[3]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < kCpt; ++e) {
+                bj[e] = 0;
+                if (cell0 + e < HW) { float b; cell_best(L, S, cell0 + e, b, bj[e]); }
+            }
         }
-    } else {
+
+        // ---- stage 2: winner's warp (8 or 16 B per cell), all four loads in flight together; the
+        //      coordinates are parked in this thread's own LDS slots (the slots later receive the cell's
+        //      outputs), so the geometry loop below carries no per-cell register arrays ------------------
 #pragma unroll
         for (int e = 0; e < kCpt; ++e) {
-            bj[e] = 0;
-            if (cell0 + e < HW) { float b; cell_best(L, S, cell0 + e, b, bj[e]); }
+            float xan = 0.0f, yan = 0.0f, xbn = 0.0f, ybn = 0.0f;
+            if (cell0 + e < HW) cell_coords(L, S, cell0 + e, bj[e], xan, yan, xbn, ybn);
+            const int sl = tid * kCpt + e;
+            stage.xyz[3 * sl + 0] = xan; stage.xyz[3 * sl + 1] = yan; stage.xyz[3 * sl + 2] = xbn;
+            stage.err[sl] = ybn;
+            stage.slot[sl] = (unsigned char)bj[e];
         }
-    }
 
-    // ---- stage 2: winner's warp (8 or 16 B per cell), issued together so the loads overlap --------
-    float xan[kCpt], yan[kCpt], xbn[kCpt], ybn[kCpt];
-#pragma unroll
-    for (int e = 0; e < kCpt; ++e) {
-        xan[e] = yan[e] = xbn[e] = ybn[e] = 0.0f;
-        if (cell0 + e < HW) cell_coords(L, S, cell0 + e, bj[e], xan[e], yan[e], xbn[e], ybn[e]);
-    }
-
-    // ---- stage 3: per-correspondence geometry ---------------------------------------------------
-    float ox[kCpt], oy[kCpt], oz[kCpt], oe[kCpt], opx[kCpt], opy[kCpt];
-    unsigned keep_bits = 0;
-#pragma unroll
-    for (int e = 0; e < kCpt; ++e) {
-        LfdCellResult res;
-        res.keep = 0; res.x = res.y = res.z = res.err = res.xa_px = res.ya_px = 0.0f;
-        if (cell0 + e < HW) lfd_eval_correspondence(S.rc, S.pc[bj[e]], xan[e], yan[e], xbn[e], ybn[e], L.kp, res);
-        ox[e] = res.x; oy[e] = res.y; oz[e] = res.z; oe[e] = res.err; opx[e] = res.xa_px; opy[e] = res.ya_px;
-        keep_bits |= (res.keep ? 1u : 0u) << e;
-    }
-
-    // ---- stage 4: ordered compaction: thread -> wave -> workgroup -> grid (look-back) ----------------
-    const unsigned my_cnt = __popc(keep_bits);
-    unsigned incl = my_cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned n = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += n;
-    }
-    if (lane == 63) s_wave_cnt[wave] = incl;
-    // survivors per neighbour slot (order-independent integer sums)
-    for (int j = 0; j < ns; ++j) {
-        unsigned c = 0;
-#pragma unroll
-        for (int e = 0; e < kCpt; ++e) c += ((keep_bits >> e) & 1u) && (bj[e] == j);
-        c = (unsigned)wave_sum_u64(c);
-        if (lane == 0 && c) atomicAdd(&s_slot_cnt[j], c);
-    }
-    __syncthreads();
-    unsigned wave_off = 0, block_total = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) {
-        if (w < wave) wave_off += s_wave_cnt[w];
-        block_total += s_wave_cnt[w];
-    }
-    if (wave == 0) {
-        const u64 excl = lookback_exclusive(L.tile_state, L.epoch, ticket, block_total);
-        if (lane == 0) {
-            s_tile_excl = excl;
-            if (tile_in_ref == 0) L.ref_offsets[r] = (long long)excl;
-            if (ticket == (unsigned)(L.n_refs * L.tiles_per_ref) - 1u) L.ref_offsets[L.n_refs] = (long long)(excl + block_total);
+        // ---- stage 3: per-correspondence geometry + colour; survivors overwrite their slot -------------
+        unsigned keep_bits = 0;
+        const float sx_img = 1.0f, sy_img = 1.0f;    // the image handed over is already at match resolution
+#pragma unroll 1
+        for (int e = 0; e < kCpt; ++e) {
+            // re-read the camera constants from LDS every cell instead of pinning ~60 registers on them
+            asm volatile("" ::: "memory");
+            const int sl = tid * kCpt + e;
+            const float xan = stage.xyz[3 * sl + 0], yan = stage.xyz[3 * sl + 1], xbn = stage.xyz[3 * sl + 2];
+            const float ybn = stage.err[sl];
+            const int bje = (int)stage.slot[sl];
+            LfdCellResult res;
+            res.keep = 0; res.x = res.y = res.z = res.err = res.xa_px = res.ya_px = 0.0f;
+#if defined(LFD_ABLATE_EVAL)
+            if (cell0 + e < HW) { res.keep = xbn > -0.9f; res.x = xan; res.y = yan; res.z = xbn; res.err = ybn; res.xa_px = 1.0f; res.ya_px = 1.0f; }
+#else
+            if (cell0 + e < HW) lfd_eval_correspondence(S.rc, S.pc[bje], xan, yan, xbn, ybn, L.kp, res);
+#endif
+            if (res.keep) {
+                float rgb[3];
+#if defined(LFD_ABLATE_COLOUR)
+                rgb[0] = res.xa_px; rgb[1] = res.ya_px; rgb[2] = sx_img + sy_img;
+#else
+                lfd_bilinear_rgb(S.ref.image, L.w_match, L.h_match, res.xa_px, res.ya_px, sx_img, sy_img, rgb);
+#endif
+                stage.xyz[3 * sl + 0] = res.x; stage.xyz[3 * sl + 1] = res.y; stage.xyz[3 * sl + 2] = res.z;
+                stage.rgb[3 * sl + 0] = rgb[0]; stage.rgb[3 * sl + 1] = rgb[1]; stage.rgb[3 * sl + 2] = rgb[2];
+                stage.err[sl] = res.err;
+                keep_bits |= 1u << e;
+            }
+            // survivors per neighbour slot: one ballot per slot, accumulated by lane 0
+            for (int j = 0; j < ns; ++j) {
+                const unsigned c = (unsigned)__popcll(__ballot(res.keep && bje == j));
+                if (lane == 0 && c) atomicAdd(&s_slot_cnt[j], c);
+            }
         }
-    }
-    if (L.seg_counts && tid < ns && s_slot_cnt[tid]) atomicAdd(&L.seg_counts[(size_t)r * L.k + tid], (int)s_slot_cnt[tid]);
-    __syncthreads();
 
-    // ---- stage 5: colour for survivors + write --------------------------------------------------------
-    long long pos = (long long)s_tile_excl + wave_off + (incl - my_cnt);
-    const float sx_img = 1.0f, sy_img = 1.0f;   // the image handed over is already at match resolution
+        // ---- stage 4: ordered compaction: thread -> wave -> workgroup -> grid (look-back) ----------------
+        const unsigned my_cnt = __popc(keep_bits);
+        unsigned incl = my_cnt;
 #pragma unroll
-    for (int e = 0; e < kCpt; ++e) {
-        if (!((keep_bits >> e) & 1u)) continue;
-        if (pos < L.capacity) {
-            float rgb[3];
-            lfd_bilinear_rgb(S.ref.image, L.w_match, L.h_match, opx[e], opy[e], sx_img, sy_img, rgb);
-            L.xyz[pos * 3 + 0] = ox[e]; L.xyz[pos * 3 + 1] = oy[e]; L.xyz[pos * 3 + 2] = oz[e];
-            L.rgb[pos * 3 + 0] = rgb[0]; L.rgb[pos * 3 + 1] = rgb[1]; L.rgb[pos * 3 + 2] = rgb[2];
-            L.err[pos] = oe[e];
-            if (L.cell) L.cell[pos] = cell0 + e;
-            if (L.slot) L.slot[pos] = (uint8_t)bj[e];
-        }   // beyond capacity: counted, not written (the caller compares the total with capacity)
-        ++pos;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned n = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += n;
+        }
+        if (lane == 63) s_wave_cnt[wave] = incl;
+        __syncthreads();                          // s_wave_cnt written
+        unsigned wave_off = 0, block_total = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) {
+            if (w < wave) wave_off += s_wave_cnt[w];
+            block_total += s_wave_cnt[w];
+        }
+        {
+            unsigned lpos = wave_off + (incl - my_cnt);
+#pragma unroll
+            for (int e = 0; e < kCpt; ++e)
+                if ((keep_bits >> e) & 1u) stage.order[lpos++] = (unsigned short)(tid * kCpt + e);
+        }
+        if (wave == 0) {
+#if defined(LFD_ABLATE_LOOKBACK)
+            const u64 excl = (u64)tile * kTile;
+#else
+            const u64 excl = lookback_exclusive(L, tile, block_total);
+#endif
+            if (lane == 0) {
+                s_tile_excl = excl;
+                if (tile_in_ref == 0) L.ref_offsets[r] = (long long)excl;
+                if (tile == n_tiles - 1u) L.ref_offsets[L.n_refs] = (long long)(excl + block_total);
+            }
+        }
+        __syncthreads();                          // staging complete, prefix known
+        if (L.seg_counts && tid < ns && s_slot_cnt[tid]) atomicAdd(&L.seg_counts[(size_t)r * L.k + tid], (int)s_slot_cnt[tid]);
+
+        // ---- stage 5: coalesced copy-out ----------------------------------------------------------------
+        {
+            const long long base = (long long)s_tile_excl;
+            long long room = L.capacity - base;          // beyond capacity: counted, not written
+            int n = (int)block_total;
+            if (room < (long long)n) n = room > 0 ? (int)room : 0;
+#if !defined(LFD_ABLATE_STORES)
+            copy_out_gather<3>(L.xyz + 3 * base, stage.xyz, stage.order, n, tid);
+            copy_out_gather<3>(L.rgb + 3 * base, stage.rgb, stage.order, n, tid);
+            copy_out_gather<1>(L.err + base, stage.err, stage.order, n, tid);
+            if (L.cell) for (int i = tid; i < n; i += kBlock) L.cell[base + i] = tile_cell0 + (int)stage.order[i];
+            if (L.slot) for (int i = tid; i < n; i += kBlock) L.slot[base + i] = stage.slot[stage.order[i]];
+#endif
+        }
     }
 }
 
@@ -442,7 +525,7 @@ extern "C" __global__ void __launch_bounds__(LFD_INDEXED_BLOCK) lfd_indexed_kern
     if (L.seg_counts && tid < L.k) L.seg_counts[(size_t)r * L.k + tid] = (tid < ns) ? (int)s_cnt[tid] : 0;
     __syncthreads();
     if (wave == 0) {
-        const u64 excl = lookback_exclusive(L.tile_state, L.epoch, (unsigned)r, s_total);
+        const u64 excl = lookback_exclusive(L, (unsigned)r, s_total);
         if (lane == 0) {
             s_excl = excl;
             L.ref_offsets[r] = (long long)excl;

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Instruction-mix / stall counters of the fused kernel (rocprofv3 --pmc, 8 SQ counters per pass).
+set -u
+TAG=${1:-mix}; shift || true
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 6 --warmup 2 --cpu-sample-refs 0 $*"
+i=0
+for set in "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32" \
+           "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
+           "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAVES"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o p$i -- python3 $REPO/bench.py $ARGS > $OUT/p$i.log 2>&1
+done
+python3 - <<PY > $OUT/summary.txt
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if row["Kernel_Name"].startswith("lfd_dense"):
+            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k in sorted(acc):
+    v = acc[k]; print(f"{k:32s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
+PY
+cat $OUT/summary.txt
+for f in $(find $OUT -name "*counter_collection.csv" -o -name "*kernel_trace.csv"); do head -1 $f > $f.tmp; grep "lfd_" $f >> $f.tmp; mv $f.tmp $f; done
+find $OUT -name "*.db" -delete
