@@ -48,7 +48,8 @@ def parse_args():
     ap.add_argument("--preset", default="fast", choices=sorted(synthetic.ROMA_PRESETS))
     ap.add_argument("--noise-px", type=float, default=0.5)
     ap.add_argument("--outliers", type=float, default=0.05)
-    ap.add_argument("--cpu-sample-refs", type=int, default=2, help="references timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample-refs", type=int, default=24,
+                    help="references timed on the CPU oracle, ~0.5 s each (0 = skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc run of this same command (profiles/)")
     return ap.parse_args()
@@ -143,6 +144,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # untimed spin-up (clocks, first-touch of the output pages), then the W warm-up steps
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.25:
+        dens.launch_dense(batch, params, out)
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         dens.launch_dense(batch, params, out)
     barrier()
@@ -164,6 +170,7 @@ def main():
     if os.environ.get("LFD_BENCH_DEBUG"):
         print(f"[rank {rank}] per-launch ms: min {min(per_launch):.3f} max {max(per_launch):.3f} mean {kernel_ms:.3f}; "
               f"wall {elapsed * 1e3:.2f} ms for {args.steps} steps", file=sys.stderr)
+    dens.check_launches()
     res = out.collect()
     n_pts = res.count
 

@@ -48,6 +48,8 @@ struct LfdLaunch {              // kernel argument, passed by value
     const float* axis_y;        // [H]
     int32_t n_refs, k, H, W, w_match, h_match, warp_channels, tiles_per_ref;
     float mask_sx, mask_sy;     // (float)w_match/(float)W, (float)h_match/(float)H  (nearest resize)
+    float inv_w;                // 1.0f / W (cell -> row estimate)
+    float pad1;
     LfdKernelParams kp;
     // outputs
     float* xyz;

@@ -142,14 +142,14 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
 // ---- smallest right singular vector of a 4x4 matrix, f64 ---------------------------------------
 // adj(A) = det(A) A^-1, so G = adj(A) adj(A)^T = det(A)^2 (A^T A)^-1 has the right singular vectors
 // of A as eigenvectors with eigenvalues prod_{j!=i} sigma_j^2: the wanted vector v4 dominates by the
-// factor (sigma_3/sigma_4)^2.  Repeated squaring of G (each squaring squares that factor) converges
-// to a multiple of v4 v4^T; for a PSD matrix trace(G^2) = trace(G)^2 exactly when rank 1, so
-// trace(G)^2 - trace(G^2) <= tol * trace(G)^2  (~ 2*lambda_2/lambda_1 <= tol) is the stopping test.
-// No pivoting and no division: G is rescaled by an exact power of two before each squaring.  Unlike
+// factor (sigma_3/sigma_4)^2.  Squaring G squares that factor and every product of the squared matrix
+// with its own dominant column multiplies the remaining error by it again; for a PSD matrix
+// trace(G)^2 - trace(G^2) ~ 2*(lambda_2/lambda_1)*trace(G)^2 measures the factor, which fixes the number
+// of products up front.  No pivoting and no division: G is rescaled once by an exact power of two.  Unlike
 // eig(A^T A) the conditioning is that of A, not of A^T A: the entries of A are f32, so every 2x2
 // minor is the difference of two EXACT f64 products (fma below changes nothing there).
 #ifndef LFD_NULLVEC_TOL
-#define LFD_NULLVEC_TOL 2e-8
+#define LFD_NULLVEC_TOL 2e-8   /* legacy knob (the product count is derived from the trace test) */
 #endif
 #ifndef LFD_NULLVEC_MAXIT
 #define LFD_NULLVEC_MAXIT 6
@@ -218,37 +218,56 @@ LFD_HD int lfd_null_vector(const float* Af, double* c) {
         g22 = fma(j2, j2, g22); g23 = fma(j2, j3, g23); g33 = fma(j3, j3, g33);
     }
     double tr = (g00 + g11) + (g22 + g33);
-    {   // one exact power-of-two rescale to trace in [0.5, 1): six squarings then stay far inside the
-        // f64 range (trace(G^2) is between trace(G)^2/4 and trace(G)^2), so the loop needs no rescaling
+    {   // one exact power-of-two rescale to trace in [0.5, 1): the squarings below then stay far inside
+        // the f64 range (trace(G^2) lies between trace(G)^2/4 and trace(G)^2)
         const double s = lfd_pow2_inv_scale(tr);
         g00 *= s; g01 *= s; g02 *= s; g03 *= s; g11 *= s; g12 *= s; g13 *= s; g22 *= s; g23 *= s; g33 *= s;
         tr *= s;
     }
-    int it = 0;
-    for (; it < LFD_NULLVEC_MAXIT; ++it) {
-        const double t1 = tr;
-        const double h00 = fma(g03, g03, fma(g02, g02, fma(g01, g01, g00 * g00)));
-        const double h01 = fma(g03, g13, fma(g02, g12, fma(g01, g11, g00 * g01)));
-        const double h02 = fma(g03, g23, fma(g02, g22, fma(g01, g12, g00 * g02)));
-        const double h03 = fma(g03, g33, fma(g02, g23, fma(g01, g13, g00 * g03)));
-        const double h11 = fma(g13, g13, fma(g12, g12, fma(g11, g11, g01 * g01)));
-        const double h12 = fma(g13, g23, fma(g12, g22, fma(g11, g12, g01 * g02)));
-        const double h13 = fma(g13, g33, fma(g12, g23, fma(g11, g13, g01 * g03)));
-        const double h22 = fma(g23, g23, fma(g22, g22, fma(g12, g12, g02 * g02)));
-        const double h23 = fma(g23, g33, fma(g22, g23, fma(g12, g13, g02 * g03)));
-        const double h33 = fma(g33, g33, fma(g23, g23, fma(g13, g13, g03 * g03)));
+    // H = G^2.  q = lambda_2/lambda_1 of G follows from the traces: tr(G)^2 - tr(G^2) ~ 2 q tr(G)^2.
+    // The dominant column of H is off by q^2; every further product with H multiplies that by q^2, so
+    // the number of products needed for a 1e-9-ish error is known up front (no per-step test); only
+    // badly conditioned cells (q > 0.06, i.e. sigma_4/sigma_3 > 0.25) keep squaring.
+    int it = 1;
+    double h00, h01, h02, h03, h11, h12, h13, h22, h23, h33, trh, q2t;
+    for (;;) {
+#define LFD_SQUARE()                                                                  \
+        h00 = fma(g03, g03, fma(g02, g02, fma(g01, g01, g00 * g00)));                  \
+        h01 = fma(g03, g13, fma(g02, g12, fma(g01, g11, g00 * g01)));                  \
+        h02 = fma(g03, g23, fma(g02, g22, fma(g01, g12, g00 * g02)));                  \
+        h03 = fma(g03, g33, fma(g02, g23, fma(g01, g13, g00 * g03)));                  \
+        h11 = fma(g13, g13, fma(g12, g12, fma(g11, g11, g01 * g01)));                  \
+        h12 = fma(g13, g23, fma(g12, g22, fma(g11, g12, g01 * g02)));                  \
+        h13 = fma(g13, g33, fma(g12, g23, fma(g11, g13, g01 * g03)));                  \
+        h22 = fma(g23, g23, fma(g22, g22, fma(g12, g12, g02 * g02)));                  \
+        h23 = fma(g23, g33, fma(g22, g23, fma(g12, g13, g02 * g03)));                  \
+        h33 = fma(g33, g33, fma(g23, g23, fma(g13, g13, g03 * g03)));                  \
+        trh = (h00 + h11) + (h22 + h33);                                               \
+        q2t = tr * tr - trh                 /* ~ 2 q tr^2 */
+        LFD_SQUARE();
+        if (!(q2t > 0.12 * (tr * tr)) || it >= LFD_NULLVEC_MAXIT) break;   // q <= 0.06 (or NaN): finish below
         g00 = h00; g01 = h01; g02 = h02; g03 = h03; g11 = h11; g12 = h12; g13 = h13; g22 = h22; g23 = h23; g33 = h33;
-        tr = (g00 + g11) + (g22 + g33);
-        const double t2 = t1 * t1;
-        if (!((t2 - tr) > LFD_NULLVEC_TOL * t2)) { ++it; break; }   // rank 1 reached (also leaves on NaN)
+        tr = trh;
+        ++it;
     }
-    // dominant column = column of the largest diagonal entry
-    double best = g00;
-    c[0] = g00; c[1] = g01; c[2] = g02; c[3] = g03;
-    if (g11 > best) { best = g11; c[0] = g01; c[1] = g11; c[2] = g12; c[3] = g13; }
-    if (g22 > best) { best = g22; c[0] = g02; c[1] = g12; c[2] = g22; c[3] = g23; }
-    if (g33 > best) { best = g33; c[0] = g03; c[1] = g13; c[2] = g23; c[3] = g33; }
-    return it;
+#undef LFD_SQUARE
+    // dominant column of H = column of its largest diagonal entry
+    double best = h00;
+    c[0] = h00; c[1] = h01; c[2] = h02; c[3] = h03;
+    if (h11 > best) { best = h11; c[0] = h01; c[1] = h11; c[2] = h12; c[3] = h13; }
+    if (h22 > best) { best = h22; c[0] = h02; c[1] = h12; c[2] = h22; c[3] = h23; }
+    if (h33 > best) { best = h33; c[0] = h03; c[1] = h13; c[2] = h23; c[3] = h33; }
+    // error of c is q^2; products needed: 0 if q <= 1e-4, 1 if q <= 3e-3, 2 if q <= 2e-2, else 3
+    const double t2 = tr * tr;
+    const int extra = (q2t > 2e-4 * t2) + (q2t > 6e-3 * t2) + (q2t > 4e-2 * t2);
+    for (int m = 0; m < extra; ++m) {
+        const double y0 = fma(h03, c[3], fma(h02, c[2], fma(h01, c[1], h00 * c[0])));
+        const double y1 = fma(h13, c[3], fma(h12, c[2], fma(h11, c[1], h01 * c[0])));
+        const double y2 = fma(h23, c[3], fma(h22, c[2], fma(h12, c[1], h02 * c[0])));
+        const double y3 = fma(h33, c[3], fma(h23, c[2], fma(h13, c[1], h03 * c[0])));
+        c[0] = y0; c[1] = y1; c[2] = y2; c[3] = y3;
+    }
+    return it + extra;
 }
 
 // a / b for f64 with ONE division shared by several numerators: r = RN(1/b); q = RN(a*r);
@@ -263,6 +282,15 @@ LFD_HD float lfd_match_px(float n, float size_m1) {   // (n + 1.0) * 0.5 * (size
     return ((n + 1.0f) * 0.5f) * size_m1;
 }
 
+// a / b in f32 from r = RN(1/b): q = RN(a*r); q' = RN(q + (a - b*q)*r) is the correctly rounded quotient
+// (Markstein), i.e. bit-identical to the IEEE division, whenever the intermediate products stay in
+// the normal range; otherwise (overflow / NaN somewhere) fall back to the division itself.
+LFD_HD float lfd_div_by_recip_f32(float a, float b, float r) {
+    const float q = a * r;
+    const float q1 = fmaf(fmaf(-b, q, a), r, q);
+    return (fabsf(q1) <= 3.402823466e+38f && fabsf(q) >= 1.17549435e-38f) ? q1 : a / b;
+}
+
 LFD_HD float lfd_proj_row(const float* P, int row, float X0, float X1, float X2, float X3) {
     // (X @ P.T)[row] as sgemm accumulates it: forward FMA chain over the 4 terms
     const float* p = P + row * 4;
@@ -274,8 +302,9 @@ LFD_HD float lfd_reproj(const float* P, float X0, float X1, float X2, float X3, 
     const float py = lfd_proj_row(P, 1, X0, X1, X2, X3);
     pz = lfd_proj_row(P, 2, X0, X1, X2, X3);
     const float z = (pz < 1e-12f) ? 1e-12f : pz;          // np.maximum(z, 1e-12): NaN stays NaN
-    const float du = px / z - u;
-    const float dv = py / z - v;
+    const float rz = 1.0f / z;                             // one division, two correctly rounded quotients
+    const float du = lfd_div_by_recip_f32(px, z, rz) - u;
+    const float dv = lfd_div_by_recip_f32(py, z, rz) - v;
     return sqrtf(du * du + dv * dv);
 }
 
@@ -350,8 +379,9 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
         float b0 = X0 - pc.C[0], b1 = X1 - pc.C[1], b2 = X2 - pc.C[2];
         const float na = sqrtf((a0 * a0 + a1 * a1) + a2 * a2) + 1e-12f;
         const float nb = sqrtf((b0 * b0 + b1 * b1) + b2 * b2) + 1e-12f;
-        a0 /= na; a1 /= na; a2 /= na;
-        b0 /= nb; b1 /= nb; b2 /= nb;
+        const float ra = 1.0f / na, rb = 1.0f / nb;
+        a0 = lfd_div_by_recip_f32(a0, na, ra); a1 = lfd_div_by_recip_f32(a1, na, ra); a2 = lfd_div_by_recip_f32(a2, na, ra);
+        b0 = lfd_div_by_recip_f32(b0, nb, rb); b1 = lfd_div_by_recip_f32(b1, nb, rb); b2 = lfd_div_by_recip_f32(b2, nb, rb);
         const float dot = (a0 * b0 + a1 * b1) + a2 * b2;
         keep = dot <= kp.dot_thresh;      // == degrees(arccos(clip(dot,-1,1))) >= min_deg
     }

@@ -109,23 +109,38 @@ struct BlockShared {
 };
 
 __device__ __forceinline__ void block_prologue(const LfdLaunch& L, int r, BlockShared& S) {
+    // One level of global loads, then one barrier: the descriptors and the per-pair constants of all k
+    // slots of reference r are fetched together (rows of unused slots are never read afterwards).
     const int tid = (int)threadIdx.x;
-    if (tid == 0) S.ref = L.refs[r];
-    if (tid < L.k) S.slot[tid] = L.slots[(size_t)r * L.k + tid];
-    __syncthreads();
-    // per-pair constants (P, C, pixel scales, F) were derived once per batch by lfd_pair_setup_kernel;
-    // stage this reference's rows in LDS with coalesced dword copies
-    const int ns = S.ref.n_slots;
     {
         const unsigned* src = reinterpret_cast<const unsigned*>(L.pair_const + (size_t)r * L.k);
         unsigned* dst = reinterpret_cast<unsigned*>(S.pc);
-        const int nw = ns * (int)(sizeof(LfdPairConst) / 4);
+        const int nw = L.k * (int)(sizeof(LfdPairConst) / 4);
         for (int i = tid; i < nw; i += (int)blockDim.x) dst[i] = src[i];
+        const unsigned* ssrc = reinterpret_cast<const unsigned*>(L.slots + (size_t)r * L.k);
+        unsigned* sdst = reinterpret_cast<unsigned*>(S.slot);
+        const int nsw = L.k * (int)(sizeof(LfdSlotDesc) / 4);
+        for (int i = tid; i < nsw; i += (int)blockDim.x) sdst[i] = ssrc[i];
         const unsigned* rsrc = reinterpret_cast<const unsigned*>(L.ref_const + r);
         unsigned* rdst = reinterpret_cast<unsigned*>(&S.rc);
         if (tid < (int)(sizeof(LfdRefConst) / 4)) rdst[tid] = rsrc[tid];
+        const unsigned* dsrc = reinterpret_cast<const unsigned*>(L.refs + r);
+        unsigned* ddst = reinterpret_cast<unsigned*>(&S.ref);
+        if (tid >= 64 && tid < 64 + (int)(sizeof(LfdRefDesc) / 4)) ddst[tid - 64] = dsrc[tid - 64];
     }
     __syncthreads();
+}
+
+// cell -> (row, column) without an integer division: float estimate + one-step correction (exact for
+// cell < 2^24 * ... any grid this library accepts: cell < 2^31, W < 2^16)
+__device__ __forceinline__ void lfd_divmod(int cell, int W, float inv_w, int& y, int& x) {
+    int q = (int)((float)cell * inv_w);
+    int r = cell - q * W;
+    if (r < 0) { --q; r += W; }
+    if (r >= W) { ++q; r -= W; }
+    if (r < 0) { --q; r += W; }
+    if (r >= W) { ++q; r -= W; }
+    y = q; x = r;
 }
 
 // certainty of one slot at one cell after the prologue of core/pipeline.py:407-430
@@ -158,7 +173,8 @@ __device__ __forceinline__ void argmax_step(float c, int j, float& best, int& bj
 }
 
 __device__ __forceinline__ void cell_best(const LfdLaunch& L, const BlockShared& S, int cell, float& best, int& bj) {
-    const int y = cell / L.W, x = cell - y * L.W;
+    int y, x;
+    lfd_divmod(cell, L.W, L.inv_w, y, x);
     const float ma = cell_mask_a(L, S, x, y);
     const int ns = S.ref.n_slots;
     best = cell_cert(L, S, 0, cell, x, y, S.slot[0].cert[cell], ma);
@@ -175,7 +191,8 @@ __device__ __forceinline__ void cell_coords(const LfdLaunch& L, const BlockShare
         xan = v.x; yan = v.y; xbn = v.z; ybn = v.w;
     } else {
         const float2 v = *reinterpret_cast<const float2*>(wp + (size_t)cell * 2);
-        const int y = cell / L.W, x = cell - y * L.W;
+        int y, x;
+        lfd_divmod(cell, L.W, L.inv_w, y, x);
         xan = L.axis_x[x]; yan = L.axis_y[y];
         xbn = v.x; ybn = v.y;
     }
