@@ -55,6 +55,22 @@ def parse_args():
     return ap.parse_args()
 
 
+def traffic_bytes(args):
+    """HBM bytes per launch of the fused kernel: --traffic-bytes, else the committed PMC measurement
+    (profiles/traffic.json) when it was taken on this same workload, else null."""
+    if args.traffic_bytes is not None:
+        return args.traffic_bytes
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            t = json.load(fh)
+        w = t.get("workload", {})
+        if (w.get("refs"), w.get("k"), w.get("preset")) == (args.refs, args.k, args.preset):
+            return float(t["traffic_bytes"])
+    except Exception:
+        pass
+    return None
+
+
 def build_workload(args, rank, world, dev):
     """Global reference list dealt round-robin; this rank generates and keeps only its share."""
     h_lr, w_lr, H, W = synthetic.ROMA_PRESETS[args.preset]
@@ -212,7 +228,7 @@ def main():
             "survivor_fraction": s_frac,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": args.traffic_bytes,
+                         "traffic": traffic_bytes(args),
                          "kernel": "lfd_dense_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_cell": bytes_per_cell},
         }
