@@ -119,6 +119,22 @@ int lfd_triangulate_indexed(lfd_context* ctx, const lfd_batch* batch, const lfd_
                             const int64_t* sel_idx, const int64_t* sel_offsets, const lfd_points* out,
                             int64_t* ref_offsets, int32_t* seg_counts, int32_t* seg_order);
 
+/* S: coverage sampling on the device (core/sampling.py:8-53, filter mode).  The context owns a legacy
+ * MT19937 stream seeded like np.random.seed(seed); every call consumes it exactly as upstream's
+ * np.random.choice does, so successive references see the same stream upstream would.
+ * best_cert: device f32 [H*W] (one reference, from lfd_aggregate).  sel_out: device i64 [capacity],
+ * ascending cell indices (capacity >= M + tiles*tiles is always enough).  Synchronises; the count and
+ * a status (0 ok; 1 NaN, 2 negative, 3 "Fewer non-zero entries in p than size" - the conditions
+ * under which upstream's np.random.choice raises ValueError; 4.. internal) are returned on the host.
+ * s_override > 0 replaces the normaliser sum(weights) (upstream's is a torch f32 reduction whose
+ * rounding depends on the host's thread count; the device uses the correctly rounded exact sum). */
+int lfd_rng_seed(lfd_context* ctx, uint32_t seed);
+int lfd_rng_get_state(lfd_context* ctx, uint32_t* key624_host, int32_t* pos_host);
+int lfd_rng_set_state(lfd_context* ctx, const uint32_t* key624_host, int32_t pos);
+int lfd_select_samples(lfd_context* ctx, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
+                       int32_t border, int32_t tiles, float s_override, int64_t* sel_out, int64_t capacity,
+                       int32_t* n_sel_host, int32_t* status_host);
+
 /* Synchronise the context's stream and report whether the last launches completed normally.
  * *status_out = 0, or 1 when a bounded look-back spin gave up (results invalid; returns LFD_ERR_HIP). */
 int lfd_launch_status(lfd_context* ctx, int32_t* status_out);

@@ -82,6 +82,11 @@ def load_library() -> C.CDLL:
                                             C.POINTER(C.c_int64), C.POINTER(lfd_points), C.c_void_p, C.c_void_p,
                                             C.c_void_p]
     lib.lfd_launch_status.argtypes = [ctxp, C.POINTER(C.c_int32)]
+    lib.lfd_rng_seed.argtypes = [ctxp, C.c_uint32]
+    lib.lfd_rng_get_state.argtypes = [ctxp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+    lib.lfd_rng_set_state.argtypes = [ctxp, C.POINTER(C.c_uint32), C.c_int32]
+    lib.lfd_select_samples.argtypes = [ctxp, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32,
+                                       C.c_float, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.lfd_identity_axis.argtypes = [C.c_int32, fptr]
     lib.lfd_parallax_dot_threshold.argtypes = [C.c_float]
     lib.lfd_parallax_dot_threshold.restype = C.c_float
@@ -89,7 +94,8 @@ def load_library() -> C.CDLL:
     lib.lfd_host_eval_correspondence.argtypes = [fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                                  C.c_int32, C.POINTER(lfd_params), fptr]
     for name in ("lfd_create", "lfd_set_stream", "lfd_upload_cameras", "lfd_aggregate", "lfd_triangulate_dense",
-                 "lfd_triangulate_indexed", "lfd_launch_status", "lfd_identity_axis", "lfd_host_fundamental",
+                 "lfd_triangulate_indexed", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
+                 "lfd_select_samples", "lfd_identity_axis", "lfd_host_fundamental",
                  "lfd_host_eval_correspondence"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
@@ -328,6 +334,42 @@ class HipDensifier:
         """Synchronise and raise if a kernel reported a look-back timeout."""
         st = C.c_int32(0)
         self._check(self._lib.lfd_launch_status(self._ctx, C.byref(st)), "lfd_launch_status")
+
+    # -- S: selection stage on the device ----------------------------------------------------------------
+    def seed_rng(self, seed: int) -> None:
+        """Seed the context's legacy MT19937 stream like ``np.random.seed(seed)``."""
+        self._check(self._lib.lfd_rng_seed(self._ctx, C.c_uint32(int(seed) & 0xFFFFFFFF)), "lfd_rng_seed")
+
+    def rng_state(self):
+        key = (C.c_uint32 * 624)()
+        pos = C.c_int32(0)
+        self._check(self._lib.lfd_rng_get_state(self._ctx, key, C.byref(pos)), "lfd_rng_get_state")
+        return np.frombuffer(key, dtype=np.uint32).copy(), int(pos.value)
+
+    def set_rng_state(self, key: np.ndarray, pos: int) -> None:
+        k = np.ascontiguousarray(key, dtype=np.uint32)
+        self._check(self._lib.lfd_rng_set_state(self._ctx, k.ctypes.data_as(C.POINTER(C.c_uint32)), int(pos)),
+                    "lfd_rng_set_state")
+
+    def select_samples(self, best_cert: torch.Tensor, M: int, cap: float = 0.9, border: int = 2, tiles: int = 24,
+                       s_override: float = 0.0) -> torch.Tensor:
+        """Coverage sampling (filter mode) of one reference's aggregated certainty map on the device;
+        returns the selected cells (int64 device tensor, ascending).  Raises ValueError in the cases
+        upstream's ``np.random.choice`` does."""
+        if best_cert.dtype != torch.float32 or not best_cert.is_cuda or best_cert.dim() != 2:
+            raise ValueError("best_cert must be a 2-D float32 device tensor")
+        bc = best_cert.contiguous()
+        H, W = bc.shape
+        cap_n = int(M) + int(tiles) * int(tiles) + 64
+        out = torch.empty((cap_n,), dtype=torch.int64, device=bc.device)
+        n = C.c_int32(0)
+        st = C.c_int32(0)
+        rc = self._lib.lfd_select_samples(self._ctx, bc.data_ptr(), H, W, int(M), C.c_float(cap), int(border), int(tiles),
+                                          C.c_float(s_override), out.data_ptr(), cap_n, C.byref(n), C.byref(st))
+        if rc != 0 and st.value in (1, 2, 3):
+            raise ValueError(self._lib.lfd_last_error(self._ctx).decode().replace("selection: ", ""))
+        self._check(rc, "lfd_select_samples")
+        return out[:int(n.value)]
 
     # -- launches (asynchronous on self.stream) -------------------------------------------------------
     def launch_aggregate(self, batch: PreparedBatch, params: lfd_params, best_cert: torch.Tensor,

@@ -197,8 +197,12 @@ def _as_device_maps(results, dev) -> Tuple[List[torch.Tensor], List[torch.Tensor
     return warps, certs
 
 
+def _reference_seed(seed: int, uid: int) -> int:
+    return (int(seed) * 1000003 + int(uid) * 7919 + 12345) & 0xFFFFFFFF
+
+
 def _reference_rng(seed: int, uid: int) -> np.random.RandomState:
-    return np.random.RandomState((int(seed) * 1000003 + int(uid) * 7919 + 12345) & 0xFFFFFFFF)
+    return np.random.RandomState(_reference_seed(seed, uid))
 
 
 def _build_preview(packed: _PackedReference, slot: int, cams, matches: np.ndarray, cert_norm: np.ndarray,
@@ -250,16 +254,24 @@ class _HotPath:
             mask_a=torch.from_numpy(np.array(packed.mask_a, dtype=np.uint8, copy=True)).to(dev) if packed.mask_a is not None else None,
             mask_b=mask_b)
 
-    def sampled(self, ref: hb.ReferenceInputs, axes, rng) -> Tuple[Optional[hb.TriangulationOutput], Optional[torch.Tensor]]:
-        """aggregate (GPU) -> coverage sampling (host stage, see core/sampling.py) -> indexed kernel (GPU)."""
+    def sampled(self, ref: hb.ReferenceInputs, axes, rng, device_seed: Optional[int]
+                ) -> Tuple[Optional[hb.TriangulationOutput], Optional[torch.Tensor]]:
+        """aggregate kernel -> coverage sampling -> indexed kernel.  The sampling stage runs on the
+        device (lfd_select_samples, consuming the context's MT19937 stream) unless the configuration
+        asks for the host stage or no_filter is set (top-M by argsort: core/sampling.py)."""
         batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes)
         best, _ = self.dens.aggregate(batch, self.params)
-        sel = select_samples_with_coverage(best[0], self.config.matches_per_ref, cap=self.sample_cap, border=2,
-                                           tiles=24, no_filter=self.config.no_filter, rng=rng)
-        if sel.size == 0:
+        if self.config.selection_backend == "device" and not self.config.no_filter:
+            if device_seed is not None:
+                self.dens.seed_rng(device_seed)
+            sel_t = self.dens.select_samples(best[0], self.config.matches_per_ref, cap=self.sample_cap, border=2, tiles=24)
+        else:
+            sel = select_samples_with_coverage(best[0], self.config.matches_per_ref, cap=self.sample_cap, border=2,
+                                               tiles=24, no_filter=self.config.no_filter, rng=rng)
+            sel_t = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int64)).to(self.dev)
+        if sel_t.numel() == 0:
             return None, best[0]
-        sel_t = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int64)).to(self.dev)
-        out = self.dens.triangulate_indexed(batch, self.params, sel_t, [0, int(sel.size)])
+        out = self.dens.triangulate_indexed(batch, self.params, sel_t, [0, int(sel_t.numel())])
         return (out if out.count else None), best[0]
 
     def dense(self, refs: List[hb.ReferenceInputs], axes) -> hb.TriangulationOutput:
@@ -362,6 +374,7 @@ def run_dense_pipeline(
 
         w_match, h_match = int(matcher.w_resized), int(matcher.h_resized)
         hot = _HotPath(camera_records, config, float(matcher.sample_thresh), w_match, h_match, dev, densifier)
+        hot.dens.seed_rng(int(config.seed))      # upstream: np.random.seed(config.seed) (core/pipeline.py:793)
         jobs = [(lambda p=p: _pack_reference(p, refs_local[p], camera_records, nn_table, config.nns_per_ref,
                                              (w_match, h_match), cancel_requested)) for p in my_positions]
         prefetch = _OrderedPrefetcher(jobs, workers=int(getattr(config, "pack_workers", 4)),
@@ -454,7 +467,8 @@ def run_dense_pipeline(
 
             try:
                 rng = _reference_rng(config.seed, packed.ref_uid) if per_ref_rng else stream_rng
-                out, best = hot.sampled(ref, axes, rng)
+                dseed = _reference_seed(config.seed, packed.ref_uid) if per_ref_rng else None
+                out, best = hot.sampled(ref, axes, rng, dseed)
             except Exception as ex:
                 log.error(f"Triangulation error for ref {packed.ref_uid}: {ex}")
                 out = None

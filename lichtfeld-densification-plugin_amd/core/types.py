@@ -46,6 +46,10 @@ class DensePipelineConfig:
     # forced on when references are sharded over several GPUs (results then do not depend on
     # the shard count).
     per_reference_rng: bool = False
+    # where the coverage-sampling stage of the "sampled" mode runs: "device" (lfd_select_samples: the
+    # whole per-reference path stays on the GPU) or "host" (core/sampling.py: the library calls
+    # upstream makes, including torch's own f32 sum as the normaliser).  no_filter always uses "host".
+    selection_backend: str = "device"
 
     def __post_init__(self) -> None:
         if self.triangulation_mode not in TRIANGULATION_MODES:
@@ -53,6 +57,8 @@ class DensePipelineConfig:
                              f"got {self.triangulation_mode!r}")
         if int(self.refs_per_launch) < 1:
             raise ValueError("refs_per_launch must be >= 1")
+        if self.selection_backend not in ("device", "host"):
+            raise ValueError("selection_backend must be 'device' or 'host'")
 
 
 @dataclasses.dataclass

@@ -15,6 +15,8 @@
 extern "C" __global__ void lfd_aggregate_kernel(LfdLaunch L, float* best_cert, uint8_t* best_slot);
 extern "C" __global__ void lfd_dense_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* ref_out, LfdPairConst* pair_out);
+extern "C" __global__ void lfd_select_filter_kernel(LfdSelectArgs A);
+extern "C" __global__ void lfd_mt_seed_kernel(unsigned* mt, unsigned seed);
 extern "C" __global__ void lfd_indexed_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets,
                                               float* scratch, uint8_t* codes, int32_t* seg_order);
 
@@ -58,6 +60,9 @@ struct lfd_context {
     int consts_wm = 0, consts_hm = 0;
     // indexed-mode scratch
     DeviceBuffer scratch, codes;
+    // selection stage: legacy MT19937 stream (625 words) + scratch
+    DeviceBuffer mt, sel_scratch;
+    bool mt_seeded = false;
 };
 
 namespace {
@@ -305,7 +310,7 @@ void lfd_destroy(lfd_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes})
+    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->mt, &ctx->sel_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_free) (void)hipEventDestroy(ctx->pinned_free);
@@ -429,6 +434,95 @@ int lfd_triangulate_indexed(lfd_context* ctx, const lfd_batch* batch, const lfd_
                        reinterpret_cast<const long long*>(sel_idx), d_off, static_cast<float*>(ctx->scratch.ptr),
                        static_cast<uint8_t*>(ctx->codes.ptr), seg_order);
     LFD_HIP(ctx, hipGetLastError());
+    return LFD_OK;
+}
+
+// ---- S: selection ---------------------------------------------------------------------------------
+int lfd_rng_seed(lfd_context* ctx, uint32_t seed) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, ctx->mt, 625 * sizeof(unsigned));
+    if (rc != LFD_OK) return rc;
+    hipLaunchKernelGGL(lfd_mt_seed_kernel, dim3(1), dim3(64), 0, ctx->stream, static_cast<unsigned*>(ctx->mt.ptr), seed);
+    LFD_HIP(ctx, hipGetLastError());
+    ctx->mt_seeded = true;
+    return LFD_OK;
+}
+
+int lfd_rng_get_state(lfd_context* ctx, uint32_t* key624, int32_t* pos) {
+    if (!ctx || !key624 || !pos) return fail(ctx, LFD_ERR_INVALID, "null argument");
+    if (!ctx->mt_seeded) return fail(ctx, LFD_ERR_STATE, "lfd_rng_seed / lfd_rng_set_state must be called first");
+    unsigned host[625];
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    LFD_HIP(ctx, hipMemcpyAsync(host, ctx->mt.ptr, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(key624, host, 624 * sizeof(unsigned));
+    *pos = (int32_t)host[624];
+    return LFD_OK;
+}
+
+int lfd_rng_set_state(lfd_context* ctx, const uint32_t* key624, int32_t pos) {
+    if (!ctx || !key624 || pos < 0 || pos > 624) return fail(ctx, LFD_ERR_INVALID, "bad MT19937 state");
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, ctx->mt, 625 * sizeof(unsigned));
+    if (rc != LFD_OK) return rc;
+    unsigned host[625];
+    std::memcpy(host, key624, 624 * sizeof(unsigned));
+    host[624] = (unsigned)pos;
+    LFD_HIP(ctx, hipMemcpyAsync(ctx->mt.ptr, host, sizeof(host), hipMemcpyHostToDevice, ctx->stream));
+    LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->mt_seeded = true;
+    return LFD_OK;
+}
+
+int lfd_select_samples(lfd_context* ctx, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
+                       int32_t border, int32_t tiles, float s_override, int64_t* sel_out, int64_t capacity,
+                       int32_t* n_sel_host, int32_t* status_host) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (!best_cert || !sel_out || !n_sel_host || !status_host) return fail(ctx, LFD_ERR_INVALID, "null argument");
+    if (H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL || M < 0 || tiles <= 0 || border < 0 || capacity < 0)
+        return fail(ctx, LFD_ERR_INVALID, "bad selection arguments");
+    if (!ctx->mt_seeded) return fail(ctx, LFD_ERR_STATE, "lfd_rng_seed must be called before lfd_select_samples");
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)H * W, Mz = (size_t)std::max(M, 1);
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t o_w = 0, o_p = o_w + up(N * 4), o_cdf = o_p + up(N * 8), o_first = o_cdf + up(N * 8), o_mark = o_first + up(N * 4),
+                 o_draws = o_mark + up(N), o_cand = o_draws + up(Mz * 8), o_found = o_cand + up(Mz * 4), o_out = o_found + up(Mz * 4),
+                 total = o_out + 256;
+    int rc = ensure(ctx, ctx->sel_scratch, total);
+    if (rc != LFD_OK) return rc;
+    unsigned char* base = static_cast<unsigned char*>(ctx->sel_scratch.ptr);
+    LfdSelectArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.best_cert = best_cert;
+    A.weights = reinterpret_cast<float*>(base + o_w);
+    A.p = reinterpret_cast<double*>(base + o_p);
+    A.cdf = reinterpret_cast<double*>(base + o_cdf);
+    A.first = reinterpret_cast<int*>(base + o_first);
+    A.mark = base + o_mark;
+    A.draws = reinterpret_cast<double*>(base + o_draws);
+    A.cand = reinterpret_cast<int*>(base + o_cand);
+    A.found = reinterpret_cast<int*>(base + o_found);
+    A.mt = static_cast<unsigned*>(ctx->mt.ptr);
+    A.sel_out = reinterpret_cast<long long*>(sel_out);
+    A.n_out = reinterpret_cast<int*>(base + o_out);
+    A.status = reinterpret_cast<int*>(base + o_out + 4);
+    A.capacity = capacity;
+    A.H = H; A.W = W; A.M = M; A.border = border; A.tiles = tiles; A.cap = cap; A.s_override = s_override;
+    hipLaunchKernelGGL(lfd_select_filter_kernel, dim3(1), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A);
+    LFD_HIP(ctx, hipGetLastError());
+    int host[2] = {0, 0};
+    LFD_HIP(ctx, hipMemcpyAsync(host, base + o_out, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_sel_host = host[0];
+    *status_host = host[1];
+    if (host[1] != LFD_SELECT_OK) {
+        static const char* names[] = {"ok", "probabilities contain NaN", "probabilities are not non-negative",
+                                      "Fewer non-zero entries in p than size", "weight below 2^-29: exact parallel cumsum not guaranteed",
+                                      "no progress", "too many coverage bins", "sel_out capacity too small"};
+        return fail(ctx, host[1] == LFD_SELECT_CAPACITY ? LFD_ERR_CAPACITY : LFD_ERR_INVALID,
+                    std::string("selection: ") + names[std::min(host[1], 7)]);
+    }
     return LFD_OK;
 }
 

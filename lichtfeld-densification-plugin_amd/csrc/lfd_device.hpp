@@ -69,3 +69,35 @@ struct LfdLaunch {              // kernel argument, passed by value
     unsigned int pad0;
     unsigned int* status;         // 0 = ok, LFD_LAUNCH_TIMEOUT if a look-back spin gave up
 };
+
+// ---- S: on-device coverage sampling (lfd_select.hip) ---------------------------------------------
+#define LFD_SELECT_BLOCK 1024
+#define LFD_SELECT_MAX_BINS 1024
+#define LFD_SELECT_OK 0
+#define LFD_SELECT_NAN 1             // a weight is NaN           (upstream: ValueError from np.random.choice)
+#define LFD_SELECT_NEGATIVE 2        // a weight is negative      (upstream: ValueError)
+#define LFD_SELECT_FEWER_NONZERO 3   // fewer non-zero weights than draws requested (upstream: ValueError)
+#define LFD_SELECT_INEXACT 4         // a weight < 2^-29: the parallel cumsum would not be exact
+#define LFD_SELECT_NO_PROGRESS 5
+#define LFD_SELECT_TOO_MANY_BINS 6
+#define LFD_SELECT_CAPACITY 7
+
+struct LfdSelectArgs {
+    const float* best_cert;   // [H*W] aggregated certainty of ONE reference (output of lfd_aggregate)
+    float* weights;           // [H*W] scratch: capped, border-masked, normalised f32 weights
+    double* p;                // [H*W] scratch
+    double* cdf;              // [H*W] scratch
+    int* first;               // [H*W] scratch
+    unsigned char* mark;      // [H*W] scratch
+    double* draws;            // [M]   scratch
+    int* cand;                // [M]   scratch
+    int* found;               // [M]   scratch
+    unsigned* mt;             // [625] MT19937 key + position (the context's legacy stream)
+    long long* sel_out;       // [capacity] selected cells, ascending
+    int* n_out;               // [1]
+    int* status;              // [1]
+    long long capacity;
+    int H, W, M, border, tiles;
+    float cap;
+    float s_override;         // > 0: use this normaliser instead of the exact device sum (parity tests)
+};

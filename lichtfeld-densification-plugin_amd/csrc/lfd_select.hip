@@ -1,0 +1,312 @@
+// S: coverage sampling of the aggregated certainty map, on the device
+// (upstream core/sampling.py:8-53 = torch clamp/sum + legacy numpy.random.choice + argsort walk).
+//
+// One 1024-thread workgroup per reference view runs the whole selection: the problem is ~260k
+// weights and ~9k draws, far too small to need the whole chip, and a single workgroup keeps every
+// phase ordered with plain barriers.
+//
+// Restated third-party algorithms (absent from /root/reference; NumPy 2.2.6 numpy/random/mtrand.pyx
+// `RandomState.choice(a, size, replace=False, p)` and `_legacy_seeding`, randomkit's MT19937):
+//   * MT19937: init_genrand(seed) (Knuth multiplier 1812433253), 624-word twist, tempering;
+//     random_sample() = ((a >> 5) * 67108864 + (b >> 6)) / 2^53 from two successive outputs a, b.
+//   * choice without replacement: repeat { x = random_sample(size - n_uniq); p[found] = 0;
+//     cdf = cumsum(p) / cdf[-1]; new = searchsorted(cdf, x, side="right"); keep the first occurrence
+//     of every distinct value, in draw order; append } until `size` distinct cells are found.
+//   * the f64 cumsum is reproduced exactly although it is evaluated as a parallel scan: every p_i is
+//     an f32 value >= 2^-29 or exactly 0 (certainties are floored at certainty_thresh before they get
+//     here), so every partial sum below 1.0 is a multiple of 2^-52 and NO addition rounds - the
+//     result does not depend on the order of the additions.  Inputs that violate the precondition are
+//     detected (LFD_SELECT_INEXACT) and the caller falls back to an ordered single-lane scan.
+//   * upstream's normaliser `s = weights.sum()` is a torch CPU f32 reduction whose rounding depends
+//     on the host's thread count and vector ISA; here s = RN_f32(exact sum), which is what every
+//     such order approximates.  Given the same s the drawn cells are identical to upstream's.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lfd_device.hpp"
+
+namespace {
+
+constexpr int kSelBlock = LFD_SELECT_BLOCK;
+
+// ---- MT19937 --------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mt_temper(unsigned y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// regenerate the 624-word state in place (three dependency-free segments), whole workgroup
+__device__ void mt_twist(unsigned* mt, int tid) {
+    auto mix = [](unsigned a, unsigned b) { const unsigned y = (a & 0x80000000u) | (b & 0x7fffffffu); return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); };
+    // i in [0,227): uses old mt[i], mt[i+1], mt[i+397]
+    unsigned v = 0;
+    if (tid < 227) v = mt[tid + 397] ^ mix(mt[tid], mt[tid + 1]);
+    __syncthreads();
+    if (tid < 227) mt[tid] = v;
+    __syncthreads();
+    // i in [227,454): uses old mt[i], mt[i+1] (i+1 <= 454 still old for i<453; i=453 -> mt[454] old) and NEW mt[i-227]
+    if (tid < 227) { const int i = tid + 227; v = mt[i - 227] ^ mix(mt[i], mt[i + 1]); }
+    __syncthreads();
+    if (tid < 227) mt[tid + 227] = v;
+    __syncthreads();
+    // i in [454,623): uses old mt[i], mt[i+1] and new mt[i-227]; i = 623 uses new mt[0]
+    if (tid < 169) { const int i = tid + 454; v = mt[i - 227] ^ mix(mt[i], mt[i + 1]); }
+    __syncthreads();
+    if (tid < 169) mt[tid + 454] = v;
+    __syncthreads();
+    if (tid == 0) mt[623] = mt[396] ^ mix(mt[623], mt[0]);
+    __syncthreads();
+}
+
+// draws[0..n) = next n legacy random_sample() doubles; mt[624] = position
+__device__ void mt_fill_doubles(unsigned* mt, double* draws, int n, int tid) {
+    __shared__ unsigned s_words[2 * 312];       // one twist yields 624 words = 312 doubles
+    int produced = 0;
+    while (produced < n) {
+        __syncthreads();
+        int pos = (int)mt[624];
+        if (pos >= 624) {
+            mt_twist(mt, tid);
+            if (tid == 0) mt[624] = 0;
+            __syncthreads();
+            pos = 0;
+        }
+        // consume whole pairs from pos; a pair may straddle a twist boundary only if pos is odd at 623,
+        // which cannot be reached from pair-wise consumption starting at an even position... handle
+        // the general case word by word through a small staging buffer
+        const int avail = 624 - pos;
+        const int want_words = 2 * (n - produced);
+        const int take = avail < want_words ? avail : want_words;
+        for (int i = tid; i < take; i += kSelBlock) s_words[i] = mt_temper(mt[pos + i]);
+        __syncthreads();
+        if (take & 1) {
+            // odd number of words left before the twist: the last word pairs with the first of the
+            // next block; generate the next block now and complete the pair
+            const unsigned a = s_words[take - 1];
+            __syncthreads();
+            mt_twist(mt, tid);
+            const unsigned b = mt_temper(mt[0]);
+            const int pairs = take >> 1;
+            for (int i = tid; i < pairs; i += kSelBlock)
+                draws[produced + i] = ((double)(s_words[2 * i] >> 5) * 67108864.0 + (double)(s_words[2 * i + 1] >> 6)) / 9007199254740992.0;
+            if (tid == 0) {
+                draws[produced + pairs] = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+                mt[624] = 1;
+            }
+            produced += pairs + 1;
+        } else {
+            const int pairs = take >> 1;
+            for (int i = tid; i < pairs; i += kSelBlock)
+                draws[produced + i] = ((double)(s_words[2 * i] >> 5) * 67108864.0 + (double)(s_words[2 * i + 1] >> 6)) / 9007199254740992.0;
+            if (tid == 0) mt[624] = (unsigned)(pos + take);
+            produced += pairs;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- workgroup-wide helpers --------------------------------------------------------------------------
+__device__ double block_sum_f64(double v, double* s_tmp, int tid) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) s_tmp[tid >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < kSelBlock / 64; ++w) t += s_tmp[w];
+    return t;
+}
+
+__device__ int block_sum_i32(int v, int* s_tmp, int tid) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) s_tmp[tid >> 6] = v;
+    __syncthreads();
+    int t = 0;
+    for (int w = 0; w < kSelBlock / 64; ++w) t += s_tmp[w];
+    return t;
+}
+
+// exclusive scan of one int per thread, returns (exclusive prefix, workgroup total)
+__device__ int block_excl_scan_i32(int v, int* s_tmp, int tid, int& total) {
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int n = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += n;
+    }
+    __syncthreads();
+    if (lane == 63) s_tmp[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    total = 0;
+    for (int w = 0; w < kSelBlock / 64; ++w) {
+        if (w < wave) base += s_tmp[w];
+        total += s_tmp[w];
+    }
+    return base + incl - v;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter_kernel(LfdSelectArgs A) {
+    __shared__ double s_d[kSelBlock / 64];
+    __shared__ int s_i[kSelBlock / 64];
+    __shared__ double s_chunk[kSelBlock];
+    __shared__ unsigned long long s_bin[LFD_SELECT_MAX_BINS];
+    __shared__ int s_n_uniq, s_kept;
+
+    const int tid = (int)threadIdx.x;
+    const int H = A.H, W = A.W, N = H * W;
+    const float* cert = A.best_cert;
+    float* wbuf = A.weights;
+    double* p = A.p;
+    double* cdf = A.cdf;
+
+    if (tid == 0) { *A.n_out = 0; *A.status = LFD_SELECT_OK; }
+
+    // ---- weights, exact sum, NaN check --------------------------------------------------------------
+    double acc = 0.0;
+    int bad = 0;
+    for (int i = tid; i < N; i += kSelBlock) {
+        const int y = i / W, x = i - y * W;
+        float c = cert[i];
+        c = (c > A.cap) ? A.cap : c;                               // torch.clamp(max=cap); NaN stays
+        const bool inside = x >= A.border && x <= W - 1 - A.border && y >= A.border && y <= H - 1 - A.border;
+        const float w = c * (inside ? 1.0f : 0.0f);
+        wbuf[i] = w;
+        if (w != w) bad = 1;
+        acc += (double)w;
+    }
+    const double s64 = block_sum_f64(acc, s_d, tid);
+    const int any_bad = block_sum_i32(bad, s_i, tid);
+    const float s32 = (A.s_override > 0.0f) ? A.s_override : (float)s64;
+    if (any_bad) { if (tid == 0) *A.status = LFD_SELECT_NAN; return; }
+    if (!(s32 > 0.0f)) return;                                   // upstream: `if s <= 0: return empty`
+
+    // ---- p = (weights / s) as f32, widened; exactness precondition; non-zero count -------------------------
+    int nz = 0, inexact = 0;
+    for (int i = tid; i < N; i += kSelBlock) {
+        const float pf = wbuf[i] / s32;
+        wbuf[i] = pf;                                              // the normalised f32 weights (coverage uses them)
+        p[i] = (double)pf;
+        if (pf > 0.0f) { ++nz; if (pf < 1.862645149230957e-09f) inexact = 1; }   // 2^-29
+        if (pf < 0.0f) bad = 1;
+    }
+    nz = block_sum_i32(nz, s_i, tid);
+    inexact = block_sum_i32(inexact, s_i, tid);
+    const int neg = block_sum_i32(bad, s_i, tid);
+    const int size = min((int)((double)A.M * 0.85), N);           // int(M * 0.85), f64 product like Python
+    if (neg) { if (tid == 0) *A.status = LFD_SELECT_NEGATIVE; return; }
+    if (nz < size) { if (tid == 0) *A.status = LFD_SELECT_FEWER_NONZERO; return; }
+    if (inexact) { if (tid == 0) *A.status = LFD_SELECT_INEXACT; return; }
+
+    // ---- legacy choice(replace=False, p) -----------------------------------------------------------------------
+    if (tid == 0) s_n_uniq = 0;
+    __syncthreads();
+    const int per = (N + kSelBlock - 1) / kSelBlock;              // contiguous chunk per thread for the scan
+    int guard = 0;
+    while (true) {
+        const int n_uniq = s_n_uniq;
+        if (n_uniq >= size) break;
+        if (++guard > 64) { if (tid == 0) *A.status = LFD_SELECT_NO_PROGRESS; return; }
+        const int need = size - n_uniq;
+        mt_fill_doubles(A.mt, A.draws, need, tid);
+        for (int j = tid; j < n_uniq; j += kSelBlock) p[A.found[j]] = 0.0;
+        __syncthreads();
+        // cdf = cumsum(p) (exact, see header), then /= cdf[-1]
+        {
+            const int lo = tid * per, hi = min(lo + per, N);
+            double t = 0.0;
+            for (int i = lo; i < hi; ++i) t += p[i];
+            s_chunk[tid] = t;
+            __syncthreads();
+            if (tid == 0) { double run = 0.0; for (int k = 0; k < kSelBlock; ++k) { const double c0 = s_chunk[k]; s_chunk[k] = run; run += c0; } s_d[0] = run; }
+            __syncthreads();
+            const double total = s_d[0];
+            double run = s_chunk[tid];
+            for (int i = lo; i < hi; ++i) { run += p[i]; cdf[i] = run / total; }
+        }
+        __syncthreads();
+        // new = searchsorted(cdf, x, side="right"); first occurrence of each value, in draw order
+        for (int j = tid; j < need; j += kSelBlock) {
+            const double x = A.draws[j];
+            int lo = 0, hi = N;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= x) lo = mid + 1; else hi = mid; }
+            A.cand[j] = lo;
+            A.first[lo] = 0x7fffffff;
+        }
+        __syncthreads();
+        for (int j = tid; j < need; j += kSelBlock) atomicMin(&A.first[A.cand[j]], j);
+        __syncthreads();
+        int appended = 0;
+        for (int base = 0; base < need; base += kSelBlock) {
+            const int j = base + tid;
+            const int keep = (j < need) && (A.first[A.cand[j]] == j);
+            int total;
+            const int pos = block_excl_scan_i32(keep, s_i, tid, total);
+            if (keep) A.found[n_uniq + appended + pos] = A.cand[j];
+            appended += total;
+            __syncthreads();
+        }
+        if (tid == 0) s_n_uniq = n_uniq + appended;
+        __syncthreads();
+    }
+
+    // ---- tile coverage: best cell of every tile bin, bins by descending weight (ties: lower index) ----------
+    const int tile = max(1, W / A.tiles);
+    const int nbx = (W - 1) / tile + 1, nby = (H - 1) / tile + 1;
+    const int nbins = nbx * nby;
+    if (nbins > LFD_SELECT_MAX_BINS) { if (tid == 0) *A.status = LFD_SELECT_TOO_MANY_BINS; return; }
+    for (int b = tid; b < nbins; b += kSelBlock) s_bin[b] = 0ull;
+    __syncthreads();
+    for (int i = tid; i < N; i += kSelBlock) {
+        const float wv = wbuf[i];
+        if (wv > 0.0f) {
+            const int y = i / W, x = i - y * W;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(wv) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+            atomicMax(&s_bin[(x / tile) * nby + (y / tile)], key);     // positive floats order like their bit patterns
+        }
+    }
+    __syncthreads();
+    const int budget = max(A.M - size, 1);
+    // mark array: the random part, then the `budget` heaviest bins
+    unsigned char* mark = A.mark;
+    for (int i = tid; i < N; i += kSelBlock) mark[i] = 0;
+    __syncthreads();
+    for (int j = tid; j < size; j += kSelBlock) mark[A.found[j]] = 1;
+    for (int b = tid; b < nbins; b += kSelBlock) {
+        const unsigned long long mine = s_bin[b];
+        if (mine == 0ull) continue;
+        int rank = 0;
+        for (int o = 0; o < nbins; ++o) rank += (s_bin[o] > mine);  // keys are distinct (they embed the cell index)
+        if (rank < budget) mark[0xffffffffu - (unsigned)(mine & 0xffffffffull)] = 1;
+    }
+    __syncthreads();
+    // ---- np.unique(concat): marked cells in ascending order --------------------------------------------------------
+    {
+        const int lo = tid * per, hi = min(lo + per, N);
+        int cnt = 0;
+        for (int i = lo; i < hi; ++i) cnt += mark[i];
+        int total;
+        int pos = block_excl_scan_i32(cnt, s_i, tid, total);
+        if ((long long)total > A.capacity) { if (tid == 0) { *A.status = LFD_SELECT_CAPACITY; *A.n_out = total; } return; }
+        for (int i = lo; i < hi; ++i) if (mark[i]) A.sel_out[pos++] = (long long)i;
+        if (tid == 0) *A.n_out = total;
+    }
+}
+
+// seed exactly like np.random.seed(uint32): init_genrand
+extern "C" __global__ void lfd_mt_seed_kernel(unsigned* mt, unsigned seed) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        mt[0] = seed;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (unsigned)i;
+        mt[624] = 624;      // position: a twist is due before the first output
+    }
+}

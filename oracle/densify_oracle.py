@@ -231,7 +231,7 @@ def _torch_sum_f32(x: np.ndarray) -> np.float32:
 
 def select_samples(best_cert: np.ndarray, M: int, cap: float = 0.9, border: int = 2,
                    tiles: int = 24, no_filter: bool = False,
-                   rng: Optional[np.random.RandomState] = None) -> np.ndarray:
+                   rng: Optional[np.random.RandomState] = None, s_override: Optional[float] = None) -> np.ndarray:
     """Which grid cells get triangulated.
 
     no_filter: the ``M`` largest capped certainties in ``argsort(-flat)`` order (unsorted index
@@ -254,7 +254,9 @@ def select_samples(best_cert: np.ndarray, M: int, cap: float = 0.9, border: int 
     yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
     inside = (xx >= border) & (xx <= w - 1 - border) & (yy >= border) & (yy <= h - 1 - border)
     weights = (cert * inside.astype(np.float32)).reshape(-1).astype(np.float32)
-    s = _torch_sum_f32(weights)
+    # s_override: the normaliser another implementation used (torch's own f32 sum depends on the host's
+    # thread count and vector ISA, so it is an input of the comparison, not part of the algorithm)
+    s = _torch_sum_f32(weights) if s_override is None else np.float32(s_override)
     if not (s > 0):
         return np.zeros((0,), np.int64)
     weights = (weights / s).astype(np.float32)

@@ -128,6 +128,10 @@ def g2_selection():
         if h * w <= 96 * 96:
             out[f"c{ci}_cert"] = cert
         out[f"c{ci}_cert_sha256"] = np.array(hashlib.sha256(cert.tobytes()).hexdigest())
+        yy, xx = np.mgrid[0:h, 0:w]
+        inside = (xx >= 2) & (xx <= w - 3) & (yy >= 2) & (yy <= h - 3)
+        wts = torch.clamp(torch.from_numpy(cert), max=0.9) * torch.from_numpy(inside).float()
+        out[f"c{ci}_s"] = np.float32(wts.reshape(-1).sum().item())     # the normaliser upstream's torch sum produced here
         meta.append([h, w, M, seed, 100 + ci])
     out["cases"] = np.array(meta, np.int64)
     # a case with massive ties (floor + cap) - only order-insensitive facts are pinned for it

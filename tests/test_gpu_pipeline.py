@@ -50,12 +50,17 @@ def _scene(g4, tmp_path):
     return cams, refs, g4["nn_table"], table
 
 
-@pytest.mark.parametrize("mode,two_channel", [("filter", False), ("nofilter", False), ("filter", True)])
-def test_pipeline_matches_upstream_run(g4, tmp_path, mode, two_channel):
+@pytest.mark.parametrize("mode,two_channel,backend", [("filter", False, "host"), ("nofilter", False, "host"),
+                                                      ("filter", True, "host"), ("filter", False, "device")])
+def test_pipeline_matches_upstream_run(g4, tmp_path, mode, two_channel, backend):
+    """backend="host": the sampling stage makes upstream's own library calls -> identical run.
+    backend="device": everything on the GPU; the only difference from upstream is the rounding of the
+    weight normaliser (exact sum vs torch's thread-count-dependent f32 sum), which at this size leaves
+    the drawn cells unchanged (tests/test_gpu_selection.py pins the draws themselves)."""
     cams, refs, nn, table = _scene(g4, str(tmp_path))
     kw = json.loads(str(g4[mode + "_cfg"]))
     cfg = lfd.DensePipelineConfig(output_path=os.path.join(str(tmp_path), "out", "dense.ply"), roma_setting="fast",
-                                  nns_per_ref=2, seed=5, viz_interval=2, pack_workers=1, **kw)
+                                  nns_per_ref=2, seed=5, viz_interval=2, pack_workers=1, selection_backend=backend, **kw)
     fm = FakeMatcher(64, 64, table, two_channel)
     progress, viz = [], []
     res = pl.run_dense_pipeline(cams, refs, nn, cfg, progress_callback=lambda p, m: progress.append((p, m)),
