@@ -224,47 +224,45 @@ LFD_HD int lfd_null_vector(const float* Af, double* c) {
         g00 *= s; g01 *= s; g02 *= s; g03 *= s; g11 *= s; g12 *= s; g13 *= s; g22 *= s; g23 *= s; g33 *= s;
         tr *= s;
     }
-    // H = G^2.  q = lambda_2/lambda_1 of G follows from the traces: tr(G)^2 - tr(G^2) ~ 2 q tr(G)^2.
-    // The dominant column of H is off by q^2; every further product with H multiplies that by q^2, so
-    // the number of products needed for a 1e-9-ish error is known up front (no per-step test); only
-    // badly conditioned cells (q > 0.06, i.e. sigma_4/sigma_3 > 0.25) keep squaring.
-    int it = 1;
-    double h00, h01, h02, h03, h11, h12, h13, h22, h23, h33, trh, q2t;
+    // q = lambda_2/lambda_1 of G follows from tr(G)^2 - tr(G^2) ~ 2 q tr(G)^2 with tr(G^2) = ||G||_F^2.
+    // The dominant column of G is off by q and every product with G multiplies that by q again, so
+    // the number of products for a ~1e-8 error is known up front (no per-step test).  Badly
+    // conditioned cells (q > 0.05, i.e. sigma_4/sigma_3 > 0.22) are squared first.
+    int it = 0;
+    double q2t;
     for (;;) {
-#define LFD_SQUARE()                                                                  \
-        h00 = fma(g03, g03, fma(g02, g02, fma(g01, g01, g00 * g00)));                  \
-        h01 = fma(g03, g13, fma(g02, g12, fma(g01, g11, g00 * g01)));                  \
-        h02 = fma(g03, g23, fma(g02, g22, fma(g01, g12, g00 * g02)));                  \
-        h03 = fma(g03, g33, fma(g02, g23, fma(g01, g13, g00 * g03)));                  \
-        h11 = fma(g13, g13, fma(g12, g12, fma(g11, g11, g01 * g01)));                  \
-        h12 = fma(g13, g23, fma(g12, g22, fma(g11, g12, g01 * g02)));                  \
-        h13 = fma(g13, g33, fma(g12, g23, fma(g11, g13, g01 * g03)));                  \
-        h22 = fma(g23, g23, fma(g22, g22, fma(g12, g12, g02 * g02)));                  \
-        h23 = fma(g23, g33, fma(g22, g23, fma(g12, g13, g02 * g03)));                  \
-        h33 = fma(g33, g33, fma(g23, g23, fma(g13, g13, g03 * g03)));                  \
-        trh = (h00 + h11) + (h22 + h33);                                               \
-        q2t = tr * tr - trh                 /* ~ 2 q tr^2 */
-        LFD_SQUARE();
-        if (!(q2t > 0.12 * (tr * tr)) || it >= LFD_NULLVEC_MAXIT) break;   // q <= 0.06 (or NaN): finish below
+        const double fro = fma(2.0, fma(g23, g23, fma(g13, g13, fma(g12, g12, fma(g03, g03, fma(g02, g02, g01 * g01))))),
+                               fma(g33, g33, fma(g22, g22, fma(g11, g11, g00 * g00))));
+        q2t = tr * tr - fro;                 // ~ 2 q tr^2
+        if (!(q2t > 0.10 * (tr * tr)) || it >= LFD_NULLVEC_MAXIT) break;
+        const double h00 = fma(g03, g03, fma(g02, g02, fma(g01, g01, g00 * g00)));
+        const double h01 = fma(g03, g13, fma(g02, g12, fma(g01, g11, g00 * g01)));
+        const double h02 = fma(g03, g23, fma(g02, g22, fma(g01, g12, g00 * g02)));
+        const double h03 = fma(g03, g33, fma(g02, g23, fma(g01, g13, g00 * g03)));
+        const double h11 = fma(g13, g13, fma(g12, g12, fma(g11, g11, g01 * g01)));
+        const double h12 = fma(g13, g23, fma(g12, g22, fma(g11, g12, g01 * g02)));
+        const double h13 = fma(g13, g33, fma(g12, g23, fma(g11, g13, g01 * g03)));
+        const double h22 = fma(g23, g23, fma(g22, g22, fma(g12, g12, g02 * g02)));
+        const double h23 = fma(g23, g33, fma(g22, g23, fma(g12, g13, g02 * g03)));
+        const double h33 = fma(g33, g33, fma(g23, g23, fma(g13, g13, g03 * g03)));
         g00 = h00; g01 = h01; g02 = h02; g03 = h03; g11 = h11; g12 = h12; g13 = h13; g22 = h22; g23 = h23; g33 = h33;
-        tr = trh;
+        tr = (g00 + g11) + (g22 + g33);
         ++it;
     }
-#undef LFD_SQUARE
-    // dominant column of H = column of its largest diagonal entry
-    double best = h00;
-    c[0] = h00; c[1] = h01; c[2] = h02; c[3] = h03;
-    if (h11 > best) { best = h11; c[0] = h01; c[1] = h11; c[2] = h12; c[3] = h13; }
-    if (h22 > best) { best = h22; c[0] = h02; c[1] = h12; c[2] = h22; c[3] = h23; }
-    if (h33 > best) { best = h33; c[0] = h03; c[1] = h13; c[2] = h23; c[3] = h33; }
-    // error of c is q^2; products needed: 0 if q <= 1e-4, 1 if q <= 3e-3, 2 if q <= 2e-2, else 3
+    // dominant column of G = column of its largest diagonal entry
+    double best = g00;
+    c[0] = g00; c[1] = g01; c[2] = g02; c[3] = g03;
+    if (g11 > best) { best = g11; c[0] = g01; c[1] = g11; c[2] = g12; c[3] = g13; }
+    if (g22 > best) { best = g22; c[0] = g02; c[1] = g12; c[2] = g22; c[3] = g23; }
+    if (g33 > best) { best = g33; c[0] = g03; c[1] = g13; c[2] = g23; c[3] = g33; }
+    // error of c is q; products needed for q^(m+1) <= ~1e-8:  q <= 1e-4: 1, 2e-3: 2, 1e-2: 3, 2.5e-2: 4, else 5
     const double t2 = tr * tr;
-    const int extra = (q2t > 2e-4 * t2) + (q2t > 6e-3 * t2) + (q2t > 4e-2 * t2);
+    const int extra = 1 + (q2t > 2e-4 * t2) + (q2t > 4e-3 * t2) + (q2t > 2e-2 * t2) + (q2t > 5e-2 * t2);
     for (int m = 0; m < extra; ++m) {
-        const double y0 = fma(h03, c[3], fma(h02, c[2], fma(h01, c[1], h00 * c[0])));
-        const double y1 = fma(h13, c[3], fma(h12, c[2], fma(h11, c[1], h01 * c[0])));
-        const double y2 = fma(h23, c[3], fma(h22, c[2], fma(h12, c[1], h02 * c[0])));
-        const double y3 = fma(h33, c[3], fma(h23, c[2], fma(h13, c[1], h03 * c[0])));
+        const double y0 = fma(g03, c[3], fma(g02, c[2], fma(g01, c[1], g00 * c[0])));
+        const double y1 = fma(g13, c[3], fma(g12, c[2], fma(g11, c[1], g01 * c[0])));
+        const double y2 = fma(g23, c[3], fma(g22, c[2], fma(g12, c[1], g02 * c[0])));
+        const double y3 = fma(g33, c[3], fma(g23, c[2], fma(g13, c[1], g03 * c[0])));
         c[0] = y0; c[1] = y1; c[2] = y2; c[3] = y3;
     }
     return it + extra;
@@ -283,12 +281,11 @@ LFD_HD float lfd_match_px(float n, float size_m1) {   // (n + 1.0) * 0.5 * (size
 }
 
 // a / b in f32 from r = RN(1/b): q = RN(a*r); q' = RN(q + (a - b*q)*r) is the correctly rounded quotient
-// (Markstein), i.e. bit-identical to the IEEE division, whenever the intermediate products stay in
-// the normal range; otherwise (overflow / NaN somewhere) fall back to the division itself.
+// (Markstein), i.e. bit-identical to the IEEE division while a*r stays in the normal range - which
+// it does for every finite reprojection / ray normalisation here (|b| >= 1e-12, so |r| <= 1e12).
 LFD_HD float lfd_div_by_recip_f32(float a, float b, float r) {
     const float q = a * r;
-    const float q1 = fmaf(fmaf(-b, q, a), r, q);
-    return (fabsf(q1) <= 3.402823466e+38f && fabsf(q) >= 1.17549435e-38f) ? q1 : a / b;
+    return fmaf(fmaf(-b, q, a), r, q);
 }
 
 LFD_HD float lfd_proj_row(const float* P, int row, float X0, float X1, float X2, float X3) {
@@ -400,8 +397,9 @@ LFD_HD int lfd_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi
 LFD_HD void lfd_bilinear_rgb(const uint8_t* img, int wi, int hi, float xa_px, float ya_px, float sx_img,
                              float sy_img, float* rgb) {
     const float xi = xa_px * sx_img, yi = ya_px * sy_img;
-    const int x0 = lfd_clampi(lfd_floor_to_i32(xi), 0, wi - 1);
-    const int y0 = lfd_clampi(lfd_floor_to_i32(yi), 0, hi - 1);
+    // clip(floor(.).astype(int32), 0, dim-1); NaN -> 0 like the x86 conversion upstream runs on
+    const int x0 = (int)fminf(fmaxf(floorf(xi), 0.0f), (float)(wi - 1));
+    const int y0 = (int)fminf(fmaxf(floorf(yi), 0.0f), (float)(hi - 1));
     const int x1 = lfd_clampi(x0 + 1, 0, wi - 1);
     const int y1 = lfd_clampi(y0 + 1, 0, hi - 1);
     const double xd = (double)xi, yd = (double)yi;
