@@ -342,3 +342,83 @@ def test_invalid_arguments_are_reported_not_fatal(dev):
     with pytest.raises(hb.HipBackendError, match="out of range"):
         dens.triangulate_dense(batch, p)
     dens.close()
+
+
+def test_precise_grid_k8_max_size(dev):
+    """`precise` preset shape (1280^2 grid, 800-px match images) with 8 neighbours: the largest
+    configuration upstream offers.  Dense mode properties + an oracle check of 30k random cells through
+    the indexed kernel (the oracle's per-cell LAPACK path is too slow for all 1.6M cells)."""
+    H = W = 1280
+    wm = hm = 800
+    n_cams = 12                                   # ROI subset: 12 cameras on a partial arc
+    cams = synthetic.ring_cameras(n_cams, seed=3, arc=1.2)
+    ref, k = 5, 8
+    nbrs = synthetic.ring_neighbours(n_cams, ref, k)
+    s = synthetic.synth_reference(cams, ref, nbrs, H, W, wm, hm, noise_px=0.5, outlier_frac=0.05, channels=2, seed=8,
+                                  cert_mode="smooth", device="cpu")
+    inp = hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=[s.cert[j].to(dev) for j in range(k)],
+                             warp=[s.warp[j].contiguous().to(dev) for j in range(k)], image=s.image.to(dev))
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    batch = hb.PreparedBatch([inp], wm, hm)
+    cfg = lfd.DensePipelineConfig(output_path="")
+    p = hb.make_params(cfg)
+    out = dens.triangulate_dense(batch, p)
+    cell = out.cell.cpu().numpy().astype(np.int64)
+    assert out.count == int(out.ref_offsets[1]) and 0.2 * H * W < out.count <= H * W
+    assert np.all(np.diff(cell) > 0) and cell.max() < H * W
+    assert int(out.seg_counts.sum()) == out.count and out.seg_counts.shape == (1, 8)
+    # random cells through the upstream-equivalent path vs the oracle
+    rs = np.random.RandomState(1)
+    sel = np.sort(rs.choice(H * W, size=30000, replace=False)).astype(np.int64)
+    idx = dens.triangulate_indexed(batch, p, torch.from_numpy(sel).to(dev), [0, sel.size])
+    params = orc.OracleParams()
+    axes_np = (orc.identity_axis_scalar(W), orc.identity_axis_scalar(H))
+    ca, cbs = _oracle_cam(cams[ref]), [_oracle_cam(cams[n]) for n in nbrs]
+    certs, warps = [s.cert[j].numpy() for j in range(k)], [s.warp[j].numpy() for j in range(k)]
+    with np.errstate(all="ignore"):
+        res, _ = orc.triangulate_reference(certs, warps, s.image.numpy(), ca, cbs, wm, hm, params, sel_idx=sel, axes=axes_np)
+        _, bk, agg = orc.prepare_reference(certs, warps, params)
+        diag = orc.cell_diagnostics(sel, bk, agg, ca, cbs, wm, hm, axes=axes_np)
+    sure = guard_band_ok(diag, params)
+    keep_h = np.isin(sel, idx.cell.cpu().numpy())
+    keep_o = np.isin(sel, res.cell)
+    np.testing.assert_array_equal(keep_h[sure], keep_o[sure])
+    assert (~sure).sum() < 0.01 * sel.size
+    # the dense kernel and the indexed kernel agree cell by cell
+    np.testing.assert_array_equal(np.isin(sel, cell), keep_h)
+    both = np.intersect1d(idx.cell.cpu().numpy(), res.cell)
+    ih = np.nonzero(np.isin(idx.cell.cpu().numpy(), both))[0]
+    io = np.nonzero(np.isin(res.cell, both))[0]
+    order_h = ih[np.argsort(idx.cell.cpu().numpy()[ih], kind="stable")]
+    order_o = io[np.argsort(res.cell[io], kind="stable")]
+    noise = diag["err_noise"][np.searchsorted(sel, np.sort(both))]
+    _assert_values(idx.xyz.cpu().numpy()[order_h], idx.rgb.cpu().numpy()[order_h], idx.err.cpu().numpy()[order_h],
+                   res.xyz[order_o], res.rgb[order_o], res.err[order_o], noise)
+    dens.close()
+
+
+def test_non_finite_inputs_are_rejected_not_fatal(dev):
+    """NaN / Inf in the warp or the certainty must neither crash nor leak into the output in filter
+    mode (every comparison with NaN is false, as in NumPy)."""
+    cams, refs, srefs = _synthetic_batch(dev, 1, [3], 64, 64, 64, 64, seed=4, channels=2)
+    w0 = refs[0].warp[0].clone()
+    w0[10:14, 5:9, 0] = float("nan")
+    w0[20:22, 30:40, 1] = float("inf")
+    refs[0].warp[0] = w0
+    c1 = refs[0].cert[1].clone()
+    c1[40:44, 40:44] = float("nan")               # a NaN certainty wins the arg-max (torch.max semantics)
+    refs[0].cert[1] = c1
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    out = dens.triangulate_dense(hb.PreparedBatch(refs, 64, 64), hb.make_params(lfd.DensePipelineConfig(output_path="")))
+    assert out.count > 500
+    for t in (out.xyz, out.rgb, out.err):
+        assert torch.isfinite(t).all()
+    cell = out.cell.cpu().numpy()
+    slot = out.slot.cpu().numpy()
+    nan_cert_cells = [y * 64 + x for y in range(40, 44) for x in range(40, 44)]
+    assert np.all(slot[np.isin(cell, nan_cert_cells)] == 1)
+    best, bslot = dens.aggregate(hb.PreparedBatch(refs, 64, 64), hb.make_params(lfd.DensePipelineConfig(output_path="")))
+    assert torch.isnan(best[0, 41, 41]) and int(bslot[0, 41, 41]) == 1
+    dens.close()
