@@ -135,6 +135,17 @@ int lfd_select_samples(lfd_context* ctx, const float* best_cert, int32_t H, int3
                        int32_t border, int32_t tiles, float s_override, int64_t* sel_out, int64_t capacity,
                        int32_t* n_sel_host, int32_t* status_host);
 
+/* N1: file payloads on the device (core/writers.py:15-46, core/image_utils.py:24-26).  Colours are
+ * quantised like upstream's to_uint8_rgb: clip(round_half_even(c * 255), 0, 255).
+ * lfd_pack_ply:      out[n*15] = per point x y z (f32 LE) r g b (u8): the PLY body after upstream's header.
+ * lfd_pack_points3d: out[n*43] = per point u64 id (id_base + i + 1), xyz as f64, rgb u8, error f64
+ *                    (err may be NULL -> 0.0): upstream's points3D.bin body after the u64 count.
+ * out must be 4-byte aligned.  Asynchronous on the context's stream. */
+int lfd_pack_ply(lfd_context* ctx, const float* xyz, const float* rgb, int64_t n, uint8_t* out);
+int lfd_pack_points3d(lfd_context* ctx, const float* xyz, const float* rgb, const float* err, int64_t n,
+                      uint64_t id_base, uint8_t* out);
+int lfd_quantise_rgb(lfd_context* ctx, const float* rgb, int64_t n, uint8_t* out);
+
 /* Synchronise the context's stream and report whether the last launches completed normally.
  * *status_out = 0, or 1 when a bounded look-back spin gave up (results invalid; returns LFD_ERR_HIP). */
 int lfd_launch_status(lfd_context* ctx, int32_t* status_out);

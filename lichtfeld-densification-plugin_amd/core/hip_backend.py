@@ -81,6 +81,9 @@ def load_library() -> C.CDLL:
     lib.lfd_triangulate_indexed.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p,
                                             C.POINTER(C.c_int64), C.POINTER(lfd_points), C.c_void_p, C.c_void_p,
                                             C.c_void_p]
+    lib.lfd_pack_ply.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.lfd_pack_points3d.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]
+    lib.lfd_quantise_rgb.argtypes = [ctxp, C.c_void_p, C.c_int64, C.c_void_p]
     lib.lfd_launch_status.argtypes = [ctxp, C.POINTER(C.c_int32)]
     lib.lfd_rng_seed.argtypes = [ctxp, C.c_uint32]
     lib.lfd_rng_get_state.argtypes = [ctxp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
@@ -95,7 +98,8 @@ def load_library() -> C.CDLL:
                                                  C.c_int32, C.POINTER(lfd_params), fptr]
     for name in ("lfd_create", "lfd_set_stream", "lfd_upload_cameras", "lfd_aggregate", "lfd_triangulate_dense",
                  "lfd_triangulate_indexed", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
-                 "lfd_select_samples", "lfd_identity_axis", "lfd_host_fundamental",
+                 "lfd_select_samples", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_identity_axis",
+                 "lfd_host_fundamental",
                  "lfd_host_eval_correspondence"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
@@ -334,6 +338,41 @@ class HipDensifier:
         """Synchronise and raise if a kernel reported a look-back timeout."""
         st = C.c_int32(0)
         self._check(self._lib.lfd_launch_status(self._ctx, C.byref(st)), "lfd_launch_status")
+
+    # -- N1: file payloads packed on the device ------------------------------------------------------------
+    @staticmethod
+    def _pts(t: torch.Tensor, cols: int, what: str) -> torch.Tensor:
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise ValueError(f"{what} must be a float32 device tensor")
+        t = t.contiguous()
+        if cols and (t.dim() != 2 or t.shape[1] != cols):
+            raise ValueError(f"{what} must have shape (n,{cols})")
+        return t
+
+    def pack_ply(self, xyz: torch.Tensor, rgb: torch.Tensor) -> torch.Tensor:
+        """(n*15,) u8 device tensor: the PLY body upstream's write_ply emits after its header."""
+        xyz, rgb = self._pts(xyz, 3, "xyz"), self._pts(rgb, 3, "rgb")
+        n = int(xyz.shape[0])
+        out = torch.empty((max(n * 15, 4),), dtype=torch.uint8, device=xyz.device)
+        self._check(self._lib.lfd_pack_ply(self._ctx, xyz.data_ptr(), rgb.data_ptr(), n, out.data_ptr()), "lfd_pack_ply")
+        return out[:n * 15]
+
+    def pack_points3d(self, xyz: torch.Tensor, rgb: torch.Tensor, err: Optional[torch.Tensor] = None,
+                      id_base: int = 0) -> torch.Tensor:
+        """(n*43,) u8 device tensor: upstream's points3D.bin body (without the leading u64 count)."""
+        xyz, rgb = self._pts(xyz, 3, "xyz"), self._pts(rgb, 3, "rgb")
+        e = self._pts(err, 0, "err") if err is not None else None
+        n = int(xyz.shape[0])
+        out = torch.empty((max(n * 43, 4),), dtype=torch.uint8, device=xyz.device)
+        self._check(self._lib.lfd_pack_points3d(self._ctx, xyz.data_ptr(), rgb.data_ptr(), e.data_ptr() if e is not None else None,
+                                                n, int(id_base), out.data_ptr()), "lfd_pack_points3d")
+        return out[:n * 43]
+
+    def quantise_rgb(self, rgb: torch.Tensor) -> torch.Tensor:
+        rgb = self._pts(rgb, 3, "rgb")
+        out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
+        self._check(self._lib.lfd_quantise_rgb(self._ctx, rgb.data_ptr(), int(rgb.shape[0]), out.data_ptr()), "lfd_quantise_rgb")
+        return out
 
     # -- S: selection stage on the device ----------------------------------------------------------------
     def seed_rng(self, seed: int) -> None:

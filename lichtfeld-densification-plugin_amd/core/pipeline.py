@@ -58,6 +58,7 @@ class PipelineResult:
     # extras (not present upstream)
     pairs_matched: int = 0          # actual (reference, neighbour) pairs matched
     points_per_reference: Optional[np.ndarray] = None
+    device_points: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None   # same points, still on the GPU
 
 
 class PipelineCancelled(RuntimeError):
@@ -350,6 +351,7 @@ def run_dense_pipeline(
     xyz_parts: List[np.ndarray] = []
     rgb_parts: List[np.ndarray] = []
     err_parts: List[np.ndarray] = []
+    dev_parts: List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = []
     counts_local = [0] * len(my_positions)
     refs_with_points = 0
     pair_counter = 0
@@ -428,6 +430,7 @@ def run_dense_pipeline(
             for bi, (local_i, packed, ref, _axes) in enumerate(pending):
                 lo, hi = int(offs[bi]), int(offs[bi + 1])
                 if hi > lo:
+                    dev_parts.append((out.xyz[lo:hi], out.rgb[lo:hi], out.err[lo:hi]))
                     emit(local_i, packed, xyz[lo:hi], rgb[lo:hi], err[lo:hi], None)
             pending.clear()
 
@@ -478,6 +481,7 @@ def run_dense_pipeline(
             if want_debug:
                 dbg = {"matches": hot.debug_matches(ref, out.cell, out.slot, axes, best),
                        "pair_index": {j: first_pair + j for j in range(len(certs))}}
+            dev_parts.append((out.xyz, out.rgb, out.err))
             emit(local_i, packed, out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy(), dbg)
         flush_dense()
     finally:
@@ -505,11 +509,16 @@ def run_dense_pipeline(
     else:
         xyz, rgb, err = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0,), np.float32)
     counts = np.asarray(counts_local, np.int64)
+    device_points = None
+    if world == 1 and dev_parts:
+        device_points = (torch.cat([p[0] for p in dev_parts], 0), torch.cat([p[1] for p in dev_parts], 0),
+                         torch.cat([p[2] for p in dev_parts], 0))
     if world > 1:       # the one exchange step: ordered all-gather of the survivors over RCCL
         gx, gc_, ge, counts = lfd_dist.all_gather_by_reference(
             torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev), torch.from_numpy(err).to(dev),
             counts_local, len(refs_local), dist)
         xyz, rgb, err = gx.cpu().numpy(), gc_.cpu().numpy(), ge.cpu().numpy()
+        device_points = (gx, gc_, ge)
         t = torch.tensor([refs_with_points, pair_counter], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
         refs_with_points, pair_counter = int(t[0].item()), int(t[1].item())
@@ -517,4 +526,5 @@ def run_dense_pipeline(
     if xyz.shape[0] == 0:
         raise RuntimeError("No points triangulated. Try adjusting parameters.")
     return PipelineResult(xyz=xyz, rgb=rgb, err=err, elapsed_seconds=time.time() - t0,
-                          pairs_processed=refs_with_points, pairs_matched=pair_counter, points_per_reference=counts)
+                          pairs_processed=refs_with_points, pairs_matched=pair_counter, points_per_reference=counts,
+                          device_points=device_points)

@@ -99,3 +99,20 @@ class StreamedPlyWriter:
 
     def __exit__(self, *exc):
         self.close()
+
+
+def write_ply_packed(path_out: str, n: int, body: bytes) -> None:
+    """PLY from a body packed on the device (HipDensifier.pack_ply): header + n 15-byte records."""
+    if len(body) != 15 * int(n):
+        raise ValueError("PLY body must be 15 bytes per vertex")
+    with open(path_out, "wb") as f:
+        f.write(ply_header(n))
+        f.write(body)
+
+
+def write_points3D_bin_packed(path_out: str, n: int, body: bytes) -> None:
+    if len(body) != 43 * int(n):
+        raise ValueError("points3D.bin body must be 43 bytes per point")
+    with open(path_out, "wb") as f:
+        f.write(np.uint64(n).tobytes())
+        f.write(body)

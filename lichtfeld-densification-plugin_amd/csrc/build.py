@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "liblfd_densify.so")
-SOURCES = ["lfd_api.hip", "lfd_kernels.hip", "lfd_select.hip"]
+SOURCES = ["lfd_api.hip", "lfd_kernels.hip", "lfd_select.hip", "lfd_writer.hip"]
 HEADERS = ["lfd_device.hpp", "lfd_geometry.hpp", os.path.join("..", "..", "include", "lfd_densify.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]

@@ -16,6 +16,10 @@ extern "C" __global__ void lfd_aggregate_kernel(LfdLaunch L, float* best_cert, u
 extern "C" __global__ void lfd_dense_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* ref_out, LfdPairConst* pair_out);
 extern "C" __global__ void lfd_select_filter_kernel(LfdSelectArgs A);
+extern "C" __global__ void lfd_pack_ply_kernel(const float* xyz, const float* rgb, long long n, unsigned char* out);
+extern "C" __global__ void lfd_pack_points3d_kernel(const float* xyz, const float* rgb, const float* err, long long n,
+                                                    unsigned long long id_base, unsigned char* out);
+extern "C" __global__ void lfd_quantise_rgb_kernel(const float* rgb, long long n3, unsigned char* out);
 extern "C" __global__ void lfd_mt_seed_kernel(unsigned* mt, unsigned seed);
 extern "C" __global__ void lfd_indexed_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets,
                                               float* scratch, uint8_t* codes, int32_t* seg_order);
@@ -523,6 +527,45 @@ int lfd_select_samples(lfd_context* ctx, const float* best_cert, int32_t H, int3
         return fail(ctx, host[1] == LFD_SELECT_CAPACITY ? LFD_ERR_CAPACITY : LFD_ERR_INVALID,
                     std::string("selection: ") + names[std::min(host[1], 7)]);
     }
+    return LFD_OK;
+}
+
+// ---- N1: writers ----------------------------------------------------------------------------------
+int lfd_pack_ply(lfd_context* ctx, const float* xyz, const float* rgb, int64_t n, uint8_t* out) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (n < 0 || (n > 0 && (!xyz || !rgb || !out))) return fail(ctx, LFD_ERR_INVALID, "bad arguments");
+    if (reinterpret_cast<uintptr_t>(out) & 3u) return fail(ctx, LFD_ERR_INVALID, "out must be 4-byte aligned");
+    if (n == 0) return LFD_OK;
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(lfd_pack_ply_kernel, dim3(grid), dim3(256), 0, ctx->stream, xyz, rgb, (long long)n, out);
+    LFD_HIP(ctx, hipGetLastError());
+    return LFD_OK;
+}
+
+int lfd_pack_points3d(lfd_context* ctx, const float* xyz, const float* rgb, const float* err, int64_t n, uint64_t id_base,
+                      uint8_t* out) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (n < 0 || (n > 0 && (!xyz || !rgb || !out))) return fail(ctx, LFD_ERR_INVALID, "bad arguments");
+    if (reinterpret_cast<uintptr_t>(out) & 3u) return fail(ctx, LFD_ERR_INVALID, "out must be 4-byte aligned");
+    if (n == 0) return LFD_OK;
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(lfd_pack_points3d_kernel, dim3(grid), dim3(256), 0, ctx->stream, xyz, rgb, err, (long long)n,
+                       (unsigned long long)id_base, out);
+    LFD_HIP(ctx, hipGetLastError());
+    return LFD_OK;
+}
+
+int lfd_quantise_rgb(lfd_context* ctx, const float* rgb, int64_t n, uint8_t* out) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (n < 0 || (n > 0 && (!rgb || !out))) return fail(ctx, LFD_ERR_INVALID, "bad arguments");
+    if (n == 0) return LFD_OK;
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    const long long n3 = 3 * (long long)n;
+    const unsigned grid = (unsigned)std::min<long long>((n3 + 255) / 256, 4096);
+    hipLaunchKernelGGL(lfd_quantise_rgb_kernel, dim3(grid), dim3(256), 0, ctx->stream, rgb, n3, out);
+    LFD_HIP(ctx, hipGetLastError());
     return LFD_OK;
 }
 

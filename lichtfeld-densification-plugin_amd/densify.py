@@ -136,15 +136,42 @@ def _voxel_downsample(xyz: np.ndarray, rgb: np.ndarray, voxel_size: float) -> Tu
         return (p / cnt[:, None]).astype(np.float32), (c / cnt[:, None]).astype(np.float32)
 
 
-def _write_output(path: str, xyz, rgb, err) -> None:
+def _write_output(path: str, xyz, rgb, err, device_points=None) -> None:
+    """``.ply`` -> upstream's PLY, anything else -> upstream's points3D.bin (densify.py:129-135).  When
+    the points are still on the GPU the records are quantised and packed there (lfd_pack_*) and only
+    the final bytes are copied to the host; the files are byte-identical either way."""
     d = os.path.dirname(path)
     if d:
         os.makedirs(d, exist_ok=True)
+    as_ply = path.lower().endswith(".ply")
+    if device_points is not None and int(device_points[0].shape[0]) == int(xyz.shape[0]):
+        from .core import hip_backend as hb
+        from .core.writers import write_ply_packed, write_points3D_bin_packed
+        dens = hb.HipDensifier(device_points[0].device)
+        try:
+            n = int(xyz.shape[0])
+            if as_ply:
+                write_ply_packed(path, n, dens.pack_ply(device_points[0], device_points[1]).cpu().numpy().tobytes())
+            else:
+                write_points3D_bin_packed(path, n, dens.pack_points3d(*device_points).cpu().numpy().tobytes())
+        finally:
+            dens.close()
+        return
     rgb8 = to_uint8_rgb(rgb)
-    if path.lower().endswith(".ply"):
+    if as_ply:
         write_ply(path, xyz, rgb8)
     else:
         write_points3D_bin(path, xyz, rgb8, err)
+
+
+def _cap_device_points(device_points, n_before: int, max_points: int, seed: int):
+    """The same subset _apply_point_cap picks, applied to the GPU copy."""
+    if device_points is None or not (max_points > 0 and n_before > max_points):
+        return device_points
+    import torch
+    keep = np.random.default_rng(seed).choice(n_before, size=max_points, replace=False)
+    idx = torch.from_numpy(keep).to(device_points[0].device)
+    return tuple(t[idx] for t in device_points)
 
 
 def _was_cancelled(cb) -> bool:
@@ -196,9 +223,10 @@ def dense_init(args, progress_callback: Optional[Callable[[float, str], None]] =
             progress_callback(0.0, "Cancelled")
         return 2
     xyz, rgb, err = _apply_point_cap(result.xyz, result.rgb, result.err, args.max_points, args.seed)
+    dev_pts = _cap_device_points(result.device_points, result.xyz.shape[0], args.max_points, args.seed)
     if progress_callback:
         progress_callback(95.0, "Writing output...")
-    _write_output(config.output_path, xyz, rgb, err)
+    _write_output(config.output_path, xyz, rgb, err, dev_pts)
     log.info(f"Dense reconstruction finished: {xyz.shape[0]:,} points -> {config.output_path}")
     if progress_callback:
         progress_callback(100.0, f"Done! {xyz.shape[0]:,} points")
@@ -239,17 +267,23 @@ def dense_init_from_lfs(camera_nodes, config: DensePipelineConfig,
     if _was_cancelled(cancel_requested):
         return 2, "Cancelled"
     xyz, rgb, err = _apply_point_cap(result.xyz, result.rgb, result.err, config.max_points, config.seed)
+    dev_pts = _cap_device_points(result.device_points, result.xyz.shape[0], config.max_points, config.seed)
     if config.voxel_size > 0.0:
         if progress_callback:
             progress_callback(93.0, "Applying distance filter...")
         xyz, rgb = _voxel_downsample(xyz, rgb, config.voxel_size)
+        dev_pts = None                                   # the voxel average lives on the host
         log.info(f"Distance filter ({config.voxel_size:.4f}): {xyz.shape[0]:,} points remaining")
     if progress_callback:
         progress_callback(95.0, "Writing output PLY...")
-    d = os.path.dirname(config.output_path)
-    if d:
-        os.makedirs(d, exist_ok=True)
-    write_ply(config.output_path, xyz, to_uint8_rgb(rgb))
+    out_path = config.output_path if config.output_path.lower().endswith(".ply") else config.output_path + ".ply"
+    if out_path != config.output_path:                  # upstream always writes a PLY here, whatever the name
+        d = os.path.dirname(config.output_path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        write_ply(config.output_path, xyz, to_uint8_rgb(rgb))
+    else:
+        _write_output(config.output_path, xyz, rgb, err, dev_pts)
     log.info(f"Dense point cloud saved to {config.output_path} ({xyz.shape[0]:,} points)")
     if progress_callback:
         progress_callback(100.0, f"Done! {xyz.shape[0]:,} points")

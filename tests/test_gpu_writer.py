@@ -1,0 +1,49 @@
+"""Device-side record packing (N1) against upstream's writers: byte-exact."""
+import numpy as np
+import pytest
+import torch
+
+from lichtfeld_densification_plugin_amd.core import hip_backend as hb
+from lichtfeld_densification_plugin_amd.core import writers
+from helpers import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dens():
+    d = hb.HipDensifier(torch.device("cuda:0"))
+    yield d
+    d.close()
+
+
+def test_packed_files_equal_upstream_golden(g5, dens, tmp_path):
+    dev = dens.device
+    xyz, rgb, err = (torch.from_numpy(g5[k]).to(dev) for k in ("xyz", "rgb", "err"))
+    ply = dens.pack_ply(xyz, rgb).cpu().numpy().tobytes()
+    p3d = dens.pack_points3d(xyz, rgb, err).cpu().numpy().tobytes()
+    np.testing.assert_array_equal(dens.quantise_rgb(rgb).cpu().numpy(), g5["rgb_u8"])
+    p1, p2 = tmp_path / "a.ply", tmp_path / "a.bin"
+    writers.write_ply_packed(str(p1), 5, ply)
+    writers.write_points3D_bin_packed(str(p2), 5, p3d)
+    assert p1.read_bytes() == g5["ply"].tobytes()
+    assert p2.read_bytes() == g5["points3d_bin"].tobytes()
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 255, 256, 257, 100003])
+def test_packing_matches_oracle_writer_for_ragged_sizes(dens, n):
+    rs = np.random.RandomState(n)
+    xyz = rs.normal(0, 5, (n, 3)).astype(np.float32)
+    rgb = rs.uniform(-0.1, 1.1, (n, 3)).astype(np.float32)
+    if n > 10:
+        rgb[:6] = np.array([[0.5 / 255, 1.5 / 255, 2.5 / 255], [254.5 / 255, 255.5 / 255, 0.0], [np.nan, np.inf, -np.inf],
+                            [1.0, 0.0, 0.5], [0.49803922, 0.5019608, 0.0019607844], [1e-8, -1e-8, 0.99999994]], np.float32)
+    err = rs.uniform(0, 2, n).astype(np.float32)
+    dev = dens.device
+    tx, tc, te = torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev), torch.from_numpy(err).to(dev)
+    with np.errstate(invalid="ignore"):
+        u8 = orc.to_uint8_rgb(rgb)
+    head = orc.ply_bytes(xyz, u8)[:-15 * n] if n else orc.ply_bytes(xyz, u8)
+    assert head + dens.pack_ply(tx, tc).cpu().numpy().tobytes() == orc.ply_bytes(xyz, u8)
+    assert np.uint64(n).tobytes() + dens.pack_points3d(tx, tc, te).cpu().numpy().tobytes() == orc.points3d_bin_bytes(xyz, u8, err)
+    assert np.uint64(n).tobytes() + dens.pack_points3d(tx, tc, None).cpu().numpy().tobytes() == orc.points3d_bin_bytes(xyz, u8, None)
