@@ -135,6 +135,12 @@ int lfd_select_samples(lfd_context* ctx, const float* best_cert, int32_t H, int3
                        int32_t border, int32_t tiles, float s_override, int64_t* sel_out, int64_t capacity,
                        int32_t* n_sel_host, int32_t* status_host);
 
+/* no_filter branch of the selection (core/sampling.py:15-21): the min(M, H*W) largest capped
+ * certainties in descending order (ties: ascending cell index; NumPy leaves tie order unspecified;
+ * NaN last).  M <= 16384.  Does not touch the RNG stream.  Synchronises like lfd_select_samples. */
+int lfd_select_top_m(lfd_context* ctx, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
+                     int64_t* sel_out, int64_t capacity, int32_t* n_sel_host, int32_t* status_host);
+
 /* N1: file payloads on the device (core/writers.py:15-46, core/image_utils.py:24-26).  Colours are
  * quantised like upstream's to_uint8_rgb: clip(round_half_even(c * 255), 0, 255).
  * lfd_pack_ply:      out[n*15] = per point x y z (f32 LE) r g b (u8): the PLY body after upstream's header.

@@ -81,6 +81,8 @@ def load_library() -> C.CDLL:
     lib.lfd_triangulate_indexed.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p,
                                             C.POINTER(C.c_int64), C.POINTER(lfd_points), C.c_void_p, C.c_void_p,
                                             C.c_void_p]
+    lib.lfd_select_top_m.argtypes = [ctxp, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int64,
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.lfd_pack_ply.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.lfd_pack_points3d.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]
     lib.lfd_quantise_rgb.argtypes = [ctxp, C.c_void_p, C.c_int64, C.c_void_p]
@@ -98,7 +100,7 @@ def load_library() -> C.CDLL:
                                                  C.c_int32, C.POINTER(lfd_params), fptr]
     for name in ("lfd_create", "lfd_set_stream", "lfd_upload_cameras", "lfd_aggregate", "lfd_triangulate_dense",
                  "lfd_triangulate_indexed", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
-                 "lfd_select_samples", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_identity_axis",
+                 "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_identity_axis",
                  "lfd_host_fundamental",
                  "lfd_host_eval_correspondence"):
         getattr(lib, name).restype = C.c_int
@@ -408,6 +410,21 @@ class HipDensifier:
         if rc != 0 and st.value in (1, 2, 3):
             raise ValueError(self._lib.lfd_last_error(self._ctx).decode().replace("selection: ", ""))
         self._check(rc, "lfd_select_samples")
+        return out[:int(n.value)]
+
+    TOP_M_MAX = 16384
+
+    def select_top_m(self, best_cert: torch.Tensor, M: int, cap: float = 0.9) -> torch.Tensor:
+        """no_filter selection: the M largest capped certainties, descending (ties by cell index)."""
+        if best_cert.dtype != torch.float32 or not best_cert.is_cuda or best_cert.dim() != 2:
+            raise ValueError("best_cert must be a 2-D float32 device tensor")
+        bc = best_cert.contiguous()
+        H, W = bc.shape
+        cap_n = max(min(int(M), H * W), 1)
+        out = torch.empty((cap_n,), dtype=torch.int64, device=bc.device)
+        n, st = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.lfd_select_top_m(self._ctx, bc.data_ptr(), H, W, int(M), C.c_float(cap), out.data_ptr(), cap_n,
+                                               C.byref(n), C.byref(st)), "lfd_select_top_m")
         return out[:int(n.value)]
 
     # -- launches (asynchronous on self.stream) -------------------------------------------------------

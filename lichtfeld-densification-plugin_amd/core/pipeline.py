@@ -258,11 +258,14 @@ class _HotPath:
     def sampled(self, ref: hb.ReferenceInputs, axes, rng, device_seed: Optional[int]
                 ) -> Tuple[Optional[hb.TriangulationOutput], Optional[torch.Tensor]]:
         """aggregate kernel -> coverage sampling -> indexed kernel.  The sampling stage runs on the
-        device (lfd_select_samples, consuming the context's MT19937 stream) unless the configuration
-        asks for the host stage or no_filter is set (top-M by argsort: core/sampling.py)."""
+        device (lfd_select_samples consuming the context's MT19937 stream; lfd_select_top_m for
+        no_filter) unless the configuration asks for the host stage (core/sampling.py)."""
         batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes)
         best, _ = self.dens.aggregate(batch, self.params)
-        if self.config.selection_backend == "device" and not self.config.no_filter:
+        on_device = self.config.selection_backend == "device"
+        if on_device and self.config.no_filter and self.config.matches_per_ref <= self.dens.TOP_M_MAX:
+            sel_t = self.dens.select_top_m(best[0], self.config.matches_per_ref, cap=self.sample_cap)
+        elif on_device and not self.config.no_filter:
             if device_seed is not None:
                 self.dens.seed_rng(device_seed)
             sel_t = self.dens.select_samples(best[0], self.config.matches_per_ref, cap=self.sample_cap, border=2, tiles=24)

@@ -48,7 +48,7 @@ class DensePipelineConfig:
     per_reference_rng: bool = False
     # where the coverage-sampling stage of the "sampled" mode runs: "device" (lfd_select_samples: the
     # whole per-reference path stays on the GPU) or "host" (core/sampling.py: the library calls
-    # upstream makes, including torch's own f32 sum as the normaliser).  no_filter always uses "host".
+    # upstream makes, including torch's own f32 sum as the normaliser).
     selection_backend: str = "device"
 
     def __post_init__(self) -> None:

@@ -20,6 +20,7 @@ extern "C" __global__ void lfd_pack_ply_kernel(const float* xyz, const float* rg
 extern "C" __global__ void lfd_pack_points3d_kernel(const float* xyz, const float* rgb, const float* err, long long n,
                                                     unsigned long long id_base, unsigned char* out);
 extern "C" __global__ void lfd_quantise_rgb_kernel(const float* rgb, long long n3, unsigned char* out);
+extern "C" __global__ void lfd_select_topm_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_mt_seed_kernel(unsigned* mt, unsigned seed);
 extern "C" __global__ void lfd_indexed_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets,
                                               float* scratch, uint8_t* codes, int32_t* seg_order);
@@ -479,15 +480,16 @@ int lfd_rng_set_state(lfd_context* ctx, const uint32_t* key624, int32_t pos) {
     return LFD_OK;
 }
 
-int lfd_select_samples(lfd_context* ctx, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
+static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
                        int32_t border, int32_t tiles, float s_override, int64_t* sel_out, int64_t capacity,
                        int32_t* n_sel_host, int32_t* status_host) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
     if (!best_cert || !sel_out || !n_sel_host || !status_host) return fail(ctx, LFD_ERR_INVALID, "null argument");
     if (H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL || M < 0 || tiles <= 0 || border < 0 || capacity < 0)
         return fail(ctx, LFD_ERR_INVALID, "bad selection arguments");
-    if (!ctx->mt_seeded) return fail(ctx, LFD_ERR_STATE, "lfd_rng_seed must be called before lfd_select_samples");
+    if (!topm && !ctx->mt_seeded) return fail(ctx, LFD_ERR_STATE, "lfd_rng_seed must be called before lfd_select_samples");
     LFD_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->mt.ptr) { int rc0 = ensure(ctx, ctx->mt, 625 * sizeof(unsigned)); if (rc0 != LFD_OK) return rc0; }
     const size_t N = (size_t)H * W, Mz = (size_t)std::max(M, 1);
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t o_w = 0, o_p = o_w + up(N * 4), o_cdf = o_p + up(N * 8), o_first = o_cdf + up(N * 8), o_mark = o_first + up(N * 4),
@@ -513,7 +515,18 @@ int lfd_select_samples(lfd_context* ctx, const float* best_cert, int32_t H, int3
     A.status = reinterpret_cast<int*>(base + o_out + 4);
     A.capacity = capacity;
     A.H = H; A.W = W; A.M = M; A.border = border; A.tiles = tiles; A.cap = cap; A.s_override = s_override;
-    hipLaunchKernelGGL(lfd_select_filter_kernel, dim3(1), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A);
+    if (topm) {
+        static bool attr_set = false;
+        const size_t lds = (size_t)LFD_SELECT_TOPM_MAX * sizeof(unsigned long long);
+        if (!attr_set) {
+            LFD_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lfd_select_topm_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(lfd_select_topm_kernel, dim3(1), dim3(LFD_SELECT_BLOCK), lds, ctx->stream, A);
+    } else {
+        hipLaunchKernelGGL(lfd_select_filter_kernel, dim3(1), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A);
+    }
     LFD_HIP(ctx, hipGetLastError());
     int host[2] = {0, 0};
     LFD_HIP(ctx, hipMemcpyAsync(host, base + o_out, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
@@ -528,6 +541,17 @@ int lfd_select_samples(lfd_context* ctx, const float* best_cert, int32_t H, int3
                     std::string("selection: ") + names[std::min(host[1], 7)]);
     }
     return LFD_OK;
+}
+
+int lfd_select_samples(lfd_context* ctx, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
+                       int32_t border, int32_t tiles, float s_override, int64_t* sel_out, int64_t capacity,
+                       int32_t* n_sel_host, int32_t* status_host) {
+    return select_impl(ctx, false, best_cert, H, W, M, cap, border, tiles, s_override, sel_out, capacity, n_sel_host, status_host);
+}
+
+int lfd_select_top_m(lfd_context* ctx, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
+                     int64_t* sel_out, int64_t capacity, int32_t* n_sel_host, int32_t* status_host) {
+    return select_impl(ctx, true, best_cert, H, W, M, cap, 0, 1, 0.0f, sel_out, capacity, n_sel_host, status_host);
 }
 
 // ---- N1: writers ----------------------------------------------------------------------------------

@@ -73,6 +73,7 @@ struct LfdLaunch {              // kernel argument, passed by value
 // ---- S: on-device coverage sampling (lfd_select.hip) ---------------------------------------------
 #define LFD_SELECT_BLOCK 1024
 #define LFD_SELECT_MAX_BINS 1024
+#define LFD_SELECT_TOPM_MAX 16384    // no_filter: winners sorted in LDS (128 KiB)
 #define LFD_SELECT_OK 0
 #define LFD_SELECT_NAN 1             // a weight is NaN           (upstream: ValueError from np.random.choice)
 #define LFD_SELECT_NEGATIVE 2        // a weight is negative      (upstream: ValueError)

@@ -406,10 +406,11 @@ LFD_HD void lfd_bilinear_rgb(const uint8_t* img, int wi, int hi, float xa_px, fl
     const double ax = (double)x1 - xd, bx = xd - (double)x0;
     const double ay = (double)y1 - yd, by = yd - (double)y0;
     const double wa = ax * ay, wb = bx * ay, wc = ax * by, wd = bx * by;
-    const uint8_t* pa = img + ((size_t)y0 * wi + x0) * 3;
-    const uint8_t* pb = img + ((size_t)y0 * wi + x1) * 3;
-    const uint8_t* pcx = img + ((size_t)y1 * wi + x0) * 3;
-    const uint8_t* pd = img + ((size_t)y1 * wi + x1) * 3;
+    // 32-bit offsets from the (uniform) image base: the compiler keeps the base in SGPRs
+    const uint8_t* pa = img + ((unsigned)y0 * (unsigned)wi + (unsigned)x0) * 3u;
+    const uint8_t* pb = img + ((unsigned)y0 * (unsigned)wi + (unsigned)x1) * 3u;
+    const uint8_t* pcx = img + ((unsigned)y1 * (unsigned)wi + (unsigned)x0) * 3u;
+    const uint8_t* pd = img + ((unsigned)y1 * (unsigned)wi + (unsigned)x1) * 3u;
     for (int c = 0; c < 3; ++c) {
         const double s = (((double)(float)pa[c] * wa + (double)(float)pb[c] * wb) + (double)(float)pcx[c] * wc) +
                          (double)(float)pd[c] * wd;

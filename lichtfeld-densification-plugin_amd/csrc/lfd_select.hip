@@ -174,6 +174,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     // ---- weights, exact sum, NaN check --------------------------------------------------------------
     double acc = 0.0;
     int bad = 0;
+#pragma unroll 4
     for (int i = tid; i < N; i += kSelBlock) {
         const int y = i / W, x = i - y * W;
         float c = cert[i];
@@ -192,6 +193,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
 
     // ---- p = (weights / s) as f32, widened; exactness precondition; non-zero count -------------------------
     int nz = 0, inexact = 0;
+#pragma unroll 4
     for (int i = tid; i < N; i += kSelBlock) {
         const float pf = wbuf[i] / s32;
         wbuf[i] = pf;                                              // the normalised f32 weights (coverage uses them)
@@ -210,7 +212,8 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     // ---- legacy choice(replace=False, p) -----------------------------------------------------------------------
     if (tid == 0) s_n_uniq = 0;
     __syncthreads();
-    const int per = (N + kSelBlock - 1) / kSelBlock;              // contiguous chunk per thread for the scan
+    const int per = (N + kSelBlock - 1) / kSelBlock;              // run length of the coarse search table / final compaction
+    constexpr int nwaves = kSelBlock / 64;
     int guard = 0;
     while (true) {
         const int n_uniq = s_n_uniq;
@@ -220,24 +223,43 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         mt_fill_doubles(A.mt, A.draws, need, tid);
         for (int j = tid; j < n_uniq; j += kSelBlock) p[A.found[j]] = 0.0;
         __syncthreads();
-        // cdf = cumsum(p) (exact, see header), then /= cdf[-1]
+        // cdf = cumsum(p) (exact, see header), then /= cdf[-1].  Each wave owns one contiguous span and
+        // walks it 64 elements at a time (coalesced), scanning inside the wave with shuffles.
         {
-            const int lo = tid * per, hi = min(lo + per, N);
-            double t = 0.0;
-            for (int i = lo; i < hi; ++i) t += p[i];
-            s_chunk[tid] = t;
+            const int lane = tid & 63, wave = tid >> 6;
+            const int span = ((N + nwaves - 1) / nwaves + 63) & ~63;      // multiple of 64
+            const int w_lo = wave * span, w_hi = min(w_lo + span, N);
+            double part = 0.0;
+#pragma unroll 4
+            for (int i = w_lo + lane; i < w_hi; i += 64) part += p[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (lane == 0) s_d[wave] = part;
             __syncthreads();
-            if (tid == 0) { double run = 0.0; for (int k = 0; k < kSelBlock; ++k) { const double c0 = s_chunk[k]; s_chunk[k] = run; run += c0; } s_d[0] = run; }
-            __syncthreads();
-            const double total = s_d[0];
-            double run = s_chunk[tid];
-            for (int i = lo; i < hi; ++i) { run += p[i]; cdf[i] = run / total; }
+            double carry = 0.0, total = 0.0;
+            for (int w = 0; w < nwaves; ++w) { if (w < wave) carry += s_d[w]; total += s_d[w]; }
+            for (int base = w_lo; base < w_hi; base += 64) {
+                const int i = base + lane;
+                double v = (i < w_hi) ? p[i] : 0.0;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const double n = __shfl_up(v, off, 64);
+                    if (lane >= off) v += n;
+                }
+                if (i < w_hi) cdf[i] = (carry + v) / total;
+                carry += __shfl(v, 63, 64);
+            }
         }
+        __syncthreads();
+        // coarse table for a two-level search: s_chunk[k] = cdf at the end of the k-th run of `per` cells
+        s_chunk[tid] = cdf[min((tid + 1) * per, N) - 1];
         __syncthreads();
         // new = searchsorted(cdf, x, side="right"); first occurrence of each value, in draw order
         for (int j = tid; j < need; j += kSelBlock) {
             const double x = A.draws[j];
-            int lo = 0, hi = N;
+            int klo = 0, khi = kSelBlock;                       // first run whose last cdf value exceeds x
+            while (klo < khi) { const int mid = (klo + khi) >> 1; if (s_chunk[mid] <= x) klo = mid + 1; else khi = mid; }
+            int lo = min(klo * per, N), hi = min(lo + per, N);
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= x) lo = mid + 1; else hi = mid; }
             A.cand[j] = lo;
             A.first[lo] = 0x7fffffff;
@@ -266,6 +288,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     if (nbins > LFD_SELECT_MAX_BINS) { if (tid == 0) *A.status = LFD_SELECT_TOO_MANY_BINS; return; }
     for (int b = tid; b < nbins; b += kSelBlock) s_bin[b] = 0ull;
     __syncthreads();
+#pragma unroll 4
     for (int i = tid; i < N; i += kSelBlock) {
         const float wv = wbuf[i];
         if (wv > 0.0f) {
@@ -278,6 +301,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     const int budget = max(A.M - size, 1);
     // mark array: the random part, then the `budget` heaviest bins
     unsigned char* mark = A.mark;
+#pragma unroll 8
     for (int i = tid; i < N; i += kSelBlock) mark[i] = 0;
     __syncthreads();
     for (int j = tid; j < size; j += kSelBlock) mark[A.found[j]] = 1;
@@ -300,6 +324,96 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         for (int i = lo; i < hi; ++i) if (mark[i]) A.sel_out[pos++] = (long long)i;
         if (tid == 0) *A.n_out = total;
     }
+}
+
+// =================================================================================================
+// no_filter: the M largest capped certainties, in descending order (upstream: argsort(-flat)[:M],
+// core/sampling.py:15-21).  NumPy's introsort leaves the order of EQUAL values unspecified; here ties
+// are broken by ascending cell index.  NaN sorts last, as in NumPy.
+// Radix-select the M-th largest 64-bit key {value bits, ~index} (8 rounds of 8-bit histograms), gather
+// the M winners, bitonic-sort them in LDS.
+// =================================================================================================
+extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_topm_kernel(LfdSelectArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];   // [LFD_SELECT_TOPM_MAX]
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned s_remaining, s_count;
+    __shared__ int s_i[kSelBlock / 64];
+
+    const int tid = (int)threadIdx.x;
+    const int N = A.H * A.W;
+    const int M = min(A.M, N);
+    if (tid == 0) { *A.n_out = 0; *A.status = LFD_SELECT_OK; }
+    if (M <= 0) return;
+    if (M > LFD_SELECT_TOPM_MAX || (long long)M > A.capacity) { if (tid == 0) *A.status = LFD_SELECT_CAPACITY; return; }
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(A.cdf);     // [N] scratch
+
+    // key: larger = earlier in the output.  -NaN sorts last in NumPy -> key 0..; finite values map to
+    // an order-preserving unsigned (sign flip), ties resolved by lower index first.
+#pragma unroll 4
+    for (int i = tid; i < N; i += kSelBlock) {
+        float c = A.best_cert[i];
+        c = (c > A.cap) ? A.cap : c;
+        unsigned u = __float_as_uint(c);
+        unsigned ord;
+        if (c != c) ord = 0u;                                              // NaN: last
+        else ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);            // total order of finite floats (+0 > -0 irrelevant)
+        if (ord == 0u && !(c != c)) ord = 1u;
+        keys[i] = ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+    }
+    if (tid == 0) { s_prefix = 0ull; s_remaining = (unsigned)M; }
+    __syncthreads();
+    // MSB-first radix select of the M-th largest key
+    for (int round = 7; round >= 0; --round) {
+        const int shift = round * 8;
+        for (int b = tid; b < 256; b += kSelBlock) s_hist[b] = 0;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        const unsigned long long himask = (round == 7) ? 0ull : (~0ull << (shift + 8));
+#pragma unroll 4
+        for (int i = tid; i < N; i += kSelBlock) {
+            const unsigned long long kx = keys[i];
+            if ((kx & himask) == prefix) atomicAdd(&s_hist[(unsigned)(kx >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned need = s_remaining, acc = 0;
+            int b = 255;
+            for (; b >= 0; --b) { if (acc + s_hist[b] >= need) break; acc += s_hist[b]; }
+            s_remaining = need - acc;                     // still wanted inside bucket b
+            s_prefix = prefix | ((unsigned long long)(unsigned)b << shift);
+        }
+        __syncthreads();
+    }
+    const unsigned long long kth = s_prefix;               // exactly M keys are >= kth (keys are distinct)
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += kSelBlock) {
+        const unsigned long long kx = keys[i];
+        if (kx >= kth) { const unsigned pos = atomicAdd(&s_count, 1u); if (pos < (unsigned)LFD_SELECT_TOPM_MAX) s_keys[pos] = kx; }
+    }
+    __syncthreads();
+    // pad to a power of two with 0 (sorts last), bitonic sort descending
+    int P = 1;
+    while (P < M) P <<= 1;
+    for (int i = M + tid; i < P; i += kSelBlock) s_keys[i] = 0ull;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += kSelBlock) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = s_keys[i], b = s_keys[l];
+                    const bool desc = ((i & k) == 0);
+                    if (desc ? (a < b) : (a > b)) { s_keys[i] = b; s_keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < M; i += kSelBlock) A.sel_out[i] = (long long)(0xffffffffu - (unsigned)(s_keys[i] & 0xffffffffull));
+    if (tid == 0) *A.n_out = M;
+    (void)s_i;
 }
 
 // seed exactly like np.random.seed(uint32): init_genrand

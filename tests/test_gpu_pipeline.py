@@ -51,7 +51,8 @@ def _scene(g4, tmp_path):
 
 
 @pytest.mark.parametrize("mode,two_channel,backend", [("filter", False, "host"), ("nofilter", False, "host"),
-                                                      ("filter", True, "host"), ("filter", False, "device")])
+                                                      ("filter", True, "host"), ("filter", False, "device"),
+                                                      ("nofilter", False, "device")])
 def test_pipeline_matches_upstream_run(g4, tmp_path, mode, two_channel, backend):
     """backend="host": the sampling stage makes upstream's own library calls -> identical run.
     backend="device": everything on the GPU; the only difference from upstream is the rounding of the

@@ -105,3 +105,31 @@ def test_edge_cases_follow_upstream(dens, g2):
     w = np.minimum(cert, np.float32(0.9)).reshape(-1)
     only_dev, only_ref = np.setdiff1d(sel, ref), np.setdiff1d(ref, sel)
     assert np.all(w[only_dev] == np.float32(0.9)) and np.all(w[only_ref] == np.float32(0.9))   # tied at the cap
+
+
+@pytest.mark.parametrize("h,w,M", [(64, 64, 600), (80, 96, 5000), (512, 512, 12000), (48, 48, 5000)])
+def test_top_m_equals_upstream_argsort_on_tie_free_maps(dens, g2, h, w, M):
+    cert = _tiefree(h, w, 77)
+    sel = dens.select_top_m(torch.from_numpy(cert).to(dens.device), M).cpu().numpy()
+    ref = orc.select_samples(cert, M, no_filter=True)
+    np.testing.assert_array_equal(sel, ref)
+
+
+def test_top_m_matches_golden_and_orders_ties_by_index(dens, g2):
+    for ci, (h, w, M, seed, cseed) in enumerate(g2["cases"]):
+        if int(M) > 16384:
+            continue
+        cert = _tiefree(int(h), int(w), int(cseed))
+        sel = dens.select_top_m(torch.from_numpy(cert).to(dens.device), int(M)).cpu().numpy()
+        np.testing.assert_array_equal(sel, g2[f"c{ci}_nf_sel"])
+    cert = g2["ties_cert"].copy()                       # floor / cap clamps: massive ties
+    cert[5, 7] = np.nan
+    sel = dens.select_top_m(torch.from_numpy(cert).to(dens.device), 1500).cpu().numpy()
+    flat = np.minimum(cert, np.float32(0.9)).reshape(-1)
+    v = flat[sel]
+    assert sel.size == 1500 and np.unique(sel).size == 1500 and not np.isnan(v).any()
+    assert np.all(np.diff(v) <= 0)                                   # descending values
+    same = np.diff(v) == 0
+    assert np.all(np.diff(sel)[same] > 0)                            # equal values: ascending cell index
+    kth = v[-1]
+    assert np.sum(flat > kth) <= 1500 <= np.sum(flat >= kth)        # exactly the M largest
