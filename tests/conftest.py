@@ -13,6 +13,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # the C-ABI library is a build artefact (git-ignored): cross-compile it once if it is not there
+    lib = os.path.join(ROOT, "lichtfeld-densification-plugin_amd", "liblfd_densify.so")
+    if not os.path.exists(lib):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location(
+            "_lfd_build", os.path.join(ROOT, "lichtfeld-densification-plugin_amd", "csrc", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
 
 
 def load_golden(name):
