@@ -36,11 +36,22 @@ def _pack(xyz: torch.Tensor, rgb: torch.Tensor, err: torch.Tensor, rows: int) ->
     return buf
 
 
+def _collective_device(t: torch.Tensor, dist, group=None) -> torch.device:
+    """RCCL ("nccl") moves device buffers; gloo (CPU tests, or several ranks sharing one GPU) host ones."""
+    try:
+        backend = str(dist.get_backend(group)).lower()
+    except Exception:
+        backend = "nccl"
+    return torch.device("cpu") if "gloo" in backend else t.device
+
+
 def all_gather_points(xyz: torch.Tensor, rgb: torch.Tensor, err: torch.Tensor, dist, group=None
                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, List[int]]:
     """Concatenate every rank's survivors in rank order.  Returns (xyz, rgb, err, counts)."""
     world = dist.get_world_size(group)
-    dev = xyz.device
+    home = xyz.device
+    dev = _collective_device(xyz, dist, group)
+    xyz, rgb, err = xyz.to(dev), rgb.to(dev), err.to(dev)
     n_local = torch.tensor([xyz.shape[0]], dtype=torch.int64, device=dev)
     counts_t = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts_t, n_local, group=group)
@@ -50,6 +61,7 @@ def all_gather_points(xyz: torch.Tensor, rgb: torch.Tensor, err: torch.Tensor, d
     bufs = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(bufs, mine, group=group)
     cat = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0) if sum(counts) else mine[:0]
+    cat = cat.to(home)
     return cat[:, 0:3].contiguous(), cat[:, 3:6].contiguous(), cat[:, 6].contiguous(), counts
 
 
@@ -63,7 +75,8 @@ def all_gather_by_reference(xyz: torch.Tensor, rgb: torch.Tensor, err: torch.Ten
     reference position and the per-reference counts ``(n_refs_global,)``."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    dev = xyz.device
+    home = xyz.device
+    dev = _collective_device(xyz, dist, group)
     per_rank = (n_refs_global + world - 1) // world
     local = torch.zeros(per_rank, dtype=torch.int64, device=dev)
     expected = len(shard_references(n_refs_global, rank, world))
@@ -88,6 +101,6 @@ def all_gather_by_reference(xyz: torch.Tensor, rgb: torch.Tensor, err: torch.Ten
         if hi > lo:
             pieces.append(torch.arange(lo, hi, device=dev))
     if pieces:
-        order = torch.cat(pieces)
+        order = torch.cat(pieces).to(gx.device)
         gx, gc, ge = gx[order], gc[order], ge[order]
-    return gx, gc, ge, global_counts
+    return gx.to(home), gc.to(home), ge.to(home), global_counts

@@ -522,7 +522,8 @@ def run_dense_pipeline(
             counts_local, len(refs_local), dist)
         xyz, rgb, err = gx.cpu().numpy(), gc_.cpu().numpy(), ge.cpu().numpy()
         device_points = (gx, gc_, ge)
-        t = torch.tensor([refs_with_points, pair_counter], dtype=torch.int64, device=dev)
+        t = torch.tensor([refs_with_points, pair_counter], dtype=torch.int64,
+                         device=lfd_dist._collective_device(gx, dist))
         dist.all_reduce(t)
         refs_with_points, pair_counter = int(t[0].item()), int(t[1].item())
 

@@ -160,3 +160,46 @@ def test_dense_init_from_lfs_writes_the_same_ply_as_the_host_writer(g4, tmp_path
     x, c, e = densify._apply_point_cap(res.xyz, res.rgb, res.err, 2000, 5)
     writers.write_ply(cfg2.output_path, x, to_uint8_rgb(c))
     assert open(cfg2.output_path, "rb").read() == raw
+
+
+def _rank_worker(rank, world, port, scene, cfg_kw, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # two ranks share the one GPU: host collectives
+    try:
+        cams, refs, nn, tables = scene
+        mine = [tables[i] for i in range(len(refs)) if i % world == rank]
+        cfg = lfd.DensePipelineConfig(**cfg_kw)
+        res = pl.run_dense_pipeline(cams, refs, nn, cfg, matcher=FakeMatcher(64, 64, mine))
+        q.put((rank, res.xyz, res.rgb, res.err, res.points_per_reference, res.pairs_processed, res.pairs_matched))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["sampled", "dense"])
+def test_two_ranks_reproduce_the_single_process_sequence(g4, tmp_path, mode):
+    """References dealt round-robin to 2 ranks (each with its own HIP context) + ordered all-gather ==
+    the 1-rank run with per-reference RNG streams: same points, same order."""
+    import socket
+    import torch.multiprocessing as mp
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+    kw = dict(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=2, seed=5, viz_interval=0, matches_per_ref=1200,
+              triangulation_mode=mode, per_reference_rng=True)
+    single = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**kw), matcher=FakeMatcher(64, 64, table))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, (cams, refs, nn, table), kw, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, xyz, rgb, err, counts, n_refs, n_pairs in results:
+        np.testing.assert_array_equal(counts, single.points_per_reference)
+        np.testing.assert_array_equal(xyz, single.xyz)
+        np.testing.assert_array_equal(rgb, single.rgb)
+        np.testing.assert_array_equal(err, single.err)
+        assert n_refs == single.pairs_processed and n_pairs == single.pairs_matched
