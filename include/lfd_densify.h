@@ -167,6 +167,10 @@ float lfd_parallax_dot_threshold(float min_deg);
  * (core/geometry.py:122-130). */
 int lfd_host_fundamental(const float* K1, const float* R1, const float* t1, const float* K2,
                          const float* R2, const float* t2, float* F_out);
+/* Smallest right singular vector of a row-major 4x4 f32 matrix, the routine the kernels triangulate with
+ * (f64 inverse iteration on A^T A), on the HOST build of the same source; out4 is un-normalised.  Returns the
+ * number of solves made (>= 3) or a negative lfd_status.  CPU unit tests compare it with an f64 SVD. */
+int lfd_host_null_vector(const float* A16, double* out4);
 /* One correspondence through the per-cell routine on the HOST build of the same source (debug /
  * CPU unit tests of the arithmetic; not a fallback: no batch entry point uses it).
  * cam1/cam2: K[9] R[9] t[3] P[12] C[3] w h (as floats, 38 values).  out: x y z r g b err keep. */

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,7 +15,15 @@
 
 extern "C" __global__ void lfd_aggregate_kernel(LfdLaunch L, float* best_cert, uint8_t* best_slot);
 extern "C" __global__ void lfd_dense_kernel(LfdLaunch L);
-extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* ref_out, LfdPairConst* pair_out);
+#if defined(LFD_PHASE_TIMING)
+extern __device__ unsigned long long lfd_phase_acc[16];
+#endif
+#define LFD_DECL_FAST(KK) \
+    extern "C" __global__ void lfd_dense_fast_kernel_k##KK##_m0(LfdLaunch L); \
+    extern "C" __global__ void lfd_dense_fast_kernel_k##KK##_m1(LfdLaunch L); \
+    extern "C" __global__ void lfd_dense_fast_kernel_k##KK##_m2(LfdLaunch L);
+LFD_DECL_FAST(1) LFD_DECL_FAST(2) LFD_DECL_FAST(3) LFD_DECL_FAST(4)
+extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* ref_out, LfdPairConst* pair_out, LfdFastRef* fast_out);
 extern "C" __global__ void lfd_select_filter_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_pack_ply_kernel(const float* xyz, const float* rgb, long long n, unsigned char* out);
 extern "C" __global__ void lfd_pack_points3d_kernel(const float* xyz, const float* rgb, const float* err, long long n,
@@ -55,7 +64,7 @@ struct lfd_context {
     unsigned long long tickets_issued = 0;   // host mirror of the device ticket counter
     unsigned epoch = 0;
     int n_cus = 0;                 // compute units of the device
-    int dense_blocks_per_cu = 0;   // resident lfd_dense_kernel workgroups per CU (persistent grid size)
+    int fast_blocks_per_cu[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // resident workgroups per CU of lfd_dense_fast_kernel_k<K> (persistent grid size)
     // default A-grid axes
     DeviceBuffer axes;
     int axes_w = 0, axes_h = 0;
@@ -217,7 +226,10 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
     else {
         rc = default_axes(ctx, b->W, b->H, &L.axis_x, &L.axis_y);
         if (rc != LFD_OK) return rc;
+        L.axes_identity = 1;
     }
+    L.ax = lfd_make_axis(b->W);
+    L.ay = lfd_make_axis(b->H);
     L.n_refs = b->n_refs; L.k = b->k; L.H = b->H; L.W = b->W;
     L.w_match = b->w_match; L.h_match = b->h_match; L.warp_channels = b->warp_channels;
     const long long HW = (long long)b->H * b->W;
@@ -229,17 +241,20 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
     fill_kernel_params(b, p, L.kp);
     // per-pair constants: (re)derive when the batch tables, the cameras or the match size changed
     const size_t ref_bytes = ((size_t)b->n_refs * sizeof(LfdRefConst) + 15) & ~size_t(15);
-    const size_t need = ref_bytes + (size_t)b->n_refs * b->k * sizeof(LfdPairConst);
+    const size_t pair_bytes = ((size_t)b->n_refs * b->k * sizeof(LfdPairConst) + 63) & ~size_t(63);
+    const size_t need = ref_bytes + pair_bytes + (size_t)b->n_refs * sizeof(LfdFastRef);
     if (ctx->consts.bytes < need) ctx->consts_valid = false;
     rc = ensure(ctx, ctx->consts, need);
     if (rc != LFD_OK) return rc;
     LfdRefConst* d_rc = static_cast<LfdRefConst*>(ctx->consts.ptr);
     LfdPairConst* d_pc = reinterpret_cast<LfdPairConst*>(static_cast<unsigned char*>(ctx->consts.ptr) + ref_bytes);
+    LfdFastRef* d_fast = (b->k <= 4) ? reinterpret_cast<LfdFastRef*>(reinterpret_cast<unsigned char*>(d_pc) + pair_bytes) : nullptr;
     L.ref_const = d_rc;
     L.pair_const = d_pc;
+    L.fast = d_fast;
     if (!ctx->consts_valid || ctx->consts_wm != b->w_match || ctx->consts_hm != b->h_match) {
         const int n = b->n_refs * b->k + b->n_refs;
-        hipLaunchKernelGGL(lfd_pair_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, L, d_rc, d_pc);
+        hipLaunchKernelGGL(lfd_pair_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, L, d_rc, d_pc, d_fast);
         LFD_HIP(ctx, hipGetLastError());
         ctx->consts_valid = true;
         ctx->consts_wm = b->w_match;
@@ -393,16 +408,68 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
     if (rc != LFD_OK) return rc;
     rc = check_points(ctx, out, reinterpret_cast<long long*>(ref_offsets));
     if (rc != LFD_OK) return rc;
-    const size_t n_tiles = (size_t)batch->n_refs * (size_t)L.tiles_per_ref;
+    size_t n_tiles = (size_t)batch->n_refs * (size_t)L.tiles_per_ref;
     if (n_tiles > 0x7fffffffu) return fail(ctx, LFD_ERR_INVALID, "too many tiles in one launch");
-    const size_t grid = n_tiles;              // one workgroup per tile, numbered by ticket
-    rc = prepare_lookback(ctx, n_tiles, grid, L);
+    // fast path: no masks and k <= 4 -> persistent software-pipelined kernel (tiles dealt statically, so the
+    // grid must be co-resident: it is sized from the occupancy the runtime reports for this kernel)
+    bool any_mask = false;
+    for (int r = 0; r < batch->n_refs; ++r) {
+        if (batch->mask_a && batch->mask_a[r]) any_mask = true;
+        if (batch->mask_b)
+            for (int j = 0; j < batch->k; ++j) if (batch->mask_b[(size_t)r * batch->k + j]) any_mask = true;
+    }
+    const bool force_general = std::getenv("LFD_DENSE_GENERAL") != nullptr;     // A/B switch for profiling and tests
+    const bool fast = !any_mask && batch->k <= 4 && !force_general;
+    typedef void (*dense_fn)(LfdLaunch);
+    dense_fn fast_fn = nullptr;
+    size_t grid = n_tiles;                    // general path: one workgroup per tile, numbered by ticket
+    if (fast) {
+        // mode 0: [xB,yB] warp + default axes (closed form); 1: [xB,yB] warp + caller's axes; 2: [xA,yA,xB,yB] warp
+        const int mode = (batch->warp_channels == 4) ? 2 : (batch->axis_x ? 1 : 0);
+        static const dense_fn table[4][3] = {
+            {lfd_dense_fast_kernel_k1_m0, lfd_dense_fast_kernel_k1_m1, lfd_dense_fast_kernel_k1_m2},
+            {lfd_dense_fast_kernel_k2_m0, lfd_dense_fast_kernel_k2_m1, lfd_dense_fast_kernel_k2_m2},
+            {lfd_dense_fast_kernel_k3_m0, lfd_dense_fast_kernel_k3_m1, lfd_dense_fast_kernel_k3_m2},
+            {lfd_dense_fast_kernel_k4_m0, lfd_dense_fast_kernel_k4_m1, lfd_dense_fast_kernel_k4_m2}};
+        fast_fn = table[batch->k - 1][mode];
+        int& per_cu = ctx->fast_blocks_per_cu[(batch->k - 1) * 3 + mode];
+        if (per_cu <= 0) {
+            int nb = 0;
+            LFD_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(fast_fn), LFD_DENSE_FAST_THREADS, 0));
+            per_cu = std::max(1, nb);
+            if (const char* o = std::getenv("LFD_DENSE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(o)));
+        }
+        L.tiles_per_ref = (int)(((long long)batch->H * batch->W + LFD_DENSE_FAST_TILE - 1) / LFD_DENSE_FAST_TILE);
+        n_tiles = (size_t)batch->n_refs * (size_t)L.tiles_per_ref;
+        grid = std::min<size_t>(n_tiles, (size_t)ctx->n_cus * (size_t)per_cu);
+        L.stagger_ns = 0.0f;
+        if (const char* o = std::getenv("LFD_DENSE_STAGGER_NS")) L.stagger_ns = (float)std::atof(o);
+    }
+    rc = prepare_lookback(ctx, n_tiles, fast ? 0 : grid, L);
     if (rc != LFD_OK) return rc;
     L.xyz = out->xyz; L.rgb = out->rgb; L.err = out->err; L.cell = out->cell; L.slot = out->slot;
     L.capacity = out->capacity;
     L.ref_offsets = reinterpret_cast<long long*>(ref_offsets);
     L.seg_counts = seg_counts;
     if (seg_counts) LFD_HIP(ctx, hipMemsetAsync(seg_counts, 0, sizeof(int32_t) * (size_t)batch->n_refs * batch->k, ctx->stream));
+    if (fast) {
+        hipLaunchKernelGGL(fast_fn, dim3((unsigned)grid), dim3(LFD_DENSE_FAST_THREADS), 0, ctx->stream, L);
+        LFD_HIP(ctx, hipGetLastError());
+#if defined(LFD_PHASE_TIMING)
+        {   // debug build only: per-phase wall time summed over waves (100 MHz ticks)
+            static int calls = 0;
+            if (++calls == 20) {
+                unsigned long long acc[16];
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipMemcpyFromSymbol(acc, HIP_SYMBOL(lfd_phase_acc), sizeof(acc));
+                double tot = 0; for (int i = 0; i < 12; ++i) tot += (double)acc[i];
+                const double per_wave_tile = 1.0 / (20.0 * (double)n_tiles * 4.0) * 10.0;   // ns per (wave, tile)
+                for (int i = 0; i < 12; ++i) std::fprintf(stderr, "phase %d: %8.0f ns per wave-tile (%.1f%%)\n", i, (double)acc[i] * per_wave_tile, 100.0 * acc[i] / tot);
+            }
+        }
+#endif
+        return LFD_OK;
+    }
     hipLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), 0, ctx->stream, L);
     LFD_HIP(ctx, hipGetLastError());
     return LFD_OK;
@@ -596,15 +663,8 @@ int lfd_quantise_rgb(lfd_context* ctx, const float* rgb, int64_t n, uint8_t* out
 // ---- host-side helpers -----------------------------------------------------------------------
 int lfd_identity_axis(int32_t n, float* out) {
     if (n <= 0 || !out) return LFD_ERR_INVALID;
-    const float start = (float)(-1.0 + 1.0 / (double)n);
-    const float end = (float)(1.0 - 1.0 / (double)n);
-    if (n == 1) { out[0] = start; return LFD_OK; }
-    const float step = (end - start) / (float)(n - 1);
-    const int half = n / 2;
-    for (int j = 0; j < n; ++j) {
-        if (j < half) { const float m = step * (float)j; out[j] = start + m; }
-        else { const float m = step * (float)(n - 1 - j); out[j] = end - m; }
-    }
+    const LfdAxis a = lfd_make_axis(n);
+    for (int j = 0; j < n; ++j) out[j] = lfd_axis_value(a, j);
     return LFD_OK;
 }
 
@@ -636,6 +696,11 @@ static void unpack_cam(const float* v, LfdCam& c) {
     std::memcpy(c.K, v, 9 * 4); std::memcpy(c.R, v + 9, 9 * 4); std::memcpy(c.t, v + 18, 3 * 4);
     std::memcpy(c.P, v + 21, 12 * 4); std::memcpy(c.C, v + 33, 3 * 4);
     c.w = (int32_t)v[36]; c.h = (int32_t)v[37]; c.pad[0] = c.pad[1] = 0;
+}
+
+int lfd_host_null_vector(const float* A16, double* out4) {
+    if (!A16 || !out4) return -LFD_ERR_INVALID;
+    return lfd_null_vector(A16, out4);
 }
 
 int lfd_host_eval_correspondence(const float* cam1, const float* cam2, float xa_norm, float ya_norm, float xb_norm,

@@ -10,6 +10,9 @@
 #endif
 
 #define LFD_DENSE_BLOCK 256     // threads per workgroup of the fused dense kernel (4 waves)
+#define LFD_DENSE_FAST_GEO_WAVES 3                                    // persistent kernel: geometry waves per workgroup
+#define LFD_DENSE_FAST_THREADS ((LFD_DENSE_FAST_GEO_WAVES + 1) * 64)  // + 1 service wave
+#define LFD_DENSE_FAST_TILE (LFD_DENSE_FAST_GEO_WAVES * 256)          // cells per tile of the persistent kernel
 #define LFD_DENSE_CPT 4         // consecutive grid cells per thread (one 16-byte certainty load per slot)
 #ifndef LFD_DENSE_WAVES_PER_SIMD
 #define LFD_DENSE_WAVES_PER_SIMD 4       // register budget of the fused kernel: 512/4 -> <=128 VGPRs
@@ -38,18 +41,31 @@ struct LfdSlotDesc {            // one per (reference, slot)
     int32_t pad;
 };
 
+struct LfdFastRef {             // per reference, fast path: everything a tile needs in three scalar loads
+    const float* cert[4];       // slots >= n_slots repeat slot 0 (loads stay valid, the arg-max ignores them)
+    const float* warp[4];
+    const uint8_t* image;
+    int32_t n_slots;
+    int32_t pad;
+    LfdRefConst rc;
+};
+
 struct LfdLaunch {              // kernel argument, passed by value
     const LfdCam* cams;
     const LfdRefDesc* refs;
     const LfdSlotDesc* slots;
     const LfdRefConst* ref_const;    // [n_refs]    written by lfd_pair_setup_kernel
     const LfdPairConst* pair_const;  // [n_refs*k]
+    const LfdFastRef* fast;     // [n_refs]    written by lfd_pair_setup_kernel when k <= 4
     const float* axis_x;        // [W]
     const float* axis_y;        // [H]
+    LfdAxis ax, ay;             // closed form of the default axes (used when axes_identity)
+    int32_t axes_identity;      // the caller gave no axes: axis_x/axis_y hold lfd_axis_value(ax/ay, j)
+    int32_t pad2;
     int32_t n_refs, k, H, W, w_match, h_match, warp_channels, tiles_per_ref;
     float mask_sx, mask_sy;     // (float)w_match/(float)W, (float)h_match/(float)H  (nearest resize)
     float inv_w;                // 1.0f / W (cell -> row estimate)
-    float pad1;
+    float stagger_ns;           // persistent kernel: workgroup b starts b*stagger_ns late (spreads the phases of co-resident workgroups)
     LfdKernelParams kp;
     // outputs
     float* xyz;

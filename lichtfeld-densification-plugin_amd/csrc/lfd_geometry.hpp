@@ -65,6 +65,30 @@ struct LfdCellResult {
     int32_t keep;
 };
 
+// A-grid axis of the matcher, torch.linspace(-1 + 1/n, 1 - 1/n, n) (core/matcher.py:132-133), element j:
+// start + step*j below the midpoint, end - step*(n-1-j) from it on, all f32 (torch's CPU/GPU kernels).
+struct LfdAxis {
+    float start, end, step;
+    int32_t half, n;
+};
+
+LFD_HD LfdAxis lfd_make_axis(int n) {
+    LfdAxis a;
+    a.start = (float)(-1.0 + 1.0 / (double)n);
+    a.end = (float)(1.0 - 1.0 / (double)n);
+    a.step = (n > 1) ? (a.end - a.start) / (float)(n - 1) : 0.0f;
+    a.half = n / 2;
+    a.n = n;
+    return a;
+}
+
+LFD_HD float lfd_axis_value(const LfdAxis& a, int j) {
+    if (a.n == 1) return a.start;
+    if (j < a.half) { const float m = a.step * (float)j; return a.start + m; }
+    const float m = a.step * (float)(a.n - 1 - j);
+    return a.end - m;
+}
+
 // ---- 3x3 helpers: the accumulation order NumPy/OpenBLAS sgemm uses (forward FMA chain) ------------
 LFD_HD float lfd_dot3_chain(float a0, float b0, float a1, float b1, float a2, float b2) {
     return fmaf(a2, b2, fmaf(a1, b1, a0 * b0));
@@ -140,132 +164,142 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
 }
 
 // ---- smallest right singular vector of a 4x4 matrix, f64 ---------------------------------------
-// adj(A) = det(A) A^-1, so G = adj(A) adj(A)^T = det(A)^2 (A^T A)^-1 has the right singular vectors
-// of A as eigenvectors with eigenvalues prod_{j!=i} sigma_j^2: the wanted vector v4 dominates by the
-// factor (sigma_3/sigma_4)^2.  Squaring G squares that factor and every product of the squared matrix
-// with its own dominant column multiplies the remaining error by it again; for a PSD matrix
-// trace(G)^2 - trace(G^2) ~ 2*(lambda_2/lambda_1)*trace(G)^2 measures the factor, which fixes the number
-// of products up front.  No pivoting and no division: G is rescaled once by an exact power of two.  Unlike
-// eig(A^T A) the conditioning is that of A, not of A^T A: the entries of A are f32, so every 2x2
-// minor is the difference of two EXACT f64 products (fma below changes nothing there).
+// Inverse iteration on M = A^T A through one LDL^T factorisation (no pivoting: M is positive
+// semi-definite):
+//   * the entries of A are f32, so every product in M is exact in f64 and M carries only the rounding of
+//     three additions per entry; the wanted vector v4 (eigenvalue mu4 = sigma4^2) is then determined to
+//     ~1e-16 (sigma1/sigma3)^2, far below what LAPACK's f32 SVD delivers upstream;
+//   * x <- d4 * M^-1 x multiplies the v4 component by d4/mu4 and every other one by at most d4/mu3: the error
+//     shrinks by q = (sigma4/sigma3)^2 per solve (15 flops).  The first solve from e4 is free:
+//     d4 * M^-1 e4 = L^-T e4, the last column of L^-T;
+//   * a nearly singular M is the good case (inverse iteration converges in one step); d4 may then come
+//     out as rounding noise of either sign or exactly 0 - it only ever multiplies, so nothing blows up;
+//   * reciprocals of the pivots are Newton-refined to full precision: an approximate reciprocal would
+//     perturb L by its error times sigma1^2, far above sigma4^2.
+// Two solves are always made; more follow only while the growth factor has not settled (bad
+// conditioning: sigma4/sigma3 not small).
 #ifndef LFD_NULLVEC_TOL
-#define LFD_NULLVEC_TOL 2e-8   /* legacy knob (the product count is derived from the trace test) */
+#define LFD_NULLVEC_TOL 1e-10
 #endif
 #ifndef LFD_NULLVEC_MAXIT
-#define LFD_NULLVEC_MAXIT 6
+#define LFD_NULLVEC_MAXIT 8       /* solves per pass */
+#endif
+#ifndef LFD_NULLVEC_PASSES
+#define LFD_NULLVEC_PASSES 4      /* first pass unshifted, the others shifted by the Rayleigh quotient */
 #endif
 
 LFD_HD double lfd_pow2_inv_scale(double t) {
-    // 2^-e with t = m * 2^e, m in [0.5, 1): exact rescaling to keep the squarings inside f64 range.
-    // t <= 0, Inf or NaN give 1.0 (the caller's tests then fail and the cell is rejected downstream).
+    // 2^-e with t = m * 2^e, m in [0.5, 1): exact rescaling.  t <= 0, Inf or NaN give 1.0.
     if (!(t > 0.0) || !(t < 1.7976931348623157e308)) return 1.0;
     int e;
     (void)frexp(t, &e);
     return ldexp(1.0, -e);
 }
 
-// c[4]: un-normalised dominant column (a multiple of the null vector); returns squarings used.
+LFD_HD double lfd_recip_refined(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);       // v_rcp_f64 is an approximation; two Newton steps bring it to ~1 ulp
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / d;
+#endif
+}
+
+// c[4]: un-normalised multiple of the singular vector; returns the number of solves made.
 LFD_HD int lfd_null_vector(const float* Af, double* c) {
-    double a[16];
-    for (int i = 0; i < 16; ++i) a[i] = (double)Af[i];
-#define A_(i, j) a[(i) * 4 + (j)]
-#define MINOR(p, q, r, s) fma(p, q, -((r) * (s)))      /* p*q - r*s, single rounding (products exact) */
-    const double s0 = MINOR(A_(0, 0), A_(1, 1), A_(1, 0), A_(0, 1));
-    const double s1 = MINOR(A_(0, 0), A_(1, 2), A_(1, 0), A_(0, 2));
-    const double s2 = MINOR(A_(0, 0), A_(1, 3), A_(1, 0), A_(0, 3));
-    const double s3 = MINOR(A_(0, 1), A_(1, 2), A_(1, 1), A_(0, 2));
-    const double s4 = MINOR(A_(0, 1), A_(1, 3), A_(1, 1), A_(0, 3));
-    const double s5 = MINOR(A_(0, 2), A_(1, 3), A_(1, 2), A_(0, 3));
-    const double c5 = MINOR(A_(2, 2), A_(3, 3), A_(3, 2), A_(2, 3));
-    const double c4 = MINOR(A_(2, 1), A_(3, 3), A_(3, 1), A_(2, 3));
-    const double c3 = MINOR(A_(2, 1), A_(3, 2), A_(3, 1), A_(2, 2));
-    const double c2 = MINOR(A_(2, 0), A_(3, 3), A_(3, 0), A_(2, 3));
-    const double c1 = MINOR(A_(2, 0), A_(3, 2), A_(3, 0), A_(2, 2));
-    const double c0 = MINOR(A_(2, 0), A_(3, 1), A_(3, 0), A_(2, 1));
-#undef MINOR
-    // adjugate, each entry x*u - y*v + z*w as fma(z, w, fma(-y, v, x*u))
-#define ADJ(x, u, y, v, z, w) fma(z, w, fma(-(y), v, (x) * (u)))
-    double J[16];
-    J[0] = ADJ(A_(1, 1), c5, A_(1, 2), c4, A_(1, 3), c3);
-    J[1] = -ADJ(A_(0, 1), c5, A_(0, 2), c4, A_(0, 3), c3);
-    J[2] = ADJ(A_(3, 1), s5, A_(3, 2), s4, A_(3, 3), s3);
-    J[3] = -ADJ(A_(2, 1), s5, A_(2, 2), s4, A_(2, 3), s3);
-    J[4] = -ADJ(A_(1, 0), c5, A_(1, 2), c2, A_(1, 3), c1);
-    J[5] = ADJ(A_(0, 0), c5, A_(0, 2), c2, A_(0, 3), c1);
-    J[6] = -ADJ(A_(3, 0), s5, A_(3, 2), s2, A_(3, 3), s1);
-    J[7] = ADJ(A_(2, 0), s5, A_(2, 2), s2, A_(2, 3), s1);
-    J[8] = ADJ(A_(1, 0), c4, A_(1, 1), c2, A_(1, 3), c0);
-    J[9] = -ADJ(A_(0, 0), c4, A_(0, 1), c2, A_(0, 3), c0);
-    J[10] = ADJ(A_(3, 0), s4, A_(3, 1), s2, A_(3, 3), s0);
-    J[11] = -ADJ(A_(2, 0), s4, A_(2, 1), s2, A_(2, 3), s0);
-    J[12] = -ADJ(A_(1, 0), c3, A_(1, 1), c1, A_(1, 2), c0);
-    J[13] = ADJ(A_(0, 0), c3, A_(0, 1), c1, A_(0, 2), c0);
-    J[14] = -ADJ(A_(3, 0), s3, A_(3, 1), s1, A_(3, 2), s0);
-    J[15] = ADJ(A_(2, 0), s3, A_(2, 1), s1, A_(2, 2), s0);
-#undef ADJ
-#undef A_
-    // G = J J^T (symmetric, upper triangle g00 g01 g02 g03 g11 g12 g13 g22 g23 g33)
-    double g00, g01, g02, g03, g11, g12, g13, g22, g23, g33;
+    // M = A^T A, upper triangle (products of f32 values are exact in f64)
+    double m00, m01, m02, m03, m11, m12, m13, m22, m23, m33;
     {
-        const double j0 = J[0], j1 = J[4], j2 = J[8], j3 = J[12];
-        g00 = j0 * j0; g01 = j0 * j1; g02 = j0 * j2; g03 = j0 * j3;
-        g11 = j1 * j1; g12 = j1 * j2; g13 = j1 * j3; g22 = j2 * j2; g23 = j2 * j3; g33 = j3 * j3;
+        const double a0 = (double)Af[0], a1 = (double)Af[1], a2 = (double)Af[2], a3 = (double)Af[3];
+        m00 = a0 * a0; m01 = a0 * a1; m02 = a0 * a2; m03 = a0 * a3;
+        m11 = a1 * a1; m12 = a1 * a2; m13 = a1 * a3; m22 = a2 * a2; m23 = a2 * a3; m33 = a3 * a3;
     }
+#pragma unroll
     for (int r = 1; r < 4; ++r) {
-        const double j0 = J[0 + r], j1 = J[4 + r], j2 = J[8 + r], j3 = J[12 + r];
-        g00 = fma(j0, j0, g00); g01 = fma(j0, j1, g01); g02 = fma(j0, j2, g02); g03 = fma(j0, j3, g03);
-        g11 = fma(j1, j1, g11); g12 = fma(j1, j2, g12); g13 = fma(j1, j3, g13);
-        g22 = fma(j2, j2, g22); g23 = fma(j2, j3, g23); g33 = fma(j3, j3, g33);
+        const double a0 = (double)Af[4 * r + 0], a1 = (double)Af[4 * r + 1], a2 = (double)Af[4 * r + 2], a3 = (double)Af[4 * r + 3];
+        m00 = fma(a0, a0, m00); m01 = fma(a0, a1, m01); m02 = fma(a0, a2, m02); m03 = fma(a0, a3, m03);
+        m11 = fma(a1, a1, m11); m12 = fma(a1, a2, m12); m13 = fma(a1, a3, m13);
+        m22 = fma(a2, a2, m22); m23 = fma(a2, a3, m23); m33 = fma(a3, a3, m33);
     }
-    double tr = (g00 + g11) + (g22 + g33);
-    {   // one exact power-of-two rescale to trace in [0.5, 1): the squarings below then stay far inside
-        // the f64 range (trace(G^2) lies between trace(G)^2/4 and trace(G)^2)
-        const double s = lfd_pow2_inv_scale(tr);
-        g00 *= s; g01 *= s; g02 *= s; g03 *= s; g11 *= s; g12 *= s; g13 *= s; g22 *= s; g23 *= s; g33 *= s;
-        tr *= s;
-    }
-    // q = lambda_2/lambda_1 of G follows from tr(G)^2 - tr(G^2) ~ 2 q tr(G)^2 with tr(G^2) = ||G||_F^2.
-    // The dominant column of G is off by q and every product with G multiplies that by q again, so
-    // the number of products for a ~1e-8 error is known up front (no per-step test).  Badly
-    // conditioned cells (q > 0.05, i.e. sigma_4/sigma_3 > 0.22) are squared first.
+    // Convergence monitor: for a symmetric iteration the growth of |x|^2 settles quadratically, so
+    // n_{k+1} n_{k-1} = n_k^2 up to LFD_NULLVEC_TOL means iterate k-1 is within ~sqrt(tol) of v4 and iterate
+    // k+1, the one returned, within q^2 times that.  (NaN compares false: bad input leaves at once.)
+    // A pass that has not settled after LFD_NULLVEC_MAXIT solves (sigma4/sigma3 close to 1) is followed by a
+    // pass shifted by the Rayleigh quotient of its result, which separates the two smallest eigenvalues.
+    double sh = 0.0;
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 1.0;
     int it = 0;
-    double q2t;
-    for (;;) {
-        const double fro = fma(2.0, fma(g23, g23, fma(g13, g13, fma(g12, g12, fma(g03, g03, fma(g02, g02, g01 * g01))))),
-                               fma(g33, g33, fma(g22, g22, fma(g11, g11, g00 * g00))));
-        q2t = tr * tr - fro;                 // ~ 2 q tr^2
-        if (!(q2t > 0.10 * (tr * tr)) || it >= LFD_NULLVEC_MAXIT) break;
-        const double h00 = fma(g03, g03, fma(g02, g02, fma(g01, g01, g00 * g00)));
-        const double h01 = fma(g03, g13, fma(g02, g12, fma(g01, g11, g00 * g01)));
-        const double h02 = fma(g03, g23, fma(g02, g22, fma(g01, g12, g00 * g02)));
-        const double h03 = fma(g03, g33, fma(g02, g23, fma(g01, g13, g00 * g03)));
-        const double h11 = fma(g13, g13, fma(g12, g12, fma(g11, g11, g01 * g01)));
-        const double h12 = fma(g13, g23, fma(g12, g22, fma(g11, g12, g01 * g02)));
-        const double h13 = fma(g13, g33, fma(g12, g23, fma(g11, g13, g01 * g03)));
-        const double h22 = fma(g23, g23, fma(g22, g22, fma(g12, g12, g02 * g02)));
-        const double h23 = fma(g23, g33, fma(g22, g23, fma(g12, g13, g02 * g03)));
-        const double h33 = fma(g33, g33, fma(g23, g23, fma(g13, g13, g03 * g03)));
-        g00 = h00; g01 = h01; g02 = h02; g03 = h03; g11 = h11; g12 = h12; g13 = h13; g22 = h22; g23 = h23; g33 = h33;
-        tr = (g00 + g11) + (g22 + g33);
-        ++it;
+    for (int pass = 0;; ++pass) {
+        // M - sh I = L D L^T
+        const double q00 = m00 - sh, q11 = m11 - sh, q22 = m22 - sh, q33 = m33 - sh;
+        const double r0 = lfd_recip_refined(q00);
+        const double l10 = m01 * r0, l20 = m02 * r0, l30 = m03 * r0;
+        const double d1 = fma(-l10, m01, q11);
+        const double n12 = fma(-l10, m02, m12), n13 = fma(-l10, m03, m13);
+        const double n22 = fma(-l20, m02, q22), n23 = fma(-l20, m03, m23), n33 = fma(-l30, m03, q33);
+        const double r1 = lfd_recip_refined(d1);
+        const double l21 = n12 * r1, l31 = n13 * r1;
+        const double d2 = fma(-l21, n12, n22);
+        const double p23 = fma(-l21, n13, n23), p33 = fma(-l31, n13, n33);
+        const double r2 = lfd_recip_refined(d2);
+        const double l32 = p23 * r2;
+        const double d3 = fma(-l32, p23, p33);
+        const double s0 = d3 * r0, s1 = d3 * r1, s2 = d3 * r2;     // d3 / d_i
+        if (pass == 0) {        // first solve from e4: the last column of L^-T
+            x3 = 1.0;
+            x2 = -l32;
+            x1 = fma(-l21, x2, -l31);
+            x0 = fma(-l10, x1, fma(-l20, x2, -l30));
+            it = 1;
+        }
+        double n_prev = 0.0;
+        double n_cur = fma(x0, x0, fma(x1, x1, fma(x2, x2, x3 * x3)));
+        bool settled = false;
+        for (int k = 1;; ++k) {
+            // x <- d3 * (M - sh I)^-1 x : forward (L), diagonal, backward (L^T)
+            const double y1 = fma(-l10, x0, x1);
+            const double y2 = fma(-l21, y1, fma(-l20, x0, x2));
+            const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, x0, x3)));
+            const double z0 = x0 * s0, z1 = y1 * s1, z2 = y2 * s2;
+            x3 = y3;
+            x2 = fma(-l32, x3, z2);
+            x1 = fma(-l21, x2, fma(-l31, x3, z1));
+            x0 = fma(-l10, x1, fma(-l20, x2, fma(-l30, x3, z0)));
+            const double n_new = fma(x0, x0, fma(x1, x1, fma(x2, x2, x3 * x3)));
+            ++it;
+            if (k >= 2) {
+                const double sq = n_cur * n_cur;
+                const bool more = fabs(fma(n_new, n_prev, -sq)) > LFD_NULLVEC_TOL * sq;
+                if (!more) { settled = true; break; }
+                if (k >= LFD_NULLVEC_MAXIT) break;
+            }
+            n_prev = n_cur; n_cur = n_new;
+        }
+        if (settled || pass >= LFD_NULLVEC_PASSES - 1) break;
+        // Rayleigh quotient of x as the next shift; x rescaled by an exact power of two
+        {
+            const double sc = lfd_pow2_inv_scale(fabs(x0) + fabs(x1) + fabs(x2) + fabs(x3));
+            x0 *= sc; x1 *= sc; x2 *= sc; x3 *= sc;
+            const double t0 = fma(m03, x3, fma(m02, x2, fma(m01, x1, m00 * x0)));
+            const double t1 = fma(m13, x3, fma(m12, x2, fma(m11, x1, m01 * x0)));
+            const double t2 = fma(m23, x3, fma(m22, x2, fma(m12, x1, m02 * x0)));
+            const double t3 = fma(m33, x3, fma(m23, x2, fma(m13, x1, m03 * x0)));
+            const double num = fma(x3, t3, fma(x2, t2, fma(x1, t1, x0 * t0)));
+            const double den = fma(x3, x3, fma(x2, x2, fma(x1, x1, x0 * x0)));
+            const double rden = lfd_recip_refined(den);
+            const double rho = num * rden;
+            // rho >= mu4 lies between the two smallest eigenvalues and could sit closer to mu3; backing off by the
+            // residual norm |Mx - rho x| / |x| ~ eps (mu3 - mu4) puts the shift below mu4, so the shifted matrix
+            // stays positive definite and the iteration cannot lock on to v3 (rate ~eps instead of q)
+            const double e0 = fma(-rho, x0, t0), e1 = fma(-rho, x1, t1), e2 = fma(-rho, x2, t2), e3 = fma(-rho, x3, t3);
+            const double rr = fma(e3, e3, fma(e2, e2, fma(e1, e1, e0 * e0)));
+            sh = rho - sqrt(rr * rden);
+        }
     }
-    // dominant column of G = column of its largest diagonal entry
-    double best = g00;
-    c[0] = g00; c[1] = g01; c[2] = g02; c[3] = g03;
-    if (g11 > best) { best = g11; c[0] = g01; c[1] = g11; c[2] = g12; c[3] = g13; }
-    if (g22 > best) { best = g22; c[0] = g02; c[1] = g12; c[2] = g22; c[3] = g23; }
-    if (g33 > best) { best = g33; c[0] = g03; c[1] = g13; c[2] = g23; c[3] = g33; }
-    // error of c is q; products needed for q^(m+1) <= ~1e-8:  q <= 1e-4: 1, 2e-3: 2, 1e-2: 3, 2.5e-2: 4, else 5
-    const double t2 = tr * tr;
-    const int extra = 1 + (q2t > 2e-4 * t2) + (q2t > 4e-3 * t2) + (q2t > 2e-2 * t2) + (q2t > 5e-2 * t2);
-    for (int m = 0; m < extra; ++m) {
-        const double y0 = fma(g03, c[3], fma(g02, c[2], fma(g01, c[1], g00 * c[0])));
-        const double y1 = fma(g13, c[3], fma(g12, c[2], fma(g11, c[1], g01 * c[0])));
-        const double y2 = fma(g23, c[3], fma(g22, c[2], fma(g12, c[1], g02 * c[0])));
-        const double y3 = fma(g33, c[3], fma(g23, c[2], fma(g13, c[1], g03 * c[0])));
-        c[0] = y0; c[1] = y1; c[2] = y2; c[3] = y3;
-    }
-    return it + extra;
+    c[0] = x0; c[1] = x1; c[2] = x2; c[3] = x3;
+    return it;
 }
 
 // a / b for f64 with ONE division shared by several numerators: r = RN(1/b); q = RN(a*r);
@@ -417,6 +451,59 @@ LFD_HD void lfd_bilinear_rgb(const uint8_t* img, int wi, int hi, float xa_px, fl
         rgb[c] = (float)lfd_div_by_recip(s, 255.0, 1.0 / 255.0);   // == s / 255.0, correctly rounded
     }
 }
+
+#if defined(__HIPCC__)
+// Same arithmetic as lfd_bilinear_rgb, fewer memory instructions: the two taps of a row are 6
+// consecutive bytes, fetched with ONE unaligned 8-byte load per row (2 loads per point instead of 12),
+// split into an issue half and an evaluate half so that several points' loads can be in flight.
+// The load window is clamped to the image so that it never reads past the buffer; n_bytes = h*w*3 >= 8.
+__device__ __forceinline__ unsigned long long lfd_load_u64_unaligned(const uint8_t* p) {
+    typedef unsigned long long __attribute__((aligned(1), may_alias)) u64_u;
+    return *reinterpret_cast<const u64_u*>(p);
+}
+
+struct LfdTapRows { unsigned long long r0, r1; };   // the 8-byte windows of the two image rows, already shifted to the first tap
+
+// issue half: the two loads (nothing waits on them here)
+__device__ __forceinline__ LfdTapRows lfd_bilinear_fetch(const uint8_t* img, int wi, int hi, float xa_px, float ya_px,
+                                                         unsigned& sh0, unsigned& sh1) {
+    const int x0 = (int)fminf(fmaxf(floorf(xa_px), 0.0f), (float)(wi - 1));
+    const int y0 = (int)fminf(fmaxf(floorf(ya_px), 0.0f), (float)(hi - 1));
+    const int y1 = lfd_clampi(y0 + 1, 0, hi - 1);
+    const unsigned last = (unsigned)hi * (unsigned)wi * 3u - 8u;
+    const unsigned o0 = ((unsigned)y0 * (unsigned)wi + (unsigned)x0) * 3u;
+    const unsigned o1 = ((unsigned)y1 * (unsigned)wi + (unsigned)x0) * 3u;
+    const unsigned l0 = o0 < last ? o0 : last, l1 = o1 < last ? o1 : last;
+    sh0 = (o0 - l0) * 8u; sh1 = (o1 - l1) * 8u;
+    LfdTapRows t;
+    t.r0 = lfd_load_u64_unaligned(img + l0);
+    t.r1 = lfd_load_u64_unaligned(img + l1);
+    return t;
+}
+
+// evaluate half: upstream's f64 weights and accumulation (core/pipeline.py:661-679), bit-identical to lfd_bilinear_rgb
+__device__ __forceinline__ void lfd_bilinear_eval(LfdTapRows t, unsigned sh0, unsigned sh1, int wi, int hi, float xa_px, float ya_px, float* rgb) {
+    const int x0 = (int)fminf(fmaxf(floorf(xa_px), 0.0f), (float)(wi - 1));
+    const int y0 = (int)fminf(fmaxf(floorf(ya_px), 0.0f), (float)(hi - 1));
+    const int x1 = lfd_clampi(x0 + 1, 0, wi - 1);
+    const int y1 = lfd_clampi(y0 + 1, 0, hi - 1);
+    const double xd = (double)xa_px, yd = (double)ya_px;
+    const double ax = (double)x1 - xd, bx = xd - (double)x0;
+    const double ay = (double)y1 - yd, by = yd - (double)y0;
+    const double wa = ax * ay, wb = bx * ay, wc = ax * by, wd = bx * by;
+    const unsigned long long r0 = t.r0 >> sh0, r1 = t.r1 >> sh1;
+    const unsigned a3 = (unsigned)r0 & 0xffffffu, c3 = (unsigned)r1 & 0xffffffu;
+    const unsigned b3 = (x1 != x0) ? (unsigned)(r0 >> 24) & 0xffffffu : a3;
+    const unsigned d3 = (x1 != x0) ? (unsigned)(r1 >> 24) & 0xffffffu : c3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double pa = (double)((a3 >> (8 * c)) & 0xffu), pb = (double)((b3 >> (8 * c)) & 0xffu);
+        const double pc = (double)((c3 >> (8 * c)) & 0xffu), pd = (double)((d3 >> (8 * c)) & 0xffu);
+        const double s = ((pa * wa + pb * wb) + pc * wc) + pd * wd;
+        rgb[c] = (float)lfd_div_by_recip(s, 255.0, 1.0 / 255.0);   // == s / 255.0, correctly rounded
+    }
+}
+#endif
 
 // ---- certainty prologue pieces (core/pipeline.py:361-382,405-430) --------------------------------
 LFD_HD float lfd_cert_floor(float c, float thresh) { return (c < thresh) ? thresh : c; }   // NaN stays NaN

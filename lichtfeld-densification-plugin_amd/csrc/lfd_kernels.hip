@@ -204,7 +204,7 @@ __device__ __forceinline__ void cell_coords(const LfdLaunch& L, const BlockShare
 // F5: per-(reference, neighbour) constants, once per batch (skipped when the batch is unchanged)
 // =================================================================================================
 extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* __restrict__ ref_out,
-                                                 LfdPairConst* __restrict__ pair_out) {
+                                                 LfdPairConst* __restrict__ pair_out, LfdFastRef* __restrict__ fast_out) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int n_pairs = L.n_refs * L.k;
     if (i < n_pairs) {
@@ -214,6 +214,20 @@ extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* __res
     } else if (i < n_pairs + L.n_refs) {
         const int r = i - n_pairs;
         lfd_make_ref_const(L.cams[L.refs[r].cam], L.w_match, L.h_match, ref_out[r]);
+        if (fast_out) {           // k <= 4: the record the persistent kernel reads with scalar loads
+            LfdFastRef f;
+            const int ns = L.refs[r].n_slots;
+            for (int j = 0; j < 4; ++j) {
+                const int jj = (j < ns) ? j : 0;
+                f.cert[j] = L.slots[(size_t)r * L.k + jj].cert;
+                f.warp[j] = L.slots[(size_t)r * L.k + jj].warp;
+            }
+            f.image = L.refs[r].image;
+            f.n_slots = ns;
+            f.pad = 0;
+            lfd_make_ref_const(L.cams[L.refs[r].cam], L.w_match, L.h_match, f.rc);
+            fast_out[r] = f;
+        }
     }
 }
 
@@ -284,30 +298,7 @@ struct DenseStage {                // per-tile results, indexed by the cell's sl
     unsigned char slot[kTile];
 };
 
-// copy n records of `width` floats each (gathered through stage.order) to g, coalesced; g is only
-// 4-byte aligned (it starts at an arbitrary survivor index): peel to 16 bytes, then float4 stores
-template <int WIDTH>
-__device__ __forceinline__ void copy_out_gather(float* __restrict__ g, const float* __restrict__ l,
-                                                const unsigned short* __restrict__ order, int n, int tid) {
-    const int total = n * WIDTH;
-    auto fetch = [&](int t) -> float {
-        const int i = (WIDTH == 1) ? t : t / WIDTH;
-        const int c = (WIDTH == 1) ? 0 : t - i * WIDTH;
-        return l[(int)order[i] * WIDTH + c];
-    };
-    const int mis = (int)((reinterpret_cast<uintptr_t>(g) >> 2) & 3u);
-    int head = (4 - mis) & 3;
-    if (head > total) head = total;
-    if (tid < head) g[tid] = fetch(tid);
-    const int nvec = (total - head) >> 2;
-    float4* g4 = reinterpret_cast<float4*>(g + head);
-    for (int i = tid; i < nvec; i += kBlock) {
-        const int t = head + 4 * i;
-        g4[i] = make_float4(fetch(t), fetch(t + 1), fetch(t + 2), fetch(t + 3));
-    }
-    const int done = head + 4 * nvec;
-    if (tid < total - done) g[done + tid] = fetch(done + tid);
-}
+struct __attribute__((packed, aligned(4))) LfdF3 { float a, b, c; };
 
 extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_kernel(LfdLaunch L) {
     __shared__ BlockShared S;
@@ -319,9 +310,13 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+#if defined(LFD_ABLATE_TICKET)
+    const unsigned tile = blockIdx.x;
+#else
     if (tid == 0) s_ticket = (unsigned)(atomicAdd(L.ticket, 1ull) - L.ticket_base);
     __syncthreads();
     const unsigned tile = s_ticket;
+#endif
     const unsigned n_tiles = (unsigned)L.n_refs * (unsigned)L.tiles_per_ref;
     const int HW = L.H * L.W;
     {
@@ -361,15 +356,45 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
         // ---- stage 2: winner's warp (8 or 16 B per cell), all four loads in flight together; the
         //      coordinates are parked in this thread's own LDS slots (the slots later receive the cell's
         //      outputs), so the geometry loop below carries no per-cell register arrays ------------------
+        unsigned bj_packed = 0;                   // 4 x 8 bits: the winning slot of each of this thread's cells
+        if (kCpt == 4 && (L.W & 3) == 0 && cell0 + 3 < HW) {
+            // W % 4 == 0: the four cells share a row, so one cell -> (row, column) conversion serves all
+            float xa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ya = 0.0f;
+            if (L.warp_channels != 4) {
+                int y0, x0;
+                lfd_divmod(cell0, L.W, L.inv_w, y0, x0);
+                const float4 ax = *reinterpret_cast<const float4*>(L.axis_x + x0);
+                xa[0] = ax.x; xa[1] = ax.y; xa[2] = ax.z; xa[3] = ax.w;
+                ya = L.axis_y[y0];
+            }
 #pragma unroll
-        for (int e = 0; e < kCpt; ++e) {
-            float xan = 0.0f, yan = 0.0f, xbn = 0.0f, ybn = 0.0f;
-            if (cell0 + e < HW) cell_coords(L, S, cell0 + e, bj[e], xan, yan, xbn, ybn);
-            const int sl = tid * kCpt + e;
-            stage.xyz[3 * sl + 0] = xan; stage.xyz[3 * sl + 1] = yan; stage.xyz[3 * sl + 2] = xbn;
-            stage.err[sl] = ybn;
-            stage.slot[sl] = (unsigned char)bj[e];
+            for (int e = 0; e < 4; ++e) {
+                const float* wp = S.slot[bj[e]].warp;
+                float xan, yan, xbn, ybn;
+                if (L.warp_channels == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(wp + (size_t)(unsigned)(cell0 + e) * 4);
+                    xan = v.x; yan = v.y; xbn = v.z; ybn = v.w;
+                } else {
+                    const float2 v = *reinterpret_cast<const float2*>(wp + (size_t)(unsigned)(cell0 + e) * 2);
+                    xan = xa[e]; yan = ya; xbn = v.x; ybn = v.y;
+                }
+                const int sl = tid * kCpt + e;
+                stage.xyz[3 * sl + 0] = xan; stage.xyz[3 * sl + 1] = yan; stage.xyz[3 * sl + 2] = xbn;
+                stage.err[sl] = ybn;
+                bj_packed |= (unsigned)bj[e] << (8 * e);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < kCpt; ++e) {
+                float xan = 0.0f, yan = 0.0f, xbn = 0.0f, ybn = 0.0f;
+                if (cell0 + e < HW) cell_coords(L, S, cell0 + e, bj[e], xan, yan, xbn, ybn);
+                const int sl = tid * kCpt + e;
+                stage.xyz[3 * sl + 0] = xan; stage.xyz[3 * sl + 1] = yan; stage.xyz[3 * sl + 2] = xbn;
+                stage.err[sl] = ybn;
+                bj_packed |= (unsigned)bj[e] << (8 * e);
+            }
         }
+        *reinterpret_cast<unsigned*>(&stage.slot[tid * kCpt]) = bj_packed;
 
         // ---- stage 3: per-correspondence geometry + colour; survivors overwrite their slot -------------
         unsigned keep_bits = 0;
@@ -381,7 +406,7 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
             const int sl = tid * kCpt + e;
             const float xan = stage.xyz[3 * sl + 0], yan = stage.xyz[3 * sl + 1], xbn = stage.xyz[3 * sl + 2];
             const float ybn = stage.err[sl];
-            const int bje = (int)stage.slot[sl];
+            const int bje = (int)((bj_packed >> (8 * e)) & 0xffu);
             LfdCellResult res;
             res.keep = 0; res.x = res.y = res.z = res.err = res.xa_px = res.ya_px = 0.0f;
 #if defined(LFD_ABLATE_EVAL)
@@ -401,9 +426,14 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
                 stage.err[sl] = res.err;
                 keep_bits |= 1u << e;
             }
-            // survivors per neighbour slot: one ballot per slot, accumulated by lane 0
+        }
+        // survivors per neighbour slot (outside the divergent loop): ballots over the kept cells of each slot
+        if (L.seg_counts) {
             for (int j = 0; j < ns; ++j) {
-                const unsigned c = (unsigned)__popcll(__ballot(res.keep && bje == j));
+                unsigned c = 0;
+#pragma unroll
+                for (int e = 0; e < kCpt; ++e)
+                    c += (unsigned)__popcll(__ballot(((keep_bits >> e) & 1u) && ((bj_packed >> (8 * e)) & 0xffu) == (unsigned)j));
                 if (lane == 0 && c) atomicAdd(&s_slot_cnt[j], c);
             }
         }
@@ -452,15 +482,465 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
             int n = (int)block_total;
             if (room < (long long)n) n = room > 0 ? (int)room : 0;
 #if !defined(LFD_ABLATE_STORES)
-            copy_out_gather<3>(L.xyz + 3 * base, stage.xyz, stage.order, n, tid);
-            copy_out_gather<3>(L.rgb + 3 * base, stage.rgb, stage.order, n, tid);
-            copy_out_gather<1>(L.err + base, stage.err, stage.order, n, tid);
-            if (L.cell) for (int i = tid; i < n; i += kBlock) L.cell[base + i] = tile_cell0 + (int)stage.order[i];
-            if (L.slot) for (int i = tid; i < n; i += kBlock) L.slot[base + i] = stage.slot[stage.order[i]];
+            // one survivor record per thread: consecutive threads write consecutive records, so every
+            // wave-wide store covers one contiguous span of the output arrays
+            LfdF3* gx = reinterpret_cast<LfdF3*>(L.xyz + 3 * base);
+            LfdF3* gc = reinterpret_cast<LfdF3*>(L.rgb + 3 * base);
+            float* ge = L.err + base;
+            for (int i = tid; i < n; i += kBlock) {
+                const int sl = (int)stage.order[i];
+                LfdF3 p, c;
+                p.a = stage.xyz[3 * sl + 0]; p.b = stage.xyz[3 * sl + 1]; p.c = stage.xyz[3 * sl + 2];
+                c.a = stage.rgb[3 * sl + 0]; c.b = stage.rgb[3 * sl + 1]; c.c = stage.rgb[3 * sl + 2];
+                gx[i] = p;
+                gc[i] = c;
+                ge[i] = stage.err[sl];
+                if (L.cell) L.cell[base + i] = tile_cell0 + sl;
+                if (L.slot) L.slot[base + i] = stage.slot[sl];
+            }
 #endif
         }
     }
 }
+
+// =================================================================================================
+// fused dense kernel, fast path: persistent, software-pipelined (no masks, k <= 4)
+// =================================================================================================
+// Measured on MI355X (profiles/r1/ablation.txt): with one tile per workgroup the kernel is bound by
+// the chain of dependent round trips every tile pays (ticket -> descriptors -> certainty -> warp ->
+// look-back), not by arithmetic or bandwidth.  This variant removes the chain from the critical path:
+//   * persistent grid, tiles dealt statically (tile = block + i*grid): no ticket; every workgroup the
+//     look-back can wait for is resident because the grid is sized from the occupancy of the kernel;
+//   * while tile n is being evaluated, the certainty planes and per-pair constants of tile n+1 are
+//     already in flight (registers -> LDS double buffer);
+//   * the look-back reads a window of 256 predecessors per round trip instead of 64;
+//   * a wave owns 256 consecutive cells, 64 per step, so survivors are compacted with one ballot per
+//     step straight into the wave's staging area (raster order, no order map) and copied out linearly.
+#if defined(LFD_PHASE_TIMING)
+__device__ unsigned long long lfd_phase_acc[16];
+#ifndef LFD_PHASE_MASK
+#define LFD_PHASE_MASK 0xfff
+#endif
+#define LFD_PHASE_MARK(idx) do { if ((LFD_PHASE_MASK >> (idx)) & 1) { const long long t_ = (long long)wall_clock64(); t_acc[idx] += (unsigned)(t_ - t_phase); t_phase = t_; } } while (0)
+#else
+#define LFD_PHASE_MARK(idx) do { } while (0)
+#endif
+
+#define LFD_CONST_AS __attribute__((address_space(4)))
+// Loads through a constant-address-space pointer with a uniform address are selected as scalar loads
+// (s_load_*): the per-tile descriptors then cost no vector-memory round trip and land in SGPRs.
+template <class T>
+__device__ __forceinline__ const T LFD_CONST_AS* lfd_const_as(const T* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const T LFD_CONST_AS*)p;
+#pragma clang diagnostic pop
+}
+
+constexpr int kFastGeoWaves = LFD_DENSE_FAST_GEO_WAVES;    // geometry waves per workgroup (+1 service wave)
+constexpr int kFastTile = kFastGeoWaves * 256;              // cells per tile of the persistent kernel
+constexpr int kFastThreads = (kFastGeoWaves + 1) * 64;
+
+template <int K>
+struct FastShared {
+    LfdPairConst pc[2][K];                     // [constants buffer][slot]
+    // survivors of a tile wait in LDS for one tile period: two staging buffers.
+    // Colours are not staged: they are sampled when the records are copied out.
+    float xyz[2][kFastGeoWaves][3 * 256];      // [staging buffer][wave][record]
+    float err[2][kFastGeoWaves][256];
+    unsigned char cellq[2][kFastGeoWaves][256];  // survivor -> cell inside the wave's 256-cell chunk
+    unsigned char slot[2][kFastGeoWaves][256];
+    unsigned slot_cnt[2][K];
+    unsigned wave_cnt[2][kFastGeoWaves];
+};
+
+// ---- look-back of the persistent kernel ------------------------------------------------------------
+// A window of LFD_LB_ROWS x 64 predecessors is read per round trip.  The first window's loads are issued
+// early (lookback_issue) so that their latency is covered by the work issued after them; lookback_finish
+// consumes them and only falls back to polling when a needed predecessor has not published yet.
+#ifndef LFD_LB_ROWS
+#define LFD_LB_ROWS 4
+#endif
+struct LookbackWindow { u64 s[LFD_LB_ROWS]; };
+
+__device__ __forceinline__ void lookback_issue(const LfdLaunch& L, unsigned tile, LookbackWindow& w) {
+    const int lane = lane_id();
+    const long long base = (long long)tile - 1;
+#pragma unroll
+    for (int q = 0; q < LFD_LB_ROWS; ++q) {
+        const long long j = base - (long long)(q * 64 + lane);
+        w.s[q] = state_load(L.tile_state + (j >= 0 ? j : 0));
+        if (j < 0) w.s[q] = pack_state(kStPrefix, L.epoch, 0);   // virtual tiles < 0: prefix 0
+    }
+}
+
+// returns true when the window settled the prefix (done) or was fully consumed (continue further back);
+// false when a needed predecessor is still empty
+__device__ __forceinline__ bool lookback_consume(const LookbackWindow& w, unsigned epoch, u64& acc, bool& done) {
+    const int lane = lane_id();
+    int qp = LFD_LB_ROWS, first = 64;
+    bool blocked = false;
+#pragma unroll
+    for (int q = 0; q < LFD_LB_ROWS; ++q) {
+        if (qp == LFD_LB_ROWS && !blocked) {
+            const u64 st = state_status(w.s[q], epoch);
+            const u64 pm = __ballot(st == kStPrefix);
+            const u64 em = __ballot(st == kStEmpty);
+            if (pm) {
+                const int f = __ffsll((long long)pm) - 1;
+                if (em & ((f == 0) ? 0ull : (~0ull >> (64 - f)))) blocked = true;
+                else { qp = q; first = f; }
+            } else if (em) {
+                blocked = true;
+            }
+        }
+    }
+    if (blocked) return false;
+#pragma unroll
+    for (int q = 0; q < LFD_LB_ROWS; ++q)
+        if (q < qp || (q == qp && lane <= first)) acc += w.s[q] & kValueMask;
+    done = qp < LFD_LB_ROWS;
+    return true;
+}
+
+__device__ __forceinline__ u64 lookback_finish(const LfdLaunch& L, unsigned tile, u64 my_total, LookbackWindow& w) {
+    const unsigned epoch = L.epoch;
+    const int lane = lane_id();
+    if (tile == 0) return 0;           // published as a prefix right away
+    u64 acc = 0;                       // per-lane partial sum of the aggregates taken so far
+    unsigned base_tile = tile;         // the window in w covers [base_tile-1 ... base_tile-64*ROWS]
+    unsigned spins = 0;
+    bool done = false;
+    for (;;) {
+        if (lookback_consume(w, epoch, acc, done)) {
+            if (done) break;
+            base_tile -= 64 * LFD_LB_ROWS;
+        } else {                       // a needed predecessor has not published yet: poll again
+            if (++spins > LFD_SPIN_LIMIT) {
+                if (lane == 0) atomicExch(L.status, LFD_LAUNCH_TIMEOUT);
+                return 0;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        lookback_issue(L, base_tile, w);
+    }
+    const u64 excl = wave_sum_u64(acc);
+    if (lane == 0) state_store(L.tile_state + tile, pack_state(kStPrefix, epoch, excl + my_total));
+    return excl;
+}
+
+// MODE 0: warp = [xB,yB], default A-grid axes (closed form); 1: warp = [xB,yB], axes given by the caller;
+//      2: warp = [xA,yA,xB,yB]
+//
+// Wave specialisation: a workgroup is 3 geometry waves + 1 service wave (4 waves: one per SIMD, so that
+// 4 workgroups per CU are resident whatever SIMD the dispatcher starts a workgroup on).  While the geometry waves evaluate
+// tile n, the service wave retires tile n-1: it publishes the tile's count, resolves its prefix (look-back),
+// samples the survivors' colours and copies the records out.  The two kinds of work need different registers
+// and wait on different things (arithmetic vs memory round trips), so running them as different waves of the
+// same SIMDs overlaps them without adding their register demands, and no geometry wave ever waits for a
+// look-back.  One barrier per tile hands the staging buffer over.
+
+template <int K, int MODE>
+__device__ __forceinline__ void lfd_dense_fast_body(const LfdLaunch& L, FastShared<K>& sm) {
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool service = wave == kFastGeoWaves;
+    const unsigned G = gridDim.x;
+    const unsigned tpr = (unsigned)L.tiles_per_ref;
+    const unsigned n_tiles = (unsigned)L.n_refs * tpr;
+    const int HW = L.H * L.W;
+    const float th = L.kp.certainty_thresh;
+    constexpr int kConstWords = 36 * K;          // LfdPairConst = 36 dwords
+    static_assert(sizeof(LfdPairConst) == 144, "LfdPairConst layout");
+    static_assert(kConstWords <= kFastGeoWaves * 64, "one prefetched word per geometry thread");
+    const LfdFastRef LFD_CONST_AS* fast = lfd_const_as(L.fast);
+
+    unsigned tile = blockIdx.x;                  // uniform; (r, tin) are advanced without divisions
+    if (tile >= n_tiles) return;
+    unsigned r = tile / tpr;
+    unsigned tin = tile - r * tpr;
+    r = __builtin_amdgcn_readfirstlane(r);
+    tin = __builtin_amdgcn_readfirstlane(tin);
+
+    // one word of the per-pair constants per geometry thread (unconditional load, predicated LDS store)
+    const int cw = tid < kConstWords ? tid : 0;
+    auto fetch_const_word = [&](unsigned rr) -> unsigned {
+        return reinterpret_cast<const unsigned*>(L.pair_const + (size_t)rr * K)[cw];
+    };
+    auto store_const_word = [&](int b, unsigned v) {
+        if (tid < kConstWords) reinterpret_cast<unsigned*>(sm.pc[b])[tid] = v;
+    };
+
+    float cn[K][4];                       // raw certainty of this thread's 4 cells, all slots
+    auto fetch_cert = [&](unsigned rr, unsigned tt) {
+        const int c0 = (int)tt * kFastTile + wave * 256 + lane;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float* cp = fast[rr].cert[j];       // slots >= n_slots alias slot 0: always loadable
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int cell = c0 + 64 * e;
+                cn[j][e] = cp[cell < HW ? cell : HW - 1];
+            }
+        }
+    };
+
+    // ---- service wave: retire the tile whose survivors wait in staging buffer p ---------------------------------
+    auto retire = [&](int p, unsigned t_tile, unsigned t_r, unsigned t_tin) {
+        unsigned off[kFastGeoWaves + 1];
+        off[0] = 0;
+#pragma unroll
+        for (int w = 0; w < kFastGeoWaves; ++w) off[w + 1] = off[w] + sm.wave_cnt[p][w];
+        const unsigned total = off[kFastGeoWaves];
+        // publish the count at once (the first tile of the launch is its own prefix), then resolve the prefix
+        if (lane == 0) state_store(L.tile_state + t_tile, pack_state(t_tile == 0 ? kStPrefix : kStAggregate, L.epoch, total));
+        LookbackWindow lbw;
+#if !defined(LFD_ABLATE_LOOKBACK)
+        if (t_tile != 0) lookback_issue(L, t_tile, lbw);       // in flight while the first colour rows are fetched
+#endif
+        const int t_ns = fast[t_r].n_slots;
+        if (L.seg_counts && lane < t_ns) {
+            const unsigned c = sm.slot_cnt[p][lane];
+            if (c) atomicAdd(&L.seg_counts[(size_t)t_r * K + lane], (int)c);
+            sm.slot_cnt[p][lane] = 0;
+        }
+        const int nt = (int)total;
+        const uint8_t* image = fast[t_r].image;
+        const int tile_cell0 = (int)t_tin * kFastTile;
+        long long base = 0;
+        int n = 0;
+        LfdF3* gx = nullptr;
+        LfdF3* gc = nullptr;
+        // the geometry waves' compacted records form one list; 64 records per step, the image rows of the next
+        // four steps are in flight while a step's colours are evaluated
+        struct Rec { int cell, w, li; float xa, ya; LfdTapRows taps; unsigned sh0, sh1; };
+        auto prepare = [&](int i, Rec& q) {
+            const int ii = i < nt ? i : (nt > 0 ? nt - 1 : 0);
+            q.w = 0;
+            int o = 0;
+#pragma unroll
+            for (int w = 1; w < kFastGeoWaves; ++w)
+                if (ii >= (int)off[w]) { q.w = w; o = (int)off[w]; }
+            q.li = ii - o;
+            q.cell = tile_cell0 + q.w * 256 + (int)sm.cellq[p][q.w][q.li];
+            float xan, yan;
+            if (MODE == 2) {
+                const int sj = (int)sm.slot[p][q.w][q.li];
+                const float* wp = fast[t_r].warp[0];
+#pragma unroll
+                for (int j = 1; j < K; ++j) wp = (sj == j) ? fast[t_r].warp[j] : wp;
+                const unsigned cc = (unsigned)(q.cell < HW ? q.cell : HW - 1);
+                const float2 v = *reinterpret_cast<const float2*>(wp + (size_t)cc * 4);
+                xan = v.x; yan = v.y;
+            } else {
+                int y, x;
+                lfd_divmod(q.cell < HW ? q.cell : 0, L.W, L.inv_w, y, x);
+                if (MODE == 0) { xan = lfd_axis_value(L.ax, x); yan = lfd_axis_value(L.ay, y); }
+                else { xan = L.axis_x[x]; yan = L.axis_y[y]; }
+            }
+            q.xa = lfd_match_px(xan, L.kp.wm1); q.ya = lfd_match_px(yan, L.kp.hm1);
+            q.taps = lfd_bilinear_fetch(image, L.w_match, L.h_match, q.xa, q.ya, q.sh0, q.sh1);
+        };
+        auto finish = [&](int i, const Rec& q) {
+            float rgb[3];
+#if defined(LFD_ABLATE_COLOUR)
+            rgb[0] = q.xa; rgb[1] = q.ya; rgb[2] = (float)(q.taps.r0 + q.taps.r1 + q.sh0 + q.sh1);
+#else
+            lfd_bilinear_eval(q.taps, q.sh0, q.sh1, L.w_match, L.h_match, q.xa, q.ya, rgb);
+#endif
+#if defined(LFD_ABLATE_STORES)
+            if (i < n && rgb[0] == -12345.0f) {
+#else
+            if (i < n) {
+#endif
+                LfdF3 c; c.a = rgb[0]; c.b = rgb[1]; c.c = rgb[2];
+                LfdF3 v; v.a = sm.xyz[p][q.w][3 * q.li + 0]; v.b = sm.xyz[p][q.w][3 * q.li + 1]; v.c = sm.xyz[p][q.w][3 * q.li + 2];
+                gx[i] = v;
+                gc[i] = c;
+                L.err[base + i] = sm.err[p][q.w][q.li];
+                if (L.cell) L.cell[base + i] = q.cell;
+                if (L.slot) L.slot[base + i] = sm.slot[p][q.w][q.li];
+            }
+        };
+        Rec q0, q1, q2, q3;
+        if (nt > 0) { prepare(lane, q0); prepare(64 + lane, q1); prepare(128 + lane, q2); prepare(192 + lane, q3); }
+#if defined(LFD_ABLATE_LOOKBACK)
+        const u64 excl = (u64)t_tile * kFastTile;
+#else
+        const u64 excl = lookback_finish(L, t_tile, total, lbw);
+#endif
+        if (lane == 0) {
+            if (t_tin == 0) L.ref_offsets[t_r] = (long long)excl;
+            if (t_tile == n_tiles - 1u) L.ref_offsets[L.n_refs] = (long long)(excl + total);
+        }
+        base = (long long)excl;
+        {
+            const long long room = L.capacity - base;          // beyond capacity: counted, not written
+            n = nt;
+            if (room < (long long)n) n = room > 0 ? (int)room : 0;
+        }
+        gx = reinterpret_cast<LfdF3*>(L.xyz + 3 * base);
+        gc = reinterpret_cast<LfdF3*>(L.rgb + 3 * base);
+        for (int i0 = 0; i0 < n; i0 += 256) {
+            finish(i0 + lane, q0);       if (i0 + 256 < n) prepare(i0 + 256 + lane, q0);
+            if (i0 + 64 < n)  { finish(i0 + 64 + lane, q1);  if (i0 + 320 < n) prepare(i0 + 320 + lane, q1); }
+            if (i0 + 128 < n) { finish(i0 + 128 + lane, q2); if (i0 + 384 < n) prepare(i0 + 384 + lane, q2); }
+            if (i0 + 192 < n) { finish(i0 + 192 + lane, q3); if (i0 + 448 < n) prepare(i0 + 448 + lane, q3); }
+        }
+    };
+
+    // ---- pipeline prologue: constants and certainties of the first tile ------------------------------
+    if (tid < 2 * K) { sm.slot_cnt[0][tid % K] = 0; sm.slot_cnt[1][tid % K] = 0; }
+    if (!service) {
+        store_const_word(0, fetch_const_word(r));
+        fetch_cert(r, tin);
+    }
+    __syncthreads();
+    int buf = 0;
+    bool has_cur = true, have_prev = false;
+    unsigned p_tile = 0, p_r = 0, p_tin = 0;
+
+    while (has_cur) {
+        const unsigned next = tile + G;
+        const bool has_next = next < n_tiles;
+        unsigned r_next = r, tin_next = tin + G;
+        while (tin_next >= tpr) { tin_next -= tpr; ++r_next; }
+        if (!has_next) { r_next = r; tin_next = tin; }
+
+        if (service) {
+            if (have_prev) retire(buf ^ 1, p_tile, p_r, p_tin);
+        } else {
+            const int ns = fast[r].n_slots;
+            const int tile_cell0 = (int)tin * kFastTile;
+            const int cell0 = tile_cell0 + wave * 256 + lane;     // + 64*e
+
+            // ---- stage 1: certainty floor + arg-max over the slots ------------------------------------------
+            unsigned bj_packed = 0;
+            int bj[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float best = lfd_cert_floor(cn[0][e], th);
+#pragma unroll
+                for (int j = 1; j < K; ++j)
+                    if (j < ns) argmax_step(lfd_cert_floor(cn[j][e], th), j, best, bj[e]);
+                bj_packed |= (unsigned)bj[e] << (8 * e);
+            }
+
+            // ---- stage 2: the winner's warp, then (behind it) the prefetch of tile n+1 ---------------------------
+            float wv[4][4];
+            {
+                const float* wbase[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) wbase[j] = fast[r].warp[j];
+                int y = 0, x = 0;
+                if (MODE == 1) lfd_divmod(cell0 < HW ? cell0 : 0, L.W, L.inv_w, y, x);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cell = cell0 + 64 * e;
+                    const unsigned cc = (unsigned)(cell < HW ? cell : HW - 1);
+                    const float* wp = wbase[0];
+#pragma unroll
+                    for (int j = 1; j < K; ++j) wp = (bj[e] == j) ? wbase[j] : wp;
+                    if (MODE == 2) {
+                        const float4 v = *reinterpret_cast<const float4*>(wp + (size_t)cc * 4);
+                        wv[e][0] = v.x; wv[e][1] = v.y; wv[e][2] = v.z; wv[e][3] = v.w;
+                    } else {
+                        const float2 v = *reinterpret_cast<const float2*>(wp + (size_t)cc * 2);
+                        wv[e][2] = v.x; wv[e][3] = v.y;
+                        if (MODE == 1) {
+                            wv[e][0] = L.axis_x[x]; wv[e][1] = L.axis_y[y];
+                            x += 64;
+                            while (x >= L.W) { x -= L.W; ++y; }
+                        }
+                    }
+                }
+            }
+            unsigned pre = 0;
+            if (has_next) {
+                pre = fetch_const_word(r_next);
+                fetch_cert(r_next, tin_next);
+            }
+            {   // park the correspondences in the wave's staging slots of these cells
+                int y = 0, x = 0;
+                if (MODE == 0) lfd_divmod(cell0 < HW ? cell0 : 0, L.W, L.inv_w, y, x);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int sl = e * 64 + lane;
+                    if (MODE == 0) {      // default axes: closed form, nothing was loaded for them
+                        wv[e][0] = lfd_axis_value(L.ax, x); wv[e][1] = lfd_axis_value(L.ay, y);
+                        x += 64;
+                        while (x >= L.W) { x -= L.W; ++y; }
+                    }
+                    sm.xyz[buf][wave][3 * sl + 0] = wv[e][0]; sm.xyz[buf][wave][3 * sl + 1] = wv[e][1]; sm.xyz[buf][wave][3 * sl + 2] = wv[e][2];
+                    sm.err[buf][wave][sl] = wv[e][3];
+                }
+            }
+
+            // ---- stage 3: geometry, 64 cells of the wave per step, survivors compacted in place ---------------
+            LfdRefConst rc;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) rc.P[i] = fast[r].rc.P[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rc.C[i] = fast[r].rc.C[i];
+            rc.sx = fast[r].rc.sx; rc.sy = fast[r].rc.sy; rc.pad = 0.0f;
+            unsigned keep_bits = 0;
+            unsigned run = 0;                       // survivors of this wave so far (uniform)
+#pragma unroll 1
+            for (int e = 0; e < 4; ++e) {
+                asm volatile("" ::: "memory");      // per-pair constants are re-read from LDS per step instead of pinned in registers
+                const int sl = e * 64 + lane;
+                const float xan = sm.xyz[buf][wave][3 * sl + 0], yan = sm.xyz[buf][wave][3 * sl + 1], xbn = sm.xyz[buf][wave][3 * sl + 2];
+                const float ybn = sm.err[buf][wave][sl];
+                const int bje = (int)((bj_packed >> (8 * e)) & 0xffu);
+                LfdCellResult res;
+                res.keep = 0; res.x = res.y = res.z = res.err = res.xa_px = res.ya_px = 0.0f;
+#if defined(LFD_ABLATE_EVAL)
+                if (cell0 + 64 * e < HW) { res.keep = xbn > -0.9f; res.x = xan + rc.P[0]; res.y = yan + sm.pc[buf][bje].P[1]; res.z = xbn; res.err = ybn; }
+#else
+                if (cell0 + 64 * e < HW) lfd_eval_correspondence(rc, sm.pc[buf][bje], xan, yan, xbn, ybn, L.kp, res);
+#endif
+                const u64 km = __ballot(res.keep != 0);
+                if (res.keep) {
+                    const unsigned pos = run + __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+                    sm.xyz[buf][wave][3 * pos + 0] = res.x; sm.xyz[buf][wave][3 * pos + 1] = res.y; sm.xyz[buf][wave][3 * pos + 2] = res.z;
+                    sm.err[buf][wave][pos] = res.err;
+                    sm.cellq[buf][wave][pos] = (unsigned char)sl;
+                    sm.slot[buf][wave][pos] = (unsigned char)bje;
+                    keep_bits |= 1u << e;
+                }
+                run += (unsigned)__popcll(km);
+            }
+            if (L.seg_counts) {
+                for (int j = 0; j < ns; ++j) {
+                    unsigned c = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        c += (unsigned)__popcll(__ballot(((keep_bits >> e) & 1u) && ((bj_packed >> (8 * e)) & 0xffu) == (unsigned)j));
+                    if (lane == 0 && c) atomicAdd(&sm.slot_cnt[buf][j], c);
+                }
+            }
+            if (lane == 0) sm.wave_cnt[buf][wave] = run;
+            if (has_next) store_const_word(buf ^ 1, pre);
+        }
+        __syncthreads();                          // tile n staged (and tile n-1 retired): hand-over
+        have_prev = true;
+        p_tile = tile; p_r = r; p_tin = tin;
+        has_cur = has_next;
+        tile = next; r = r_next; tin = tin_next; buf ^= 1;
+    }
+    if (service) retire(buf ^ 1, p_tile, p_r, p_tin);     // drain: the last tile of this workgroup
+}
+
+#define LFD_DENSE_FAST_KERNEL(KK, MM)                                                                          \
+    extern "C" __global__ void __launch_bounds__(kFastThreads, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_fast_kernel_k##KK##_m##MM(LfdLaunch L) { \
+        __shared__ FastShared<KK> sm;                                                                          \
+        lfd_dense_fast_body<KK, MM>(L, sm);                                                                    \
+    }
+LFD_DENSE_FAST_KERNEL(1, 0) LFD_DENSE_FAST_KERNEL(1, 1) LFD_DENSE_FAST_KERNEL(1, 2)
+LFD_DENSE_FAST_KERNEL(2, 0) LFD_DENSE_FAST_KERNEL(2, 1) LFD_DENSE_FAST_KERNEL(2, 2)
+LFD_DENSE_FAST_KERNEL(3, 0) LFD_DENSE_FAST_KERNEL(3, 1) LFD_DENSE_FAST_KERNEL(3, 2)
+LFD_DENSE_FAST_KERNEL(4, 0) LFD_DENSE_FAST_KERNEL(4, 1) LFD_DENSE_FAST_KERNEL(4, 2)
 
 // =================================================================================================
 // upstream-equivalent indexed kernel: one workgroup per reference
