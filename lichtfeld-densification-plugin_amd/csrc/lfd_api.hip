@@ -61,7 +61,8 @@ struct lfd_context {
     std::vector<unsigned char> desc_cache;   // what the device table currently holds
     // look-back workspace: [0] u64 ticket counter, [1..] tile states
     DeviceBuffer ws;
-    unsigned long long tickets_issued = 0;   // host mirror of the device ticket counter
+    unsigned long long tickets_issued = 0;   // host mirror of the device ticket counter (indexed kernel)
+    unsigned long long lane_issued[LFD_TICKET_LANES] = {};   // host mirrors of the dense kernel's ticket sequences
     unsigned epoch = 0;
     int n_cus = 0;                 // compute units of the device
     int fast_blocks_per_cu[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // resident workgroups per CU of lfd_dense_fast_kernel_k<K> (persistent grid size)
@@ -267,23 +268,39 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
 // counter holds when it starts; tile-state words carry a launch epoch, so stale words of earlier
 // launches read as "empty" and no per-launch memset is needed.
 // workspace: [0] u64 ticket counter, [8] u32 launch status, [16..] tile states
-int prepare_lookback(lfd_context* ctx, size_t n_tiles, size_t n_tickets, LfdLaunch& L) {
-    const size_t need = 16 + n_tiles * sizeof(unsigned long long);
+// workspace: [0] u64 ticket counter (indexed kernel), [8] u32 launch status, [128 + 128*s] u64 ticket counter of
+// sequence s (dense kernel), [kWsHeader..] tile states
+constexpr size_t kWsHeader = 128 + 128 * LFD_TICKET_LANES;
+
+int prepare_lookback(lfd_context* ctx, size_t n_tiles, size_t n_tickets, bool lanes, LfdLaunch& L) {
+    const size_t need = kWsHeader + n_tiles * sizeof(unsigned long long);
     const bool fresh = ctx->ws.bytes < need || !ctx->ws.ptr;
     int rc = ensure(ctx, ctx->ws, need, true);
     if (rc != LFD_OK) return rc;
-    if (fresh) { ctx->tickets_issued = 0; ctx->epoch = 0; }
+    if (fresh) {
+        ctx->tickets_issued = 0; ctx->epoch = 0;
+        for (int s = 0; s < LFD_TICKET_LANES; ++s) ctx->lane_issued[s] = 0;
+    }
     ctx->epoch = (ctx->epoch + 1) & LFD_EPOCH_MASK;
     if (ctx->epoch == 0) {   // epoch wrapped: clear stale words once
-        LFD_HIP(ctx, hipMemsetAsync(static_cast<unsigned char*>(ctx->ws.ptr) + 16, 0, ctx->ws.bytes - 16, ctx->stream));
+        LFD_HIP(ctx, hipMemsetAsync(static_cast<unsigned char*>(ctx->ws.ptr) + kWsHeader, 0, ctx->ws.bytes - kWsHeader, ctx->stream));
         ctx->epoch = 1;
     }
-    L.ticket = static_cast<unsigned long long*>(ctx->ws.ptr);
-    L.tile_state = static_cast<unsigned long long*>(ctx->ws.ptr) + 2;
-    L.status = reinterpret_cast<unsigned int*>(static_cast<unsigned char*>(ctx->ws.ptr) + 8);
+    unsigned char* base = static_cast<unsigned char*>(ctx->ws.ptr);
+    L.ticket = reinterpret_cast<unsigned long long*>(base);
+    L.ticket_lanes = reinterpret_cast<unsigned long long*>(base + 128);
+    L.tile_state = reinterpret_cast<unsigned long long*>(base + kWsHeader);
+    L.status = reinterpret_cast<unsigned int*>(base + 8);
     L.ticket_base = ctx->tickets_issued;
     L.epoch = ctx->epoch;
-    ctx->tickets_issued += n_tickets;
+    if (lanes) {             // n_tickets workgroups, workgroup b draws from sequence b % LANES
+        for (int s = 0; s < LFD_TICKET_LANES; ++s) {
+            L.ticket_base_lane[s] = ctx->lane_issued[s];
+            if ((size_t)s < n_tickets) ctx->lane_issued[s] += (n_tickets - (size_t)s + LFD_TICKET_LANES - 1) / LFD_TICKET_LANES;
+        }
+    } else {
+        ctx->tickets_issued += n_tickets;
+    }
     return LFD_OK;
 }
 
@@ -445,7 +462,7 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
         L.stagger_ns = 0.0f;
         if (const char* o = std::getenv("LFD_DENSE_STAGGER_NS")) L.stagger_ns = (float)std::atof(o);
     }
-    rc = prepare_lookback(ctx, n_tiles, fast ? 0 : grid, L);
+    rc = prepare_lookback(ctx, n_tiles, fast ? 0 : grid, true, L);
     if (rc != LFD_OK) return rc;
     L.xyz = out->xyz; L.rgb = out->rgb; L.err = out->err; L.cell = out->cell; L.slot = out->slot;
     L.capacity = out->capacity;
@@ -492,7 +509,7 @@ int lfd_triangulate_indexed(lfd_context* ctx, const lfd_batch* batch, const lfd_
     rc = check_points(ctx, out, reinterpret_cast<long long*>(ref_offsets));
     if (rc != LFD_OK) return rc;
     const size_t n_sel = (size_t)sel_offsets[batch->n_refs];
-    rc = prepare_lookback(ctx, (size_t)batch->n_refs, (size_t)batch->n_refs, L);
+    rc = prepare_lookback(ctx, (size_t)batch->n_refs, (size_t)batch->n_refs, false, L);
     if (rc != LFD_OK) return rc;
     rc = ensure(ctx, ctx->scratch, std::max<size_t>(n_sel, 1) * 8 * sizeof(float));
     if (rc != LFD_OK) return rc;

@@ -13,6 +13,9 @@
 #define LFD_DENSE_FAST_GEO_WAVES 3                                    // persistent kernel: geometry waves per workgroup
 #define LFD_DENSE_FAST_THREADS ((LFD_DENSE_FAST_GEO_WAVES + 1) * 64)  // + 1 service wave
 #define LFD_DENSE_FAST_TILE (LFD_DENSE_FAST_GEO_WAVES * 256)          // cells per tile of the persistent kernel
+#ifndef LFD_TICKET_LANES
+#define LFD_TICKET_LANES 8        // interleaved ticket sequences of the ticketed dense kernel (one per XCD)
+#endif
 #define LFD_DENSE_CPT 4         // consecutive grid cells per thread (one 16-byte certainty load per slot)
 #ifndef LFD_DENSE_WAVES_PER_SIMD
 #define LFD_DENSE_WAVES_PER_SIMD 4       // register budget of the fused kernel: 512/4 -> <=128 VGPRs
@@ -80,7 +83,9 @@ struct LfdLaunch {              // kernel argument, passed by value
     // and tile-state words carry the launch epoch, so nothing is memset between launches.
     unsigned long long* tile_state;
     unsigned long long* ticket;
-    unsigned long long ticket_base;
+    unsigned long long* ticket_lanes;   // dense kernel: sequence s counts at ticket_lanes[16 * s] (one cache line each)
+    unsigned long long ticket_base;                         // indexed kernel: one sequence
+    unsigned long long ticket_base_lane[LFD_TICKET_LANES];   // dense kernel: value of each sequence's counter at launch
     unsigned int epoch;
     unsigned int pad0;
     unsigned int* status;         // 0 = ok, LFD_LAUNCH_TIMEOUT if a look-back spin gave up

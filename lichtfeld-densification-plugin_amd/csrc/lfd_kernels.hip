@@ -277,6 +277,91 @@ extern "C" __global__ void __launch_bounds__(256) lfd_aggregate_kernel(LfdLaunch
     }
 }
 
+// ---- wide look-back (both dense kernels) ------------------------------------------------------------
+// A window of LFD_LB_ROWS x 64 predecessors is read per round trip.  The first window's loads are issued
+// early (lookback_issue) so that their latency is covered by the work issued after them; lookback_finish
+// consumes them and only falls back to polling when a needed predecessor has not published yet.
+#ifndef LFD_LB_ROWS
+#define LFD_LB_ROWS 4
+#endif
+struct LookbackWindow { u64 s[LFD_LB_ROWS]; };
+
+__device__ __forceinline__ void lookback_issue(const LfdLaunch& L, unsigned tile, LookbackWindow& w) {
+    const int lane = lane_id();
+    const long long base = (long long)tile - 1;
+#pragma unroll
+    for (int q = 0; q < LFD_LB_ROWS; ++q) {
+        const long long j = base - (long long)(q * 64 + lane);
+        w.s[q] = state_load(L.tile_state + (j >= 0 ? j : 0));
+        if (j < 0) w.s[q] = pack_state(kStPrefix, L.epoch, 0);   // virtual tiles < 0: prefix 0
+    }
+}
+
+// returns true when the window settled the prefix (done) or was fully consumed (continue further back);
+// false when a needed predecessor is still empty
+__device__ __forceinline__ bool lookback_consume(const LookbackWindow& w, unsigned epoch, u64& acc, bool& done) {
+    const int lane = lane_id();
+    int qp = LFD_LB_ROWS, first = 64;
+    bool blocked = false;
+#pragma unroll
+    for (int q = 0; q < LFD_LB_ROWS; ++q) {
+        if (qp == LFD_LB_ROWS && !blocked) {
+            const u64 st = state_status(w.s[q], epoch);
+            const u64 pm = __ballot(st == kStPrefix);
+            const u64 em = __ballot(st == kStEmpty);
+            if (pm) {
+                const int f = __ffsll((long long)pm) - 1;
+                if (em & ((f == 0) ? 0ull : (~0ull >> (64 - f)))) blocked = true;
+                else { qp = q; first = f; }
+            } else if (em) {
+                blocked = true;
+            }
+        }
+    }
+    if (blocked) return false;
+#pragma unroll
+    for (int q = 0; q < LFD_LB_ROWS; ++q)
+        if (q < qp || (q == qp && lane <= first)) acc += w.s[q] & kValueMask;
+    done = qp < LFD_LB_ROWS;
+    return true;
+}
+
+__device__ __forceinline__ u64 lookback_finish(const LfdLaunch& L, unsigned tile, u64 my_total, LookbackWindow& w) {
+    const unsigned epoch = L.epoch;
+    const int lane = lane_id();
+    if (tile == 0) return 0;           // published as a prefix right away
+    u64 acc = 0;                       // per-lane partial sum of the aggregates taken so far
+    unsigned base_tile = tile;         // the window in w covers [base_tile-1 ... base_tile-64*ROWS]
+    unsigned spins = 0;
+    bool done = false;
+    for (;;) {
+        if (lookback_consume(w, epoch, acc, done)) {
+            if (done) break;
+            base_tile -= 64 * LFD_LB_ROWS;
+        } else {                       // a needed predecessor has not published yet: poll again
+            if (++spins > LFD_SPIN_LIMIT) {
+                if (lane == 0) atomicExch(L.status, LFD_LAUNCH_TIMEOUT);
+                return 0;
+            }
+            // back off: every poll is LFD_LB_ROWS x 512 B of uncached traffic, and hundreds of tiles may be polling
+            if (spins < 4) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(32);
+        }
+        lookback_issue(L, base_tile, w);
+    }
+    const u64 excl = wave_sum_u64(acc);
+    if (lane == 0) state_store(L.tile_state + tile, pack_state(kStPrefix, epoch, excl + my_total));
+    return excl;
+}
+
+// publish + resolve in one go (ticketed kernel: the count is published when the look-back starts)
+__device__ __forceinline__ u64 lookback_exclusive_wide(const LfdLaunch& L, unsigned tile, u64 my_total) {
+    if (lane_id() == 0) state_store(L.tile_state + tile, pack_state(tile == 0 ? kStPrefix : kStAggregate, L.epoch, my_total));
+    if (tile == 0) return 0;
+    LookbackWindow w;
+    lookback_issue(L, tile, w);
+    return lookback_finish(L, tile, my_total, w);
+}
+
 // =================================================================================================
 // fused dense kernel
 // =================================================================================================
@@ -292,7 +377,7 @@ extern "C" __global__ void __launch_bounds__(256) lfd_aggregate_kernel(LfdLaunch
 // then copied out through an order map with coalesced 16-byte stores.
 struct DenseStage {                // per-tile results, indexed by the cell's slot inside the tile
     float xyz[3 * kTile];
-    float rgb[3 * kTile];
+    float pxy[2 * kTile];          // reference position in match pixels: colours are sampled at copy-out
     float err[kTile];
     unsigned short order[kTile];   // order[i] = tile slot of the i-th survivor (raster order)
     unsigned char slot[kTile];
@@ -310,16 +395,22 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-#if defined(LFD_ABLATE_TICKET)
-    const unsigned tile = blockIdx.x;
-#else
-    if (tid == 0) s_ticket = (unsigned)(atomicAdd(L.ticket, 1ull) - L.ticket_base);
+    // Tickets: a workgroup learns its tile from an atomic counter, so every tile a look-back can wait for is
+    // already being worked on.  Returning atomics on ONE address complete at ~12 ns each on MI355X
+    // (profiles/microbench/latency.hip: 16384 tickets = 0.2 ms), so the counter is split in LFD_TICKET_LANES
+    // interleaved sequences on separate cache lines: workgroup b draws from sequence b % LANES, whose k-th
+    // ticket is tile k*LANES + b % LANES.  Workgroups are dealt round-robin to the 8 XCDs, so each sequence
+    // is served by one XCD and always has resident workgroups.
+    const unsigned seq = blockIdx.x % LFD_TICKET_LANES;
+    if (tid == 0) {
+        const unsigned long long k = atomicAdd(L.ticket_lanes + (size_t)seq * 16, 1ull) - L.ticket_base_lane[seq];
+        s_ticket = (unsigned)k * LFD_TICKET_LANES + seq;
+    }
     __syncthreads();
     const unsigned tile = s_ticket;
-#endif
     const unsigned n_tiles = (unsigned)L.n_refs * (unsigned)L.tiles_per_ref;
     const int HW = L.H * L.W;
-    {
+    if (tile < n_tiles) {
         const int r = (int)(tile / (unsigned)L.tiles_per_ref);
         const int tile_in_ref = (int)(tile - (unsigned)r * (unsigned)L.tiles_per_ref);
         if (tid < LFD_MAX_SLOTS) s_slot_cnt[tid] = 0;
@@ -398,7 +489,6 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
 
         // ---- stage 3: per-correspondence geometry + colour; survivors overwrite their slot -------------
         unsigned keep_bits = 0;
-        const float sx_img = 1.0f, sy_img = 1.0f;    // the image handed over is already at match resolution
 #pragma unroll 1
         for (int e = 0; e < kCpt; ++e) {
             // re-read the camera constants from LDS every cell instead of pinning ~60 registers on them
@@ -415,14 +505,8 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
             if (cell0 + e < HW) lfd_eval_correspondence(S.rc, S.pc[bje], xan, yan, xbn, ybn, L.kp, res);
 #endif
             if (res.keep) {
-                float rgb[3];
-#if defined(LFD_ABLATE_COLOUR)
-                rgb[0] = res.xa_px; rgb[1] = res.ya_px; rgb[2] = sx_img + sy_img;
-#else
-                lfd_bilinear_rgb(S.ref.image, L.w_match, L.h_match, res.xa_px, res.ya_px, sx_img, sy_img, rgb);
-#endif
                 stage.xyz[3 * sl + 0] = res.x; stage.xyz[3 * sl + 1] = res.y; stage.xyz[3 * sl + 2] = res.z;
-                stage.rgb[3 * sl + 0] = rgb[0]; stage.rgb[3 * sl + 1] = rgb[1]; stage.rgb[3 * sl + 2] = rgb[2];
+                stage.pxy[2 * sl + 0] = res.xa_px; stage.pxy[2 * sl + 1] = res.ya_px;
                 stage.err[sl] = res.err;
                 keep_bits |= 1u << e;
             }
@@ -464,7 +548,7 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
 #if defined(LFD_ABLATE_LOOKBACK)
             const u64 excl = (u64)tile * kTile;
 #else
-            const u64 excl = lookback_exclusive(L, tile, block_total);
+            const u64 excl = lookback_exclusive(L, tile, block_total);    // 64-wide window: measured faster here than 256
 #endif
             if (lane == 0) {
                 s_tile_excl = excl;
@@ -491,7 +575,13 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
                 const int sl = (int)stage.order[i];
                 LfdF3 p, c;
                 p.a = stage.xyz[3 * sl + 0]; p.b = stage.xyz[3 * sl + 1]; p.c = stage.xyz[3 * sl + 2];
-                c.a = stage.rgb[3 * sl + 0]; c.b = stage.rgb[3 * sl + 1]; c.c = stage.rgb[3 * sl + 2];
+                float rgb[3];
+#if defined(LFD_ABLATE_COLOUR)
+                rgb[0] = stage.pxy[2 * sl + 0]; rgb[1] = stage.pxy[2 * sl + 1]; rgb[2] = 0.0f;
+#else
+                lfd_bilinear_rgb(S.ref.image, L.w_match, L.h_match, stage.pxy[2 * sl + 0], stage.pxy[2 * sl + 1], 1.0f, 1.0f, rgb);
+#endif
+                c.a = rgb[0]; c.b = rgb[1]; c.c = rgb[2];
                 gx[i] = p;
                 gc[i] = c;
                 ge[i] = stage.err[sl];
@@ -553,81 +643,6 @@ struct FastShared {
     unsigned slot_cnt[2][K];
     unsigned wave_cnt[2][kFastGeoWaves];
 };
-
-// ---- look-back of the persistent kernel ------------------------------------------------------------
-// A window of LFD_LB_ROWS x 64 predecessors is read per round trip.  The first window's loads are issued
-// early (lookback_issue) so that their latency is covered by the work issued after them; lookback_finish
-// consumes them and only falls back to polling when a needed predecessor has not published yet.
-#ifndef LFD_LB_ROWS
-#define LFD_LB_ROWS 4
-#endif
-struct LookbackWindow { u64 s[LFD_LB_ROWS]; };
-
-__device__ __forceinline__ void lookback_issue(const LfdLaunch& L, unsigned tile, LookbackWindow& w) {
-    const int lane = lane_id();
-    const long long base = (long long)tile - 1;
-#pragma unroll
-    for (int q = 0; q < LFD_LB_ROWS; ++q) {
-        const long long j = base - (long long)(q * 64 + lane);
-        w.s[q] = state_load(L.tile_state + (j >= 0 ? j : 0));
-        if (j < 0) w.s[q] = pack_state(kStPrefix, L.epoch, 0);   // virtual tiles < 0: prefix 0
-    }
-}
-
-// returns true when the window settled the prefix (done) or was fully consumed (continue further back);
-// false when a needed predecessor is still empty
-__device__ __forceinline__ bool lookback_consume(const LookbackWindow& w, unsigned epoch, u64& acc, bool& done) {
-    const int lane = lane_id();
-    int qp = LFD_LB_ROWS, first = 64;
-    bool blocked = false;
-#pragma unroll
-    for (int q = 0; q < LFD_LB_ROWS; ++q) {
-        if (qp == LFD_LB_ROWS && !blocked) {
-            const u64 st = state_status(w.s[q], epoch);
-            const u64 pm = __ballot(st == kStPrefix);
-            const u64 em = __ballot(st == kStEmpty);
-            if (pm) {
-                const int f = __ffsll((long long)pm) - 1;
-                if (em & ((f == 0) ? 0ull : (~0ull >> (64 - f)))) blocked = true;
-                else { qp = q; first = f; }
-            } else if (em) {
-                blocked = true;
-            }
-        }
-    }
-    if (blocked) return false;
-#pragma unroll
-    for (int q = 0; q < LFD_LB_ROWS; ++q)
-        if (q < qp || (q == qp && lane <= first)) acc += w.s[q] & kValueMask;
-    done = qp < LFD_LB_ROWS;
-    return true;
-}
-
-__device__ __forceinline__ u64 lookback_finish(const LfdLaunch& L, unsigned tile, u64 my_total, LookbackWindow& w) {
-    const unsigned epoch = L.epoch;
-    const int lane = lane_id();
-    if (tile == 0) return 0;           // published as a prefix right away
-    u64 acc = 0;                       // per-lane partial sum of the aggregates taken so far
-    unsigned base_tile = tile;         // the window in w covers [base_tile-1 ... base_tile-64*ROWS]
-    unsigned spins = 0;
-    bool done = false;
-    for (;;) {
-        if (lookback_consume(w, epoch, acc, done)) {
-            if (done) break;
-            base_tile -= 64 * LFD_LB_ROWS;
-        } else {                       // a needed predecessor has not published yet: poll again
-            if (++spins > LFD_SPIN_LIMIT) {
-                if (lane == 0) atomicExch(L.status, LFD_LAUNCH_TIMEOUT);
-                return 0;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        lookback_issue(L, base_tile, w);
-    }
-    const u64 excl = wave_sum_u64(acc);
-    if (lane == 0) state_store(L.tile_state + tile, pack_state(kStPrefix, epoch, excl + my_total));
-    return excl;
-}
 
 // MODE 0: warp = [xB,yB], default A-grid axes (closed form); 1: warp = [xB,yB], axes given by the caller;
 //      2: warp = [xA,yA,xB,yB]
