@@ -291,9 +291,19 @@ int prepare_lookback(lfd_context* ctx, size_t n_tiles, size_t n_tickets, bool la
     L.ticket_lanes = reinterpret_cast<unsigned long long*>(base + 128);
     L.tile_state = reinterpret_cast<unsigned long long*>(base + kWsHeader);
     L.status = reinterpret_cast<unsigned int*>(base + 8);
+    L.exit_count = reinterpret_cast<unsigned int*>(base + 16);
     L.ticket_base = ctx->tickets_issued;
     L.epoch = ctx->epoch;
-    if (lanes) {             // n_tickets workgroups, workgroup b draws from sequence b % LANES
+    if (lanes && n_tickets == 0) {      // persistent kernel: sequences start at zero and are reset by the kernel itself
+        for (int s = 0; s < LFD_TICKET_LANES; ++s) {
+            if (ctx->lane_issued[s] != 0) {   // a ticketed launch left them elsewhere: put them back once
+                LFD_HIP(ctx, hipMemsetAsync(base + 128, 0, 128 * LFD_TICKET_LANES, ctx->stream));
+                for (int q = 0; q < LFD_TICKET_LANES; ++q) ctx->lane_issued[q] = 0;
+                break;
+            }
+        }
+        for (int s = 0; s < LFD_TICKET_LANES; ++s) L.ticket_base_lane[s] = 0;
+    } else if (lanes) {      // n_tickets workgroups, workgroup b draws from sequence b % LANES
         for (int s = 0; s < LFD_TICKET_LANES; ++s) {
             L.ticket_base_lane[s] = ctx->lane_issued[s];
             if ((size_t)s < n_tickets) ctx->lane_issued[s] += (n_tickets - (size_t)s + LFD_TICKET_LANES - 1) / LFD_TICKET_LANES;
@@ -456,8 +466,6 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
             per_cu = std::max(1, nb);
             if (const char* o = std::getenv("LFD_DENSE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(o)));
         }
-        L.tiles_per_ref = (int)(((long long)batch->H * batch->W + LFD_DENSE_FAST_TILE - 1) / LFD_DENSE_FAST_TILE);
-        n_tiles = (size_t)batch->n_refs * (size_t)L.tiles_per_ref;
         grid = std::min<size_t>(n_tiles, (size_t)ctx->n_cus * (size_t)per_cu);
         L.stagger_ns = 0.0f;
         if (const char* o = std::getenv("LFD_DENSE_STAGGER_NS")) L.stagger_ns = (float)std::atof(o);

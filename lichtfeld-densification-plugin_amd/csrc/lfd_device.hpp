@@ -10,9 +10,8 @@
 #endif
 
 #define LFD_DENSE_BLOCK 256     // threads per workgroup of the fused dense kernel (4 waves)
-#define LFD_DENSE_FAST_GEO_WAVES 3                                    // persistent kernel: geometry waves per workgroup
-#define LFD_DENSE_FAST_THREADS ((LFD_DENSE_FAST_GEO_WAVES + 1) * 64)  // + 1 service wave
-#define LFD_DENSE_FAST_TILE (LFD_DENSE_FAST_GEO_WAVES * 256)          // cells per tile of the persistent kernel
+#define LFD_DENSE_FAST_THREADS 256                                     // persistent kernel: 4 waves, 256 cells each per tile
+#define LFD_DENSE_FAST_TILE 1024                                       // cells per tile of the persistent kernel
 #ifndef LFD_TICKET_LANES
 #define LFD_TICKET_LANES 8        // interleaved ticket sequences of the ticketed dense kernel (one per XCD)
 #endif
@@ -89,6 +88,7 @@ struct LfdLaunch {              // kernel argument, passed by value
     unsigned int epoch;
     unsigned int pad0;
     unsigned int* status;         // 0 = ok, LFD_LAUNCH_TIMEOUT if a look-back spin gave up
+    unsigned int* exit_count;     // persistent kernel: workgroups that have left (the last one resets the ticket sequences)
 };
 
 // ---- S: on-device coverage sampling (lfd_select.hip) ---------------------------------------------

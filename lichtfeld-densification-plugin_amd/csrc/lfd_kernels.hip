@@ -571,22 +571,40 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
             LfdF3* gx = reinterpret_cast<LfdF3*>(L.xyz + 3 * base);
             LfdF3* gc = reinterpret_cast<LfdF3*>(L.rgb + 3 * base);
             float* ge = L.err + base;
-            for (int i = tid; i < n; i += kBlock) {
-                const int sl = (int)stage.order[i];
-                LfdF3 p, c;
-                p.a = stage.xyz[3 * sl + 0]; p.b = stage.xyz[3 * sl + 1]; p.c = stage.xyz[3 * sl + 2];
-                float rgb[3];
+            // two records per thread per step: the image rows of both are in flight before either colour is evaluated
+            const uint8_t* image = S.ref.image;
+            for (int i0 = tid; i0 < n; i0 += 2 * kBlock) {
+                int sl[2];
+                float px[2], py[2];
+                LfdTapRows taps[2];
+                unsigned sh0[2], sh1[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = i0 + u * kBlock;
+                    sl[u] = (int)stage.order[i < n ? i : n - 1];
+                    px[u] = stage.pxy[2 * sl[u] + 0]; py[u] = stage.pxy[2 * sl[u] + 1];
+                    taps[u] = lfd_bilinear_fetch(image, L.w_match, L.h_match, px[u], py[u], sh0[u], sh1[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = i0 + u * kBlock;
+                    float rgb[3];
 #if defined(LFD_ABLATE_COLOUR)
-                rgb[0] = stage.pxy[2 * sl + 0]; rgb[1] = stage.pxy[2 * sl + 1]; rgb[2] = 0.0f;
+                    rgb[0] = px[u]; rgb[1] = py[u]; rgb[2] = (float)(taps[u].r0 + taps[u].r1 + sh0[u] + sh1[u]);
 #else
-                lfd_bilinear_rgb(S.ref.image, L.w_match, L.h_match, stage.pxy[2 * sl + 0], stage.pxy[2 * sl + 1], 1.0f, 1.0f, rgb);
+                    lfd_bilinear_eval(taps[u], sh0[u], sh1[u], L.w_match, L.h_match, px[u], py[u], rgb);
 #endif
-                c.a = rgb[0]; c.b = rgb[1]; c.c = rgb[2];
-                gx[i] = p;
-                gc[i] = c;
-                ge[i] = stage.err[sl];
-                if (L.cell) L.cell[base + i] = tile_cell0 + sl;
-                if (L.slot) L.slot[base + i] = stage.slot[sl];
+                    if (i < n) {
+                        LfdF3 p, c;
+                        p.a = stage.xyz[3 * sl[u] + 0]; p.b = stage.xyz[3 * sl[u] + 1]; p.c = stage.xyz[3 * sl[u] + 2];
+                        c.a = rgb[0]; c.b = rgb[1]; c.c = rgb[2];
+                        gx[i] = p;
+                        gc[i] = c;
+                        ge[i] = stage.err[sl[u]];
+                        if (L.cell) L.cell[base + i] = tile_cell0 + sl[u];
+                        if (L.slot) L.slot[base + i] = stage.slot[sl[u]];
+                    }
+                }
             }
 #endif
         }
@@ -627,58 +645,66 @@ __device__ __forceinline__ const T LFD_CONST_AS* lfd_const_as(const T* p) {
 #pragma clang diagnostic pop
 }
 
-constexpr int kFastGeoWaves = LFD_DENSE_FAST_GEO_WAVES;    // geometry waves per workgroup (+1 service wave)
-constexpr int kFastTile = kFastGeoWaves * 256;              // cells per tile of the persistent kernel
-constexpr int kFastThreads = (kFastGeoWaves + 1) * 64;
+constexpr int kFastWaves = LFD_DENSE_FAST_THREADS / 64;    // waves per workgroup of the persistent kernel
+constexpr int kFastTile = LFD_DENSE_FAST_TILE;              // cells per tile (256 per wave)
+constexpr int kFastThreads = LFD_DENSE_FAST_THREADS;
 
 template <int K>
 struct FastShared {
     LfdPairConst pc[2][K];                     // [constants buffer][slot]
-    // survivors of a tile wait in LDS for one tile period: two staging buffers.
+    // survivors of a tile wait in LDS for one tile period (deferred look-back): two staging buffers.
     // Colours are not staged: they are sampled when the records are copied out.
-    float xyz[2][kFastGeoWaves][3 * 256];      // [staging buffer][wave][record]
-    float err[2][kFastGeoWaves][256];
-    unsigned char cellq[2][kFastGeoWaves][256];  // survivor -> cell inside the wave's 256-cell chunk
-    unsigned char slot[2][kFastGeoWaves][256];
+    float xyz[2][kFastWaves][3 * 256];         // [staging buffer][wave][record]
+    float err[2][kFastWaves][256];
+    unsigned char cellq[2][kFastWaves][256];   // survivor -> cell inside the wave's 256-cell chunk
+    unsigned char slot[2][kFastWaves][256];
     unsigned slot_cnt[2][K];
-    unsigned wave_cnt[2][kFastGeoWaves];
+    unsigned wave_cnt[2][kFastWaves];
+    unsigned claim[4];                         // ring of claimed tiles (0xffffffff: sequence exhausted)
+    u64 tile_excl;
 };
 
 // MODE 0: warp = [xB,yB], default A-grid axes (closed form); 1: warp = [xB,yB], axes given by the caller;
 //      2: warp = [xA,yA,xB,yB]
 //
-// Wave specialisation: a workgroup is 3 geometry waves + 1 service wave (4 waves: one per SIMD, so that
-// 4 workgroups per CU are resident whatever SIMD the dispatcher starts a workgroup on).  While the geometry waves evaluate
-// tile n, the service wave retires tile n-1: it publishes the tile's count, resolves its prefix (look-back),
-// samples the survivors' colours and copies the records out.  The two kinds of work need different registers
-// and wait on different things (arithmetic vs memory round trips), so running them as different waves of the
-// same SIMDs overlaps them without adding their register demands, and no geometry wave ever waits for a
-// look-back.  One barrier per tile hands the staging buffer over.
-
+// Persistent, software-pipelined dense kernel.  What the one-tile-per-workgroup kernel pays in sequence for
+// every tile (ticket -> descriptors -> certainty -> warp -> geometry -> look-back -> copy-out) is spread over
+// three consecutive tiles of a resident workgroup:
+//   tile n+2  claimed (ticket in flight, nobody waits for it)
+//   tile n+1  certainty planes and per-pair constants in flight (registers -> LDS double buffer)
+//   tile n    arg-max, warp, geometry; survivors compacted per wave into staging buffer n&1; count published
+//   tile n-1  retired: prefix resolved by a look-back whose loads were issued before anything else of this
+//             iteration, colours sampled, records copied out of staging buffer (n-1)&1
+// Tickets come from LFD_TICKET_LANES interleaved counters (see lfd_dense_kernel); a claimed tile is always
+// evaluated without waiting for anything, so every count a look-back polls for is on its way.
 template <int K, int MODE>
 __device__ __forceinline__ void lfd_dense_fast_body(const LfdLaunch& L, FastShared<K>& sm) {
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool service = wave == kFastGeoWaves;
-    const unsigned G = gridDim.x;
     const unsigned tpr = (unsigned)L.tiles_per_ref;
     const unsigned n_tiles = (unsigned)L.n_refs * tpr;
     const int HW = L.H * L.W;
     const float th = L.kp.certainty_thresh;
     constexpr int kConstWords = 36 * K;          // LfdPairConst = 36 dwords
+    constexpr unsigned kNone = 0xffffffffu;
     static_assert(sizeof(LfdPairConst) == 144, "LfdPairConst layout");
-    static_assert(kConstWords <= kFastGeoWaves * 64, "one prefetched word per geometry thread");
+    static_assert(kConstWords <= kFastThreads, "one prefetched word per thread");
     const LfdFastRef LFD_CONST_AS* fast = lfd_const_as(L.fast);
+    const unsigned seq = blockIdx.x % LFD_TICKET_LANES;
 
-    unsigned tile = blockIdx.x;                  // uniform; (r, tin) are advanced without divisions
-    if (tile >= n_tiles) return;
-    unsigned r = tile / tpr;
-    unsigned tin = tile - r * tpr;
-    r = __builtin_amdgcn_readfirstlane(r);
-    tin = __builtin_amdgcn_readfirstlane(tin);
+    auto claim = [&]() -> unsigned {            // lane 0 of wave 0 only
+        const unsigned long long k = atomicAdd(L.ticket_lanes + (size_t)seq * 16, 1ull) - L.ticket_base_lane[seq];
+        const unsigned long long t = k * LFD_TICKET_LANES + seq;
+        return t < (unsigned long long)n_tiles ? (unsigned)t : kNone;
+    };
+    auto split = [&](unsigned t, unsigned& rr, unsigned& tt) {       // tile -> (reference, tile in reference), uniform
+        const unsigned q = t / tpr;
+        rr = __builtin_amdgcn_readfirstlane(q);
+        tt = __builtin_amdgcn_readfirstlane(t - q * tpr);
+    };
 
-    // one word of the per-pair constants per geometry thread (unconditional load, predicated LDS store)
+    // one word of the per-pair constants per thread (unconditional load, predicated LDS store)
     const int cw = tid < kConstWords ? tid : 0;
     auto fetch_const_word = [&](unsigned rr) -> unsigned {
         return reinterpret_cast<const unsigned*>(L.pair_const + (size_t)rr * K)[cw];
@@ -701,137 +727,78 @@ __device__ __forceinline__ void lfd_dense_fast_body(const LfdLaunch& L, FastShar
         }
     };
 
-    // ---- service wave: retire the tile whose survivors wait in staging buffer p ---------------------------------
-    auto retire = [&](int p, unsigned t_tile, unsigned t_r, unsigned t_tin) {
-        unsigned off[kFastGeoWaves + 1];
-        off[0] = 0;
-#pragma unroll
-        for (int w = 0; w < kFastGeoWaves; ++w) off[w + 1] = off[w] + sm.wave_cnt[p][w];
-        const unsigned total = off[kFastGeoWaves];
-        // publish the count at once (the first tile of the launch is its own prefix), then resolve the prefix
-        if (lane == 0) state_store(L.tile_state + t_tile, pack_state(t_tile == 0 ? kStPrefix : kStAggregate, L.epoch, total));
-        LookbackWindow lbw;
-#if !defined(LFD_ABLATE_LOOKBACK)
-        if (t_tile != 0) lookback_issue(L, t_tile, lbw);       // in flight while the first colour rows are fetched
-#endif
-        const int t_ns = fast[t_r].n_slots;
-        if (L.seg_counts && lane < t_ns) {
-            const unsigned c = sm.slot_cnt[p][lane];
-            if (c) atomicAdd(&L.seg_counts[(size_t)t_r * K + lane], (int)c);
-            sm.slot_cnt[p][lane] = 0;
-        }
-        const int nt = (int)total;
-        const uint8_t* image = fast[t_r].image;
-        const int tile_cell0 = (int)t_tin * kFastTile;
-        long long base = 0;
-        int n = 0;
-        LfdF3* gx = nullptr;
-        LfdF3* gc = nullptr;
-        // the geometry waves' compacted records form one list; 64 records per step, the image rows of the next
-        // four steps are in flight while a step's colours are evaluated
-        struct Rec { int cell, w, li; float xa, ya; LfdTapRows taps; unsigned sh0, sh1; };
-        auto prepare = [&](int i, Rec& q) {
-            const int ii = i < nt ? i : (nt > 0 ? nt - 1 : 0);
-            q.w = 0;
-            int o = 0;
-#pragma unroll
-            for (int w = 1; w < kFastGeoWaves; ++w)
-                if (ii >= (int)off[w]) { q.w = w; o = (int)off[w]; }
-            q.li = ii - o;
-            q.cell = tile_cell0 + q.w * 256 + (int)sm.cellq[p][q.w][q.li];
-            float xan, yan;
-            if (MODE == 2) {
-                const int sj = (int)sm.slot[p][q.w][q.li];
-                const float* wp = fast[t_r].warp[0];
-#pragma unroll
-                for (int j = 1; j < K; ++j) wp = (sj == j) ? fast[t_r].warp[j] : wp;
-                const unsigned cc = (unsigned)(q.cell < HW ? q.cell : HW - 1);
-                const float2 v = *reinterpret_cast<const float2*>(wp + (size_t)cc * 4);
-                xan = v.x; yan = v.y;
-            } else {
-                int y, x;
-                lfd_divmod(q.cell < HW ? q.cell : 0, L.W, L.inv_w, y, x);
-                if (MODE == 0) { xan = lfd_axis_value(L.ax, x); yan = lfd_axis_value(L.ay, y); }
-                else { xan = L.axis_x[x]; yan = L.axis_y[y]; }
-            }
-            q.xa = lfd_match_px(xan, L.kp.wm1); q.ya = lfd_match_px(yan, L.kp.hm1);
-            q.taps = lfd_bilinear_fetch(image, L.w_match, L.h_match, q.xa, q.ya, q.sh0, q.sh1);
-        };
-        auto finish = [&](int i, const Rec& q) {
-            float rgb[3];
-#if defined(LFD_ABLATE_COLOUR)
-            rgb[0] = q.xa; rgb[1] = q.ya; rgb[2] = (float)(q.taps.r0 + q.taps.r1 + q.sh0 + q.sh1);
-#else
-            lfd_bilinear_eval(q.taps, q.sh0, q.sh1, L.w_match, L.h_match, q.xa, q.ya, rgb);
-#endif
-#if defined(LFD_ABLATE_STORES)
-            if (i < n && rgb[0] == -12345.0f) {
-#else
-            if (i < n) {
-#endif
-                LfdF3 c; c.a = rgb[0]; c.b = rgb[1]; c.c = rgb[2];
-                LfdF3 v; v.a = sm.xyz[p][q.w][3 * q.li + 0]; v.b = sm.xyz[p][q.w][3 * q.li + 1]; v.c = sm.xyz[p][q.w][3 * q.li + 2];
-                gx[i] = v;
-                gc[i] = c;
-                L.err[base + i] = sm.err[p][q.w][q.li];
-                if (L.cell) L.cell[base + i] = q.cell;
-                if (L.slot) L.slot[base + i] = sm.slot[p][q.w][q.li];
-            }
-        };
-        Rec q0, q1, q2, q3;
-        if (nt > 0) { prepare(lane, q0); prepare(64 + lane, q1); prepare(128 + lane, q2); prepare(192 + lane, q3); }
-#if defined(LFD_ABLATE_LOOKBACK)
-        const u64 excl = (u64)t_tile * kFastTile;
-#else
-        const u64 excl = lookback_finish(L, t_tile, total, lbw);
-#endif
-        if (lane == 0) {
-            if (t_tin == 0) L.ref_offsets[t_r] = (long long)excl;
-            if (t_tile == n_tiles - 1u) L.ref_offsets[L.n_refs] = (long long)(excl + total);
-        }
-        base = (long long)excl;
-        {
-            const long long room = L.capacity - base;          // beyond capacity: counted, not written
-            n = nt;
-            if (room < (long long)n) n = room > 0 ? (int)room : 0;
-        }
-        gx = reinterpret_cast<LfdF3*>(L.xyz + 3 * base);
-        gc = reinterpret_cast<LfdF3*>(L.rgb + 3 * base);
-        for (int i0 = 0; i0 < n; i0 += 256) {
-            finish(i0 + lane, q0);       if (i0 + 256 < n) prepare(i0 + 256 + lane, q0);
-            if (i0 + 64 < n)  { finish(i0 + 64 + lane, q1);  if (i0 + 320 < n) prepare(i0 + 320 + lane, q1); }
-            if (i0 + 128 < n) { finish(i0 + 128 + lane, q2); if (i0 + 384 < n) prepare(i0 + 384 + lane, q2); }
-            if (i0 + 192 < n) { finish(i0 + 192 + lane, q3); if (i0 + 448 < n) prepare(i0 + 448 + lane, q3); }
-        }
-    };
-
-    // ---- pipeline prologue: constants and certainties of the first tile ------------------------------
+    // ---- pipeline prologue: claim three tiles, constants and certainties of the first ------------------
+    if (tid == 0) { sm.claim[0] = claim(); sm.claim[1] = claim(); sm.claim[2] = claim(); }
     if (tid < 2 * K) { sm.slot_cnt[0][tid % K] = 0; sm.slot_cnt[1][tid % K] = 0; }
-    if (!service) {
-        store_const_word(0, fetch_const_word(r));
-        fetch_cert(r, tin);
-    }
+    __syncthreads();
+    unsigned tile = sm.claim[0];
+    if (tile == kNone) return;                // (uniform) nothing left for this workgroup
+    unsigned r, tin;
+    split(tile, r, tin);
+    store_const_word(0, fetch_const_word(r));
+    fetch_cert(r, tin);
     __syncthreads();
     int buf = 0;
+    unsigned it = 0;                          // iteration = position in the claim ring
     bool has_cur = true, have_prev = false;
-    unsigned p_tile = 0, p_r = 0, p_tin = 0;
+    unsigned p_tile = 0, p_r = 0, p_tin = 0, p_total = 0, p_wave_off = 0, p_run = 0;
 
-    while (has_cur) {
-        const unsigned next = tile + G;
-        const bool has_next = next < n_tiles;
-        unsigned r_next = r, tin_next = tin + G;
-        while (tin_next >= tpr) { tin_next -= tpr; ++r_next; }
-        if (!has_next) { r_next = r; tin_next = tin; }
+    while (has_cur || have_prev) {
+        const unsigned next = has_cur ? sm.claim[(it + 1) & 3] : kNone;
+        const bool has_next = next != kNone;
+        unsigned r_next = r, tin_next = tin;
+        if (has_next) split(next, r_next, tin_next);
+        unsigned claimed = kNone;
+        if (tid == 0 && has_next) claimed = claim();          // tile n+3's ticket: consumed at the end of the iteration
+        const int ns = fast[r].n_slots;
+        const int tile_cell0 = (int)tin * kFastTile;
+        const int cell0 = tile_cell0 + wave * 256 + lane;     // + 64*e
+        const int pbuf = buf ^ 1;
 
-        if (service) {
-            if (have_prev) retire(buf ^ 1, p_tile, p_r, p_tin);
-        } else {
-            const int ns = fast[r].n_slots;
-            const int tile_cell0 = (int)tin * kFastTile;
-            const int cell0 = tile_cell0 + wave * 256 + lane;     // + 64*e
+        // ---- retire (tile n-1), issue half: look-back window first, then the image rows of this wave's survivors ----
+        LookbackWindow lbw;
+        int rcell[4];
+        float rxa[4], rya[4];
+        LfdTapRows taps[4];
+        unsigned sh0[4], sh1[4];
+        if (have_prev) {
+            if (wave == 0 && p_tile != 0) lookback_issue(L, p_tile, lbw);
+            const uint8_t* image = fast[p_r].image;
+            const int rchunk0 = (int)p_tin * kFastTile + wave * 256;
+            const int nn = (int)p_run > 0 ? (int)p_run : 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = g * 64 + lane;
+                const int ii = i < nn ? i : nn - 1;                 // clamped: loads stay unconditional
+                rcell[g] = rchunk0 + (int)sm.cellq[pbuf][wave][ii];
+                float xan, yan;
+                if (MODE == 2) {
+                    const int sj = (int)sm.slot[pbuf][wave][ii];
+                    const float* wp = fast[p_r].warp[0];
+#pragma unroll
+                    for (int j = 1; j < K; ++j) wp = (sj == j) ? fast[p_r].warp[j] : wp;
+                    const unsigned cc = (unsigned)(rcell[g] < HW ? rcell[g] : HW - 1);
+                    const float2 v = *reinterpret_cast<const float2*>(wp + (size_t)cc * 4);
+                    xan = v.x; yan = v.y;
+                } else {
+                    int y, x;
+                    lfd_divmod(rcell[g] < HW ? rcell[g] : 0, L.W, L.inv_w, y, x);
+                    if (MODE == 0) { xan = lfd_axis_value(L.ax, x); yan = lfd_axis_value(L.ay, y); }
+                    else { xan = L.axis_x[x]; yan = L.axis_y[y]; }
+                }
+                rxa[g] = lfd_match_px(xan, L.kp.wm1); rya[g] = lfd_match_px(yan, L.kp.hm1);
+                if (MODE == 0) taps[g] = lfd_bilinear_fetch(image, L.w_match, L.h_match, rxa[g], rya[g], sh0[g], sh1[g]);
+            }
+            if (MODE != 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) taps[g] = lfd_bilinear_fetch(image, L.w_match, L.h_match, rxa[g], rya[g], sh0[g], sh1[g]);
+            }
+        }
 
-            // ---- stage 1: certainty floor + arg-max over the slots ------------------------------------------
-            unsigned bj_packed = 0;
+        // ---- stage 1 (tile n): certainty floor + arg-max over the slots; stage 2a: the winner's warp --------------
+        unsigned bj_packed = 0;
+        float wv[4][4];
+        if (has_cur) {
             int bj[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -841,116 +808,196 @@ __device__ __forceinline__ void lfd_dense_fast_body(const LfdLaunch& L, FastShar
                     if (j < ns) argmax_step(lfd_cert_floor(cn[j][e], th), j, best, bj[e]);
                 bj_packed |= (unsigned)bj[e] << (8 * e);
             }
-
-            // ---- stage 2: the winner's warp, then (behind it) the prefetch of tile n+1 ---------------------------
-            float wv[4][4];
-            {
-                const float* wbase[K];
+            const float* wbase[K];
 #pragma unroll
-                for (int j = 0; j < K; ++j) wbase[j] = fast[r].warp[j];
-                int y = 0, x = 0;
-                if (MODE == 1) lfd_divmod(cell0 < HW ? cell0 : 0, L.W, L.inv_w, y, x);
+            for (int j = 0; j < K; ++j) wbase[j] = fast[r].warp[j];
+            int y = 0, x = 0;
+            if (MODE == 1) lfd_divmod(cell0 < HW ? cell0 : 0, L.W, L.inv_w, y, x);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int cell = cell0 + 64 * e;
-                    const unsigned cc = (unsigned)(cell < HW ? cell : HW - 1);
-                    const float* wp = wbase[0];
+            for (int e = 0; e < 4; ++e) {
+                const int cell = cell0 + 64 * e;
+                const unsigned cc = (unsigned)(cell < HW ? cell : HW - 1);
+                const float* wp = wbase[0];
 #pragma unroll
-                    for (int j = 1; j < K; ++j) wp = (bj[e] == j) ? wbase[j] : wp;
-                    if (MODE == 2) {
-                        const float4 v = *reinterpret_cast<const float4*>(wp + (size_t)cc * 4);
-                        wv[e][0] = v.x; wv[e][1] = v.y; wv[e][2] = v.z; wv[e][3] = v.w;
-                    } else {
-                        const float2 v = *reinterpret_cast<const float2*>(wp + (size_t)cc * 2);
-                        wv[e][2] = v.x; wv[e][3] = v.y;
-                        if (MODE == 1) {
-                            wv[e][0] = L.axis_x[x]; wv[e][1] = L.axis_y[y];
-                            x += 64;
-                            while (x >= L.W) { x -= L.W; ++y; }
-                        }
-                    }
-                }
-            }
-            unsigned pre = 0;
-            if (has_next) {
-                pre = fetch_const_word(r_next);
-                fetch_cert(r_next, tin_next);
-            }
-            {   // park the correspondences in the wave's staging slots of these cells
-                int y = 0, x = 0;
-                if (MODE == 0) lfd_divmod(cell0 < HW ? cell0 : 0, L.W, L.inv_w, y, x);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int sl = e * 64 + lane;
-                    if (MODE == 0) {      // default axes: closed form, nothing was loaded for them
-                        wv[e][0] = lfd_axis_value(L.ax, x); wv[e][1] = lfd_axis_value(L.ay, y);
+                for (int j = 1; j < K; ++j) wp = (bj[e] == j) ? wbase[j] : wp;
+                if (MODE == 2) {
+                    const float4 v = *reinterpret_cast<const float4*>(wp + (size_t)cc * 4);
+                    wv[e][0] = v.x; wv[e][1] = v.y; wv[e][2] = v.z; wv[e][3] = v.w;
+                } else {
+                    const float2 v = *reinterpret_cast<const float2*>(wp + (size_t)cc * 2);
+                    wv[e][2] = v.x; wv[e][3] = v.y;
+                    if (MODE == 1) {
+                        wv[e][0] = L.axis_x[x]; wv[e][1] = L.axis_y[y];
                         x += 64;
                         while (x >= L.W) { x -= L.W; ++y; }
                     }
-                    sm.xyz[buf][wave][3 * sl + 0] = wv[e][0]; sm.xyz[buf][wave][3 * sl + 1] = wv[e][1]; sm.xyz[buf][wave][3 * sl + 2] = wv[e][2];
-                    sm.err[buf][wave][sl] = wv[e][3];
                 }
             }
-
-            // ---- stage 3: geometry, 64 cells of the wave per step, survivors compacted in place ---------------
-            LfdRefConst rc;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) rc.P[i] = fast[r].rc.P[i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) rc.C[i] = fast[r].rc.C[i];
-            rc.sx = fast[r].rc.sx; rc.sy = fast[r].rc.sy; rc.pad = 0.0f;
-            unsigned keep_bits = 0;
-            unsigned run = 0;                       // survivors of this wave so far (uniform)
-#pragma unroll 1
-            for (int e = 0; e < 4; ++e) {
-                asm volatile("" ::: "memory");      // per-pair constants are re-read from LDS per step instead of pinned in registers
-                const int sl = e * 64 + lane;
-                const float xan = sm.xyz[buf][wave][3 * sl + 0], yan = sm.xyz[buf][wave][3 * sl + 1], xbn = sm.xyz[buf][wave][3 * sl + 2];
-                const float ybn = sm.err[buf][wave][sl];
-                const int bje = (int)((bj_packed >> (8 * e)) & 0xffu);
-                LfdCellResult res;
-                res.keep = 0; res.x = res.y = res.z = res.err = res.xa_px = res.ya_px = 0.0f;
-#if defined(LFD_ABLATE_EVAL)
-                if (cell0 + 64 * e < HW) { res.keep = xbn > -0.9f; res.x = xan + rc.P[0]; res.y = yan + sm.pc[buf][bje].P[1]; res.z = xbn; res.err = ybn; }
-#else
-                if (cell0 + 64 * e < HW) lfd_eval_correspondence(rc, sm.pc[buf][bje], xan, yan, xbn, ybn, L.kp, res);
-#endif
-                const u64 km = __ballot(res.keep != 0);
-                if (res.keep) {
-                    const unsigned pos = run + __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-                    sm.xyz[buf][wave][3 * pos + 0] = res.x; sm.xyz[buf][wave][3 * pos + 1] = res.y; sm.xyz[buf][wave][3 * pos + 2] = res.z;
-                    sm.err[buf][wave][pos] = res.err;
-                    sm.cellq[buf][wave][pos] = (unsigned char)sl;
-                    sm.slot[buf][wave][pos] = (unsigned char)bje;
-                    keep_bits |= 1u << e;
-                }
-                run += (unsigned)__popcll(km);
-            }
-            if (L.seg_counts) {
-                for (int j = 0; j < ns; ++j) {
-                    unsigned c = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        c += (unsigned)__popcll(__ballot(((keep_bits >> e) & 1u) && ((bj_packed >> (8 * e)) & 0xffu) == (unsigned)j));
-                    if (lane == 0 && c) atomicAdd(&sm.slot_cnt[buf][j], c);
-                }
-            }
-            if (lane == 0) sm.wave_cnt[buf][wave] = run;
-            if (has_next) store_const_word(buf ^ 1, pre);
         }
-        __syncthreads();                          // tile n staged (and tile n-1 retired): hand-over
+
+        // ---- prefetch (tile n+1): per-pair constants (one word per thread) and certainty planes; issued last, ----
+        //      consumed a whole tile period later
+        unsigned pre = 0;
+        if (has_next) {
+            pre = fetch_const_word(r_next);
+            fetch_cert(r_next, tin_next);
+        }
+
+        // ---- retire (tile n-1), finish half: prefix, colours, copy-out --------------------------------------------
+        if (have_prev) {
+            if (wave == 0) {
+#if defined(LFD_ABLATE_LOOKBACK)
+                const u64 excl = (u64)p_tile * kFastTile;
+#else
+                const u64 excl = lookback_finish(L, p_tile, p_total, lbw);
+#endif
+                if (lane == 0) {
+                    sm.tile_excl = excl;
+                    if (p_tin == 0) L.ref_offsets[p_r] = (long long)excl;
+                    if (p_tile == n_tiles - 1u) L.ref_offsets[L.n_refs] = (long long)(excl + p_total);
+                }
+            }
+            __syncthreads();                          // prefix known
+            const long long base = (long long)sm.tile_excl + (long long)p_wave_off;
+            long long room = L.capacity - base;          // beyond capacity: counted, not written
+            int n = (int)p_run;
+            if (room < (long long)n) n = room > 0 ? (int)room : 0;
+            LfdF3* gx = reinterpret_cast<LfdF3*>(L.xyz + 3 * base);
+            LfdF3* gc = reinterpret_cast<LfdF3*>(L.rgb + 3 * base);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = g * 64 + lane;
+                float rgb[3];
+#if defined(LFD_ABLATE_COLOUR)
+                rgb[0] = rxa[g]; rgb[1] = rya[g]; rgb[2] = (float)(taps[g].r0 + taps[g].r1 + sh0[g] + sh1[g]);
+#else
+                lfd_bilinear_eval(taps[g], sh0[g], sh1[g], L.w_match, L.h_match, rxa[g], rya[g], rgb);
+#endif
+#if defined(LFD_ABLATE_STORES)
+                if (i < n && rgb[0] == -12345.0f) {
+#else
+                if (i < n) {
+#endif
+                    LfdF3 c; c.a = rgb[0]; c.b = rgb[1]; c.c = rgb[2];
+                    LfdF3 q; q.a = sm.xyz[pbuf][wave][3 * i + 0]; q.b = sm.xyz[pbuf][wave][3 * i + 1]; q.c = sm.xyz[pbuf][wave][3 * i + 2];
+                    gx[i] = q;
+                    gc[i] = c;
+                    L.err[base + i] = sm.err[pbuf][wave][i];
+                    if (L.cell) L.cell[base + i] = rcell[g];
+                    if (L.slot) L.slot[base + i] = sm.slot[pbuf][wave][i];
+                }
+            }
+            have_prev = false;
+        }
+        if (!has_cur) break;
+
+        // ---- stage 2b (tile n): park the correspondences in the wave's staging slots of these cells --------------
+        {
+            int y = 0, x = 0;
+            if (MODE == 0) lfd_divmod(cell0 < HW ? cell0 : 0, L.W, L.inv_w, y, x);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int sl = e * 64 + lane;
+                if (MODE == 0) {      // default axes: closed form, nothing was loaded for them
+                    wv[e][0] = lfd_axis_value(L.ax, x); wv[e][1] = lfd_axis_value(L.ay, y);
+                    x += 64;
+                    while (x >= L.W) { x -= L.W; ++y; }
+                }
+                sm.xyz[buf][wave][3 * sl + 0] = wv[e][0]; sm.xyz[buf][wave][3 * sl + 1] = wv[e][1]; sm.xyz[buf][wave][3 * sl + 2] = wv[e][2];
+                sm.err[buf][wave][sl] = wv[e][3];
+            }
+        }
+
+        // ---- stage 3 (tile n): geometry, 64 cells of the wave per step, survivors compacted in place ---------
+        LfdRefConst rc;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) rc.P[i] = fast[r].rc.P[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rc.C[i] = fast[r].rc.C[i];
+        rc.sx = fast[r].rc.sx; rc.sy = fast[r].rc.sy; rc.pad = 0.0f;
+        unsigned keep_bits = 0;
+        unsigned run = 0;                       // survivors of this wave so far (uniform)
+#pragma unroll 1
+        for (int e = 0; e < 4; ++e) {
+            asm volatile("" ::: "memory");      // per-pair constants are re-read from LDS per step instead of pinned in registers
+            const int sl = e * 64 + lane;
+            const float xan = sm.xyz[buf][wave][3 * sl + 0], yan = sm.xyz[buf][wave][3 * sl + 1], xbn = sm.xyz[buf][wave][3 * sl + 2];
+            const float ybn = sm.err[buf][wave][sl];
+            const int bje = (int)((bj_packed >> (8 * e)) & 0xffu);
+            LfdCellResult res;
+            res.keep = 0; res.x = res.y = res.z = res.err = res.xa_px = res.ya_px = 0.0f;
+#if defined(LFD_ABLATE_EVAL)
+            if (cell0 + 64 * e < HW) { res.keep = xbn > -0.9f; res.x = xan + rc.P[0]; res.y = yan + sm.pc[buf][bje].P[1]; res.z = xbn; res.err = ybn; }
+#else
+            if (cell0 + 64 * e < HW) lfd_eval_correspondence(rc, sm.pc[buf][bje], xan, yan, xbn, ybn, L.kp, res);
+#endif
+            const u64 km = __ballot(res.keep != 0);
+            if (res.keep) {
+                const unsigned pos = run + __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+                sm.xyz[buf][wave][3 * pos + 0] = res.x; sm.xyz[buf][wave][3 * pos + 1] = res.y; sm.xyz[buf][wave][3 * pos + 2] = res.z;
+                sm.err[buf][wave][pos] = res.err;
+                sm.cellq[buf][wave][pos] = (unsigned char)sl;
+                sm.slot[buf][wave][pos] = (unsigned char)bje;
+                keep_bits |= 1u << e;
+            }
+            run += (unsigned)__popcll(km);
+        }
+        if (L.seg_counts) {
+            for (int j = 0; j < ns; ++j) {
+                unsigned c = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    c += (unsigned)__popcll(__ballot(((keep_bits >> e) & 1u) && ((bj_packed >> (8 * e)) & 0xffu) == (unsigned)j));
+                if (lane == 0 && c) atomicAdd(&sm.slot_cnt[buf][j], c);
+            }
+        }
+        if (lane == 0) sm.wave_cnt[buf][wave] = run;
+        if (has_next) store_const_word(buf ^ 1, pre);
+        if (tid == 0) sm.claim[(it + 3) & 3] = claimed;       // (kNone once the sequence is exhausted)
+        __syncthreads();                          // wave counts, slot counts, next constants, next claim
+
+        // ---- stage 4 (tile n): workgroup offsets; the count is published now, the prefix is resolved one tile later ----
+        unsigned wave_off = 0, block_total = 0;
+#pragma unroll
+        for (int w = 0; w < kFastWaves; ++w) {
+            const unsigned c = sm.wave_cnt[buf][w];
+            if (w < wave) wave_off += c;
+            block_total += c;
+        }
+        if (wave == 0) {
+            if (lane == 0) state_store(L.tile_state + tile, pack_state(tile == 0 ? kStPrefix : kStAggregate, L.epoch, block_total));
+            if (L.seg_counts && lane < ns) {
+                const unsigned c = sm.slot_cnt[buf][lane];
+                if (c) atomicAdd(&L.seg_counts[(size_t)r * K + lane], (int)c);
+                sm.slot_cnt[buf][lane] = 0;
+            }
+        }
         have_prev = true;
-        p_tile = tile; p_r = r; p_tin = tin;
+        p_tile = tile; p_r = r; p_tin = tin; p_total = block_total; p_wave_off = wave_off; p_run = run;
         has_cur = has_next;
-        tile = next; r = r_next; tin = tin_next; buf ^= 1;
+        tile = next; r = r_next; tin = tin_next; buf ^= 1; ++it;
     }
-    if (service) retire(buf ^ 1, p_tile, p_r, p_tin);     // drain: the last tile of this workgroup
+}
+
+// the number of claims a launch makes depends on how the tiles fell to the workgroups, so the last workgroup
+// to leave puts the ticket sequences back to zero for the next launch on the stream
+__device__ __forceinline__ void lfd_fast_epilogue(const LfdLaunch& L) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = atomicAdd(L.exit_count, 1u);
+        if (done == gridDim.x - 1u) {
+            for (int s = 0; s < LFD_TICKET_LANES; ++s)
+                __hip_atomic_store(L.ticket_lanes + (size_t)s * 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(L.exit_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 #define LFD_DENSE_FAST_KERNEL(KK, MM)                                                                          \
     extern "C" __global__ void __launch_bounds__(kFastThreads, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_fast_kernel_k##KK##_m##MM(LfdLaunch L) { \
         __shared__ FastShared<KK> sm;                                                                          \
         lfd_dense_fast_body<KK, MM>(L, sm);                                                                    \
+        lfd_fast_epilogue(L);                                                                                  \
     }
 LFD_DENSE_FAST_KERNEL(1, 0) LFD_DENSE_FAST_KERNEL(1, 1) LFD_DENSE_FAST_KERNEL(1, 2)
 LFD_DENSE_FAST_KERNEL(2, 0) LFD_DENSE_FAST_KERNEL(2, 1) LFD_DENSE_FAST_KERNEL(2, 2)
