@@ -177,7 +177,7 @@ def main():
     dens = hb.HipDensifier(dev)
     dens.upload_cameras(cams)
     batch = hb.PreparedBatch(refs, wm, hm)
-    out = hb.OutputBuffers(len(refs) * H * W, len(refs), args.k, dev, with_cell=False)   # upstream emits xyz, rgb, err only
+    out = hb.OutputBuffers(len(refs) * H * W, len(refs), args.k, dev, with_cell=False, with_segments=False)   # upstream emits xyz, rgb, err only
 
     def barrier():
         torch.cuda.synchronize(dev)

@@ -262,8 +262,12 @@ class PreparedBatch:
 class OutputBuffers:
     """Caller-owned survivor buffers (device).  Allocate once, reuse across launches."""
 
-    def __init__(self, capacity: int, n_refs: int, k: int, device, with_cell: bool = True):
+    def __init__(self, capacity: int, n_refs: int, k: int, device, with_cell: bool = True, with_segments: bool = True):
+        """``with_cell``: also return the grid cell / neighbour slot of every survivor (debug previews);
+        ``with_segments``: also count survivors per (reference, neighbour) - upstream's group sizes.  Both are
+        optional outputs of the C-ABI; upstream's own result is xyz, rgb, err."""
         self.capacity = int(capacity)
+        self.with_segments = with_segments
         cap = max(self.capacity, 1)
         self.xyz = torch.empty((cap, 3), dtype=torch.float32, device=device)
         self.rgb = torch.empty((cap, 3), dtype=torch.float32, device=device)
@@ -435,7 +439,8 @@ class HipDensifier:
 
     def launch_dense(self, batch: PreparedBatch, params: lfd_params, out: OutputBuffers) -> None:
         self._check(self._lib.lfd_triangulate_dense(self._ctx, C.byref(batch.c), C.byref(params), C.byref(out.c),
-                                                    out.ref_offsets.data_ptr(), out.seg_counts.data_ptr()),
+                                                    out.ref_offsets.data_ptr(),
+                                                    out.seg_counts.data_ptr()),
                     "lfd_triangulate_dense")
 
     def launch_indexed(self, batch: PreparedBatch, params: lfd_params, sel_idx: torch.Tensor,

@@ -15,15 +15,7 @@
 
 extern "C" __global__ void lfd_aggregate_kernel(LfdLaunch L, float* best_cert, uint8_t* best_slot);
 extern "C" __global__ void lfd_dense_kernel(LfdLaunch L);
-#if defined(LFD_PHASE_TIMING)
-extern __device__ unsigned long long lfd_phase_acc[16];
-#endif
-#define LFD_DECL_FAST(KK) \
-    extern "C" __global__ void lfd_dense_fast_kernel_k##KK##_m0(LfdLaunch L); \
-    extern "C" __global__ void lfd_dense_fast_kernel_k##KK##_m1(LfdLaunch L); \
-    extern "C" __global__ void lfd_dense_fast_kernel_k##KK##_m2(LfdLaunch L);
-LFD_DECL_FAST(1) LFD_DECL_FAST(2) LFD_DECL_FAST(3) LFD_DECL_FAST(4)
-extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* ref_out, LfdPairConst* pair_out, LfdFastRef* fast_out);
+extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* ref_out, LfdPairConst* pair_out);
 extern "C" __global__ void lfd_select_filter_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_pack_ply_kernel(const float* xyz, const float* rgb, long long n, unsigned char* out);
 extern "C" __global__ void lfd_pack_points3d_kernel(const float* xyz, const float* rgb, const float* err, long long n,
@@ -65,7 +57,6 @@ struct lfd_context {
     unsigned long long lane_issued[LFD_TICKET_LANES] = {};   // host mirrors of the dense kernel's ticket sequences
     unsigned epoch = 0;
     int n_cus = 0;                 // compute units of the device
-    int fast_blocks_per_cu[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // resident workgroups per CU of lfd_dense_fast_kernel_k<K> (persistent grid size)
     // default A-grid axes
     DeviceBuffer axes;
     int axes_w = 0, axes_h = 0;
@@ -227,10 +218,7 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
     else {
         rc = default_axes(ctx, b->W, b->H, &L.axis_x, &L.axis_y);
         if (rc != LFD_OK) return rc;
-        L.axes_identity = 1;
     }
-    L.ax = lfd_make_axis(b->W);
-    L.ay = lfd_make_axis(b->H);
     L.n_refs = b->n_refs; L.k = b->k; L.H = b->H; L.W = b->W;
     L.w_match = b->w_match; L.h_match = b->h_match; L.warp_channels = b->warp_channels;
     const long long HW = (long long)b->H * b->W;
@@ -242,20 +230,17 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
     fill_kernel_params(b, p, L.kp);
     // per-pair constants: (re)derive when the batch tables, the cameras or the match size changed
     const size_t ref_bytes = ((size_t)b->n_refs * sizeof(LfdRefConst) + 15) & ~size_t(15);
-    const size_t pair_bytes = ((size_t)b->n_refs * b->k * sizeof(LfdPairConst) + 63) & ~size_t(63);
-    const size_t need = ref_bytes + pair_bytes + (size_t)b->n_refs * sizeof(LfdFastRef);
+    const size_t need = ref_bytes + (size_t)b->n_refs * b->k * sizeof(LfdPairConst);
     if (ctx->consts.bytes < need) ctx->consts_valid = false;
     rc = ensure(ctx, ctx->consts, need);
     if (rc != LFD_OK) return rc;
     LfdRefConst* d_rc = static_cast<LfdRefConst*>(ctx->consts.ptr);
     LfdPairConst* d_pc = reinterpret_cast<LfdPairConst*>(static_cast<unsigned char*>(ctx->consts.ptr) + ref_bytes);
-    LfdFastRef* d_fast = (b->k <= 4) ? reinterpret_cast<LfdFastRef*>(reinterpret_cast<unsigned char*>(d_pc) + pair_bytes) : nullptr;
     L.ref_const = d_rc;
     L.pair_const = d_pc;
-    L.fast = d_fast;
     if (!ctx->consts_valid || ctx->consts_wm != b->w_match || ctx->consts_hm != b->h_match) {
         const int n = b->n_refs * b->k + b->n_refs;
-        hipLaunchKernelGGL(lfd_pair_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, L, d_rc, d_pc, d_fast);
+        hipLaunchKernelGGL(lfd_pair_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, L, d_rc, d_pc);
         LFD_HIP(ctx, hipGetLastError());
         ctx->consts_valid = true;
         ctx->consts_wm = b->w_match;
@@ -268,7 +253,7 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
 // counter holds when it starts; tile-state words carry a launch epoch, so stale words of earlier
 // launches read as "empty" and no per-launch memset is needed.
 // workspace: [0] u64 ticket counter, [8] u32 launch status, [16..] tile states
-// workspace: [0] u64 ticket counter (indexed kernel), [8] u32 launch status, [128 + 128*s] u64 ticket counter of
+// workspace: [0] u64 ticket counter (indexed kernel), [8] u32 launch status, [16] u32 seg_ready, [128 + 128*s] u64 ticket counter of
 // sequence s (dense kernel), [kWsHeader..] tile states
 constexpr size_t kWsHeader = 128 + 128 * LFD_TICKET_LANES;
 
@@ -284,6 +269,7 @@ int prepare_lookback(lfd_context* ctx, size_t n_tiles, size_t n_tickets, bool la
     ctx->epoch = (ctx->epoch + 1) & LFD_EPOCH_MASK;
     if (ctx->epoch == 0) {   // epoch wrapped: clear stale words once
         LFD_HIP(ctx, hipMemsetAsync(static_cast<unsigned char*>(ctx->ws.ptr) + kWsHeader, 0, ctx->ws.bytes - kWsHeader, ctx->stream));
+        LFD_HIP(ctx, hipMemsetAsync(static_cast<unsigned char*>(ctx->ws.ptr) + 16, 0, 4, ctx->stream));   // seg_ready
         ctx->epoch = 1;
     }
     unsigned char* base = static_cast<unsigned char*>(ctx->ws.ptr);
@@ -291,19 +277,10 @@ int prepare_lookback(lfd_context* ctx, size_t n_tiles, size_t n_tickets, bool la
     L.ticket_lanes = reinterpret_cast<unsigned long long*>(base + 128);
     L.tile_state = reinterpret_cast<unsigned long long*>(base + kWsHeader);
     L.status = reinterpret_cast<unsigned int*>(base + 8);
-    L.exit_count = reinterpret_cast<unsigned int*>(base + 16);
+    L.seg_ready = reinterpret_cast<unsigned int*>(base + 16);
     L.ticket_base = ctx->tickets_issued;
     L.epoch = ctx->epoch;
-    if (lanes && n_tickets == 0) {      // persistent kernel: sequences start at zero and are reset by the kernel itself
-        for (int s = 0; s < LFD_TICKET_LANES; ++s) {
-            if (ctx->lane_issued[s] != 0) {   // a ticketed launch left them elsewhere: put them back once
-                LFD_HIP(ctx, hipMemsetAsync(base + 128, 0, 128 * LFD_TICKET_LANES, ctx->stream));
-                for (int q = 0; q < LFD_TICKET_LANES; ++q) ctx->lane_issued[q] = 0;
-                break;
-            }
-        }
-        for (int s = 0; s < LFD_TICKET_LANES; ++s) L.ticket_base_lane[s] = 0;
-    } else if (lanes) {      // n_tickets workgroups, workgroup b draws from sequence b % LANES
+    if (lanes) {             // n_tickets workgroups, workgroup b draws from sequence b % LANES
         for (int s = 0; s < LFD_TICKET_LANES; ++s) {
             L.ticket_base_lane[s] = ctx->lane_issued[s];
             if ((size_t)s < n_tickets) ctx->lane_issued[s] += (n_tickets - (size_t)s + LFD_TICKET_LANES - 1) / LFD_TICKET_LANES;
@@ -435,66 +412,15 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
     if (rc != LFD_OK) return rc;
     rc = check_points(ctx, out, reinterpret_cast<long long*>(ref_offsets));
     if (rc != LFD_OK) return rc;
-    size_t n_tiles = (size_t)batch->n_refs * (size_t)L.tiles_per_ref;
+    const size_t n_tiles = (size_t)batch->n_refs * (size_t)L.tiles_per_ref;
     if (n_tiles > 0x7fffffffu) return fail(ctx, LFD_ERR_INVALID, "too many tiles in one launch");
-    // fast path: no masks and k <= 4 -> persistent software-pipelined kernel (tiles dealt statically, so the
-    // grid must be co-resident: it is sized from the occupancy the runtime reports for this kernel)
-    bool any_mask = false;
-    for (int r = 0; r < batch->n_refs; ++r) {
-        if (batch->mask_a && batch->mask_a[r]) any_mask = true;
-        if (batch->mask_b)
-            for (int j = 0; j < batch->k; ++j) if (batch->mask_b[(size_t)r * batch->k + j]) any_mask = true;
-    }
-    const bool force_general = std::getenv("LFD_DENSE_GENERAL") != nullptr;     // A/B switch for profiling and tests
-    const bool fast = !any_mask && batch->k <= 4 && !force_general;
-    typedef void (*dense_fn)(LfdLaunch);
-    dense_fn fast_fn = nullptr;
-    size_t grid = n_tiles;                    // general path: one workgroup per tile, numbered by ticket
-    if (fast) {
-        // mode 0: [xB,yB] warp + default axes (closed form); 1: [xB,yB] warp + caller's axes; 2: [xA,yA,xB,yB] warp
-        const int mode = (batch->warp_channels == 4) ? 2 : (batch->axis_x ? 1 : 0);
-        static const dense_fn table[4][3] = {
-            {lfd_dense_fast_kernel_k1_m0, lfd_dense_fast_kernel_k1_m1, lfd_dense_fast_kernel_k1_m2},
-            {lfd_dense_fast_kernel_k2_m0, lfd_dense_fast_kernel_k2_m1, lfd_dense_fast_kernel_k2_m2},
-            {lfd_dense_fast_kernel_k3_m0, lfd_dense_fast_kernel_k3_m1, lfd_dense_fast_kernel_k3_m2},
-            {lfd_dense_fast_kernel_k4_m0, lfd_dense_fast_kernel_k4_m1, lfd_dense_fast_kernel_k4_m2}};
-        fast_fn = table[batch->k - 1][mode];
-        int& per_cu = ctx->fast_blocks_per_cu[(batch->k - 1) * 3 + mode];
-        if (per_cu <= 0) {
-            int nb = 0;
-            LFD_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(fast_fn), LFD_DENSE_FAST_THREADS, 0));
-            per_cu = std::max(1, nb);
-            if (const char* o = std::getenv("LFD_DENSE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(o)));
-        }
-        grid = std::min<size_t>(n_tiles, (size_t)ctx->n_cus * (size_t)per_cu);
-        L.stagger_ns = 0.0f;
-        if (const char* o = std::getenv("LFD_DENSE_STAGGER_NS")) L.stagger_ns = (float)std::atof(o);
-    }
-    rc = prepare_lookback(ctx, n_tiles, fast ? 0 : grid, true, L);
+    const size_t grid = n_tiles;              // one workgroup per tile, numbered by ticket
+    rc = prepare_lookback(ctx, n_tiles, grid, true, L);
     if (rc != LFD_OK) return rc;
     L.xyz = out->xyz; L.rgb = out->rgb; L.err = out->err; L.cell = out->cell; L.slot = out->slot;
     L.capacity = out->capacity;
     L.ref_offsets = reinterpret_cast<long long*>(ref_offsets);
-    L.seg_counts = seg_counts;
-    if (seg_counts) LFD_HIP(ctx, hipMemsetAsync(seg_counts, 0, sizeof(int32_t) * (size_t)batch->n_refs * batch->k, ctx->stream));
-    if (fast) {
-        hipLaunchKernelGGL(fast_fn, dim3((unsigned)grid), dim3(LFD_DENSE_FAST_THREADS), 0, ctx->stream, L);
-        LFD_HIP(ctx, hipGetLastError());
-#if defined(LFD_PHASE_TIMING)
-        {   // debug build only: per-phase wall time summed over waves (100 MHz ticks)
-            static int calls = 0;
-            if (++calls == 20) {
-                unsigned long long acc[16];
-                (void)hipStreamSynchronize(ctx->stream);
-                (void)hipMemcpyFromSymbol(acc, HIP_SYMBOL(lfd_phase_acc), sizeof(acc));
-                double tot = 0; for (int i = 0; i < 12; ++i) tot += (double)acc[i];
-                const double per_wave_tile = 1.0 / (20.0 * (double)n_tiles * 4.0) * 10.0;   // ns per (wave, tile)
-                for (int i = 0; i < 12; ++i) std::fprintf(stderr, "phase %d: %8.0f ns per wave-tile (%.1f%%)\n", i, (double)acc[i] * per_wave_tile, 100.0 * acc[i] / tot);
-            }
-        }
-#endif
-        return LFD_OK;
-    }
+    L.seg_counts = seg_counts;                // zeroed inside the kernel (tile 0), no memset launch
     hipLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), 0, ctx->stream, L);
     LFD_HIP(ctx, hipGetLastError());
     return LFD_OK;

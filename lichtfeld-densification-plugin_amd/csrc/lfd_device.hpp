@@ -10,8 +10,6 @@
 #endif
 
 #define LFD_DENSE_BLOCK 256     // threads per workgroup of the fused dense kernel (4 waves)
-#define LFD_DENSE_FAST_THREADS 256                                     // persistent kernel: 4 waves, 256 cells each per tile
-#define LFD_DENSE_FAST_TILE 1024                                       // cells per tile of the persistent kernel
 #ifndef LFD_TICKET_LANES
 #define LFD_TICKET_LANES 8        // interleaved ticket sequences of the ticketed dense kernel (one per XCD)
 #endif
@@ -19,7 +17,6 @@
 #ifndef LFD_DENSE_WAVES_PER_SIMD
 #define LFD_DENSE_WAVES_PER_SIMD 4       // register budget of the fused kernel: 512/4 -> <=128 VGPRs
 #endif
-#define LFD_DENSE_MAX_BLOCKS_PER_CU LFD_DENSE_WAVES_PER_SIMD   // persistent grid = CUs x min(occupancy, this)
 #define LFD_INDEXED_BLOCK 1024  // one workgroup (16 waves) per reference in the indexed kernel
 
 #define LFD_EPOCH_BITS 22
@@ -43,31 +40,18 @@ struct LfdSlotDesc {            // one per (reference, slot)
     int32_t pad;
 };
 
-struct LfdFastRef {             // per reference, fast path: everything a tile needs in three scalar loads
-    const float* cert[4];       // slots >= n_slots repeat slot 0 (loads stay valid, the arg-max ignores them)
-    const float* warp[4];
-    const uint8_t* image;
-    int32_t n_slots;
-    int32_t pad;
-    LfdRefConst rc;
-};
-
 struct LfdLaunch {              // kernel argument, passed by value
     const LfdCam* cams;
     const LfdRefDesc* refs;
     const LfdSlotDesc* slots;
     const LfdRefConst* ref_const;    // [n_refs]    written by lfd_pair_setup_kernel
     const LfdPairConst* pair_const;  // [n_refs*k]
-    const LfdFastRef* fast;     // [n_refs]    written by lfd_pair_setup_kernel when k <= 4
     const float* axis_x;        // [W]
     const float* axis_y;        // [H]
-    LfdAxis ax, ay;             // closed form of the default axes (used when axes_identity)
-    int32_t axes_identity;      // the caller gave no axes: axis_x/axis_y hold lfd_axis_value(ax/ay, j)
-    int32_t pad2;
     int32_t n_refs, k, H, W, w_match, h_match, warp_channels, tiles_per_ref;
     float mask_sx, mask_sy;     // (float)w_match/(float)W, (float)h_match/(float)H  (nearest resize)
     float inv_w;                // 1.0f / W (cell -> row estimate)
-    float stagger_ns;           // persistent kernel: workgroup b starts b*stagger_ns late (spreads the phases of co-resident workgroups)
+    float pad1;
     LfdKernelParams kp;
     // outputs
     float* xyz;
@@ -88,7 +72,7 @@ struct LfdLaunch {              // kernel argument, passed by value
     unsigned int epoch;
     unsigned int pad0;
     unsigned int* status;         // 0 = ok, LFD_LAUNCH_TIMEOUT if a look-back spin gave up
-    unsigned int* exit_count;     // persistent kernel: workgroups that have left (the last one resets the ticket sequences)
+    unsigned int* seg_ready;      // == epoch once the workgroup of tile 0 has zeroed seg_counts
 };
 
 // ---- S: on-device coverage sampling (lfd_select.hip) ---------------------------------------------

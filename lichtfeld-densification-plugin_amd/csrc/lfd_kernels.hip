@@ -204,7 +204,7 @@ __device__ __forceinline__ void cell_coords(const LfdLaunch& L, const BlockShare
 // F5: per-(reference, neighbour) constants, once per batch (skipped when the batch is unchanged)
 // =================================================================================================
 extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* __restrict__ ref_out,
-                                                 LfdPairConst* __restrict__ pair_out, LfdFastRef* __restrict__ fast_out) {
+                                                 LfdPairConst* __restrict__ pair_out) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int n_pairs = L.n_refs * L.k;
     if (i < n_pairs) {
@@ -214,20 +214,6 @@ extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* __res
     } else if (i < n_pairs + L.n_refs) {
         const int r = i - n_pairs;
         lfd_make_ref_const(L.cams[L.refs[r].cam], L.w_match, L.h_match, ref_out[r]);
-        if (fast_out) {           // k <= 4: the record the persistent kernel reads with scalar loads
-            LfdFastRef f;
-            const int ns = L.refs[r].n_slots;
-            for (int j = 0; j < 4; ++j) {
-                const int jj = (j < ns) ? j : 0;
-                f.cert[j] = L.slots[(size_t)r * L.k + jj].cert;
-                f.warp[j] = L.slots[(size_t)r * L.k + jj].warp;
-            }
-            f.image = L.refs[r].image;
-            f.n_slots = ns;
-            f.pad = 0;
-            lfd_make_ref_const(L.cams[L.refs[r].cam], L.w_match, L.h_match, f.rc);
-            fast_out[r] = f;
-        }
     }
 }
 
@@ -277,91 +263,6 @@ extern "C" __global__ void __launch_bounds__(256) lfd_aggregate_kernel(LfdLaunch
     }
 }
 
-// ---- wide look-back (both dense kernels) ------------------------------------------------------------
-// A window of LFD_LB_ROWS x 64 predecessors is read per round trip.  The first window's loads are issued
-// early (lookback_issue) so that their latency is covered by the work issued after them; lookback_finish
-// consumes them and only falls back to polling when a needed predecessor has not published yet.
-#ifndef LFD_LB_ROWS
-#define LFD_LB_ROWS 4
-#endif
-struct LookbackWindow { u64 s[LFD_LB_ROWS]; };
-
-__device__ __forceinline__ void lookback_issue(const LfdLaunch& L, unsigned tile, LookbackWindow& w) {
-    const int lane = lane_id();
-    const long long base = (long long)tile - 1;
-#pragma unroll
-    for (int q = 0; q < LFD_LB_ROWS; ++q) {
-        const long long j = base - (long long)(q * 64 + lane);
-        w.s[q] = state_load(L.tile_state + (j >= 0 ? j : 0));
-        if (j < 0) w.s[q] = pack_state(kStPrefix, L.epoch, 0);   // virtual tiles < 0: prefix 0
-    }
-}
-
-// returns true when the window settled the prefix (done) or was fully consumed (continue further back);
-// false when a needed predecessor is still empty
-__device__ __forceinline__ bool lookback_consume(const LookbackWindow& w, unsigned epoch, u64& acc, bool& done) {
-    const int lane = lane_id();
-    int qp = LFD_LB_ROWS, first = 64;
-    bool blocked = false;
-#pragma unroll
-    for (int q = 0; q < LFD_LB_ROWS; ++q) {
-        if (qp == LFD_LB_ROWS && !blocked) {
-            const u64 st = state_status(w.s[q], epoch);
-            const u64 pm = __ballot(st == kStPrefix);
-            const u64 em = __ballot(st == kStEmpty);
-            if (pm) {
-                const int f = __ffsll((long long)pm) - 1;
-                if (em & ((f == 0) ? 0ull : (~0ull >> (64 - f)))) blocked = true;
-                else { qp = q; first = f; }
-            } else if (em) {
-                blocked = true;
-            }
-        }
-    }
-    if (blocked) return false;
-#pragma unroll
-    for (int q = 0; q < LFD_LB_ROWS; ++q)
-        if (q < qp || (q == qp && lane <= first)) acc += w.s[q] & kValueMask;
-    done = qp < LFD_LB_ROWS;
-    return true;
-}
-
-__device__ __forceinline__ u64 lookback_finish(const LfdLaunch& L, unsigned tile, u64 my_total, LookbackWindow& w) {
-    const unsigned epoch = L.epoch;
-    const int lane = lane_id();
-    if (tile == 0) return 0;           // published as a prefix right away
-    u64 acc = 0;                       // per-lane partial sum of the aggregates taken so far
-    unsigned base_tile = tile;         // the window in w covers [base_tile-1 ... base_tile-64*ROWS]
-    unsigned spins = 0;
-    bool done = false;
-    for (;;) {
-        if (lookback_consume(w, epoch, acc, done)) {
-            if (done) break;
-            base_tile -= 64 * LFD_LB_ROWS;
-        } else {                       // a needed predecessor has not published yet: poll again
-            if (++spins > LFD_SPIN_LIMIT) {
-                if (lane == 0) atomicExch(L.status, LFD_LAUNCH_TIMEOUT);
-                return 0;
-            }
-            // back off: every poll is LFD_LB_ROWS x 512 B of uncached traffic, and hundreds of tiles may be polling
-            if (spins < 4) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(32);
-        }
-        lookback_issue(L, base_tile, w);
-    }
-    const u64 excl = wave_sum_u64(acc);
-    if (lane == 0) state_store(L.tile_state + tile, pack_state(kStPrefix, epoch, excl + my_total));
-    return excl;
-}
-
-// publish + resolve in one go (ticketed kernel: the count is published when the look-back starts)
-__device__ __forceinline__ u64 lookback_exclusive_wide(const LfdLaunch& L, unsigned tile, u64 my_total) {
-    if (lane_id() == 0) state_store(L.tile_state + tile, pack_state(tile == 0 ? kStPrefix : kStAggregate, L.epoch, my_total));
-    if (tile == 0) return 0;
-    LookbackWindow w;
-    lookback_issue(L, tile, w);
-    return lookback_finish(L, tile, my_total, w);
-}
-
 // =================================================================================================
 // fused dense kernel
 // =================================================================================================
@@ -402,6 +303,7 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
     // ticket is tile k*LANES + b % LANES.  Workgroups are dealt round-robin to the 8 XCDs, so each sequence
     // is served by one XCD and always has resident workgroups.
     const unsigned seq = blockIdx.x % LFD_TICKET_LANES;
+    const unsigned seg_ready_early = L.seg_counts ? __hip_atomic_load(L.seg_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     if (tid == 0) {
         const unsigned long long k = atomicAdd(L.ticket_lanes + (size_t)seq * 16, 1ull) - L.ticket_base_lane[seq];
         s_ticket = (unsigned)k * LFD_TICKET_LANES + seq;
@@ -410,6 +312,12 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
     const unsigned tile = s_ticket;
     const unsigned n_tiles = (unsigned)L.n_refs * (unsigned)L.tiles_per_ref;
     const int HW = L.H * L.W;
+    if (tile == 0 && L.seg_counts) {         // zero the per-(reference, slot) counters for this launch, then raise the flag
+        for (int i = tid; i < L.n_refs * L.k; i += kBlock) L.seg_counts[i] = 0;
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(L.seg_ready, L.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (tile < n_tiles) {
         const int r = (int)(tile / (unsigned)L.tiles_per_ref);
         const int tile_in_ref = (int)(tile - (unsigned)r * (unsigned)L.tiles_per_ref);
@@ -557,7 +465,19 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
             }
         }
         __syncthreads();                          // staging complete, prefix known
-        if (L.seg_counts && tid < ns && s_slot_cnt[tid]) atomicAdd(&L.seg_counts[(size_t)r * L.k + tid], (int)s_slot_cnt[tid]);
+        if (L.seg_counts && tid < ns && s_slot_cnt[tid]) {
+            // the workgroup of tile 0 zeroed the array and raised seg_ready when the launch began (no memset launch)
+            // (sampled when the workgroup started; only the first few workgroups of a launch ever have to poll.  The
+            // counters are only touched by device-scope atomics, so a relaxed read of the flag is enough.)
+            unsigned spins = 0;
+            unsigned ready = seg_ready_early;
+            while (ready != L.epoch) {
+                if (++spins > LFD_SPIN_LIMIT) { atomicExch(L.status, LFD_LAUNCH_TIMEOUT); break; }
+                __builtin_amdgcn_s_sleep(8);
+                ready = __hip_atomic_load(L.seg_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            atomicAdd(&L.seg_counts[(size_t)r * L.k + tid], (int)s_slot_cnt[tid]);
+        }
 
         // ---- stage 5: coalesced copy-out ----------------------------------------------------------------
         {
@@ -610,399 +530,6 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
         }
     }
 }
-
-// =================================================================================================
-// fused dense kernel, fast path: persistent, software-pipelined (no masks, k <= 4)
-// =================================================================================================
-// Measured on MI355X (profiles/r1/ablation.txt): with one tile per workgroup the kernel is bound by
-// the chain of dependent round trips every tile pays (ticket -> descriptors -> certainty -> warp ->
-// look-back), not by arithmetic or bandwidth.  This variant removes the chain from the critical path:
-//   * persistent grid, tiles dealt statically (tile = block + i*grid): no ticket; every workgroup the
-//     look-back can wait for is resident because the grid is sized from the occupancy of the kernel;
-//   * while tile n is being evaluated, the certainty planes and per-pair constants of tile n+1 are
-//     already in flight (registers -> LDS double buffer);
-//   * the look-back reads a window of 256 predecessors per round trip instead of 64;
-//   * a wave owns 256 consecutive cells, 64 per step, so survivors are compacted with one ballot per
-//     step straight into the wave's staging area (raster order, no order map) and copied out linearly.
-#if defined(LFD_PHASE_TIMING)
-__device__ unsigned long long lfd_phase_acc[16];
-#ifndef LFD_PHASE_MASK
-#define LFD_PHASE_MASK 0xfff
-#endif
-#define LFD_PHASE_MARK(idx) do { if ((LFD_PHASE_MASK >> (idx)) & 1) { const long long t_ = (long long)wall_clock64(); t_acc[idx] += (unsigned)(t_ - t_phase); t_phase = t_; } } while (0)
-#else
-#define LFD_PHASE_MARK(idx) do { } while (0)
-#endif
-
-#define LFD_CONST_AS __attribute__((address_space(4)))
-// Loads through a constant-address-space pointer with a uniform address are selected as scalar loads
-// (s_load_*): the per-tile descriptors then cost no vector-memory round trip and land in SGPRs.
-template <class T>
-__device__ __forceinline__ const T LFD_CONST_AS* lfd_const_as(const T* p) {
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-    return (const T LFD_CONST_AS*)p;
-#pragma clang diagnostic pop
-}
-
-constexpr int kFastWaves = LFD_DENSE_FAST_THREADS / 64;    // waves per workgroup of the persistent kernel
-constexpr int kFastTile = LFD_DENSE_FAST_TILE;              // cells per tile (256 per wave)
-constexpr int kFastThreads = LFD_DENSE_FAST_THREADS;
-
-template <int K>
-struct FastShared {
-    LfdPairConst pc[2][K];                     // [constants buffer][slot]
-    // survivors of a tile wait in LDS for one tile period (deferred look-back): two staging buffers.
-    // Colours are not staged: they are sampled when the records are copied out.
-    float xyz[2][kFastWaves][3 * 256];         // [staging buffer][wave][record]
-    float err[2][kFastWaves][256];
-    unsigned char cellq[2][kFastWaves][256];   // survivor -> cell inside the wave's 256-cell chunk
-    unsigned char slot[2][kFastWaves][256];
-    unsigned slot_cnt[2][K];
-    unsigned wave_cnt[2][kFastWaves];
-    unsigned claim[4];                         // ring of claimed tiles (0xffffffff: sequence exhausted)
-    u64 tile_excl;
-};
-
-// MODE 0: warp = [xB,yB], default A-grid axes (closed form); 1: warp = [xB,yB], axes given by the caller;
-//      2: warp = [xA,yA,xB,yB]
-//
-// Persistent, software-pipelined dense kernel.  What the one-tile-per-workgroup kernel pays in sequence for
-// every tile (ticket -> descriptors -> certainty -> warp -> geometry -> look-back -> copy-out) is spread over
-// three consecutive tiles of a resident workgroup:
-//   tile n+2  claimed (ticket in flight, nobody waits for it)
-//   tile n+1  certainty planes and per-pair constants in flight (registers -> LDS double buffer)
-//   tile n    arg-max, warp, geometry; survivors compacted per wave into staging buffer n&1; count published
-//   tile n-1  retired: prefix resolved by a look-back whose loads were issued before anything else of this
-//             iteration, colours sampled, records copied out of staging buffer (n-1)&1
-// Tickets come from LFD_TICKET_LANES interleaved counters (see lfd_dense_kernel); a claimed tile is always
-// evaluated without waiting for anything, so every count a look-back polls for is on its way.
-template <int K, int MODE>
-__device__ __forceinline__ void lfd_dense_fast_body(const LfdLaunch& L, FastShared<K>& sm) {
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned tpr = (unsigned)L.tiles_per_ref;
-    const unsigned n_tiles = (unsigned)L.n_refs * tpr;
-    const int HW = L.H * L.W;
-    const float th = L.kp.certainty_thresh;
-    constexpr int kConstWords = 36 * K;          // LfdPairConst = 36 dwords
-    constexpr unsigned kNone = 0xffffffffu;
-    static_assert(sizeof(LfdPairConst) == 144, "LfdPairConst layout");
-    static_assert(kConstWords <= kFastThreads, "one prefetched word per thread");
-    const LfdFastRef LFD_CONST_AS* fast = lfd_const_as(L.fast);
-    const unsigned seq = blockIdx.x % LFD_TICKET_LANES;
-
-    auto claim = [&]() -> unsigned {            // lane 0 of wave 0 only
-        const unsigned long long k = atomicAdd(L.ticket_lanes + (size_t)seq * 16, 1ull) - L.ticket_base_lane[seq];
-        const unsigned long long t = k * LFD_TICKET_LANES + seq;
-        return t < (unsigned long long)n_tiles ? (unsigned)t : kNone;
-    };
-    auto split = [&](unsigned t, unsigned& rr, unsigned& tt) {       // tile -> (reference, tile in reference), uniform
-        const unsigned q = t / tpr;
-        rr = __builtin_amdgcn_readfirstlane(q);
-        tt = __builtin_amdgcn_readfirstlane(t - q * tpr);
-    };
-
-    // one word of the per-pair constants per thread (unconditional load, predicated LDS store)
-    const int cw = tid < kConstWords ? tid : 0;
-    auto fetch_const_word = [&](unsigned rr) -> unsigned {
-        return reinterpret_cast<const unsigned*>(L.pair_const + (size_t)rr * K)[cw];
-    };
-    auto store_const_word = [&](int b, unsigned v) {
-        if (tid < kConstWords) reinterpret_cast<unsigned*>(sm.pc[b])[tid] = v;
-    };
-
-    float cn[K][4];                       // raw certainty of this thread's 4 cells, all slots
-    auto fetch_cert = [&](unsigned rr, unsigned tt) {
-        const int c0 = (int)tt * kFastTile + wave * 256 + lane;
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const float* cp = fast[rr].cert[j];       // slots >= n_slots alias slot 0: always loadable
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int cell = c0 + 64 * e;
-                cn[j][e] = cp[cell < HW ? cell : HW - 1];
-            }
-        }
-    };
-
-    // ---- pipeline prologue: claim three tiles, constants and certainties of the first ------------------
-    if (tid == 0) { sm.claim[0] = claim(); sm.claim[1] = claim(); sm.claim[2] = claim(); }
-    if (tid < 2 * K) { sm.slot_cnt[0][tid % K] = 0; sm.slot_cnt[1][tid % K] = 0; }
-    __syncthreads();
-    unsigned tile = sm.claim[0];
-    if (tile == kNone) return;                // (uniform) nothing left for this workgroup
-    unsigned r, tin;
-    split(tile, r, tin);
-    store_const_word(0, fetch_const_word(r));
-    fetch_cert(r, tin);
-    __syncthreads();
-    int buf = 0;
-    unsigned it = 0;                          // iteration = position in the claim ring
-    bool has_cur = true, have_prev = false;
-    unsigned p_tile = 0, p_r = 0, p_tin = 0, p_total = 0, p_wave_off = 0, p_run = 0;
-
-    while (has_cur || have_prev) {
-        const unsigned next = has_cur ? sm.claim[(it + 1) & 3] : kNone;
-        const bool has_next = next != kNone;
-        unsigned r_next = r, tin_next = tin;
-        if (has_next) split(next, r_next, tin_next);
-        unsigned claimed = kNone;
-        if (tid == 0 && has_next) claimed = claim();          // tile n+3's ticket: consumed at the end of the iteration
-        const int ns = fast[r].n_slots;
-        const int tile_cell0 = (int)tin * kFastTile;
-        const int cell0 = tile_cell0 + wave * 256 + lane;     // + 64*e
-        const int pbuf = buf ^ 1;
-
-        // ---- retire (tile n-1), issue half: look-back window first, then the image rows of this wave's survivors ----
-        LookbackWindow lbw;
-        int rcell[4];
-        float rxa[4], rya[4];
-        LfdTapRows taps[4];
-        unsigned sh0[4], sh1[4];
-        if (have_prev) {
-            if (wave == 0 && p_tile != 0) lookback_issue(L, p_tile, lbw);
-            const uint8_t* image = fast[p_r].image;
-            const int rchunk0 = (int)p_tin * kFastTile + wave * 256;
-            const int nn = (int)p_run > 0 ? (int)p_run : 1;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int i = g * 64 + lane;
-                const int ii = i < nn ? i : nn - 1;                 // clamped: loads stay unconditional
-                rcell[g] = rchunk0 + (int)sm.cellq[pbuf][wave][ii];
-                float xan, yan;
-                if (MODE == 2) {
-                    const int sj = (int)sm.slot[pbuf][wave][ii];
-                    const float* wp = fast[p_r].warp[0];
-#pragma unroll
-                    for (int j = 1; j < K; ++j) wp = (sj == j) ? fast[p_r].warp[j] : wp;
-                    const unsigned cc = (unsigned)(rcell[g] < HW ? rcell[g] : HW - 1);
-                    const float2 v = *reinterpret_cast<const float2*>(wp + (size_t)cc * 4);
-                    xan = v.x; yan = v.y;
-                } else {
-                    int y, x;
-                    lfd_divmod(rcell[g] < HW ? rcell[g] : 0, L.W, L.inv_w, y, x);
-                    if (MODE == 0) { xan = lfd_axis_value(L.ax, x); yan = lfd_axis_value(L.ay, y); }
-                    else { xan = L.axis_x[x]; yan = L.axis_y[y]; }
-                }
-                rxa[g] = lfd_match_px(xan, L.kp.wm1); rya[g] = lfd_match_px(yan, L.kp.hm1);
-                if (MODE == 0) taps[g] = lfd_bilinear_fetch(image, L.w_match, L.h_match, rxa[g], rya[g], sh0[g], sh1[g]);
-            }
-            if (MODE != 0) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) taps[g] = lfd_bilinear_fetch(image, L.w_match, L.h_match, rxa[g], rya[g], sh0[g], sh1[g]);
-            }
-        }
-
-        // ---- stage 1 (tile n): certainty floor + arg-max over the slots; stage 2a: the winner's warp --------------
-        unsigned bj_packed = 0;
-        float wv[4][4];
-        if (has_cur) {
-            int bj[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float best = lfd_cert_floor(cn[0][e], th);
-#pragma unroll
-                for (int j = 1; j < K; ++j)
-                    if (j < ns) argmax_step(lfd_cert_floor(cn[j][e], th), j, best, bj[e]);
-                bj_packed |= (unsigned)bj[e] << (8 * e);
-            }
-            const float* wbase[K];
-#pragma unroll
-            for (int j = 0; j < K; ++j) wbase[j] = fast[r].warp[j];
-            int y = 0, x = 0;
-            if (MODE == 1) lfd_divmod(cell0 < HW ? cell0 : 0, L.W, L.inv_w, y, x);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int cell = cell0 + 64 * e;
-                const unsigned cc = (unsigned)(cell < HW ? cell : HW - 1);
-                const float* wp = wbase[0];
-#pragma unroll
-                for (int j = 1; j < K; ++j) wp = (bj[e] == j) ? wbase[j] : wp;
-                if (MODE == 2) {
-                    const float4 v = *reinterpret_cast<const float4*>(wp + (size_t)cc * 4);
-                    wv[e][0] = v.x; wv[e][1] = v.y; wv[e][2] = v.z; wv[e][3] = v.w;
-                } else {
-                    const float2 v = *reinterpret_cast<const float2*>(wp + (size_t)cc * 2);
-                    wv[e][2] = v.x; wv[e][3] = v.y;
-                    if (MODE == 1) {
-                        wv[e][0] = L.axis_x[x]; wv[e][1] = L.axis_y[y];
-                        x += 64;
-                        while (x >= L.W) { x -= L.W; ++y; }
-                    }
-                }
-            }
-        }
-
-        // ---- prefetch (tile n+1): per-pair constants (one word per thread) and certainty planes; issued last, ----
-        //      consumed a whole tile period later
-        unsigned pre = 0;
-        if (has_next) {
-            pre = fetch_const_word(r_next);
-            fetch_cert(r_next, tin_next);
-        }
-
-        // ---- retire (tile n-1), finish half: prefix, colours, copy-out --------------------------------------------
-        if (have_prev) {
-            if (wave == 0) {
-#if defined(LFD_ABLATE_LOOKBACK)
-                const u64 excl = (u64)p_tile * kFastTile;
-#else
-                const u64 excl = lookback_finish(L, p_tile, p_total, lbw);
-#endif
-                if (lane == 0) {
-                    sm.tile_excl = excl;
-                    if (p_tin == 0) L.ref_offsets[p_r] = (long long)excl;
-                    if (p_tile == n_tiles - 1u) L.ref_offsets[L.n_refs] = (long long)(excl + p_total);
-                }
-            }
-            __syncthreads();                          // prefix known
-            const long long base = (long long)sm.tile_excl + (long long)p_wave_off;
-            long long room = L.capacity - base;          // beyond capacity: counted, not written
-            int n = (int)p_run;
-            if (room < (long long)n) n = room > 0 ? (int)room : 0;
-            LfdF3* gx = reinterpret_cast<LfdF3*>(L.xyz + 3 * base);
-            LfdF3* gc = reinterpret_cast<LfdF3*>(L.rgb + 3 * base);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int i = g * 64 + lane;
-                float rgb[3];
-#if defined(LFD_ABLATE_COLOUR)
-                rgb[0] = rxa[g]; rgb[1] = rya[g]; rgb[2] = (float)(taps[g].r0 + taps[g].r1 + sh0[g] + sh1[g]);
-#else
-                lfd_bilinear_eval(taps[g], sh0[g], sh1[g], L.w_match, L.h_match, rxa[g], rya[g], rgb);
-#endif
-#if defined(LFD_ABLATE_STORES)
-                if (i < n && rgb[0] == -12345.0f) {
-#else
-                if (i < n) {
-#endif
-                    LfdF3 c; c.a = rgb[0]; c.b = rgb[1]; c.c = rgb[2];
-                    LfdF3 q; q.a = sm.xyz[pbuf][wave][3 * i + 0]; q.b = sm.xyz[pbuf][wave][3 * i + 1]; q.c = sm.xyz[pbuf][wave][3 * i + 2];
-                    gx[i] = q;
-                    gc[i] = c;
-                    L.err[base + i] = sm.err[pbuf][wave][i];
-                    if (L.cell) L.cell[base + i] = rcell[g];
-                    if (L.slot) L.slot[base + i] = sm.slot[pbuf][wave][i];
-                }
-            }
-            have_prev = false;
-        }
-        if (!has_cur) break;
-
-        // ---- stage 2b (tile n): park the correspondences in the wave's staging slots of these cells --------------
-        {
-            int y = 0, x = 0;
-            if (MODE == 0) lfd_divmod(cell0 < HW ? cell0 : 0, L.W, L.inv_w, y, x);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int sl = e * 64 + lane;
-                if (MODE == 0) {      // default axes: closed form, nothing was loaded for them
-                    wv[e][0] = lfd_axis_value(L.ax, x); wv[e][1] = lfd_axis_value(L.ay, y);
-                    x += 64;
-                    while (x >= L.W) { x -= L.W; ++y; }
-                }
-                sm.xyz[buf][wave][3 * sl + 0] = wv[e][0]; sm.xyz[buf][wave][3 * sl + 1] = wv[e][1]; sm.xyz[buf][wave][3 * sl + 2] = wv[e][2];
-                sm.err[buf][wave][sl] = wv[e][3];
-            }
-        }
-
-        // ---- stage 3 (tile n): geometry, 64 cells of the wave per step, survivors compacted in place ---------
-        LfdRefConst rc;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) rc.P[i] = fast[r].rc.P[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) rc.C[i] = fast[r].rc.C[i];
-        rc.sx = fast[r].rc.sx; rc.sy = fast[r].rc.sy; rc.pad = 0.0f;
-        unsigned keep_bits = 0;
-        unsigned run = 0;                       // survivors of this wave so far (uniform)
-#pragma unroll 1
-        for (int e = 0; e < 4; ++e) {
-            asm volatile("" ::: "memory");      // per-pair constants are re-read from LDS per step instead of pinned in registers
-            const int sl = e * 64 + lane;
-            const float xan = sm.xyz[buf][wave][3 * sl + 0], yan = sm.xyz[buf][wave][3 * sl + 1], xbn = sm.xyz[buf][wave][3 * sl + 2];
-            const float ybn = sm.err[buf][wave][sl];
-            const int bje = (int)((bj_packed >> (8 * e)) & 0xffu);
-            LfdCellResult res;
-            res.keep = 0; res.x = res.y = res.z = res.err = res.xa_px = res.ya_px = 0.0f;
-#if defined(LFD_ABLATE_EVAL)
-            if (cell0 + 64 * e < HW) { res.keep = xbn > -0.9f; res.x = xan + rc.P[0]; res.y = yan + sm.pc[buf][bje].P[1]; res.z = xbn; res.err = ybn; }
-#else
-            if (cell0 + 64 * e < HW) lfd_eval_correspondence(rc, sm.pc[buf][bje], xan, yan, xbn, ybn, L.kp, res);
-#endif
-            const u64 km = __ballot(res.keep != 0);
-            if (res.keep) {
-                const unsigned pos = run + __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-                sm.xyz[buf][wave][3 * pos + 0] = res.x; sm.xyz[buf][wave][3 * pos + 1] = res.y; sm.xyz[buf][wave][3 * pos + 2] = res.z;
-                sm.err[buf][wave][pos] = res.err;
-                sm.cellq[buf][wave][pos] = (unsigned char)sl;
-                sm.slot[buf][wave][pos] = (unsigned char)bje;
-                keep_bits |= 1u << e;
-            }
-            run += (unsigned)__popcll(km);
-        }
-        if (L.seg_counts) {
-            for (int j = 0; j < ns; ++j) {
-                unsigned c = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    c += (unsigned)__popcll(__ballot(((keep_bits >> e) & 1u) && ((bj_packed >> (8 * e)) & 0xffu) == (unsigned)j));
-                if (lane == 0 && c) atomicAdd(&sm.slot_cnt[buf][j], c);
-            }
-        }
-        if (lane == 0) sm.wave_cnt[buf][wave] = run;
-        if (has_next) store_const_word(buf ^ 1, pre);
-        if (tid == 0) sm.claim[(it + 3) & 3] = claimed;       // (kNone once the sequence is exhausted)
-        __syncthreads();                          // wave counts, slot counts, next constants, next claim
-
-        // ---- stage 4 (tile n): workgroup offsets; the count is published now, the prefix is resolved one tile later ----
-        unsigned wave_off = 0, block_total = 0;
-#pragma unroll
-        for (int w = 0; w < kFastWaves; ++w) {
-            const unsigned c = sm.wave_cnt[buf][w];
-            if (w < wave) wave_off += c;
-            block_total += c;
-        }
-        if (wave == 0) {
-            if (lane == 0) state_store(L.tile_state + tile, pack_state(tile == 0 ? kStPrefix : kStAggregate, L.epoch, block_total));
-            if (L.seg_counts && lane < ns) {
-                const unsigned c = sm.slot_cnt[buf][lane];
-                if (c) atomicAdd(&L.seg_counts[(size_t)r * K + lane], (int)c);
-                sm.slot_cnt[buf][lane] = 0;
-            }
-        }
-        have_prev = true;
-        p_tile = tile; p_r = r; p_tin = tin; p_total = block_total; p_wave_off = wave_off; p_run = run;
-        has_cur = has_next;
-        tile = next; r = r_next; tin = tin_next; buf ^= 1; ++it;
-    }
-}
-
-// the number of claims a launch makes depends on how the tiles fell to the workgroups, so the last workgroup
-// to leave puts the ticket sequences back to zero for the next launch on the stream
-__device__ __forceinline__ void lfd_fast_epilogue(const LfdLaunch& L) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned done = atomicAdd(L.exit_count, 1u);
-        if (done == gridDim.x - 1u) {
-            for (int s = 0; s < LFD_TICKET_LANES; ++s)
-                __hip_atomic_store(L.ticket_lanes + (size_t)s * 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(L.exit_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-#define LFD_DENSE_FAST_KERNEL(KK, MM)                                                                          \
-    extern "C" __global__ void __launch_bounds__(kFastThreads, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_fast_kernel_k##KK##_m##MM(LfdLaunch L) { \
-        __shared__ FastShared<KK> sm;                                                                          \
-        lfd_dense_fast_body<KK, MM>(L, sm);                                                                    \
-        lfd_fast_epilogue(L);                                                                                  \
-    }
-LFD_DENSE_FAST_KERNEL(1, 0) LFD_DENSE_FAST_KERNEL(1, 1) LFD_DENSE_FAST_KERNEL(1, 2)
-LFD_DENSE_FAST_KERNEL(2, 0) LFD_DENSE_FAST_KERNEL(2, 1) LFD_DENSE_FAST_KERNEL(2, 2)
-LFD_DENSE_FAST_KERNEL(3, 0) LFD_DENSE_FAST_KERNEL(3, 1) LFD_DENSE_FAST_KERNEL(3, 2)
-LFD_DENSE_FAST_KERNEL(4, 0) LFD_DENSE_FAST_KERNEL(4, 1) LFD_DENSE_FAST_KERNEL(4, 2)
 
 // =================================================================================================
 // upstream-equivalent indexed kernel: one workgroup per reference
