@@ -96,6 +96,8 @@ def load_library() -> C.CDLL:
     lib.lfd_parallax_dot_threshold.argtypes = [C.c_float]
     lib.lfd_parallax_dot_threshold.restype = C.c_float
     lib.lfd_host_fundamental.argtypes = [fptr] * 7
+    lib.lfd_host_null_vector.argtypes = [fptr, C.POINTER(C.c_double)]
+    lib.lfd_host_null_vector.restype = C.c_int
     lib.lfd_host_eval_correspondence.argtypes = [fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                                  C.c_int32, C.POINTER(lfd_params), fptr]
     for name in ("lfd_create", "lfd_set_stream", "lfd_upload_cameras", "lfd_aggregate", "lfd_triangulate_dense",
@@ -143,6 +145,17 @@ def host_fundamental(K1, R1, t1, K2, R2, t2) -> np.ndarray:
     if rc != 0:
         raise HipBackendError("lfd_host_fundamental failed")
     return out.reshape(3, 3)
+
+
+def host_null_vector(A) -> "tuple[np.ndarray, int]":
+    """Smallest right singular vector (un-normalised, f64) of a 4x4 f32 matrix through the routine the kernels
+    triangulate with (host build of csrc/lfd_geometry.hpp), and the number of solves it made."""
+    a = _f32(A).reshape(16)
+    out = np.zeros(4, np.float64)
+    it = load_library().lfd_host_null_vector(_fp(a), out.ctypes.data_as(C.POINTER(C.c_double)))
+    if it < 0:
+        raise HipBackendError("lfd_host_null_vector failed")
+    return out, int(it)
 
 
 def pack_camera(cam: CameraRecord) -> np.ndarray:
