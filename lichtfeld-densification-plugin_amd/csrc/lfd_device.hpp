@@ -9,7 +9,9 @@
 #define LFD_MAX_SLOTS 16
 #endif
 
+#ifndef LFD_DENSE_BLOCK
 #define LFD_DENSE_BLOCK 256     // threads per workgroup of the fused dense kernel (4 waves)
+#endif
 #ifndef LFD_TICKET_LANES
 #define LFD_TICKET_LANES 8        // interleaved ticket sequences of the ticketed dense kernel (one per XCD)
 #endif
