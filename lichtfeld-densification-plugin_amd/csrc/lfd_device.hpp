@@ -12,6 +12,9 @@
 #ifndef LFD_DENSE_BLOCK
 #define LFD_DENSE_BLOCK 256     // threads per workgroup of the fused dense kernel (4 waves)
 #endif
+#ifndef LFD_COPY_UNROLL
+#define LFD_COPY_UNROLL 2          // survivor records a thread copies out per step (dense kernel)
+#endif
 #ifndef LFD_TICKET_LANES
 #define LFD_TICKET_LANES 8        // interleaved ticket sequences of the ticketed dense kernel (one per XCD)
 #endif

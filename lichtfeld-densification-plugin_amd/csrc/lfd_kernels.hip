@@ -431,14 +431,17 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
         }
 
         // ---- stage 4: ordered compaction: thread -> wave -> workgroup -> grid (look-back) ----------------
+        // survivors of the lower lanes (thread-major raster order): one ballot per cell index, counted below the lane
         const unsigned my_cnt = __popc(keep_bits);
-        unsigned incl = my_cnt;
+        unsigned before = 0, wave_total = 0;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned n = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += n;
+        for (int e = 0; e < kCpt; ++e) {
+            const u64 m = __ballot((keep_bits >> e) & 1u);
+            before += __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            wave_total += (unsigned)__popcll(m);
         }
-        if (lane == 63) s_wave_cnt[wave] = incl;
+        const unsigned incl = before + my_cnt;
+        if (lane == 0) s_wave_cnt[wave] = wave_total;
         __syncthreads();                          // s_wave_cnt written
         unsigned wave_off = 0, block_total = 0;
 #pragma unroll
@@ -491,22 +494,22 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
             LfdF3* gx = reinterpret_cast<LfdF3*>(L.xyz + 3 * base);
             LfdF3* gc = reinterpret_cast<LfdF3*>(L.rgb + 3 * base);
             float* ge = L.err + base;
-            // two records per thread per step: the image rows of both are in flight before either colour is evaluated
+            // LFD_COPY_UNROLL records per thread per step: their image rows are in flight before the first colour is evaluated
             const uint8_t* image = S.ref.image;
-            for (int i0 = tid; i0 < n; i0 += 2 * kBlock) {
-                int sl[2];
-                float px[2], py[2];
-                LfdTapRows taps[2];
-                unsigned sh0[2], sh1[2];
+            for (int i0 = tid; i0 < n; i0 += LFD_COPY_UNROLL * kBlock) {
+                int sl[LFD_COPY_UNROLL];
+                float px[LFD_COPY_UNROLL], py[LFD_COPY_UNROLL];
+                LfdTapRows taps[LFD_COPY_UNROLL];
+                unsigned sh0[LFD_COPY_UNROLL], sh1[LFD_COPY_UNROLL];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < LFD_COPY_UNROLL; ++u) {
                     const int i = i0 + u * kBlock;
                     sl[u] = (int)stage.order[i < n ? i : n - 1];
                     px[u] = stage.pxy[2 * sl[u] + 0]; py[u] = stage.pxy[2 * sl[u] + 1];
                     taps[u] = lfd_bilinear_fetch(image, L.w_match, L.h_match, px[u], py[u], sh0[u], sh1[u]);
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < LFD_COPY_UNROLL; ++u) {
                     const int i = i0 + u * kBlock;
                     float rgb[3];
 #if defined(LFD_ABLATE_COLOUR)
