@@ -300,8 +300,10 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
     // already being worked on.  Returning atomics on ONE address complete at ~12 ns each on MI355X
     // (profiles/microbench/latency.hip: 16384 tickets = 0.2 ms), so the counter is split in LFD_TICKET_LANES
     // interleaved sequences on separate cache lines: workgroup b draws from sequence b % LANES, whose k-th
-    // ticket is tile k*LANES + b % LANES.  Workgroups are dealt round-robin to the 8 XCDs, so each sequence
-    // is served by one XCD and always has resident workgroups.
+    // ticket is tile k*LANES + b % LANES.  Once workgroups 0..N-1 have started, the claimed tiles are exactly
+    // 0..N-1 (whichever workgroup of a class drew which ticket), so the lowest unfinished tile always belongs to
+    // a running workgroup, as with a single counter; the 8 classes also match the round-robin dealing of
+    // workgroups to the 8 XCDs.
     const unsigned seq = blockIdx.x % LFD_TICKET_LANES;
     const unsigned seg_ready_early = L.seg_counts ? __hip_atomic_load(L.seg_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     if (tid == 0) {
