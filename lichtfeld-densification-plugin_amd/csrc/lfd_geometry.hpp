@@ -179,7 +179,7 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
 // Two solves are always made; more follow only while the growth factor has not settled (bad
 // conditioning: sigma4/sigma3 not small).
 #ifndef LFD_NULLVEC_TOL
-#define LFD_NULLVEC_TOL 1e-10
+#define LFD_NULLVEC_TOL 1e-6      /* direction change (relative, on x_i/x_3) of the last solve that counts as settled */
 #endif
 #ifndef LFD_NULLVEC_MAXIT
 #define LFD_NULLVEC_MAXIT 8       /* solves per pass */
@@ -223,9 +223,9 @@ LFD_HD int lfd_null_vector(const float* Af, double* c) {
         m11 = fma(a1, a1, m11); m12 = fma(a1, a2, m12); m13 = fma(a1, a3, m13);
         m22 = fma(a2, a2, m22); m23 = fma(a2, a3, m23); m33 = fma(a3, a3, m33);
     }
-    // Convergence monitor: for a symmetric iteration the growth of |x|^2 settles quadratically, so
-    // n_{k+1} n_{k-1} = n_k^2 up to LFD_NULLVEC_TOL means iterate k-1 is within ~sqrt(tol) of v4 and iterate
-    // k+1, the one returned, within q^2 times that.  (NaN compares false: bad input leaves at once.)
+    // Convergence monitor: the direction change between successive iterates is the error of the older one (the
+    // iteration is linear with ratio q), so once it drops below LFD_NULLVEC_TOL the iterate just computed is within
+    // q * TOL of v4.  Ordinary cells (q ~ 1e-4) settle after two solves.
     // A pass that has not settled after LFD_NULLVEC_MAXIT solves (sigma4/sigma3 close to 1) is followed by a
     // pass shifted by the Rayleigh quotient of its result, which separates the two smallest eigenvalues.
     double sh = 0.0;
@@ -254,10 +254,9 @@ LFD_HD int lfd_null_vector(const float* Af, double* c) {
             x0 = fma(-l10, x1, fma(-l20, x2, -l30));
             it = 1;
         }
-        double n_prev = 0.0;
-        double n_cur = fma(x0, x0, fma(x1, x1, fma(x2, x2, x3 * x3)));
         bool settled = false;
         for (int k = 1;; ++k) {
+            const double o0 = x0, o1 = x1, o2 = x2, o3 = x3;
             // x <- d3 * (M - sh I)^-1 x : forward (L), diagonal, backward (L^T)
             const double y1 = fma(-l10, x0, x1);
             const double y2 = fma(-l21, y1, fma(-l20, x0, x2));
@@ -267,15 +266,18 @@ LFD_HD int lfd_null_vector(const float* Af, double* c) {
             x2 = fma(-l32, x3, z2);
             x1 = fma(-l21, x2, fma(-l31, x3, z1));
             x0 = fma(-l10, x1, fma(-l20, x2, fma(-l30, x3, z0)));
-            const double n_new = fma(x0, x0, fma(x1, x1, fma(x2, x2, x3 * x3)));
             ++it;
             if (k >= 2) {
-                const double sq = n_cur * n_cur;
-                const bool more = fabs(fma(n_new, n_prev, -sq)) > LFD_NULLVEC_TOL * sq;
-                if (!more) { settled = true; break; }
+                // direction change of the last solve, measured on the inhomogeneous coordinates x_i / x_3 (cross-multiplied):
+                // it is ~ the error of the PREVIOUS iterate, the one returned is q times closer.  A vanishing x_3 (point at
+                // infinity) never passes and runs into the iteration limits.
+                const double ref = fabs(x3 * o3) * LFD_NULLVEC_TOL;
+                const double e0 = fabs(fma(x0, o3, -(x3 * o0))), e1 = fabs(fma(x1, o3, -(x3 * o1))), e2 = fabs(fma(x2, o3, -(x3 * o2)));
+                const bool more = (e0 > ref) || (e1 > ref) || (e2 > ref) || !(ref > 0.0);
+                const bool bad = !(e0 == e0) || !(e1 == e1) || !(e2 == e2) || !(ref == ref);     // NaN: leave at once
+                if (!more || bad) { settled = true; break; }
                 if (k >= LFD_NULLVEC_MAXIT) break;
             }
-            n_prev = n_cur; n_cur = n_new;
         }
         if (settled || pass >= LFD_NULLVEC_PASSES - 1) break;
         // Rayleigh quotient of x as the next shift; x rescaled by an exact power of two
