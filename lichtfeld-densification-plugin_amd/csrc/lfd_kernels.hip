@@ -276,6 +276,17 @@ extern "C" __global__ void __launch_bounds__(256) lfd_aggregate_kernel(LfdLaunch
 // A thread owns 4 consecutive cells.  Their inputs, and later their outputs, are parked in the
 // thread's own LDS slots, so the geometry loop carries no per-cell register arrays; survivors are
 // then copied out through an order map with coalesced 16-byte stores.
+#define LFD_CONST_AS __attribute__((address_space(4)))
+// Loads through a constant-address-space pointer with a uniform address are selected as scalar loads
+// (s_load_*): they cost no vector-memory or LDS traffic and land in SGPRs.
+template <class T>
+__device__ __forceinline__ const T LFD_CONST_AS* lfd_const_as(const T* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const T LFD_CONST_AS*)p;
+#pragma clang diagnostic pop
+}
+
 struct DenseStage {                // per-tile results, indexed by the cell's slot inside the tile
     float xyz[3 * kTile];
     float pxy[2 * kTile];          // reference position in match pixels: colours are sampled at copy-out
@@ -321,8 +332,18 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
         if (tid == 0) __hip_atomic_store(L.seg_ready, L.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tile < n_tiles) {
-        const int r = (int)(tile / (unsigned)L.tiles_per_ref);
+        const int r = __builtin_amdgcn_readfirstlane((int)(tile / (unsigned)L.tiles_per_ref));
         const int tile_in_ref = (int)(tile - (unsigned)r * (unsigned)L.tiles_per_ref);
+        // the reference camera's block is the same for every lane: scalar loads keep it in SGPRs instead of LDS reads
+        LfdRefConst rc;
+        {
+            const LfdRefConst LFD_CONST_AS* rcp = lfd_const_as(L.ref_const) + r;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) rc.P[i] = rcp->P[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rc.C[i] = rcp->C[i];
+            rc.sx = rcp->sx; rc.sy = rcp->sy; rc.pad = 0.0f;
+        }
         if (tid < LFD_MAX_SLOTS) s_slot_cnt[tid] = 0;
         block_prologue(L, r, S);                 // ends with a barrier (also covers s_slot_cnt)
         const int ns = S.ref.n_slots;
@@ -412,7 +433,7 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
 #if defined(LFD_ABLATE_EVAL)
             if (cell0 + e < HW) { res.keep = xbn > -0.9f; res.x = xan; res.y = yan; res.z = xbn; res.err = ybn; res.xa_px = 1.0f; res.ya_px = 1.0f; }
 #else
-            if (cell0 + e < HW) lfd_eval_correspondence(S.rc, S.pc[bje], xan, yan, xbn, ybn, L.kp, res);
+            if (cell0 + e < HW) lfd_eval_correspondence(rc, S.pc[bje], xan, yan, xbn, ybn, L.kp, res);
 #endif
             if (res.keep) {
                 stage.xyz[3 * sl + 0] = res.x; stage.xyz[3 * sl + 1] = res.y; stage.xyz[3 * sl + 2] = res.z;
