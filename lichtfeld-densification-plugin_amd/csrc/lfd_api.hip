@@ -421,7 +421,9 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
     L.capacity = out->capacity;
     L.ref_offsets = reinterpret_cast<long long*>(ref_offsets);
     L.seg_counts = seg_counts;                // zeroed inside the kernel (tile 0), no memset launch
-    hipLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), 0, ctx->stream, L);
+    size_t extra_lds = 0;                     // profiling switch: dynamic LDS lowers the number of resident workgroups
+    if (const char* e = std::getenv("LFD_DENSE_EXTRA_LDS")) extra_lds = (size_t)std::atol(e);
+    hipLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), extra_lds, ctx->stream, L);
     LFD_HIP(ctx, hipGetLastError());
     return LFD_OK;
 }
