@@ -235,6 +235,36 @@ def test_dense_is_deterministic_and_overflow_safe(dev):
     dens.close()
 
 
+def test_dense_launch_sequence_of_varying_sizes_on_one_context(dev):
+    """One context, launches of 1..9 references x 1..2 tiles in changing order (with and without the optional
+    outputs): the ticket sequences, epochs and in-kernel counter zeroing carry over from launch to launch, so
+    every launch must reproduce what a fresh context computes for the same batch."""
+    cams, refs, _ = _synthetic_batch(dev, 9, [2, 3, 1], 40, 48, 48, 40, seed=21)      # 1920 cells = 2 tiles per reference
+    p = hb.make_params(lfd.DensePipelineConfig(output_path=""))
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    expected = {}
+    for n in (1, 2, 3, 4, 5, 8, 9):
+        fresh = hb.HipDensifier(dev)
+        fresh.upload_cameras(cams)
+        expected[n] = fresh.triangulate_dense(hb.PreparedBatch(refs[:n], 48, 40), p)
+        fresh.close()
+    for n in (9, 1, 4, 4, 2, 8, 3, 1, 5, 9, 2):
+        batch = hb.PreparedBatch(refs[:n], 48, 40)
+        got = dens.triangulate_dense(batch, p)
+        ref = expected[n]
+        assert got.count == ref.count and got.count > 0
+        np.testing.assert_array_equal(got.ref_offsets, ref.ref_offsets)
+        np.testing.assert_array_equal(got.seg_counts, ref.seg_counts)
+        for x, y in ((got.xyz, ref.xyz), (got.rgb, ref.rgb), (got.err, ref.err), (got.cell, ref.cell), (got.slot, ref.slot)):
+            assert torch.equal(x, y)
+        bare = hb.OutputBuffers(got.count, batch.n_refs, batch.k, dev, with_cell=False, with_segments=False)
+        dens.launch_dense(batch, p, bare)
+        res = bare.collect()
+        assert res.count == ref.count and torch.equal(res.xyz, ref.xyz) and torch.equal(res.err, ref.err)
+    dens.close()
+
+
 def test_dense_full_size_properties(dev):
     """512^2 x k=3 x 8 references (the bench shape, smaller batch): size-independent properties."""
     H = W = 512
