@@ -20,6 +20,11 @@
 #else
 #define LFD_HD inline
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LFD_REREAD_CONSTANTS() asm volatile("" ::: "memory")   /* values in memory (LDS) are loaded again after this point */
+#else
+#define LFD_REREAD_CONSTANTS() do { } while (0)
+#endif
 
 // ---- device-resident tables ------------------------------------------------------------------
 struct LfdCam {       // one row of the uploaded camera table (CameraRecord, f32)
@@ -396,6 +401,9 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
         X3 = 1.0f;
     }
 
+    // The neighbour's P and C were last used for the DLT rows; re-reading them from LDS here (instead of carrying
+    // 15 registers across the solver) is what keeps the kernels at five to six workgroups per CU.
+    LFD_REREAD_CONSTANTS();
     float z1, z2;
     const float e1 = lfd_reproj(rc.P, X0, X1, X2, X3, ua, va, z1);
     const float e2 = lfd_reproj(pc.P, X0, X1, X2, X3, ub, vb, z2);

@@ -289,7 +289,6 @@ __device__ __forceinline__ const T LFD_CONST_AS* lfd_const_as(const T* p) {
 
 struct DenseStage {                // per-tile results, indexed by the cell's slot inside the tile
     float xyz[3 * kTile];
-    float pxy[2 * kTile];          // reference position in match pixels: colours are sampled at copy-out
     float err[kTile];
     unsigned short order[kTile];   // order[i] = tile slot of the i-th survivor (raster order)
     unsigned char slot[kTile];
@@ -437,7 +436,6 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
 #endif
             if (res.keep) {
                 stage.xyz[3 * sl + 0] = res.x; stage.xyz[3 * sl + 1] = res.y; stage.xyz[3 * sl + 2] = res.z;
-                stage.pxy[2 * sl + 0] = res.xa_px; stage.pxy[2 * sl + 1] = res.ya_px;
                 stage.err[sl] = res.err;
                 keep_bits |= 1u << e;
             }
@@ -528,7 +526,20 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
                 for (int u = 0; u < LFD_COPY_UNROLL; ++u) {
                     const int i = i0 + u * kBlock;
                     sl[u] = (int)stage.order[i < n ? i : n - 1];
-                    px[u] = stage.pxy[2 * sl[u] + 0]; py[u] = stage.pxy[2 * sl[u] + 1];
+                    {   // reference position in match pixels, from the A-grid coordinates of the cell (not staged: LDS is
+                        // one of the two things that limit the number of resident workgroups)
+                        const int cell = tile_cell0 + sl[u];
+                        float xan, yan;
+                        if (L.warp_channels == 4) {
+                            const float2 v = *reinterpret_cast<const float2*>(S.slot[stage.slot[sl[u]]].warp + (size_t)cell * 4);
+                            xan = v.x; yan = v.y;
+                        } else {
+                            int y, x;
+                            lfd_divmod(cell, L.W, L.inv_w, y, x);
+                            xan = L.axis_x[x]; yan = L.axis_y[y];
+                        }
+                        px[u] = lfd_match_px(xan, L.kp.wm1); py[u] = lfd_match_px(yan, L.kp.hm1);
+                    }
                     taps[u] = lfd_bilinear_fetch(image, L.w_match, L.h_match, px[u], py[u], sh0[u], sh1[u]);
                 }
 #pragma unroll
