@@ -218,7 +218,10 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
     else {
         rc = default_axes(ctx, b->W, b->H, &L.axis_x, &L.axis_y);
         if (rc != LFD_OK) return rc;
+        L.axis_identity = 1;
     }
+    L.ax = lfd_make_axis(b->W);
+    L.ay = lfd_make_axis(b->H);
     L.n_refs = b->n_refs; L.k = b->k; L.H = b->H; L.W = b->W;
     L.w_match = b->w_match; L.h_match = b->h_match; L.warp_channels = b->warp_channels;
     const long long HW = (long long)b->H * b->W;

@@ -56,7 +56,9 @@ struct LfdLaunch {              // kernel argument, passed by value
     int32_t n_refs, k, H, W, w_match, h_match, warp_channels, tiles_per_ref;
     float mask_sx, mask_sy;     // (float)w_match/(float)W, (float)h_match/(float)H  (nearest resize)
     float inv_w;                // 1.0f / W (cell -> row estimate)
-    float pad1;
+    int32_t axis_identity;      // 1: axis_x/axis_y hold lfd_identity_axis() values, which the kernels may compute (ax, ay) instead of loading
+    LfdAxis ax, ay;             // the analytic A-grid axes (valid when axis_identity)
+    int32_t pad1[2];
     LfdKernelParams kp;
     // outputs
     float* xyz;

@@ -22,8 +22,10 @@
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LFD_REREAD_CONSTANTS() asm volatile("" ::: "memory")   /* values in memory (LDS) are loaded again after this point */
+#define LFD_OPAQUE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")   /* ... and these are new values to the optimiser */
 #else
 #define LFD_REREAD_CONSTANTS() do { } while (0)
+#define LFD_OPAQUE4(a, b, c, d) do { } while (0)
 #endif
 
 // ---- device-resident tables ------------------------------------------------------------------
@@ -213,20 +215,28 @@ LFD_HD double lfd_recip_refined(double d) {
 }
 
 // c[4]: un-normalised multiple of the singular vector; returns the number of solves made.
-LFD_HD int lfd_null_vector(const float* Af, double* c) {
-    // M = A^T A, upper triangle (products of f32 values are exact in f64)
+// `rows(Af)` fills the 4x4 matrix (row-major f32).  It is called at the start of EVERY pass, so neither the matrix
+// nor M = A^T A stays live across the solves (30 registers on the device); the shifted passes, which are the only
+// ones that need M a second time, are rare (sigma4/sigma3 close to 1) and simply rebuild it.
+template <class RowFn>
+LFD_HD int lfd_null_vector_rows(RowFn rows, double* c) {
     double m00, m01, m02, m03, m11, m12, m13, m22, m23, m33;
-    {
-        const double a0 = (double)Af[0], a1 = (double)Af[1], a2 = (double)Af[2], a3 = (double)Af[3];
-        m00 = a0 * a0; m01 = a0 * a1; m02 = a0 * a2; m03 = a0 * a3;
-        m11 = a1 * a1; m12 = a1 * a2; m13 = a1 * a3; m22 = a2 * a2; m23 = a2 * a3; m33 = a3 * a3;
-    }
-#pragma unroll
-    for (int r = 1; r < 4; ++r) {
-        const double a0 = (double)Af[4 * r + 0], a1 = (double)Af[4 * r + 1], a2 = (double)Af[4 * r + 2], a3 = (double)Af[4 * r + 3];
-        m00 = fma(a0, a0, m00); m01 = fma(a0, a1, m01); m02 = fma(a0, a2, m02); m03 = fma(a0, a3, m03);
-        m11 = fma(a1, a1, m11); m12 = fma(a1, a2, m12); m13 = fma(a1, a3, m13);
-        m22 = fma(a2, a2, m22); m23 = fma(a2, a3, m23); m33 = fma(a3, a3, m33);
+#define LFD_BUILD_M()                                                                                                   \
+    {                                                                                                                   \
+        float Af[16];                                                                                                   \
+        rows(Af);                                                                                                       \
+        {   /* M = A^T A, upper triangle (products of f32 values are exact in f64) */                                   \
+            const double a0 = (double)Af[0], a1 = (double)Af[1], a2 = (double)Af[2], a3 = (double)Af[3];                \
+            m00 = a0 * a0; m01 = a0 * a1; m02 = a0 * a2; m03 = a0 * a3;                                                 \
+            m11 = a1 * a1; m12 = a1 * a2; m13 = a1 * a3; m22 = a2 * a2; m23 = a2 * a3; m33 = a3 * a3;                   \
+        }                                                                                                               \
+        _Pragma("unroll") for (int r = 1; r < 4; ++r) {                                                                 \
+            const double a0 = (double)Af[4 * r + 0], a1 = (double)Af[4 * r + 1], a2 = (double)Af[4 * r + 2],            \
+                         a3 = (double)Af[4 * r + 3];                                                                    \
+            m00 = fma(a0, a0, m00); m01 = fma(a0, a1, m01); m02 = fma(a0, a2, m02); m03 = fma(a0, a3, m03);             \
+            m11 = fma(a1, a1, m11); m12 = fma(a1, a2, m12); m13 = fma(a1, a3, m13);                                     \
+            m22 = fma(a2, a2, m22); m23 = fma(a2, a3, m23); m33 = fma(a3, a3, m33);                                     \
+        }                                                                                                               \
     }
     // Convergence monitor: the direction change between successive iterates is the error of the older one (the
     // iteration is linear with ratio q), so once it drops below LFD_NULLVEC_TOL the iterate just computed is within
@@ -237,6 +247,7 @@ LFD_HD int lfd_null_vector(const float* Af, double* c) {
     double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 1.0;
     int it = 0;
     for (int pass = 0;; ++pass) {
+        LFD_BUILD_M();
         // M - sh I = L D L^T
         const double q00 = m00 - sh, q11 = m11 - sh, q22 = m22 - sh, q33 = m33 - sh;
         const double r0 = lfd_recip_refined(q00);
@@ -286,6 +297,7 @@ LFD_HD int lfd_null_vector(const float* Af, double* c) {
         }
         if (settled || pass >= LFD_NULLVEC_PASSES - 1) break;
         // Rayleigh quotient of x as the next shift; x rescaled by an exact power of two
+        LFD_BUILD_M();
         {
             const double sc = lfd_pow2_inv_scale(fabs(x0) + fabs(x1) + fabs(x2) + fabs(x3));
             x0 *= sc; x1 *= sc; x2 *= sc; x3 *= sc;
@@ -307,6 +319,16 @@ LFD_HD int lfd_null_vector(const float* Af, double* c) {
     }
     c[0] = x0; c[1] = x1; c[2] = x2; c[3] = x3;
     return it;
+#undef LFD_BUILD_M
+}
+
+struct LfdCopyRows {
+    const float* A;
+    LFD_HD void operator()(float* Af) const { for (int i = 0; i < 16; ++i) Af[i] = A[i]; }
+};
+LFD_HD int lfd_null_vector(const float* Af, double* c) {
+    LfdCopyRows rows{Af};
+    return lfd_null_vector_rows(rows, c);
 }
 
 // a / b for f64 with ONE division shared by several numerators: r = RN(1/b); q = RN(a*r);
@@ -335,15 +357,35 @@ LFD_HD float lfd_proj_row(const float* P, int row, float X0, float X1, float X2,
     return fmaf(X3, p[3], fmaf(X2, p[2], fmaf(X1, p[1], X0 * p[0])));
 }
 
-LFD_HD float lfd_reproj(const float* P, float X0, float X1, float X2, float X3, float u, float v, float& pz) {
+// 1-ulp reciprocal / square root of the vector ALU on the device (v_rcp_f32, v_sqrt_f32: one instruction each
+// instead of the ~10-instruction IEEE sequences); the host build keeps the IEEE operations.  The results only
+// feed quantities that are compared with a tolerance anyway (X comes from lfd_null_vector, not from sgesdd).
+LFD_HD float lfd_rcp_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LFD_IEEE_FINISH)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+LFD_HD float lfd_sqrt_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LFD_IEEE_FINISH)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+
+// squared reprojection distance (core/geometry.py:91-104 without the final hypot: the caller takes ONE square
+// root of the larger of the two views' squares, which equals max(sqrt, sqrt) because sqrt is monotone)
+LFD_HD float lfd_reproj_sq(const float* P, float X0, float X1, float X2, float X3, float u, float v, float& pz) {
     const float px = lfd_proj_row(P, 0, X0, X1, X2, X3);
     const float py = lfd_proj_row(P, 1, X0, X1, X2, X3);
     pz = lfd_proj_row(P, 2, X0, X1, X2, X3);
     const float z = (pz < 1e-12f) ? 1e-12f : pz;          // np.maximum(z, 1e-12): NaN stays NaN
-    const float rz = 1.0f / z;                             // one division, two correctly rounded quotients
+    const float rz = lfd_rcp_f32(z);                       // one reciprocal, two Markstein-corrected quotients
     const float du = lfd_div_by_recip_f32(px, z, rz) - u;
     const float dv = lfd_div_by_recip_f32(py, z, rz) - v;
-    return sqrtf(du * du + dv * dv);
+    return du * du + dv * dv;
 }
 
 LFD_HD bool lfd_finite(float x) { return fabsf(x) <= 3.402823466e+38f; }   // false for NaN/Inf
@@ -372,18 +414,30 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
         if (!((num * num) < kp.sampson_thresh * den)) return;
     }
 
-    float A[16];              // DLT rows, f32, multiply then subtract (core/geometry.py:72-75)
-    for (int c = 0; c < 4; ++c) {
-        A[0 + c] = ua * rc.P[8 + c] - rc.P[0 + c];
-        A[4 + c] = va * rc.P[8 + c] - rc.P[4 + c];
-        A[8 + c] = ub * pc.P[8 + c] - pc.P[0 + c];
-        A[12 + c] = vb * pc.P[8 + c] - pc.P[4 + c];
-    }
+    // DLT rows, f32, multiply then subtract (core/geometry.py:72-75), rebuilt from the pixel coordinates and the two
+    // projection matrices whenever the solver asks for them (the opaque copy keeps the compiler from hoisting the
+    // rows out of the solver's pass loop and pinning them in registers)
+    struct Rows {
+        const LfdRefConst& rc; const LfdPairConst& pc; float ua, va, ub, vb;
+        LFD_HD void operator()(float* A) const {
+            float u1 = ua, v1 = va, u2 = ub, v2 = vb;
+            LFD_OPAQUE4(u1, v1, u2, v2);
+            for (int c = 0; c < 4; ++c) {
+                A[0 + c] = u1 * rc.P[8 + c] - rc.P[0 + c];
+                A[4 + c] = v1 * rc.P[8 + c] - rc.P[4 + c];
+                A[8 + c] = u2 * pc.P[8 + c] - pc.P[0 + c];
+                A[12 + c] = v2 * pc.P[8 + c] - pc.P[4 + c];
+            }
+        }
+    };
     double c[4];
 #if defined(LFD_ABLATE_SOLVER)
-    c[0] = A[0]; c[1] = A[5]; c[2] = A[10]; c[3] = A[15];
+    c[0] = ua; c[1] = va; c[2] = ub; c[3] = vb;
 #else
-    lfd_null_vector(A, c);
+    {
+        const Rows rows{rc, pc, ua, va, ub, vb};
+        lfd_null_vector_rows(rows, c);
+    }
 #endif
     // upstream: Xh = unit null vector, w = (|Xh[3]| < 1e-12 ? 1e-12 : Xh[3]), X = Xh / w
     // (core/geometry.py:84-87).  |c3|/|c| < 1e-12 is tested on squares; the common branch divides by
@@ -394,20 +448,22 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
         const double inv = 1.0 / (sqrt(n2) * 1e-12);
         X0 = (float)(c[0] * inv); X1 = (float)(c[1] * inv); X2 = (float)(c[2] * inv); X3 = (float)(c[3] * inv);
     } else {
-        const double r = 1.0 / c[3];
-        X0 = (float)lfd_div_by_recip(c[0], c[3], r);
-        X1 = (float)lfd_div_by_recip(c[1], c[3], r);
-        X2 = (float)lfd_div_by_recip(c[2], c[3], r);
+        // r = 1/c3 to ~1 ulp of f64 (Newton-refined v_rcp_f64 on the device); the quotients are rounded to f32
+        const double r = lfd_recip_refined(c[3]);
+        X0 = (float)(c[0] * r);
+        X1 = (float)(c[1] * r);
+        X2 = (float)(c[2] * r);
         X3 = 1.0f;
     }
 
     // The neighbour's P and C were last used for the DLT rows; re-reading them from LDS here (instead of carrying
-    // 15 registers across the solver) is what keeps the kernels at five to six workgroups per CU.
+    // 15 registers across the solver) is what keeps the kernels at six workgroups per CU.
     LFD_REREAD_CONSTANTS();
     float z1, z2;
-    const float e1 = lfd_reproj(rc.P, X0, X1, X2, X3, ua, va, z1);
-    const float e2 = lfd_reproj(pc.P, X0, X1, X2, X3, ub, vb, z2);
-    const float err = (e1 > e2 || e1 != e1) ? e1 : e2;   // np.maximum: NaN wins
+    const float q1 = lfd_reproj_sq(rc.P, X0, X1, X2, X3, ua, va, z1);
+    const float q2 = lfd_reproj_sq(pc.P, X0, X1, X2, X3, ub, vb, z2);
+    const float qm = (q1 > q2 || q1 != q1) ? q1 : q2;    // np.maximum of the two distances: NaN wins
+    const float err = lfd_sqrt_f32(qm);
     o.x = X0; o.y = X1; o.z = X2; o.err = err;
 
     if (kp.no_filter) {       // core/pipeline.py:739-743
@@ -415,16 +471,16 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
         return;
     }
     bool keep = (err <= kp.reproj_thresh) && (z1 > 0.0f) && (z2 > 0.0f);
-    if (keep && kp.use_parallax) {   // core/geometry.py:113-119, all f32
-        float a0 = X0 - rc.C[0], a1 = X1 - rc.C[1], a2 = X2 - rc.C[2];
-        float b0 = X0 - pc.C[0], b1 = X1 - pc.C[1], b2 = X2 - pc.C[2];
-        const float na = sqrtf((a0 * a0 + a1 * a1) + a2 * a2) + 1e-12f;
-        const float nb = sqrtf((b0 * b0 + b1 * b1) + b2 * b2) + 1e-12f;
-        const float ra = 1.0f / na, rb = 1.0f / nb;
-        a0 = lfd_div_by_recip_f32(a0, na, ra); a1 = lfd_div_by_recip_f32(a1, na, ra); a2 = lfd_div_by_recip_f32(a2, na, ra);
-        b0 = lfd_div_by_recip_f32(b0, nb, rb); b1 = lfd_div_by_recip_f32(b1, nb, rb); b2 = lfd_div_by_recip_f32(b2, nb, rb);
+    if (keep && kp.use_parallax) {
+        // core/geometry.py:113-119 normalises both rays and compares their dot product; here the same test is
+        // cross-multiplied: a.b <= dot_thresh * (|a| + 1e-12) * (|b| + 1e-12)  (no per-component divisions).  The two
+        // forms differ by a few f32 ulp of the dot product, i.e. only where upstream's own rounding decides.
+        const float a0 = X0 - rc.C[0], a1 = X1 - rc.C[1], a2 = X2 - rc.C[2];
+        const float b0 = X0 - pc.C[0], b1 = X1 - pc.C[1], b2 = X2 - pc.C[2];
+        const float na = lfd_sqrt_f32((a0 * a0 + a1 * a1) + a2 * a2) + 1e-12f;
+        const float nb = lfd_sqrt_f32((b0 * b0 + b1 * b1) + b2 * b2) + 1e-12f;
         const float dot = (a0 * b0 + a1 * b1) + a2 * b2;
-        keep = dot <= kp.dot_thresh;      // == degrees(arccos(clip(dot,-1,1))) >= min_deg
+        keep = dot <= kp.dot_thresh * (na * nb);      // == degrees(arccos(clip(dot/(na nb),-1,1))) >= min_deg
     }
     o.keep = keep ? 1 : 0;
 }
@@ -469,7 +525,7 @@ LFD_HD void lfd_bilinear_rgb(const uint8_t* img, int wi, int hi, float xa_px, fl
 // The load window is clamped to the image so that it never reads past the buffer; n_bytes = h*w*3 >= 8.
 __device__ __forceinline__ unsigned long long lfd_load_u64_unaligned(const uint8_t* p) {
     typedef unsigned long long __attribute__((aligned(1), may_alias)) u64_u;
-    return *reinterpret_cast<const u64_u*>(p);
+    return *(const u64_u __attribute__((address_space(1)))*)p;      // the image is in device memory: global_load, not flat
 }
 
 struct LfdTapRows { unsigned long long r0, r1; };   // the 8-byte windows of the two image rows, already shifted to the first tap

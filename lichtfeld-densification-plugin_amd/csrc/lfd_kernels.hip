@@ -44,6 +44,26 @@ __device__ __forceinline__ u64 state_load(const u64* p) {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// Every plane, mask, image and axis handed to the kernels lives in device (global) memory, but the pointers reach
+// the threads through LDS descriptors, so the compiler would have to use FLAT loads (address-space check per
+// access, both wait counters).  Casting to the global address space selects global_load_* instead.
+#define LFD_GLOBAL_AS __attribute__((address_space(1)))
+typedef float lfd_f32x4 __attribute__((ext_vector_type(4)));
+typedef float lfd_f32x2 __attribute__((ext_vector_type(2)));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+template <class T>
+__device__ __forceinline__ const T LFD_GLOBAL_AS* lfd_global(const T* p) { return (const T LFD_GLOBAL_AS*)p; }
+__device__ __forceinline__ float4 load_f32x4(const float* p) {
+    const lfd_f32x4 v = *(const lfd_f32x4 LFD_GLOBAL_AS*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 load_f32x2(const float* p) {
+    const lfd_f32x2 v = *(const lfd_f32x2 LFD_GLOBAL_AS*)p;
+    return make_float2(v.x, v.y);
+}
+#pragma clang diagnostic pop
+
 __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -143,6 +163,16 @@ __device__ __forceinline__ void lfd_divmod(int cell, int W, float inv_w, int& y,
     y = q; x = r;
 }
 
+// the same for a small offset from a known (row, column): local = column0 + offset < 2^22, so the float estimate
+// is within one of the quotient and a single correction each way is enough
+__device__ __forceinline__ void lfd_divmod_local(int local, int W, float inv_w, int& dy, int& x) {
+    int q = (int)((float)local * inv_w);
+    int r = local - q * W;
+    if (r < 0) { --q; r += W; }
+    if (r >= W) { ++q; r -= W; }
+    dy = q; x = r;
+}
+
 // certainty of one slot at one cell after the prologue of core/pipeline.py:407-430
 __device__ __forceinline__ float cell_cert(const LfdLaunch& L, const BlockShared& S, int j, int cell, int x, int y,
                                            float raw, float mask_a_val) {
@@ -150,12 +180,12 @@ __device__ __forceinline__ float cell_cert(const LfdLaunch& L, const BlockShared
     if (S.ref.mask_a) c = c * mask_a_val;
     const uint8_t* mb = S.slot[j].mask_b;
     if (mb) {
-        const float* wp = S.slot[j].warp + (size_t)cell * L.warp_channels + (L.warp_channels - 2);
-        const int ix = lfd_grid_nearest(wp[0], L.W);
-        const int iy = lfd_grid_nearest(wp[1], L.H);
+        const float2 wv = load_f32x2(S.slot[j].warp + (size_t)cell * L.warp_channels + (L.warp_channels - 2));
+        const int ix = lfd_grid_nearest(wv.x, L.W);
+        const int iy = lfd_grid_nearest(wv.y, L.H);
         float m = 0.0f;
         if (ix >= 0 && iy >= 0)
-            m = (float)mb[(size_t)lfd_nearest_src(iy, L.mask_sy, L.h_match) * L.w_match + lfd_nearest_src(ix, L.mask_sx, L.w_match)];
+            m = (float)lfd_global(mb)[(size_t)lfd_nearest_src(iy, L.mask_sy, L.h_match) * L.w_match + lfd_nearest_src(ix, L.mask_sx, L.w_match)];
         c = c * m;
     }
     return c;
@@ -163,7 +193,7 @@ __device__ __forceinline__ float cell_cert(const LfdLaunch& L, const BlockShared
 
 __device__ __forceinline__ float cell_mask_a(const LfdLaunch& L, const BlockShared& S, int x, int y) {
     if (!S.ref.mask_a) return 1.0f;
-    return (float)S.ref.mask_a[(size_t)lfd_nearest_src(y, L.mask_sy, L.h_match) * L.w_match + lfd_nearest_src(x, L.mask_sx, L.w_match)];
+    return (float)lfd_global(S.ref.mask_a)[(size_t)lfd_nearest_src(y, L.mask_sy, L.h_match) * L.w_match + lfd_nearest_src(x, L.mask_sx, L.w_match)];
 }
 
 // torch.max(dim=0): first maximum wins, a NaN beats any number (first NaN)
@@ -177,9 +207,9 @@ __device__ __forceinline__ void cell_best(const LfdLaunch& L, const BlockShared&
     lfd_divmod(cell, L.W, L.inv_w, y, x);
     const float ma = cell_mask_a(L, S, x, y);
     const int ns = S.ref.n_slots;
-    best = cell_cert(L, S, 0, cell, x, y, S.slot[0].cert[cell], ma);
+    best = cell_cert(L, S, 0, cell, x, y, lfd_global(S.slot[0].cert)[cell], ma);
     bj = 0;
-    for (int j = 1; j < ns; ++j) argmax_step(cell_cert(L, S, j, cell, x, y, S.slot[j].cert[cell], ma), j, best, bj);
+    for (int j = 1; j < ns; ++j) argmax_step(cell_cert(L, S, j, cell, x, y, lfd_global(S.slot[j].cert)[cell], ma), j, best, bj);
 }
 
 // winner's warp -> normalised coordinates of the correspondence
@@ -187,13 +217,13 @@ __device__ __forceinline__ void cell_coords(const LfdLaunch& L, const BlockShare
                                             float& yan, float& xbn, float& ybn) {
     const float* wp = S.slot[bj].warp;
     if (L.warp_channels == 4) {
-        const float4 v = *reinterpret_cast<const float4*>(wp + (size_t)cell * 4);
+        const float4 v = load_f32x4(wp + (size_t)cell * 4);
         xan = v.x; yan = v.y; xbn = v.z; ybn = v.w;
     } else {
-        const float2 v = *reinterpret_cast<const float2*>(wp + (size_t)cell * 2);
+        const float2 v = load_f32x2(wp + (size_t)cell * 2);
         int y, x;
         lfd_divmod(cell, L.W, L.inv_w, y, x);
-        xan = L.axis_x[x]; yan = L.axis_y[y];
+        xan = lfd_global(L.axis_x)[x]; yan = lfd_global(L.axis_y)[y];
         xbn = v.x; ybn = v.y;
     }
 }
@@ -235,13 +265,13 @@ extern "C" __global__ void __launch_bounds__(256) lfd_aggregate_kernel(LfdLaunch
     const int ns = S.ref.n_slots;
     for (int base = ((int)blockIdx.x * 256 + tid) * 4; base < HW; base += (int)gridDim.x * 256 * 4) {
         if (plain && !any_mask_b && base + 3 < HW) {
-            float4 best = *reinterpret_cast<const float4*>(S.slot[0].cert + base);
+            float4 best = load_f32x4(S.slot[0].cert + base);
             const float th = L.kp.certainty_thresh;
             best.x = lfd_cert_floor(best.x, th); best.y = lfd_cert_floor(best.y, th);
             best.z = lfd_cert_floor(best.z, th); best.w = lfd_cert_floor(best.w, th);
             int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
             for (int j = 1; j < ns; ++j) {
-                const float4 c = *reinterpret_cast<const float4*>(S.slot[j].cert + base);
+                const float4 c = load_f32x4(S.slot[j].cert + base);
                 argmax_step(lfd_cert_floor(c.x, th), j, best.x, b0);
                 argmax_step(lfd_cert_floor(c.y, th), j, best.y, b1);
                 argmax_step(lfd_cert_floor(c.z, th), j, best.z, b2);
@@ -350,17 +380,23 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
         for (int j = 0; j < ns; ++j) any_mask |= (S.slot[j].mask_b != nullptr);
         const int tile_cell0 = tile_in_ref * kTile;
         const int cell0 = tile_cell0 + tid * kCpt;
+        int tile_y0, tile_x0;                    // (row, column) of the tile's first cell: uniform, kept in SGPRs
+        {
+            int ty, tx;
+            lfd_divmod(tile_cell0, L.W, L.inv_w, ty, tx);
+            tile_y0 = __builtin_amdgcn_readfirstlane(ty); tile_x0 = __builtin_amdgcn_readfirstlane(tx);
+        }
 
         // ---- stage 1: certainty floor + arg-max over the neighbour slots (coalesced 16-B loads) -----
         int bj[kCpt];
         if (!any_mask && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW) {
             const float th = L.kp.certainty_thresh;
-            float4 best = *reinterpret_cast<const float4*>(S.slot[0].cert + cell0);
+            float4 best = load_f32x4(S.slot[0].cert + cell0);
             best.x = lfd_cert_floor(best.x, th); best.y = lfd_cert_floor(best.y, th);
             best.z = lfd_cert_floor(best.z, th); best.w = lfd_cert_floor(best.w, th);
             bj[0] = bj[1] = bj[2] = bj[3] = 0;
             for (int j = 1; j < ns; ++j) {
-                const float4 c = *reinterpret_cast<const float4*>(S.slot[j].cert + cell0);
+                const float4 c = load_f32x4(S.slot[j].cert + cell0);
                 argmax_step(lfd_cert_floor(c.x, th), j, best.x, bj[0]);
                 argmax_step(lfd_cert_floor(c.y, th), j, best.y, bj[1]);
                 argmax_step(lfd_cert_floor(c.z, th), j, best.z, bj[2]);
@@ -382,21 +418,28 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
             // W % 4 == 0: the four cells share a row, so one cell -> (row, column) conversion serves all
             float xa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ya = 0.0f;
             if (L.warp_channels != 4) {
-                int y0, x0;
-                lfd_divmod(cell0, L.W, L.inv_w, y0, x0);
-                const float4 ax = *reinterpret_cast<const float4*>(L.axis_x + x0);
-                xa[0] = ax.x; xa[1] = ax.y; xa[2] = ax.z; xa[3] = ax.w;
-                ya = L.axis_y[y0];
+                int dy, x0;
+                lfd_divmod_local(tile_x0 + tid * kCpt, L.W, L.inv_w, dy, x0);
+                const int y0 = tile_y0 + dy;
+                if (L.axis_identity) {     // the matcher's linspace, computed instead of loaded
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xa[e] = lfd_axis_value(L.ax, x0 + e);
+                    ya = lfd_axis_value(L.ay, y0);
+                } else {
+                    const float4 ax = load_f32x4(L.axis_x + x0);
+                    xa[0] = ax.x; xa[1] = ax.y; xa[2] = ax.z; xa[3] = ax.w;
+                    ya = lfd_global(L.axis_y)[y0];
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float* wp = S.slot[bj[e]].warp;
                 float xan, yan, xbn, ybn;
                 if (L.warp_channels == 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(wp + (size_t)(unsigned)(cell0 + e) * 4);
+                    const float4 v = load_f32x4(wp + (size_t)(unsigned)(cell0 + e) * 4);
                     xan = v.x; yan = v.y; xbn = v.z; ybn = v.w;
                 } else {
-                    const float2 v = *reinterpret_cast<const float2*>(wp + (size_t)(unsigned)(cell0 + e) * 2);
+                    const float2 v = load_f32x2(wp + (size_t)(unsigned)(cell0 + e) * 2);
                     xan = xa[e]; yan = ya; xbn = v.x; ybn = v.y;
                 }
                 const int sl = tid * kCpt + e;
@@ -531,12 +574,14 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
                         const int cell = tile_cell0 + sl[u];
                         float xan, yan;
                         if (L.warp_channels == 4) {
-                            const float2 v = *reinterpret_cast<const float2*>(S.slot[stage.slot[sl[u]]].warp + (size_t)cell * 4);
+                            const float2 v = load_f32x2(S.slot[stage.slot[sl[u]]].warp + (size_t)cell * 4);
                             xan = v.x; yan = v.y;
                         } else {
-                            int y, x;
-                            lfd_divmod(cell, L.W, L.inv_w, y, x);
-                            xan = L.axis_x[x]; yan = L.axis_y[y];
+                            int dy, x;
+                            lfd_divmod_local(tile_x0 + sl[u], L.W, L.inv_w, dy, x);
+                            const int y = tile_y0 + dy;
+                            if (L.axis_identity) { xan = lfd_axis_value(L.ax, x); yan = lfd_axis_value(L.ay, y); }
+                            else { xan = lfd_global(L.axis_x)[x]; yan = lfd_global(L.axis_y)[y]; }
                         }
                         px[u] = lfd_match_px(xan, L.kp.wm1); py[u] = lfd_match_px(yan, L.kp.hm1);
                     }
