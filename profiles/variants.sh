@@ -7,7 +7,7 @@ VD=$REPO/build/variants
 mkdir -p $VD
 if [ "$1" = "build" ]; then
   shift
-  rm -f $VD/*.so
+  [ "${LFD_VARIANTS_KEEP:-0}" = "1" ] || rm -f $VD/*.so
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
     [ "$flags" = "$spec" ] && flags=""
@@ -24,6 +24,7 @@ else
     LFD_DENSIFY_LIB=$so python $REPO/bench.py --cpu-sample-refs 0 --steps 60 "$@" 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
+    if l.startswith('[lfd]'): print('  ' + l.strip())
     if l.startswith('{'):
         d = json.loads(l); r = d['roofline']
         print('%-24s kernel_ms %.4f  frac %.4f  surv %.5f' % ('$name', r['kernel_ms'], r['frac'], d['survivor_fraction']))
