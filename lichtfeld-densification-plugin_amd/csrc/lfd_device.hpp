@@ -27,6 +27,9 @@
 #define LFD_EPOCH_BITS 22
 #define LFD_EPOCH_MASK ((1u << LFD_EPOCH_BITS) - 1u)
 #define LFD_VALUE_BITS 40     // survivors-so-far fits 40 bits (1e12 points)
+#ifndef LFD_POLL_SLEEP
+#define LFD_POLL_SLEEP 8       // s_sleep argument (x64 cycles) between two polls of a look-back window
+#endif
 #define LFD_SPIN_LIMIT (1u << 24)   // ~ seconds of polling: a look-back that starves reports instead of hanging
 #define LFD_LAUNCH_TIMEOUT 1u
 

@@ -100,7 +100,7 @@ __device__ u64 lookback_exclusive(const LfdLaunch& L, unsigned tile, u64 my_tota
                     if (lane == 0) atomicExch(L.status, LFD_LAUNCH_TIMEOUT);
                     return 0;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(LFD_POLL_SLEEP);
                 if (state_status(s, epoch) == kStEmpty) s = state_load(state + j);
             }
         } else {
