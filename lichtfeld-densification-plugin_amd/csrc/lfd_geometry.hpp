@@ -402,13 +402,15 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
     if (kp.use_sampson) {     // f64 throughout (core/geometry.py:133-141)
         const double x1 = (double)ua, y1 = (double)va, x2 = (double)ub, y2 = (double)vb;
         const double* F = pc.F;
-        const double fx0 = fma(F[1], y1, F[0] * x1) + F[2];
-        const double fx1 = fma(F[4], y1, F[3] * x1) + F[5];
-        const double fx2 = fma(F[7], y1, F[6] * x1) + F[8];
-        const double ft0 = fma(F[3], y2, F[0] * x2) + F[6];
-        const double ft1 = fma(F[4], y2, F[1] * x2) + F[7];
-        const double num = (x2 * fx0 + y2 * fx1) + fx2;
-        const double den = (((fx0 * fx0 + fx1 * fx1) + ft0 * ft0) + ft1 * ft1) + 1e-12;
+        // fused multiply-adds: upstream's NumPy expression rounds every product and sum separately, which moves the
+        // f64 result by ~1e-16 relative; the comparison below already differs from `se < thresh` by that much
+        const double fx0 = fma(F[1], y1, fma(F[0], x1, F[2]));
+        const double fx1 = fma(F[4], y1, fma(F[3], x1, F[5]));
+        const double fx2 = fma(F[7], y1, fma(F[6], x1, F[8]));
+        const double ft0 = fma(F[3], y2, fma(F[0], x2, F[6]));
+        const double ft1 = fma(F[4], y2, fma(F[1], x2, F[7]));
+        const double num = fma(x2, fx0, fma(y2, fx1, fx2));
+        const double den = fma(ft1, ft1, fma(ft0, ft0, fma(fx1, fx1, fma(fx0, fx0, 1e-12))));
         // se = num^2/den < thresh  <=>  num^2 < thresh*den  (den > 0); differs from the division only
         // within one f64 ulp of the threshold, and NaN still rejects
         if (!((num * num) < kp.sampson_thresh * den)) return;
@@ -442,9 +444,10 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
     // upstream: Xh = unit null vector, w = (|Xh[3]| < 1e-12 ? 1e-12 : Xh[3]), X = Xh / w
     // (core/geometry.py:84-87).  |c3|/|c| < 1e-12 is tested on squares; the common branch divides by
     // c3 directly (X3 == 1), the guard branch normalises first (sign is lost on purpose).
-    const double n2 = (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+    const double c33 = c[3] * c[3];
+    const double n2 = fma(c[0], c[0], fma(c[1], c[1], fma(c[2], c[2], c33)));
     float X0, X1, X2, X3;
-    if (c[3] * c[3] < 1e-24 * n2) {
+    if (c33 < 1e-24 * n2) {
         const double inv = 1.0 / (sqrt(n2) * 1e-12);
         X0 = (float)(c[0] * inv); X1 = (float)(c[1] * inv); X2 = (float)(c[2] * inv); X3 = (float)(c[3] * inv);
     } else {
@@ -565,7 +568,10 @@ __device__ __forceinline__ void lfd_bilinear_eval(LfdTapRows t, unsigned sh0, un
     for (int c = 0; c < 3; ++c) {
         const double pa = (double)((a3 >> (8 * c)) & 0xffu), pb = (double)((b3 >> (8 * c)) & 0xffu);
         const double pc = (double)((c3 >> (8 * c)) & 0xffu), pd = (double)((d3 >> (8 * c)) & 0xffu);
-        const double s = ((pa * wa + pb * wb) + pc * wc) + pd * wd;
+        // upstream: ((pa*wa + pb*wb) + pc*wc) + pd*wd with every product rounded.  The products are exact in f64 whenever
+        // floor(log2 x) + floor(log2 y) >= 3 (a u8 times two differences of f32 pixel coordinates: <= 8 + 45 bits), i.e.
+        // everywhere but a few cells next to the image origin, and then the fused chain below is bit-identical
+        const double s = fma(pd, wd, fma(pc, wc, fma(pb, wb, pa * wa)));
         rgb[c] = (float)lfd_div_by_recip(s, 255.0, 1.0 / 255.0);   // == s / 255.0, correctly rounded
     }
 }
