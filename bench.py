@@ -55,20 +55,32 @@ def parse_args():
     return ap.parse_args()
 
 
-def traffic_bytes(args):
-    """HBM bytes per launch of the fused kernel: --traffic-bytes, else the committed PMC measurement
-    (profiles/traffic.json) when it was taken on this same workload, else null."""
-    if args.traffic_bytes is not None:
-        return args.traffic_bytes
+def _committed_pmc(args):
+    """profiles/traffic.json (rocprofv3 --pmc passes of this same command) when it was taken on this workload."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             t = json.load(fh)
         w = t.get("workload", {})
         if (w.get("refs"), w.get("k"), w.get("preset")) == (args.refs, args.k, args.preset):
-            return float(t["traffic_bytes"])
+            return t
     except Exception:
         pass
     return None
+
+
+def traffic_bytes(args):
+    """HBM bytes per launch of the fused kernel: --traffic-bytes, else the committed PMC measurement
+    (profiles/traffic.json) when it was taken on this same workload, else null."""
+    if args.traffic_bytes is not None:
+        return args.traffic_bytes
+    t = _committed_pmc(args)
+    return float(t["traffic_bytes"]) if t else None
+
+
+def valu_busy_frac(args):
+    """Fraction of the SIMD time the vector ALU was issuing (same PMC run): the kernel's actual bound."""
+    t = _committed_pmc(args)
+    return (t.get("valu") or {}).get("valu_busy_frac") if t else None
 
 
 def build_workload(args, rank, world, dev):
@@ -277,6 +289,7 @@ def main():
                          "kernel": "lfd_dense_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_cell": bytes_per_cell},
         }
+        line["roofline"]["valu_busy_frac"] = valu_busy_frac(args)     # the f64 geometry makes the kernel vector-ALU-bound, not HBM-bound
         line["roofline"]["traffic_over_algorithmic"] = (line["roofline"]["traffic"] / algo_bytes) if line["roofline"]["traffic"] else None
         line["with_d2h"] = d2h_inclusive_rate(dens, batch, params, out, dev)
         line["sampled_mode"] = sampled_mode_rate(args, dens, refs, dims, cfg)

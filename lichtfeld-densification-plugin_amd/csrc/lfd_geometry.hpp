@@ -203,11 +203,16 @@ LFD_HD double lfd_pow2_inv_scale(double t) {
     return ldexp(1.0, -e);
 }
 
+#ifndef LFD_RCP_NEWTON_STEPS
+#define LFD_RCP_NEWTON_STEPS 2
+#endif
 LFD_HD double lfd_recip_refined(double d) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    double r = __builtin_amdgcn_rcp(d);       // v_rcp_f64 is an approximation; two Newton steps bring it to ~1 ulp
+    double r = __builtin_amdgcn_rcp(d);       // v_rcp_f64 is an approximation (profiles/microbench/valu_rate.hip measures it); Newton steps bring it to ~1 ulp
     r = fma(fma(-d, r, 1.0), r, r);
+#if LFD_RCP_NEWTON_STEPS >= 2
     r = fma(fma(-d, r, 1.0), r, r);
+#endif
     return r;
 #else
     return 1.0 / d;

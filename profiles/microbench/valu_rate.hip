@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cmath>
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -61,7 +62,46 @@ double run(const char* name, int insts_per_op, int waves_per_simd) {
     return cyc;
 }
 
+// accuracy of v_rcp_f64 and of its Newton refinements: max relative error over n random arguments
+__global__ void rcp_accuracy_kernel(const double* x, int n, double* err3) {
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double d = x[i];
+        const double exact = 1.0 / d;
+        double r = __builtin_amdgcn_rcp(d);
+        e0 = fmax(e0, fabs(r - exact) / fabs(exact));
+        r = fma(fma(-d, r, 1.0), r, r);
+        e1 = fmax(e1, fabs(r - exact) / fabs(exact));
+        r = fma(fma(-d, r, 1.0), r, r);
+        e2 = fmax(e2, fabs(r - exact) / fabs(exact));
+    }
+    // one value per thread is enough for a max: atomics on the bit patterns (non-negative doubles order like integers)
+    atomicMax(reinterpret_cast<unsigned long long*>(err3 + 0), (unsigned long long)__double_as_longlong(e0));
+    atomicMax(reinterpret_cast<unsigned long long*>(err3 + 1), (unsigned long long)__double_as_longlong(e1));
+    atomicMax(reinterpret_cast<unsigned long long*>(err3 + 2), (unsigned long long)__double_as_longlong(e2));
+}
+
+void rcp_accuracy() {
+    const int n = 1 << 22;
+    std::vector<double> h(n);
+    unsigned long long s = 88172645463325252ull;
+    for (int i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const double m = 1.0 + (double)(s >> 11) * (1.0 / 9007199254740992.0);      // [1, 2)
+        const int e = (int)((s >> 3) % 80) - 40;
+        h[i] = ldexp(m, e) * ((s & 1) ? 1.0 : -1.0);
+    }
+    double *d, *derr; CHK(hipMalloc(&d, n * 8)); CHK(hipMalloc(&derr, 24)); CHK(hipMemset(derr, 0, 24));
+    CHK(hipMemcpy(d, h.data(), n * 8, hipMemcpyHostToDevice));
+    rcp_accuracy_kernel<<<256, 256>>>(d, n, derr);
+    double r[3]; CHK(hipMemcpy(r, derr, 24, hipMemcpyDeviceToHost));
+    printf("v_rcp_f64 max relative error over %d arguments: raw %.3e (2^%.1f), one Newton step %.3e (2^%.1f), two steps %.3e\n", n,
+           r[0], log2(r[0]), r[1], log2(r[1] > 0 ? r[1] : 1e-300), r[2]);
+    CHK(hipFree(d)); CHK(hipFree(derr));
+}
+
 int main() {
+    rcp_accuracy();
     for (int w : {1, 2, 4, 8}) {
         run<0>("v_fma_f64", 1, w);
         run<1>("v_mul_f64", 1, w);
