@@ -172,18 +172,44 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     if (tid == 0) { *A.n_out = 0; *A.status = LFD_SELECT_OK; }
 
     // ---- weights, exact sum, NaN check --------------------------------------------------------------
+    // The streaming passes below move 16 bytes per lane and keep several loads in flight: one workgroup has only its
+    // own 16 waves to cover the memory latency, so bytes in flight per lane are what sets its bandwidth.
+    const bool vec4 = ((N & 3) == 0) && ((W & 3) == 0) && ((reinterpret_cast<uintptr_t>(cert) & 15u) == 0);
     double acc = 0.0;
     int bad = 0;
+    if (vec4) {
 #pragma unroll 4
-    for (int i = tid; i < N; i += kSelBlock) {
-        const int y = i / W, x = i - y * W;
-        float c = cert[i];
-        c = (c > A.cap) ? A.cap : c;                               // torch.clamp(max=cap); NaN stays
-        const bool inside = x >= A.border && x <= W - 1 - A.border && y >= A.border && y <= H - 1 - A.border;
-        const float w = c * (inside ? 1.0f : 0.0f);
-        wbuf[i] = w;
-        if (w != w) bad = 1;
-        acc += (double)w;
+        for (int g = tid; g < (N >> 2); g += kSelBlock) {
+            const int i = g << 2;
+            const int y = i / W, x = i - y * W;                    // W % 4 == 0: the four cells share a row
+            const float4 c4 = *reinterpret_cast<const float4*>(cert + i);
+            const float cs[4] = {c4.x, c4.y, c4.z, c4.w};
+            float ws[4];
+            const bool row_in = y >= A.border && y <= H - 1 - A.border;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float c = cs[e];
+                c = (c > A.cap) ? A.cap : c;                       // torch.clamp(max=cap); NaN stays
+                const bool inside = row_in && (x + e) >= A.border && (x + e) <= W - 1 - A.border;
+                const float w = c * (inside ? 1.0f : 0.0f);
+                ws[e] = w;
+                if (w != w) bad = 1;
+                acc += (double)w;
+            }
+            *reinterpret_cast<float4*>(wbuf + i) = make_float4(ws[0], ws[1], ws[2], ws[3]);
+        }
+    } else {
+#pragma unroll 4
+        for (int i = tid; i < N; i += kSelBlock) {
+            const int y = i / W, x = i - y * W;
+            float c = cert[i];
+            c = (c > A.cap) ? A.cap : c;                               // torch.clamp(max=cap); NaN stays
+            const bool inside = x >= A.border && x <= W - 1 - A.border && y >= A.border && y <= H - 1 - A.border;
+            const float w = c * (inside ? 1.0f : 0.0f);
+            wbuf[i] = w;
+            if (w != w) bad = 1;
+            acc += (double)w;
+        }
     }
     const double s64 = block_sum_f64(acc, s_d, tid);
     const int any_bad = block_sum_i32(bad, s_i, tid);
@@ -193,13 +219,30 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
 
     // ---- p = (weights / s) as f32, widened; exactness precondition; non-zero count -------------------------
     int nz = 0, inexact = 0;
+    if (vec4) {
 #pragma unroll 4
-    for (int i = tid; i < N; i += kSelBlock) {
-        const float pf = wbuf[i] / s32;
-        wbuf[i] = pf;                                              // the normalised f32 weights (coverage uses them)
-        p[i] = (double)pf;
-        if (pf > 0.0f) { ++nz; if (pf < 1.862645149230957e-09f) inexact = 1; }   // 2^-29
-        if (pf < 0.0f) bad = 1;
+        for (int g = tid; g < (N >> 2); g += kSelBlock) {
+            const int i = g << 2;
+            const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
+            const float pf[4] = {w4.x / s32, w4.y / s32, w4.z / s32, w4.w / s32};
+            *reinterpret_cast<float4*>(wbuf + i) = make_float4(pf[0], pf[1], pf[2], pf[3]);   // the normalised f32 weights (coverage uses them)
+            *reinterpret_cast<double2*>(p + i) = make_double2((double)pf[0], (double)pf[1]);
+            *reinterpret_cast<double2*>(p + i + 2) = make_double2((double)pf[2], (double)pf[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (pf[e] > 0.0f) { ++nz; if (pf[e] < 1.862645149230957e-09f) inexact = 1; }   // 2^-29
+                if (pf[e] < 0.0f) bad = 1;
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int i = tid; i < N; i += kSelBlock) {
+            const float pf = wbuf[i] / s32;
+            wbuf[i] = pf;                                              // the normalised f32 weights (coverage uses them)
+            p[i] = (double)pf;
+            if (pf > 0.0f) { ++nz; if (pf < 1.862645149230957e-09f) inexact = 1; }   // 2^-29
+            if (pf < 0.0f) bad = 1;
+        }
     }
     nz = block_sum_i32(nz, s_i, tid);
     inexact = block_sum_i32(inexact, s_i, tid);
@@ -227,26 +270,53 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         // walks it 64 elements at a time (coalesced), scanning inside the wave with shuffles.
         {
             const int lane = tid & 63, wave = tid >> 6;
-            const int span = ((N + nwaves - 1) / nwaves + 63) & ~63;      // multiple of 64
-            const int w_lo = wave * span, w_hi = min(w_lo + span, N);
+            const int span = ((N + nwaves - 1) / nwaves + 255) & ~255;    // multiple of 256: a lane owns 4 consecutive cells per step
+            const int w_lo = min(wave * span, N), w_hi = min(w_lo + span, N);
             double part = 0.0;
 #pragma unroll 4
-            for (int i = w_lo + lane; i < w_hi; i += 64) part += p[i];
+            for (int i = w_lo + 4 * lane; i < w_hi; i += 256) {
+                if (i + 3 < w_hi) {
+                    const double2 a = *reinterpret_cast<const double2*>(p + i), b = *reinterpret_cast<const double2*>(p + i + 2);
+                    part += (a.x + a.y) + (b.x + b.y);
+                } else {
+                    for (int e = 0; e < 4 && i + e < w_hi; ++e) part += p[i + e];
+                }
+            }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
             if (lane == 0) s_d[wave] = part;
             __syncthreads();
             double carry = 0.0, total = 0.0;
             for (int w = 0; w < nwaves; ++w) { if (w < wave) carry += s_d[w]; total += s_d[w]; }
-            for (int base = w_lo; base < w_hi; base += 64) {
-                const int i = base + lane;
-                double v = (i < w_hi) ? p[i] : 0.0;
+#pragma unroll 2
+            for (int base = w_lo; base < w_hi; base += 256) {
+                const int i = base + 4 * lane;
+                double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+                const bool full = i + 3 < w_hi;
+                if (full) {
+                    const double2 a = *reinterpret_cast<const double2*>(p + i), b = *reinterpret_cast<const double2*>(p + i + 2);
+                    v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
+                } else {
+                    if (i < w_hi) v0 = p[i];
+                    if (i + 1 < w_hi) v1 = p[i + 1];
+                    if (i + 2 < w_hi) v2 = p[i + 2];
+                }
+                v1 += v0; v2 += v1; v3 += v2;                  // inclusive prefix inside the lane (every sum is exact, see header)
+                double v = v3;                                  // ... and across the lanes
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
                     const double n = __shfl_up(v, off, 64);
                     if (lane >= off) v += n;
                 }
-                if (i < w_hi) cdf[i] = (carry + v) / total;
+                const double before = carry + (v - v3);        // exact: sum of everything ahead of this lane's first cell
+                if (full) {
+                    *reinterpret_cast<double2*>(cdf + i) = make_double2((before + v0) / total, (before + v1) / total);
+                    *reinterpret_cast<double2*>(cdf + i + 2) = make_double2((before + v2) / total, (before + v3) / total);
+                } else {
+                    if (i < w_hi) cdf[i] = (before + v0) / total;
+                    if (i + 1 < w_hi) cdf[i + 1] = (before + v1) / total;
+                    if (i + 2 < w_hi) cdf[i + 2] = (before + v2) / total;
+                }
                 carry += __shfl(v, 63, 64);
             }
         }
@@ -288,21 +358,41 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     if (nbins > LFD_SELECT_MAX_BINS) { if (tid == 0) *A.status = LFD_SELECT_TOO_MANY_BINS; return; }
     for (int b = tid; b < nbins; b += kSelBlock) s_bin[b] = 0ull;
     __syncthreads();
+    if (vec4) {
 #pragma unroll 4
-    for (int i = tid; i < N; i += kSelBlock) {
-        const float wv = wbuf[i];
-        if (wv > 0.0f) {
+        for (int g = tid; g < (N >> 2); g += kSelBlock) {
+            const int i = g << 2;
+            const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
+            const float wvs[4] = {w4.x, w4.y, w4.z, w4.w};
             const int y = i / W, x = i - y * W;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(wv) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
-            atomicMax(&s_bin[(x / tile) * nby + (y / tile)], key);     // positive floats order like their bit patterns
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (wvs[e] > 0.0f) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(wvs[e]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)(i + e));
+                    atomicMax(&s_bin[((x + e) / tile) * nby + (y / tile)], key);     // positive floats order like their bit patterns
+                }
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int i = tid; i < N; i += kSelBlock) {
+            const float wv = wbuf[i];
+            if (wv > 0.0f) {
+                const int y = i / W, x = i - y * W;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(wv) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+                atomicMax(&s_bin[(x / tile) * nby + (y / tile)], key);     // positive floats order like their bit patterns
+            }
         }
     }
     __syncthreads();
     const int budget = max(A.M - size, 1);
     // mark array: the random part, then the `budget` heaviest bins
     unsigned char* mark = A.mark;
-#pragma unroll 8
-    for (int i = tid; i < N; i += kSelBlock) mark[i] = 0;
+    {
+        const int n16 = N >> 4;                                   // the scratch array is 256-byte aligned
+        for (int g = tid; g < n16; g += kSelBlock) reinterpret_cast<uint4*>(mark)[g] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = (n16 << 4) + tid; i < N; i += kSelBlock) mark[i] = 0;
+    }
     __syncthreads();
     for (int j = tid; j < size; j += kSelBlock) mark[A.found[j]] = 1;
     for (int b = tid; b < nbins; b += kSelBlock) {
@@ -315,13 +405,40 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     __syncthreads();
     // ---- np.unique(concat): marked cells in ascending order --------------------------------------------------------
     {
-        const int lo = tid * per, hi = min(lo + per, N);
+        const int lo = min(tid * per, N), hi = min(lo + per, N);
+        const bool v16 = (per & 15) == 0 && hi - lo == per;       // whole 16-byte groups (the scratch array is 256-byte aligned)
         int cnt = 0;
-        for (int i = lo; i < hi; ++i) cnt += mark[i];
+        if (v16) {
+#pragma unroll 4
+            for (int i = lo; i < hi; i += 16) {
+                const uint4 m = *reinterpret_cast<const uint4*>(mark + i);
+                cnt += __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);      // marks are 0 or 1
+            }
+        } else {
+            for (int i = lo; i < hi; ++i) cnt += mark[i];
+        }
         int total;
         int pos = block_excl_scan_i32(cnt, s_i, tid, total);
         if ((long long)total > A.capacity) { if (tid == 0) { *A.status = LFD_SELECT_CAPACITY; *A.n_out = total; } return; }
-        for (int i = lo; i < hi; ++i) if (mark[i]) A.sel_out[pos++] = (long long)i;
+        if (v16) {
+            if (cnt) {
+                for (int i = lo; i < hi; i += 16) {
+                    const uint4 m = *reinterpret_cast<const uint4*>(mark + i);
+                    const unsigned ws[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned bits = ws[q];
+                        while (bits) {
+                            const int b = __ffs((int)bits) - 1;          // bit 8*j set <=> byte j == 1
+                            A.sel_out[pos++] = (long long)(i + 4 * q + (b >> 3));
+                            bits &= bits - 1u;
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int i = lo; i < hi; ++i) if (mark[i]) A.sel_out[pos++] = (long long)i;
+        }
         if (tid == 0) *A.n_out = total;
     }
 }
