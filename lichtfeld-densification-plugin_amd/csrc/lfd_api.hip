@@ -517,7 +517,7 @@ static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int3
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t o_w = 0, o_p = o_w + up(N * 4), o_cdf = o_p + up(N * 8), o_first = o_cdf + up(N * 8), o_mark = o_first + up(N * 4),
                  o_draws = o_mark + up(N), o_cand = o_draws + up(Mz * 8), o_found = o_cand + up(Mz * 4), o_out = o_found + up(Mz * 4),
-                 total = o_out + 256;
+                 o_time = o_out + 256, total = o_time + 256;
     int rc = ensure(ctx, ctx->sel_scratch, total);
     if (rc != LFD_OK) return rc;
     unsigned char* base = static_cast<unsigned char*>(ctx->sel_scratch.ptr);
@@ -538,6 +538,11 @@ static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int3
     A.status = reinterpret_cast<int*>(base + o_out + 4);
     A.capacity = capacity;
     A.H = H; A.W = W; A.M = M; A.border = border; A.tiles = tiles; A.cap = cap; A.s_override = s_override;
+    const bool timing = !topm && std::getenv("LFD_SELECT_TIMING") != nullptr;
+    if (timing) {
+        A.timing = reinterpret_cast<unsigned long long*>(base + o_time);
+        LFD_HIP(ctx, hipMemsetAsync(base + o_time, 0, 256, ctx->stream));
+    }
     if (topm) {
         static bool attr_set = false;
         const size_t lds = (size_t)LFD_SELECT_TOPM_MAX * sizeof(unsigned long long);
@@ -556,6 +561,13 @@ static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int3
     LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_sel_host = host[0];
     *status_host = host[1];
+    if (timing) {   // phase times of the filter kernel (100 MHz wall clock), profiling only
+        unsigned long long t[32];
+        LFD_HIP(ctx, hipMemcpy(t, base + o_time, sizeof(t), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[lfd] select phases (us):");
+        for (int i = 1; i < 32 && t[i]; ++i) fprintf(stderr, " %.1f", (double)(t[i] - t[i - 1]) * 0.01);
+        fprintf(stderr, "\n");
+    }
     if (host[1] != LFD_SELECT_OK) {
         static const char* names[] = {"ok", "probabilities contain NaN", "probabilities are not non-negative",
                                       "Fewer non-zero entries in p than size", "weight below 2^-29: exact parallel cumsum not guaranteed",

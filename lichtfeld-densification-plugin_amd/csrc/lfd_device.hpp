@@ -116,4 +116,5 @@ struct LfdSelectArgs {
     int H, W, M, border, tiles;
     float cap;
     float s_override;         // > 0: use this normaliser instead of the exact device sum (parity tests)
+    unsigned long long* timing;   // profiling: wall_clock64() at the phase boundaries of the filter kernel, or null
 };

@@ -166,10 +166,12 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     const int H = A.H, W = A.W, N = H * W;
     const float* cert = A.best_cert;
     float* wbuf = A.weights;
-    double* p = A.p;
     double* cdf = A.cdf;
 
     if (tid == 0) { *A.n_out = 0; *A.status = LFD_SELECT_OK; }
+    int t_slot = 0;
+#define LFD_SEL_STAMP() do { if (A.timing && tid == 0 && t_slot < 32) A.timing[t_slot] = wall_clock64(); ++t_slot; } while (0)
+    LFD_SEL_STAMP();
 
     // ---- weights, exact sum, NaN check --------------------------------------------------------------
     // The streaming passes below move 16 bytes per lane and keep several loads in flight: one workgroup has only its
@@ -211,6 +213,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             acc += (double)w;
         }
     }
+    LFD_SEL_STAMP();      // 1: weights pass
     const double s64 = block_sum_f64(acc, s_d, tid);
     const int any_bad = block_sum_i32(bad, s_i, tid);
     const float s32 = (A.s_override > 0.0f) ? A.s_override : (float)s64;
@@ -225,9 +228,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             const int i = g << 2;
             const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
             const float pf[4] = {w4.x / s32, w4.y / s32, w4.z / s32, w4.w / s32};
-            *reinterpret_cast<float4*>(wbuf + i) = make_float4(pf[0], pf[1], pf[2], pf[3]);   // the normalised f32 weights (coverage uses them)
-            *reinterpret_cast<double2*>(p + i) = make_double2((double)pf[0], (double)pf[1]);
-            *reinterpret_cast<double2*>(p + i + 2) = make_double2((double)pf[2], (double)pf[3]);
+            *reinterpret_cast<float4*>(wbuf + i) = make_float4(pf[0], pf[1], pf[2], pf[3]);   // the normalised f32 weights
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (pf[e] > 0.0f) { ++nz; if (pf[e] < 1.862645149230957e-09f) inexact = 1; }   // 2^-29
@@ -238,12 +239,12 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
 #pragma unroll 4
         for (int i = tid; i < N; i += kSelBlock) {
             const float pf = wbuf[i] / s32;
-            wbuf[i] = pf;                                              // the normalised f32 weights (coverage uses them)
-            p[i] = (double)pf;
+            wbuf[i] = pf;                                              // the normalised f32 weights
             if (pf > 0.0f) { ++nz; if (pf < 1.862645149230957e-09f) inexact = 1; }   // 2^-29
             if (pf < 0.0f) bad = 1;
         }
     }
+    LFD_SEL_STAMP();      // 2: p pass
     nz = block_sum_i32(nz, s_i, tid);
     inexact = block_sum_i32(inexact, s_i, tid);
     const int neg = block_sum_i32(bad, s_i, tid);
@@ -253,6 +254,14 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     if (inexact) { if (tid == 0) *A.status = LFD_SELECT_INEXACT; return; }
 
     // ---- legacy choice(replace=False, p) -----------------------------------------------------------------------
+    // p is never materialised: p[i] = mark[i] ? 0 : (double)weights[i], where mark[] flags the cells drawn so far (the
+    // same array later receives the coverage picks and drives the final np.unique)
+    unsigned char* mark = A.mark;
+    {
+        const int n16 = N >> 4;                                   // the scratch array is 256-byte aligned
+        for (int g = tid; g < n16; g += kSelBlock) reinterpret_cast<uint4*>(mark)[g] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = (n16 << 4) + tid; i < N; i += kSelBlock) mark[i] = 0;
+    }
     if (tid == 0) s_n_uniq = 0;
     __syncthreads();
     const int per = (N + kSelBlock - 1) / kSelBlock;              // run length of the coarse search table / final compaction
@@ -264,7 +273,8 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         if (++guard > 64) { if (tid == 0) *A.status = LFD_SELECT_NO_PROGRESS; return; }
         const int need = size - n_uniq;
         mt_fill_doubles(A.mt, A.draws, need, tid);
-        for (int j = tid; j < n_uniq; j += kSelBlock) p[A.found[j]] = 0.0;
+        LFD_SEL_STAMP();  // per iteration: draws
+        for (int j = tid; j < n_uniq; j += kSelBlock) mark[A.found[j]] = 1;       // p[found] = 0
         __syncthreads();
         // cdf = cumsum(p) (exact, see header), then /= cdf[-1].  Each wave owns one contiguous span and
         // walks it 64 elements at a time (coalesced), scanning inside the wave with shuffles.
@@ -276,10 +286,13 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
 #pragma unroll 4
             for (int i = w_lo + 4 * lane; i < w_hi; i += 256) {
                 if (i + 3 < w_hi) {
-                    const double2 a = *reinterpret_cast<const double2*>(p + i), b = *reinterpret_cast<const double2*>(p + i + 2);
-                    part += (a.x + a.y) + (b.x + b.y);
+                    const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
+                    const unsigned m4 = *reinterpret_cast<const unsigned*>(mark + i);
+                    const double a = (m4 & 0xffu) ? 0.0 : (double)w4.x, b = (m4 & 0xff00u) ? 0.0 : (double)w4.y;
+                    const double c = (m4 & 0xff0000u) ? 0.0 : (double)w4.z, d = (m4 & 0xff000000u) ? 0.0 : (double)w4.w;
+                    part += (a + b) + (c + d);
                 } else {
-                    for (int e = 0; e < 4 && i + e < w_hi; ++e) part += p[i + e];
+                    for (int e = 0; e < 4 && i + e < w_hi; ++e) part += mark[i + e] ? 0.0 : (double)wbuf[i + e];
                 }
             }
 #pragma unroll
@@ -288,18 +301,29 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             __syncthreads();
             double carry = 0.0, total = 0.0;
             for (int w = 0; w < nwaves; ++w) { if (w < wave) carry += s_d[w]; total += s_d[w]; }
+            // cdf /= cdf[-1]: 262144 IEEE f64 divisions (~35 instructions each) made this pass ALU-bound on the one CU it runs
+            // on.  With r = RN(1/total), q = RN(a r), q' = RN(q + r (a - total q)) IS the correctly rounded a / total (Markstein;
+            // the one exception, a divisor whose significand is all ones, takes the division)
+            const double rtot = 1.0 / total;
+            const bool quick_div = (__double_as_longlong(total) & 0xfffffffffffffll) != 0xfffffffffffffll;
+            auto div_total = [&](double a) {
+                if (quick_div) { const double q = a * rtot; return fma(fma(-total, q, a), rtot, q); }
+                return a / total;
+            };
 #pragma unroll 2
             for (int base = w_lo; base < w_hi; base += 256) {
                 const int i = base + 4 * lane;
                 double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
                 const bool full = i + 3 < w_hi;
                 if (full) {
-                    const double2 a = *reinterpret_cast<const double2*>(p + i), b = *reinterpret_cast<const double2*>(p + i + 2);
-                    v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
+                    const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
+                    const unsigned m4 = *reinterpret_cast<const unsigned*>(mark + i);
+                    v0 = (m4 & 0xffu) ? 0.0 : (double)w4.x; v1 = (m4 & 0xff00u) ? 0.0 : (double)w4.y;
+                    v2 = (m4 & 0xff0000u) ? 0.0 : (double)w4.z; v3 = (m4 & 0xff000000u) ? 0.0 : (double)w4.w;
                 } else {
-                    if (i < w_hi) v0 = p[i];
-                    if (i + 1 < w_hi) v1 = p[i + 1];
-                    if (i + 2 < w_hi) v2 = p[i + 2];
+                    if (i < w_hi) v0 = mark[i] ? 0.0 : (double)wbuf[i];
+                    if (i + 1 < w_hi) v1 = mark[i + 1] ? 0.0 : (double)wbuf[i + 1];
+                    if (i + 2 < w_hi) v2 = mark[i + 2] ? 0.0 : (double)wbuf[i + 2];
                 }
                 v1 += v0; v2 += v1; v3 += v2;                  // inclusive prefix inside the lane (every sum is exact, see header)
                 double v = v3;                                  // ... and across the lanes
@@ -310,31 +334,73 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
                 }
                 const double before = carry + (v - v3);        // exact: sum of everything ahead of this lane's first cell
                 if (full) {
-                    *reinterpret_cast<double2*>(cdf + i) = make_double2((before + v0) / total, (before + v1) / total);
-                    *reinterpret_cast<double2*>(cdf + i + 2) = make_double2((before + v2) / total, (before + v3) / total);
+                    *reinterpret_cast<double2*>(cdf + i) = make_double2(div_total(before + v0), div_total(before + v1));
+                    *reinterpret_cast<double2*>(cdf + i + 2) = make_double2(div_total(before + v2), div_total(before + v3));
                 } else {
-                    if (i < w_hi) cdf[i] = (before + v0) / total;
-                    if (i + 1 < w_hi) cdf[i + 1] = (before + v1) / total;
-                    if (i + 2 < w_hi) cdf[i + 2] = (before + v2) / total;
+                    if (i < w_hi) cdf[i] = div_total(before + v0);
+                    if (i + 1 < w_hi) cdf[i + 1] = div_total(before + v1);
+                    if (i + 2 < w_hi) cdf[i + 2] = div_total(before + v2);
                 }
                 carry += __shfl(v, 63, 64);
             }
         }
         __syncthreads();
+        LFD_SEL_STAMP();  // cumsum
         // coarse table for a two-level search: s_chunk[k] = cdf at the end of the k-th run of `per` cells
         s_chunk[tid] = cdf[min((tid + 1) * per, N) - 1];
         __syncthreads();
         // new = searchsorted(cdf, x, side="right"); first occurrence of each value, in draw order
-        for (int j = tid; j < need; j += kSelBlock) {
-            const double x = A.draws[j];
-            int klo = 0, khi = kSelBlock;                       // first run whose last cdf value exceeds x
-            while (klo < khi) { const int mid = (klo + khi) >> 1; if (s_chunk[mid] <= x) klo = mid + 1; else khi = mid; }
-            int lo = min(klo * per, N), hi = min(lo + per, N);
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= x) lo = mid + 1; else hi = mid; }
-            A.cand[j] = lo;
-            A.first[lo] = 0x7fffffff;
+        // Four draws per thread advance together, so the dependent probes of one search (global loads in the second
+        // level) overlap with those of three others.
+        for (int j0 = tid; j0 < need; j0 += 4 * kSelBlock) {
+            double x[4];
+            int lo[4], len[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kSelBlock;
+                x[u] = (j < need) ? A.draws[j] : 0.0;
+                lo[u] = 0; len[u] = (j < need) ? kSelBlock : 0;     // first run whose last cdf value exceeds x
+            }
+            // (probes are issued unconditionally at a clamped index - a finished search re-reads a valid element and
+            //  ignores it - so that the four loads of a step are in flight together)
+            while ((len[0] | len[1] | len[2] | len[3]) > 0) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = s_chunk[min(lo[u] + (len[u] >> 1), kSelBlock - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int half = len[u] >> 1;
+                    const bool go = len[u] > 0, right = v[u] <= x[u];
+                    lo[u] = (go && right) ? lo[u] + half + 1 : lo[u];
+                    len[u] = go ? (right ? len[u] - half - 1 : half) : 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kSelBlock;
+                const int b = min(lo[u] * per, N);
+                lo[u] = b; len[u] = (j < need) ? (min(b + per, N) - b) : 0;
+            }
+            while ((len[0] | len[1] | len[2] | len[3]) > 0) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = cdf[min(lo[u] + (len[u] >> 1), N - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int half = len[u] >> 1;
+                    const bool go = len[u] > 0, right = v[u] <= x[u];
+                    lo[u] = (go && right) ? lo[u] + half + 1 : lo[u];
+                    len[u] = go ? (right ? len[u] - half - 1 : half) : 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kSelBlock;
+                if (j < need) { A.cand[j] = lo[u]; A.first[lo[u]] = 0x7fffffff; }
+            }
         }
         __syncthreads();
+        LFD_SEL_STAMP();  // search
         for (int j = tid; j < need; j += kSelBlock) atomicMin(&A.first[A.cand[j]], j);
         __syncthreads();
         int appended = 0;
@@ -349,6 +415,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         }
         if (tid == 0) s_n_uniq = n_uniq + appended;
         __syncthreads();
+        LFD_SEL_STAMP();  // first-occurrence compaction
     }
 
     // ---- tile coverage: best cell of every tile bin, bins by descending weight (ties: lower index) ----------
@@ -365,13 +432,22 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
             const float wvs[4] = {w4.x, w4.y, w4.z, w4.w};
             const int y = i / W, x = i - y * W;
+            // the four cells share a row and usually a bin: their maximum is formed in registers and sent as one atomic
+            const int by = y / tile;
+            int bx = x / tile, rx = x - bx * tile;
+            int cur_bin = -1;
+            unsigned long long cur_key = 0ull;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (wvs[e] > 0.0f) {
                     const unsigned long long key = ((unsigned long long)__float_as_uint(wvs[e]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)(i + e));
-                    atomicMax(&s_bin[((x + e) / tile) * nby + (y / tile)], key);     // positive floats order like their bit patterns
+                    const int b = bx * nby + by;
+                    if (b == cur_bin) { cur_key = key > cur_key ? key : cur_key; }     // positive floats order like their bit patterns
+                    else { if (cur_bin >= 0) atomicMax(&s_bin[cur_bin], cur_key); cur_bin = b; cur_key = key; }
                 }
+                if (++rx >= tile) { rx = 0; ++bx; }
             }
+            if (cur_bin >= 0) atomicMax(&s_bin[cur_bin], cur_key);
         }
     } else {
 #pragma unroll 4
@@ -385,15 +461,9 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         }
     }
     __syncthreads();
+    LFD_SEL_STAMP();      // coverage bins
     const int budget = max(A.M - size, 1);
-    // mark array: the random part, then the `budget` heaviest bins
-    unsigned char* mark = A.mark;
-    {
-        const int n16 = N >> 4;                                   // the scratch array is 256-byte aligned
-        for (int g = tid; g < n16; g += kSelBlock) reinterpret_cast<uint4*>(mark)[g] = make_uint4(0u, 0u, 0u, 0u);
-        for (int i = (n16 << 4) + tid; i < N; i += kSelBlock) mark[i] = 0;
-    }
-    __syncthreads();
+    // mark array: the random part (most of it flagged already), then the `budget` heaviest bins
     for (int j = tid; j < size; j += kSelBlock) mark[A.found[j]] = 1;
     for (int b = tid; b < nbins; b += kSelBlock) {
         const unsigned long long mine = s_bin[b];
@@ -403,6 +473,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         if (rank < budget) mark[0xffffffffu - (unsigned)(mine & 0xffffffffull)] = 1;
     }
     __syncthreads();
+    LFD_SEL_STAMP();      // marks
     // ---- np.unique(concat): marked cells in ascending order --------------------------------------------------------
     {
         const int lo = min(tid * per, N), hi = min(lo + per, N);
@@ -441,6 +512,8 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         }
         if (tid == 0) *A.n_out = total;
     }
+    LFD_SEL_STAMP();      // unique
+#undef LFD_SEL_STAMP
 }
 
 // =================================================================================================
