@@ -129,6 +129,49 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16):
             "ms_per_reference": dt / len(todo) * 1e3, "matches_per_ref": cfg.matches_per_ref, "references_timed": len(todo)}
 
 
+def _event_ms(fn, reps):
+    """Mean HIP-event time of fn() on torch's current stream (the stream the library launches on)."""
+    fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def secondary_kernels(args, dens, batch, refs, dims, cfg, res):
+    """The other kernels of the path (SURVEY section 8 rows F1, S, F4 and the N1 writers), each against its own
+    algorithmic bytes: aggregate (4k read + 5 written per cell), the PLY / points3D packers (28 read + 15 / 43
+    written per point); the selection and indexed kernels are latency-bound single-workgroup kernels, reported in
+    ms per reference view."""
+    H, W, wm, hm = dims
+    params = hb.make_params(cfg)
+    out = {}
+    best = torch.empty((batch.n_refs, H, W), dtype=torch.float32, device=dens.device)
+    slot = torch.empty((batch.n_refs, H, W), dtype=torch.uint8, device=dens.device)
+    ms = _event_ms(lambda: dens.launch_aggregate(batch, params, best, slot), 20)
+    cells = batch.n_refs * H * W
+    out["lfd_aggregate_kernel"] = {"ms": ms, "GB/s": cells * (4 * args.k + 5) / (ms * 1e-3) / 1e9, "bytes_per_cell": 4 * args.k + 5}
+    n = int(res.xyz.shape[0])
+    ms = _event_ms(lambda: dens.pack_ply(res.xyz, res.rgb), 10)
+    out["lfd_pack_ply_kernel"] = {"ms": ms, "GB/s": n * 43 / (ms * 1e-3) / 1e9, "bytes_per_point": 43, "points": n}
+    ms = _event_ms(lambda: dens.pack_points3d(res.xyz, res.rgb, res.err), 10)
+    out["lfd_pack_points3d_kernel"] = {"ms": ms, "GB/s": n * 71 / (ms * 1e-3) / 1e9, "bytes_per_point": 71, "points": n}
+    one = hb.PreparedBatch([refs[0]], wm, hm)
+    b1, _ = dens.aggregate(one, params)
+    dens.seed_rng(cfg.seed)
+    t0 = time.perf_counter()
+    reps = 8
+    for _ in range(reps):
+        sel = dens.select_samples(b1[0], cfg.matches_per_ref, cap=0.9, border=2, tiles=24)      # synchronises (count to host)
+    out["lfd_select_filter_kernel"] = {"ms_per_reference_incl_sync": (time.perf_counter() - t0) / reps * 1e3, "selected": int(sel.numel())}
+    ob = hb.OutputBuffers(int(sel.numel()), 1, args.k, dens.device)
+    ms = _event_ms(lambda: dens.launch_indexed(one, params, sel, [0, int(sel.numel())], ob), 10)
+    out["lfd_indexed_kernel"] = {"ms_per_reference": ms}
+    return out
+
+
 def d2h_inclusive_rate(dens, batch, params, out, dev, reps=3):
     """One launch + copy of the survivors (xyz, rgb, err) into pinned host memory, as a caller that wants NumPy
     arrays pays it.  The C-ABI hands over device pointers, so this is NOT the headline value: it is the
@@ -293,6 +336,7 @@ def main():
         line["roofline"]["traffic_over_algorithmic"] = (line["roofline"]["traffic"] / algo_bytes) if line["roofline"]["traffic"] else None
         line["with_d2h"] = d2h_inclusive_rate(dens, batch, params, out, dev)
         line["sampled_mode"] = sampled_mode_rate(args, dens, refs, dims, cfg)
+        line["secondary_kernels"] = secondary_kernels(args, dens, batch, refs, dims, cfg, res)
         base = cpu_baseline(args, cams, srefs, dims, cfg)
         if base is not None:
             line["cpu_baseline"] = base

@@ -160,7 +160,8 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     __shared__ int s_i[kSelBlock / 64];
     __shared__ double s_chunk[kSelBlock];
     __shared__ unsigned long long s_bin[LFD_SELECT_MAX_BINS];
-    __shared__ int s_n_uniq, s_kept;
+    __shared__ int s_n_uniq;
+    __shared__ double s_span[kSelBlock / 64];     // per-wave span: sum of the p that has not been drawn yet
 
     const int tid = (int)threadIdx.x;
     const int H = A.H, W = A.W, N = H * W;
@@ -221,28 +222,35 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     if (!(s32 > 0.0f)) return;                                   // upstream: `if s <= 0: return empty`
 
     // ---- p = (weights / s) as f32, widened; exactness precondition; non-zero count -------------------------
+    // Every wave owns one contiguous span of the map (the spans of the cumulative sum below) and leaves the span's sum of
+    // p in LDS: the first pass of the two-pass scan is then never needed - later iterations subtract what was drawn.
     int nz = 0, inexact = 0;
-    if (vec4) {
+    constexpr int nwaves = kSelBlock / 64;
+    const int span = ((N + nwaves - 1) / nwaves + 255) & ~255;    // multiple of 256: a lane owns 4 consecutive cells per step
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int w_lo = min(wave * span, N), w_hi = min(w_lo + span, N);
+        double part = 0.0;
 #pragma unroll 4
-        for (int g = tid; g < (N >> 2); g += kSelBlock) {
-            const int i = g << 2;
-            const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
-            const float pf[4] = {w4.x / s32, w4.y / s32, w4.z / s32, w4.w / s32};
-            *reinterpret_cast<float4*>(wbuf + i) = make_float4(pf[0], pf[1], pf[2], pf[3]);   // the normalised f32 weights
+        for (int i = w_lo + 4 * lane; i < w_hi; i += 256) {
+            float pf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (i + 3 < w_hi) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
+                pf[0] = w4.x / s32; pf[1] = w4.y / s32; pf[2] = w4.z / s32; pf[3] = w4.w / s32;
+                *reinterpret_cast<float4*>(wbuf + i) = make_float4(pf[0], pf[1], pf[2], pf[3]);   // the normalised f32 weights
+            } else {
+                for (int e = 0; e < 4 && i + e < w_hi; ++e) { pf[e] = wbuf[i + e] / s32; wbuf[i + e] = pf[e]; }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (pf[e] > 0.0f) { ++nz; if (pf[e] < 1.862645149230957e-09f) inexact = 1; }   // 2^-29
                 if (pf[e] < 0.0f) bad = 1;
             }
+            part += ((double)pf[0] + (double)pf[1]) + ((double)pf[2] + (double)pf[3]);     // exact (see header) unless `inexact`
         }
-    } else {
-#pragma unroll 4
-        for (int i = tid; i < N; i += kSelBlock) {
-            const float pf = wbuf[i] / s32;
-            wbuf[i] = pf;                                              // the normalised f32 weights
-            if (pf > 0.0f) { ++nz; if (pf < 1.862645149230957e-09f) inexact = 1; }   // 2^-29
-            if (pf < 0.0f) bad = 1;
-        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (lane == 0) s_span[wave] = part;
     }
     LFD_SEL_STAMP();      // 2: p pass
     nz = block_sum_i32(nz, s_i, tid);
@@ -265,8 +273,8 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     if (tid == 0) s_n_uniq = 0;
     __syncthreads();
     const int per = (N + kSelBlock - 1) / kSelBlock;              // run length of the coarse search table / final compaction
-    constexpr int nwaves = kSelBlock / 64;
     int guard = 0;
+    int n_marked = 0;                                             // found[0 .. n_marked) are flagged and subtracted already
     while (true) {
         const int n_uniq = s_n_uniq;
         if (n_uniq >= size) break;
@@ -274,33 +282,20 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         const int need = size - n_uniq;
         mt_fill_doubles(A.mt, A.draws, need, tid);
         LFD_SEL_STAMP();  // per iteration: draws
-        for (int j = tid; j < n_uniq; j += kSelBlock) mark[A.found[j]] = 1;       // p[found] = 0
+        for (int j = n_marked + tid; j < n_uniq; j += kSelBlock) {                  // p[found] = 0
+            const int c = A.found[j];
+            mark[c] = 1;
+            atomicAdd(&s_span[c / span], -(double)wbuf[c]);                         // exact, hence order-independent
+        }
+        n_marked = n_uniq;
         __syncthreads();
         // cdf = cumsum(p) (exact, see header), then /= cdf[-1].  Each wave owns one contiguous span and
         // walks it 64 elements at a time (coalesced), scanning inside the wave with shuffles.
         {
             const int lane = tid & 63, wave = tid >> 6;
-            const int span = ((N + nwaves - 1) / nwaves + 255) & ~255;    // multiple of 256: a lane owns 4 consecutive cells per step
             const int w_lo = min(wave * span, N), w_hi = min(w_lo + span, N);
-            double part = 0.0;
-#pragma unroll 4
-            for (int i = w_lo + 4 * lane; i < w_hi; i += 256) {
-                if (i + 3 < w_hi) {
-                    const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
-                    const unsigned m4 = *reinterpret_cast<const unsigned*>(mark + i);
-                    const double a = (m4 & 0xffu) ? 0.0 : (double)w4.x, b = (m4 & 0xff00u) ? 0.0 : (double)w4.y;
-                    const double c = (m4 & 0xff0000u) ? 0.0 : (double)w4.z, d = (m4 & 0xff000000u) ? 0.0 : (double)w4.w;
-                    part += (a + b) + (c + d);
-                } else {
-                    for (int e = 0; e < 4 && i + e < w_hi; ++e) part += mark[i + e] ? 0.0 : (double)wbuf[i + e];
-                }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-            if (lane == 0) s_d[wave] = part;
-            __syncthreads();
             double carry = 0.0, total = 0.0;
-            for (int w = 0; w < nwaves; ++w) { if (w < wave) carry += s_d[w]; total += s_d[w]; }
+            for (int w = 0; w < nwaves; ++w) { if (w < wave) carry += s_span[w]; total += s_span[w]; }
             // cdf /= cdf[-1]: 262144 IEEE f64 divisions (~35 instructions each) made this pass ALU-bound on the one CU it runs
             // on.  With r = RN(1/total), q = RN(a r), q' = RN(q + r (a - total q)) IS the correctly rounded a / total (Markstein;
             // the one exception, a divisor whose significand is all ones, takes the division)
@@ -403,14 +398,27 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         LFD_SEL_STAMP();  // search
         for (int j = tid; j < need; j += kSelBlock) atomicMin(&A.first[A.cand[j]], j);
         __syncthreads();
+        // thread t owns the draws [t*c, (t+1)*c): one workgroup scan over the per-thread counts keeps the draw order.
+        // (A.first was updated by L2 atomics: it is read back with agent-scope loads, past this CU's L1.)
         int appended = 0;
-        for (int base = 0; base < need; base += kSelBlock) {
-            const int j = base + tid;
-            const int keep = (j < need) && (A.first[A.cand[j]] == j);
+        {
+            const int c = (need + kSelBlock - 1) / kSelBlock;
+            const int j_lo = min(tid * c, need), j_hi = min(j_lo + c, need);
+            unsigned long long keep_bits = 0ull;                       // c <= 64 draws per thread, else re-checked below
+            int cnt = 0;
+            for (int j = j_lo; j < j_hi; ++j) {
+                const int k = __hip_atomic_load(&A.first[A.cand[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == j;
+                cnt += k;
+                if (j - j_lo < 64) keep_bits |= (unsigned long long)k << (j - j_lo);
+            }
             int total;
-            const int pos = block_excl_scan_i32(keep, s_i, tid, total);
-            if (keep) A.found[n_uniq + appended + pos] = A.cand[j];
-            appended += total;
+            int pos = block_excl_scan_i32(cnt, s_i, tid, total);
+            for (int j = j_lo; j < j_hi; ++j) {
+                const int k = (j - j_lo < 64) ? (int)((keep_bits >> (j - j_lo)) & 1ull)
+                                              : (__hip_atomic_load(&A.first[A.cand[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == j);
+                if (k) A.found[n_uniq + pos++] = A.cand[j];
+            }
+            appended = total;
             __syncthreads();
         }
         if (tid == 0) s_n_uniq = n_uniq + appended;
