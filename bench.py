@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--outliers", type=float, default=0.05)
     ap.add_argument("--cpu-sample-refs", type=int, default=24,
                     help="references timed on the CPU oracle, ~0.5 s each (0 = skip)")
+    ap.add_argument("--spinup-s", type=float, default=0.25, help="untimed spin-up (launch + sync in a loop) before the warm-up steps")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc run of this same command (profiles/)")
     return ap.parse_args()
@@ -262,7 +263,7 @@ def main():
 
     # untimed spin-up (clocks, first-touch of the output pages), then the W warm-up steps
     t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.25:
+    while time.perf_counter() - t_spin < args.spinup_s:
         dens.launch_dense(batch, params, out)
         torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
