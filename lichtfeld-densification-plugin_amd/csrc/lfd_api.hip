@@ -22,6 +22,7 @@ extern "C" __global__ void lfd_pack_points3d_kernel(const float* xyz, const floa
                                                     unsigned long long id_base, unsigned char* out);
 extern "C" __global__ void lfd_quantise_rgb_kernel(const float* rgb, long long n3, unsigned char* out);
 extern "C" __global__ void lfd_select_topm_kernel(LfdSelectArgs A);
+extern "C" __global__ void lfd_select_filter_mw_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_mt_seed_kernel(unsigned* mt, unsigned seed);
 extern "C" __global__ void lfd_indexed_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets,
                                               float* scratch, uint8_t* codes, int32_t* seg_order);
@@ -517,7 +518,7 @@ static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int3
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t o_w = 0, o_p = o_w + up(N * 4), o_cdf = o_p + up(N * 8), o_first = o_cdf + up(N * 8), o_mark = o_first + up(N * 4),
                  o_draws = o_mark + up(N), o_cand = o_draws + up(Mz * 8), o_found = o_cand + up(Mz * 4), o_out = o_found + up(Mz * 4),
-                 o_time = o_out + 256, total = o_time + 256;
+                 o_time = o_out + 256, o_coop = o_time + 256, total = o_coop + up(LFD_SELECT_COOP_BYTES);
     int rc = ensure(ctx, ctx->sel_scratch, total);
     if (rc != LFD_OK) return rc;
     unsigned char* base = static_cast<unsigned char*>(ctx->sel_scratch.ptr);
@@ -553,7 +554,19 @@ static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int3
         }
         hipLaunchKernelGGL(lfd_select_topm_kernel, dim3(1), dim3(LFD_SELECT_BLOCK), lds, ctx->stream, A);
     } else {
-        hipLaunchKernelGGL(lfd_select_filter_kernel, dim3(1), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A);
+        // several workgroups (one per CU) when the map is large enough to share out; LFD_SELECT_WORKGROUPS=0 keeps the
+        // single-workgroup kernel (both produce the same selection)
+        int n_wg = LFD_SELECT_DEFAULT_WG;
+        if (const char* e = std::getenv("LFD_SELECT_WORKGROUPS")) n_wg = std::atoi(e);
+        n_wg = std::min(std::min(n_wg, (int)LFD_SELECT_MAX_WG), (int)(N / 8192));
+        if (n_wg >= 2 && !timing) {
+            A.coop = base + o_coop;
+            A.n_wg = n_wg;
+            LFD_HIP(ctx, hipMemsetAsync(base + o_coop, 0, 64, ctx->stream));       // barrier words and flags
+            hipLaunchKernelGGL(lfd_select_filter_mw_kernel, dim3((unsigned)n_wg + 1u), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A);
+        } else {
+            hipLaunchKernelGGL(lfd_select_filter_kernel, dim3(1), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A);
+        }
     }
     LFD_HIP(ctx, hipGetLastError());
     int host[2] = {0, 0};

@@ -89,6 +89,19 @@ struct LfdLaunch {              // kernel argument, passed by value
 #define LFD_SELECT_BLOCK 1024
 #define LFD_SELECT_MAX_BINS 1024
 #define LFD_SELECT_TOPM_MAX 16384    // no_filter: winners sorted in LDS (128 KiB)
+#ifndef LFD_SELECT_DEFAULT_WG
+#define LFD_SELECT_DEFAULT_WG 16      // compute workgroups the selection uses by default (0: single-workgroup kernel)
+#endif
+#define LFD_SELECT_MAX_WG 64         // compute workgroups of the multi-workgroup selection kernel
+// shared scratch of the multi-workgroup selection kernel (byte offsets)
+#define LFD_COOP_BAR 0               // u32 arrivals, u32 generation
+#define LFD_COOP_FLAGS 16            // i32 nz, inexact, negative, nan
+#define LFD_COOP_PART 64             // f64 [MAX_WG] partial sums of the weights
+#define LFD_COOP_SPAN (LFD_COOP_PART + 8 * LFD_SELECT_MAX_WG)                       // f64 [MAX_WG * 16] span sums of the live p
+#define LFD_COOP_WGCNT (LFD_COOP_SPAN + 8 * 16 * LFD_SELECT_MAX_WG)                 // i32 [MAX_WG + 1] per-workgroup counts of an ordered compaction
+#define LFD_COOP_BINS ((LFD_COOP_WGCNT + 4 * (LFD_SELECT_MAX_WG + 1) + 7) & ~7)     // u64 [MAX_BINS] coverage bins
+#define LFD_COOP_MT (LFD_COOP_BINS + 8 * LFD_SELECT_MAX_BINS)                       // u32 [625] speculative copy of the MT19937 state
+#define LFD_SELECT_COOP_BYTES (LFD_COOP_MT + 4 * 640)
 #define LFD_SELECT_OK 0
 #define LFD_SELECT_NAN 1             // a weight is NaN           (upstream: ValueError from np.random.choice)
 #define LFD_SELECT_NEGATIVE 2        // a weight is negative      (upstream: ValueError)
@@ -117,4 +130,6 @@ struct LfdSelectArgs {
     float cap;
     float s_override;         // > 0: use this normaliser instead of the exact device sum (parity tests)
     unsigned long long* timing;   // profiling: wall_clock64() at the phase boundaries of the filter kernel, or null
+    unsigned char* coop;          // multi-workgroup kernel: shared scratch (LFD_SELECT_COOP_BYTES, header zeroed before the launch)
+    int n_wg;                     // multi-workgroup kernel: compute workgroups (the grid has one more, which runs the MT19937 stream)
 };

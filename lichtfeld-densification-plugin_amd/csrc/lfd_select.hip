@@ -305,7 +305,6 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
                 if (quick_div) { const double q = a * rtot; return fma(fma(-total, q, a), rtot, q); }
                 return a / total;
             };
-#pragma unroll 2
             for (int base = w_lo; base < w_hi; base += 256) {
                 const int i = base + 4 * lane;
                 double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
@@ -522,6 +521,331 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     }
     LFD_SEL_STAMP();      // unique
 #undef LFD_SEL_STAMP
+}
+
+// =================================================================================================
+// The same selection on several workgroups (one per CU): the streaming passes, the searches and the compactions are
+// split over n_wg workgroups that meet at grid barriers; one extra workgroup runs the MT19937 stream (sequential by
+// nature: the first round's draws are generated while the others stream the map, on a copy of the state that is
+// committed only once upstream's argument checks have passed).  Results are bit-identical to the single-workgroup
+// kernel: every sum involved is exact (see the header), so the partition does not change it, and the ordered
+// compactions keep (workgroup, thread) order = cell / draw order.
+// =================================================================================================
+namespace {
+
+// all workgroups of the grid; bounded spin (a workgroup that never arrives is reported, not waited for forever)
+__device__ bool grid_barrier(unsigned* bar, unsigned n_wg_total) {
+    __shared__ int s_ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        __threadfence();
+        const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (atomicAdd(bar, 1u) == n_wg_total - 1u) {
+            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            atomicAdd(bar + 1, 1u);
+        } else {
+            unsigned spins = 0;
+            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                if (++spins > (1u << 22)) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        __threadfence();
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter_mw_kernel(LfdSelectArgs A) {
+    __shared__ double s_d[kSelBlock / 64];
+    __shared__ int s_i[kSelBlock / 64];
+    __shared__ double s_chunk[kSelBlock];
+    __shared__ unsigned long long s_bin[LFD_SELECT_MAX_BINS];
+    __shared__ double s_tab[16 * LFD_SELECT_MAX_WG];       // span sums, fetched once per round
+
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wg = (int)blockIdx.x, G = A.n_wg, T = (int)gridDim.x;          // T = G + 1
+    const bool rng_wg = wg == G;
+    const int H = A.H, W = A.W, N = H * W;
+    const float* cert = A.best_cert;
+    float* wbuf = A.weights;
+    double* cdf = A.cdf;
+    unsigned char* mark = A.mark;
+    unsigned* bar = reinterpret_cast<unsigned*>(A.coop + LFD_COOP_BAR);
+    int* flags = reinterpret_cast<int*>(A.coop + LFD_COOP_FLAGS);
+    double* g_part = reinterpret_cast<double*>(A.coop + LFD_COOP_PART);
+    double* g_span = reinterpret_cast<double*>(A.coop + LFD_COOP_SPAN);
+    int* g_cnt = reinterpret_cast<int*>(A.coop + LFD_COOP_WGCNT);
+    unsigned long long* g_bins = reinterpret_cast<unsigned long long*>(A.coop + LFD_COOP_BINS);
+    unsigned* mt_spec = reinterpret_cast<unsigned*>(A.coop + LFD_COOP_MT);
+#define LFD_GRID_SYNC() do { if (!grid_barrier(bar, (unsigned)T)) { if (tid == 0) *A.status = LFD_SELECT_NO_PROGRESS; return; } } while (0)
+
+    if (wg == 0 && tid == 0) { *A.n_out = 0; *A.status = LFD_SELECT_OK; }
+    const int size = min((int)((double)A.M * 0.85), N);           // int(M * 0.85), f64 product like Python
+    // wave spans: span index s = wg * 16 + wave covers [s * span, (s + 1) * span), a multiple of 256 cells
+    constexpr int nwaves = kSelBlock / 64;
+    const int n_spans = G * nwaves;
+    const int span = ((N + n_spans - 1) / n_spans + 255) & ~255;
+    const int sidx = wg * nwaves + wave;
+    const int w_lo = rng_wg ? N : min(sidx * span, N), w_hi = rng_wg ? N : min(w_lo + span, N);
+    const bool cert16 = (reinterpret_cast<uintptr_t>(cert) & 15u) == 0;
+
+    // ---- weights, exact sum, NaN check | first round's draws on a copy of the stream -----------------------------------
+    if (rng_wg) {
+        for (int i = tid; i < 625; i += kSelBlock) mt_spec[i] = A.mt[i];
+        __syncthreads();
+        mt_fill_doubles(mt_spec, A.draws, size, tid);
+    } else {
+        double acc = 0.0;
+        int bad = 0;
+#pragma unroll 4
+        for (int i = w_lo + 4 * lane; i < w_hi; i += 256) {
+            float cs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const bool full = i + 3 < w_hi;
+            if (full && cert16) { const float4 c4 = *reinterpret_cast<const float4*>(cert + i); cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w; }
+            else { for (int e = 0; e < 4 && i + e < w_hi; ++e) cs[e] = cert[i + e]; }
+            float ws[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ii = i + e;
+                const int y = ii / W, x = ii - y * W;
+                float c = cs[e];
+                c = (c > A.cap) ? A.cap : c;                       // torch.clamp(max=cap); NaN stays
+                const bool inside = x >= A.border && x <= W - 1 - A.border && y >= A.border && y <= H - 1 - A.border;
+                const float w = (ii < w_hi) ? c * (inside ? 1.0f : 0.0f) : 0.0f;
+                ws[e] = w;
+                if (w != w) bad = 1;
+                acc += (double)w;
+            }
+            if (full) *reinterpret_cast<float4*>(wbuf + i) = make_float4(ws[0], ws[1], ws[2], ws[3]);
+            else { for (int e = 0; e < 4 && i + e < w_hi; ++e) wbuf[i + e] = ws[e]; }
+        }
+        const double wsum = block_sum_f64(acc, s_d, tid);
+        const int any_bad = block_sum_i32(bad, s_i, tid);
+        if (tid == 0) { g_part[wg] = wsum; if (any_bad) atomicOr(&flags[3], 1); }
+    }
+    LFD_GRID_SYNC();
+
+    double s64 = 0.0;
+    for (int g = 0; g < G; ++g) s64 += g_part[g];                  // same order in every workgroup
+    const float s32 = (A.s_override > 0.0f) ? A.s_override : (float)s64;
+    if (__hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (wg == 0 && tid == 0) *A.status = LFD_SELECT_NAN; return; }
+    if (!(s32 > 0.0f)) return;                                     // upstream: `if s <= 0: return empty` (the stream is not touched)
+
+    // ---- p = (weights / s) as f32; exactness precondition; non-zero count; span sums; marks cleared -----------------------
+    if (!rng_wg) {
+        int nz = 0, inexact = 0, neg = 0;
+        double part = 0.0;
+#pragma unroll 4
+        for (int i = w_lo + 4 * lane; i < w_hi; i += 256) {
+            float pf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (i + 3 < w_hi) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
+                pf[0] = w4.x / s32; pf[1] = w4.y / s32; pf[2] = w4.z / s32; pf[3] = w4.w / s32;
+                *reinterpret_cast<float4*>(wbuf + i) = make_float4(pf[0], pf[1], pf[2], pf[3]);
+                *reinterpret_cast<unsigned*>(mark + i) = 0u;
+            } else {
+                for (int e = 0; e < 4 && i + e < w_hi; ++e) { pf[e] = wbuf[i + e] / s32; wbuf[i + e] = pf[e]; mark[i + e] = 0; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (pf[e] > 0.0f) { ++nz; if (pf[e] < 1.862645149230957e-09f) inexact = 1; }   // 2^-29
+                if (pf[e] < 0.0f) neg = 1;
+            }
+            part += ((double)pf[0] + (double)pf[1]) + ((double)pf[2] + (double)pf[3]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (lane == 0) g_span[sidx] = part;
+        nz = block_sum_i32(nz, s_i, tid);
+        inexact = block_sum_i32(inexact, s_i, tid);
+        neg = block_sum_i32(neg, s_i, tid);
+        if (tid == 0) { atomicAdd(&flags[0], nz); if (inexact) atomicOr(&flags[1], 1); if (neg) atomicOr(&flags[2], 1); }
+        if (wg == 0) for (int b = tid; b < LFD_SELECT_MAX_BINS; b += kSelBlock) g_bins[b] = 0ull;
+    }
+    LFD_GRID_SYNC();
+    {
+        const int nz = __hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int inexact = __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int neg = __hip_atomic_load(&flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int st = LFD_SELECT_OK;
+        if (neg) st = LFD_SELECT_NEGATIVE; else if (nz < size) st = LFD_SELECT_FEWER_NONZERO; else if (inexact) st = LFD_SELECT_INEXACT;
+        if (st != LFD_SELECT_OK) { if (wg == 0 && tid == 0) *A.status = st; return; }
+    }
+    if (rng_wg) for (int i = tid; i < 625; i += kSelBlock) A.mt[i] = mt_spec[i];      // the checks passed: the draws are consumed
+
+    // ---- legacy choice(replace=False, p) -----------------------------------------------------------------------
+    const int per = (N + kSelBlock - 1) / kSelBlock;              // run length of the coarse search table
+    int n_uniq = 0, n_marked = 0, guard = 0;
+    while (n_uniq < size) {
+        if (++guard > 64) { if (wg == 0 && tid == 0) *A.status = LFD_SELECT_NO_PROGRESS; return; }
+        const int need = size - n_uniq;
+        if (rng_wg) {
+            if (guard > 1) mt_fill_doubles(A.mt, A.draws, need, tid);
+        } else {
+            for (int j = n_marked + wg * kSelBlock + tid; j < n_uniq; j += G * kSelBlock) {      // p[found] = 0
+                const int c = A.found[j];
+                mark[c] = 1;
+                atomicAdd(&g_span[c / span], -(double)wbuf[c]);                                    // exact, hence order-independent
+            }
+        }
+        n_marked = n_uniq;
+        LFD_GRID_SYNC();
+        // cdf = cumsum(p) / cdf[-1] over this wave's span; the carry comes from the table of span sums
+        if (!rng_wg) {
+            for (int i = tid; i < n_spans; i += kSelBlock) s_tab[i] = g_span[i];
+            __syncthreads();
+            double carry = 0.0, total = 0.0;
+            for (int i = lane; i < n_spans; i += 64) { const double v = s_tab[i]; total += v; if (i < sidx) carry += v; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { carry += __shfl_xor(carry, off, 64); total += __shfl_xor(total, off, 64); }
+            const double rtot = 1.0 / total;
+            const bool quick_div = (__double_as_longlong(total) & 0xfffffffffffffll) != 0xfffffffffffffll;
+            auto div_total = [&](double a) {       // correctly rounded a / total (see the single-workgroup kernel)
+                if (quick_div) { const double q = a * rtot; return fma(fma(-total, q, a), rtot, q); }
+                return a / total;
+            };
+            for (int base = w_lo; base < w_hi; base += 256) {
+                const int i = base + 4 * lane;
+                double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+                const bool full = i + 3 < w_hi;
+                if (full) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
+                    const unsigned m4 = *reinterpret_cast<const unsigned*>(mark + i);
+                    v0 = (m4 & 0xffu) ? 0.0 : (double)w4.x; v1 = (m4 & 0xff00u) ? 0.0 : (double)w4.y;
+                    v2 = (m4 & 0xff0000u) ? 0.0 : (double)w4.z; v3 = (m4 & 0xff000000u) ? 0.0 : (double)w4.w;
+                } else {
+                    if (i < w_hi) v0 = mark[i] ? 0.0 : (double)wbuf[i];
+                    if (i + 1 < w_hi) v1 = mark[i + 1] ? 0.0 : (double)wbuf[i + 1];
+                    if (i + 2 < w_hi) v2 = mark[i + 2] ? 0.0 : (double)wbuf[i + 2];
+                }
+                v1 += v0; v2 += v1; v3 += v2;
+                double v = v3;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const double n = __shfl_up(v, off, 64);
+                    if (lane >= off) v += n;
+                }
+                const double before = carry + (v - v3);
+                if (full) {
+                    *reinterpret_cast<double2*>(cdf + i) = make_double2(div_total(before + v0), div_total(before + v1));
+                    *reinterpret_cast<double2*>(cdf + i + 2) = make_double2(div_total(before + v2), div_total(before + v3));
+                } else {
+                    if (i < w_hi) cdf[i] = div_total(before + v0);
+                    if (i + 1 < w_hi) cdf[i + 1] = div_total(before + v1);
+                    if (i + 2 < w_hi) cdf[i + 2] = div_total(before + v2);
+                }
+                carry += __shfl(v, 63, 64);
+            }
+        }
+        LFD_GRID_SYNC();
+        // new = searchsorted(cdf, x, side="right"): every workgroup takes a share of the draws
+        s_chunk[tid] = cdf[min((tid + 1) * per, N) - 1];
+        __syncthreads();
+        for (int j = wg * kSelBlock + tid; j < need; j += T * kSelBlock) {
+            const double x = A.draws[j];
+            int lo = 0, len = kSelBlock;
+            while (len > 0) { const int half = len >> 1, mid = lo + half; if (s_chunk[mid] <= x) { lo = mid + 1; len -= half + 1; } else len = half; }
+            const int b = min(lo * per, N);
+            lo = b; len = min(b + per, N) - b;
+            while (len > 0) { const int half = len >> 1, mid = lo + half; if (cdf[mid] <= x) { lo = mid + 1; len -= half + 1; } else len = half; }
+            A.cand[j] = lo;
+            A.first[lo] = 0x7fffffff;
+        }
+        LFD_GRID_SYNC();
+        for (int j = wg * kSelBlock + tid; j < need; j += T * kSelBlock) atomicMin(&A.first[A.cand[j]], j);
+        LFD_GRID_SYNC();
+        // first occurrence of every distinct value, in draw order: thread (wg, tid) owns the draws [g*c, (g+1)*c), g = wg*1024 + tid
+        {
+            const int c = (need + T * kSelBlock - 1) / (T * kSelBlock);
+            const int gt = wg * kSelBlock + tid;
+            const long long jl = (long long)gt * c;
+            const int j_lo = (int)(jl < need ? jl : need), j_hi = min(j_lo + c, need);
+            int cnt = 0;
+            for (int j = j_lo; j < j_hi; ++j)
+                cnt += __hip_atomic_load(&A.first[A.cand[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == j;
+            int total;
+            int pos = block_excl_scan_i32(cnt, s_i, tid, total);
+            if (tid == 0) g_cnt[wg] = total;
+            LFD_GRID_SYNC();
+            int base = 0, appended = 0;
+            for (int g = 0; g < T; ++g) { const int v = g_cnt[g]; if (g < wg) base += v; appended += v; }
+            for (int j = j_lo; j < j_hi; ++j)
+                if (__hip_atomic_load(&A.first[A.cand[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == j) A.found[n_uniq + base + pos++] = A.cand[j];
+            n_uniq += appended;
+        }
+        LFD_GRID_SYNC();
+    }
+
+    // ---- tile coverage: best cell of every tile bin, bins by descending weight (ties: lower index) ----------
+    const int tile = max(1, W / A.tiles);
+    const int nbx = (W - 1) / tile + 1, nby = (H - 1) / tile + 1;
+    const int nbins = nbx * nby;
+    if (nbins > LFD_SELECT_MAX_BINS) { if (wg == 0 && tid == 0) *A.status = LFD_SELECT_TOO_MANY_BINS; return; }
+    for (int b = tid; b < nbins; b += kSelBlock) s_bin[b] = 0ull;
+    __syncthreads();
+    if (!rng_wg) {
+#pragma unroll 2
+        for (int i = w_lo + 4 * lane; i < w_hi; i += 256) {
+            int cur_bin = -1;
+            unsigned long long cur_key = 0ull;
+            for (int e = 0; e < 4 && i + e < w_hi; ++e) {
+                const float wv = wbuf[i + e];
+                if (wv > 0.0f) {
+                    const int ii = i + e;
+                    const int y = ii / W, x = ii - y * W;
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(wv) << 32) | (unsigned long long)(0xffffffffu - (unsigned)ii);
+                    const int b = (x / tile) * nby + (y / tile);
+                    if (b == cur_bin) { cur_key = key > cur_key ? key : cur_key; }     // positive floats order like their bit patterns
+                    else { if (cur_bin >= 0) atomicMax(&s_bin[cur_bin], cur_key); cur_bin = b; cur_key = key; }
+                }
+            }
+            if (cur_bin >= 0) atomicMax(&s_bin[cur_bin], cur_key);
+        }
+        __syncthreads();
+        for (int b = tid; b < nbins; b += kSelBlock) if (s_bin[b]) atomicMax(&g_bins[b], s_bin[b]);
+    }
+    LFD_GRID_SYNC();
+    {
+        const int budget = max(A.M - size, 1);
+        for (int b = tid; b < nbins; b += kSelBlock) s_bin[b] = g_bins[b];
+        __syncthreads();
+        for (int b = wg * kSelBlock + tid; b < nbins; b += T * kSelBlock) {
+            const unsigned long long mine = s_bin[b];
+            if (mine == 0ull) continue;
+            int rank = 0;
+            for (int o = 0; o < nbins; ++o) rank += (s_bin[o] > mine);  // keys are distinct (they embed the cell index)
+            if (rank < budget) mark[0xffffffffu - (unsigned)(mine & 0xffffffffull)] = 1;
+        }
+        for (int j = n_marked + wg * kSelBlock + tid; j < size; j += T * kSelBlock) mark[A.found[j]] = 1;
+    }
+    LFD_GRID_SYNC();
+    // ---- np.unique(concat): marked cells in ascending order; thread (wg, wave, lane) owns span/64 consecutive cells ------------
+    {
+        const int per_lane = span >> 6;                             // multiple of 4
+        const int lo = min(w_lo + lane * per_lane, w_hi), hi = min(lo + per_lane, w_hi);
+        int cnt = 0;
+        for (int i = lo; i < hi; i += 4) {
+            if (i + 3 < hi) cnt += __popc(*reinterpret_cast<const unsigned*>(mark + i));      // marks are 0 or 1
+            else for (int e = 0; i + e < hi; ++e) cnt += mark[i + e];
+        }
+        int total;
+        int pos = block_excl_scan_i32(cnt, s_i, tid, total);
+        if (tid == 0) g_cnt[wg] = total;
+        LFD_GRID_SYNC();
+        int base = 0, all = 0;
+        for (int g = 0; g < T; ++g) { const int v = g_cnt[g]; if (g < wg) base += v; all += v; }
+        if ((long long)all > A.capacity) { if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_CAPACITY; *A.n_out = all; } return; }
+        pos += base;
+        if (cnt) for (int i = lo; i < hi; ++i) if (mark[i]) A.sel_out[pos++] = (long long)i;
+        if (wg == 0 && tid == 0) *A.n_out = all;
+    }
+#undef LFD_GRID_SYNC
 }
 
 // =================================================================================================

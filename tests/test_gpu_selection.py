@@ -133,3 +133,35 @@ def test_top_m_matches_golden_and_orders_ties_by_index(dens, g2):
     assert np.all(np.diff(sel)[same] > 0)                            # equal values: ascending cell index
     kth = v[-1]
     assert np.sum(flat > kth) <= 1500 <= np.sum(flat >= kth)        # exactly the M largest
+
+
+@pytest.mark.parametrize("h,w,M,seed,n_wg", [(320, 320, 10000, 5, 4), (512, 512, 10000, 7, 16), (512, 384, 12000, 9, 7),
+                                             (1280, 1280, 10000, 13, 64), (500, 333, 6000, 17, 5)])
+def test_multi_workgroup_kernel_equals_single_workgroup_kernel(dens, monkeypatch, h, w, M, seed, n_wg):
+    """The selection shared out over several workgroups (grid barriers, one workgroup on the MT19937 stream) returns
+    the same cells and leaves the stream at the same position as the single-workgroup kernel, also on ragged sizes,
+    with masked (zero-weight) regions, and when upstream's argument checks refuse the input (stream untouched)."""
+    cert = _tiefree(h, w, 2000 + seed)
+    cert[h // 3: h // 2, w // 4: w // 2] = 0.0                       # a masked block: zero weights
+    t = torch.from_numpy(cert).to(dens.device)
+    out = {}
+    for mode, val in (("single", "0"), ("multi", str(n_wg))):
+        monkeypatch.setenv("LFD_SELECT_WORKGROUPS", val)
+        dens.seed_rng(seed)
+        sel = dens.select_samples(t, M)
+        sel2 = dens.select_samples(t, M)                              # a second reference continues the stream
+        out[mode] = (sel.cpu().numpy(), sel2.cpu().numpy(), dens.rng_state()[1], dens.rng_state()[0].copy())
+    np.testing.assert_array_equal(out["single"][0], out["multi"][0])
+    np.testing.assert_array_equal(out["single"][1], out["multi"][1])
+    assert out["single"][2] == out["multi"][2]
+    np.testing.assert_array_equal(out["single"][3], out["multi"][3])
+    # refused input (fewer non-zero weights than draws): ValueError like upstream, stream untouched
+    monkeypatch.setenv("LFD_SELECT_WORKGROUPS", str(n_wg))
+    sparse = np.zeros((h, w), np.float32)
+    sparse[h // 2, : min(w, 50)] = 0.5
+    dens.seed_rng(seed)
+    before = dens.rng_state()
+    with pytest.raises(ValueError):
+        dens.select_samples(torch.from_numpy(sparse).to(dens.device), M)
+    after = dens.rng_state()
+    assert before[1] == after[1] and np.array_equal(before[0], after[0])
