@@ -287,24 +287,32 @@ class OutputBuffers:
         self.err = torch.empty((cap,), dtype=torch.float32, device=device)
         self.cell = torch.empty((cap,), dtype=torch.int32, device=device) if with_cell else None
         self.slot = torch.empty((cap,), dtype=torch.uint8, device=device) if with_cell else None
-        self.ref_offsets = torch.zeros((n_refs + 1,), dtype=torch.int64, device=device)
-        self.seg_counts = torch.zeros((n_refs, k), dtype=torch.int32, device=device)
-        self.seg_order = torch.full((n_refs, k), -1, dtype=torch.int32, device=device)
+        # the small integer outputs share ONE buffer so that collect() needs a single device-to-host copy:
+        # [ref_offsets i64 x (R+1)] [seg_counts i32 x R*k] [seg_order i32 x R*k]
+        n_off, n_seg = 2 * (n_refs + 1), n_refs * k
+        self._meta = torch.zeros((n_off + 2 * n_seg,), dtype=torch.int32, device=device)
+        self._meta[n_off + n_seg:].fill_(-1)
+        self.ref_offsets = self._meta[:n_off].view(torch.int64)
+        self.seg_counts = self._meta[n_off:n_off + n_seg].view(n_refs, k)
+        self.seg_order = self._meta[n_off + n_seg:].view(n_refs, k)
+        self._n_refs, self._k = n_refs, k
         self.c = lfd_points(xyz=self.xyz.data_ptr(), rgb=self.rgb.data_ptr(), err=self.err.data_ptr(),
                             cell=self.cell.data_ptr() if with_cell else None,
                             slot=self.slot.data_ptr() if with_cell else None, capacity=self.capacity)
 
     def collect(self, indexed: bool = False) -> TriangulationOutput:
         """Synchronise and trim to the number of survivors."""
-        offs = self.ref_offsets.cpu().numpy()
+        meta = self._meta.cpu().numpy()                       # one copy (synchronises)
+        n_off, n_seg = 2 * (self._n_refs + 1), self._n_refs * self._k
+        offs = meta[:n_off].view(np.int64).copy()
         n = int(offs[-1])
         if n > self.capacity:
             raise HipBackendError(f"output capacity {self.capacity} too small for {n} survivors")
         return TriangulationOutput(
             xyz=self.xyz[:n], rgb=self.rgb[:n], err=self.err[:n],
             cell=self.cell[:n] if self.cell is not None else None, slot=self.slot[:n] if self.slot is not None else None,
-            ref_offsets=offs, seg_counts=self.seg_counts.cpu().numpy(),
-            seg_order=self.seg_order.cpu().numpy() if indexed else None)
+            ref_offsets=offs, seg_counts=meta[n_off:n_off + n_seg].reshape(self._n_refs, self._k).copy(),
+            seg_order=meta[n_off + n_seg:].reshape(self._n_refs, self._k).copy() if indexed else None)
 
 
 class HipDensifier:
@@ -453,7 +461,7 @@ class HipDensifier:
     def launch_dense(self, batch: PreparedBatch, params: lfd_params, out: OutputBuffers) -> None:
         self._check(self._lib.lfd_triangulate_dense(self._ctx, C.byref(batch.c), C.byref(params), C.byref(out.c),
                                                     out.ref_offsets.data_ptr(),
-                                                    out.seg_counts.data_ptr()),
+                                                    out.seg_counts.data_ptr() if out.with_segments else None),
                     "lfd_triangulate_dense")
 
     def launch_indexed(self, batch: PreparedBatch, params: lfd_params, sel_idx: torch.Tensor,
