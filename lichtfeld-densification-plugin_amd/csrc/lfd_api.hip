@@ -24,8 +24,10 @@ extern "C" __global__ void lfd_quantise_rgb_kernel(const float* rgb, long long n
 extern "C" __global__ void lfd_select_topm_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_select_filter_mw_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_mt_seed_kernel(unsigned* mt, unsigned seed);
+extern "C" __global__ void lfd_indexed_eval_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets, float* scratch,
+                                                   uint8_t* codes, unsigned* tab);
 extern "C" __global__ void lfd_indexed_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets,
-                                              float* scratch, uint8_t* codes, int32_t* seg_order);
+                                              float* scratch, uint8_t* codes, int32_t* seg_order, const unsigned* tab);
 
 namespace {
 
@@ -66,7 +68,7 @@ struct lfd_context {
     bool consts_valid = false;
     int consts_wm = 0, consts_hm = 0;
     // indexed-mode scratch
-    DeviceBuffer scratch, codes;
+    DeviceBuffer scratch, codes, idx_tab;
     // selection stage: legacy MT19937 stream (625 words) + scratch
     DeviceBuffer mt, sel_scratch;
     bool mt_seeded = false;
@@ -338,7 +340,7 @@ void lfd_destroy(lfd_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->mt, &ctx->sel_scratch})
+    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->mt, &ctx->sel_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_free) (void)hipEventDestroy(ctx->pinned_free);
@@ -459,9 +461,28 @@ int lfd_triangulate_indexed(lfd_context* ctx, const lfd_batch* batch, const lfd_
     L.capacity = out->capacity;
     L.ref_offsets = reinterpret_cast<long long*>(ref_offsets);
     L.seg_counts = seg_counts;
+    // pass A (the per-cell arithmetic) runs on the whole chip, one thread per selected cell; the per-reference workgroups
+    // of lfd_indexed_kernel then only order and scatter.  LFD_INDEXED_SPLIT=0 keeps everything in the one kernel.
+    bool split = true;
+    if (const char* e = std::getenv("LFD_INDEXED_SPLIT")) split = std::atoi(e) != 0;
+    long long max_sel = 0;
+    for (int r = 0; r < batch->n_refs; ++r) max_sel = std::max<long long>(max_sel, sel_offsets[r + 1] - sel_offsets[r]);
+    unsigned* tab = nullptr;
+    if (split && max_sel > 0) {
+        const size_t tab_bytes = (size_t)batch->n_refs * LFD_MAX_SLOTS * 2 * sizeof(unsigned);
+        rc = ensure(ctx, ctx->idx_tab, tab_bytes);
+        if (rc != LFD_OK) return rc;
+        tab = static_cast<unsigned*>(ctx->idx_tab.ptr);
+        LFD_HIP(ctx, hipMemsetAsync(tab, 0, tab_bytes, ctx->stream));
+        const unsigned chunks = (unsigned)((max_sel + LFD_INDEXED_EVAL_BLOCK - 1) / LFD_INDEXED_EVAL_BLOCK);
+        hipLaunchKernelGGL(lfd_indexed_eval_kernel, dim3(chunks, (unsigned)batch->n_refs), dim3(LFD_INDEXED_EVAL_BLOCK), 0, ctx->stream, L,
+                           reinterpret_cast<const long long*>(sel_idx), d_off, static_cast<float*>(ctx->scratch.ptr),
+                           static_cast<uint8_t*>(ctx->codes.ptr), tab);
+        LFD_HIP(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL(lfd_indexed_kernel, dim3((unsigned)batch->n_refs), dim3(LFD_INDEXED_BLOCK), 0, ctx->stream, L,
                        reinterpret_cast<const long long*>(sel_idx), d_off, static_cast<float*>(ctx->scratch.ptr),
-                       static_cast<uint8_t*>(ctx->codes.ptr), seg_order);
+                       static_cast<uint8_t*>(ctx->codes.ptr), seg_order, static_cast<const unsigned*>(tab));
     LFD_HIP(ctx, hipGetLastError());
     return LFD_OK;
 }

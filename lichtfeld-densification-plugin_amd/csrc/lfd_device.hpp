@@ -23,6 +23,7 @@
 #define LFD_DENSE_WAVES_PER_SIMD 4       // register budget of the fused kernel: 512/4 -> <=128 VGPRs
 #endif
 #define LFD_INDEXED_BLOCK 1024  // one workgroup (16 waves) per reference in the indexed kernel
+#define LFD_INDEXED_EVAL_BLOCK 256   // cells per workgroup of the indexed-mode evaluation kernel
 
 #define LFD_EPOCH_BITS 22
 #define LFD_EPOCH_MASK ((1u << LFD_EPOCH_BITS) - 1u)

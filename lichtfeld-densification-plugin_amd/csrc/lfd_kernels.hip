@@ -614,6 +614,59 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
 }
 
 // =================================================================================================
+// indexed mode, pass A on the whole chip: every selected cell is evaluated by its own thread (256 cells per workgroup,
+// grid = chunks x references); per-(reference, slot) survivor counts and first appearances are collected in `tab`
+// ([ref][slot]{count, 0xffffffff - first}, zeroed before the launch) for lfd_indexed_kernel, which then only orders and
+// scatters.
+// =================================================================================================
+extern "C" __global__ void __launch_bounds__(LFD_INDEXED_EVAL_BLOCK) lfd_indexed_eval_kernel(LfdLaunch L, const long long* __restrict__ sel_idx,
+                                                                                             const long long* __restrict__ sel_offsets,
+                                                                                             float* __restrict__ scratch, uint8_t* __restrict__ codes,
+                                                                                             unsigned* __restrict__ tab) {
+    __shared__ BlockShared S;
+    __shared__ unsigned s_cnt[LFD_MAX_SLOTS];
+    __shared__ unsigned s_first[LFD_MAX_SLOTS];
+    const int tid = (int)threadIdx.x;
+    const int r = (int)blockIdx.y;
+    const long long sel_begin = sel_offsets[r], sel_end = sel_offsets[r + 1];
+    const int n_sel = (int)(sel_end - sel_begin);
+    const int i = (int)blockIdx.x * LFD_INDEXED_EVAL_BLOCK + tid;
+    if ((int)blockIdx.x * LFD_INDEXED_EVAL_BLOCK >= n_sel) return;
+    if (tid < LFD_MAX_SLOTS) { s_cnt[tid] = 0; s_first[tid] = 0xffffffffu; }
+    block_prologue(L, r, S);
+    const int HW = L.H * L.W;
+    if (i < n_sel) {
+        const long long cl = sel_idx[sel_begin + i];
+        unsigned code = 0xffu;                       // invalid selection index: dropped
+        if (cl >= 0 && cl < HW) {
+            const int cell = (int)cl;
+            float best; int bj;
+            cell_best(L, S, cell, best, bj);
+            float xan, yan, xbn, ybn;
+            cell_coords(L, S, cell, bj, xan, yan, xbn, ybn);
+            LfdCellResult res;
+            lfd_eval_correspondence(S.rc, S.pc[bj], xan, yan, xbn, ybn, L.kp, res);
+            atomicMin(&s_first[bj], (unsigned)i);
+            code = (unsigned)bj | (res.keep ? 0x80u : 0u);
+            if (res.keep) {
+                float rgb[3];
+                lfd_bilinear_rgb(S.ref.image, L.w_match, L.h_match, res.xa_px, res.ya_px, 1.0f, 1.0f, rgb);
+                float* o = scratch + (size_t)(sel_begin + i) * 8;
+                o[0] = res.x; o[1] = res.y; o[2] = res.z; o[3] = res.err; o[4] = rgb[0]; o[5] = rgb[1]; o[6] = rgb[2];
+                atomicAdd(&s_cnt[bj], 1u);
+            }
+        }
+        codes[sel_begin + i] = (uint8_t)code;
+    }
+    __syncthreads();
+    if (tid < LFD_MAX_SLOTS) {
+        unsigned* t = tab + ((size_t)r * LFD_MAX_SLOTS + tid) * 2;
+        if (s_cnt[tid]) atomicAdd(t + 0, s_cnt[tid]);
+        if (s_first[tid] != 0xffffffffu) atomicMax(t + 1, 0xffffffffu - s_first[tid]);
+    }
+}
+
+// =================================================================================================
 // upstream-equivalent indexed kernel: one workgroup per reference
 // =================================================================================================
 // Pass A evaluates every selected cell (results parked in a scratch area, keep/slot codes in LDS or
@@ -623,7 +676,7 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
 extern "C" __global__ void __launch_bounds__(LFD_INDEXED_BLOCK) lfd_indexed_kernel(LfdLaunch L, const long long* __restrict__ sel_idx,
                                                                                    const long long* __restrict__ sel_offsets,
                                                                                    float* __restrict__ scratch, uint8_t* __restrict__ codes,
-                                                                                   int32_t* __restrict__ seg_order) {
+                                                                                   int32_t* __restrict__ seg_order, const unsigned* __restrict__ tab) {
     __shared__ BlockShared S;
     __shared__ unsigned s_ticket;
     __shared__ unsigned s_cnt[LFD_MAX_SLOTS];          // survivors per slot
@@ -646,8 +699,14 @@ extern "C" __global__ void __launch_bounds__(LFD_INDEXED_BLOCK) lfd_indexed_kern
     const int n_sel = (int)(sel_end - sel_begin);
     const int HW = L.H * L.W;
 
-    // ---- pass A ---------------------------------------------------------------------------------
-    for (int i = tid; i < n_sel; i += LFD_INDEXED_BLOCK) {
+    // ---- pass A (skipped when lfd_indexed_eval_kernel has run: `tab` then holds the per-slot counts and first appearances) ----
+    if (tab) {
+        if (tid < LFD_MAX_SLOTS) {
+            s_cnt[tid] = tab[((size_t)r * LFD_MAX_SLOTS + tid) * 2 + 0];
+            s_first[tid] = 0xffffffffu - tab[((size_t)r * LFD_MAX_SLOTS + tid) * 2 + 1];
+        }
+    }
+    for (int i = tid; i < (tab ? 0 : n_sel); i += LFD_INDEXED_BLOCK) {
         const long long cl = sel_idx[sel_begin + i];
         unsigned code = 0xffu;                       // invalid selection index: dropped
         if (cl >= 0 && cl < HW) {

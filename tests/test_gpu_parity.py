@@ -361,6 +361,32 @@ def test_indexed_batch_of_references_and_empty_selection(dev):
     dens.close()
 
 
+def test_indexed_split_kernels_equal_the_single_kernel(dev, monkeypatch):
+    """Indexed mode evaluates the selected cells chip-wide (lfd_indexed_eval_kernel) and orders them per reference;
+    with LFD_INDEXED_SPLIT=0 one workgroup per reference does both.  Same bits either way, including an empty and a
+    ragged selection and out-of-range indices."""
+    cams, refs, srefs = _synthetic_batch(dev, 4, [3, 2, 3, 1], 96, 80, 96, 80, seed=21, channels=2, cert_mode="tiefree")
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    batch = hb.PreparedBatch(refs, 96, 80)
+    rs = np.random.RandomState(3)
+    sels = [np.sort(rs.choice(96 * 80, 3000, replace=False)), np.zeros(0, np.int64), rs.permutation(96 * 80)[:1500],
+            np.concatenate([[-5, 96 * 80 + 7], rs.choice(96 * 80, 257, replace=False)])]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in sels])]).tolist()
+    sel_t = torch.from_numpy(np.concatenate(sels).astype(np.int64)).to(dev)
+    params = hb.make_params(lfd.DensePipelineConfig(output_path=""))
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LFD_INDEXED_SPLIT", mode)
+        out = dens.triangulate_indexed(batch, params, sel_t, offs)
+        got[mode] = [out.xyz.cpu().numpy().copy(), out.rgb.cpu().numpy().copy(), out.err.cpu().numpy().copy(), out.cell.cpu().numpy().copy(),
+                     out.slot.cpu().numpy().copy(), out.ref_offsets.copy(), out.seg_counts.copy(), out.seg_order.copy()]
+    assert got["0"][5][-1] > 1000
+    for a, b in zip(got["0"], got["1"]):
+        np.testing.assert_array_equal(a, b)
+    dens.close()
+
+
 def test_invalid_arguments_are_reported_not_fatal(dev):
     cams, refs, _ = _synthetic_batch(dev, 1, [2], 32, 32, 32, 32, seed=1)
     dens = hb.HipDensifier(dev)
