@@ -53,6 +53,7 @@ struct lfd_context {
     size_t pinned_bytes = 0;
     hipEvent_t pinned_free = nullptr;
     bool pinned_in_flight = false;
+    int* pinned_words = nullptr;   // 16 pinned ints: landing place of the small synchronous read-backs (status, selection count)
     std::vector<unsigned char> desc_cache;   // what the device table currently holds
     // look-back workspace: [0] u64 ticket counter, [1..] tile states
     DeviceBuffer ws;
@@ -327,6 +328,7 @@ int lfd_create(int device_index, void* hip_stream, lfd_context** out) {
     e = hipSetDevice(device_index);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device_index);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pinned_free, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned_words), 16 * sizeof(int), hipHostMallocDefault);
     if (e != hipSuccess) {
         std::string m = std::string("context init: ") + hipGetErrorString(e);
         delete ctx;
@@ -343,6 +345,7 @@ void lfd_destroy(lfd_context* ctx) {
     for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->mt, &ctx->sel_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
     if (ctx->pinned_free) (void)hipEventDestroy(ctx->pinned_free);
     delete ctx;
 }
@@ -359,10 +362,10 @@ int lfd_launch_status(lfd_context* ctx, int32_t* status_out) {
     if (!ctx || !status_out) return fail(ctx, LFD_ERR_INVALID, "null argument");
     *status_out = 0;
     LFD_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->ws.ptr) { LFD_HIP(ctx, hipStreamSynchronize(ctx->stream)); return LFD_OK; }
+    LFD_HIP(ctx, hipMemcpyAsync(ctx->pinned_words, static_cast<unsigned char*>(ctx->ws.ptr) + 8, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
     LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (!ctx->ws.ptr) return LFD_OK;
-    unsigned int st = 0;
-    LFD_HIP(ctx, hipMemcpy(&st, static_cast<unsigned char*>(ctx->ws.ptr) + 8, sizeof(st), hipMemcpyDeviceToHost));
+    const unsigned int st = (unsigned int)ctx->pinned_words[0];
     if (st != 0) {
         LFD_HIP(ctx, hipMemset(static_cast<unsigned char*>(ctx->ws.ptr) + 8, 0, sizeof(st)));
         *status_out = (int32_t)st;
@@ -590,8 +593,8 @@ static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int3
         }
     }
     LFD_HIP(ctx, hipGetLastError());
-    int host[2] = {0, 0};
-    LFD_HIP(ctx, hipMemcpyAsync(host, base + o_out, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    int* host = ctx->pinned_words + 4;
+    LFD_HIP(ctx, hipMemcpyAsync(host, base + o_out, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_sel_host = host[0];
     *status_host = host[1];

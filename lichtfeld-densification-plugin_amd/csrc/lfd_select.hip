@@ -38,74 +38,64 @@ __device__ __forceinline__ unsigned mt_temper(unsigned y) {
     return y;
 }
 
-// regenerate the 624-word state in place (three dependency-free segments), whole workgroup
-__device__ void mt_twist(unsigned* mt, int tid) {
+// One twist = the next 624-word state.  With separate source and destination arrays the three dependency-free segments
+// need only two barriers between them: new[i] = new-or-old[(i + 397) % 624] ^ mix(old[i], old-or-new[(i + 1) % 624]).
+__device__ void mt_twist_lds(const unsigned* o, unsigned* n, int tid) {
     auto mix = [](unsigned a, unsigned b) { const unsigned y = (a & 0x80000000u) | (b & 0x7fffffffu); return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); };
-    // i in [0,227): uses old mt[i], mt[i+1], mt[i+397]
-    unsigned v = 0;
-    if (tid < 227) v = mt[tid + 397] ^ mix(mt[tid], mt[tid + 1]);
+    if (tid < 227) n[tid] = o[tid + 397] ^ mix(o[tid], o[tid + 1]);                       // i in [0,227): old words only
     __syncthreads();
-    if (tid < 227) mt[tid] = v;
+    if (tid < 227) { const int i = tid + 227; n[i] = n[i - 227] ^ mix(o[i], o[i + 1]); }    // i in [227,454): new[i-227] from the first segment
     __syncthreads();
-    // i in [227,454): uses old mt[i], mt[i+1] (i+1 <= 454 still old for i<453; i=453 -> mt[454] old) and NEW mt[i-227]
-    if (tid < 227) { const int i = tid + 227; v = mt[i - 227] ^ mix(mt[i], mt[i + 1]); }
-    __syncthreads();
-    if (tid < 227) mt[tid + 227] = v;
-    __syncthreads();
-    // i in [454,623): uses old mt[i], mt[i+1] and new mt[i-227]; i = 623 uses new mt[0]
-    if (tid < 169) { const int i = tid + 454; v = mt[i - 227] ^ mix(mt[i], mt[i + 1]); }
-    __syncthreads();
-    if (tid < 169) mt[tid + 454] = v;
-    __syncthreads();
-    if (tid == 0) mt[623] = mt[396] ^ mix(mt[623], mt[0]);
+    if (tid < 169) { const int i = tid + 454; n[i] = n[i - 227] ^ mix(o[i], o[i + 1]); }    // i in [454,623): new[i-227] from the second segment
+    if (tid == 256) n[623] = n[396] ^ mix(o[623], n[0]);                                     // i = 623 wraps to the NEW word 0
     __syncthreads();
 }
 
-// draws[0..n) = next n legacy random_sample() doubles; mt[624] = position
+// draws[0..n) = next n legacy random_sample() doubles; mt[624] = position.  The state is staged in LDS for the whole
+// call (a twist in global memory costs a memory round trip per segment) and written back at the end.
 __device__ void mt_fill_doubles(unsigned* mt, double* draws, int n, int tid) {
-    __shared__ unsigned s_words[2 * 312];       // one twist yields 624 words = 312 doubles
-    int produced = 0;
+    __shared__ unsigned s_mt[2][624];
+    __shared__ int s_pos;
+    __syncthreads();
+    for (int i = tid; i < 624; i += kSelBlock) s_mt[0][i] = mt[i];
+    if (tid == 0) s_pos = (int)mt[624];
+    __syncthreads();
+    int cur = 0, pos = s_pos, produced = 0;
     while (produced < n) {
-        __syncthreads();
-        int pos = (int)mt[624];
         if (pos >= 624) {
-            mt_twist(mt, tid);
-            if (tid == 0) mt[624] = 0;
-            __syncthreads();
+            mt_twist_lds(s_mt[cur], s_mt[cur ^ 1], tid);
+            cur ^= 1;
             pos = 0;
         }
-        // consume whole pairs from pos; a pair may straddle a twist boundary only if pos is odd at 623,
-        // which cannot be reached from pair-wise consumption starting at an even position... handle
-        // the general case word by word through a small staging buffer
         const int avail = 624 - pos;
         const int want_words = 2 * (n - produced);
         const int take = avail < want_words ? avail : want_words;
-        for (int i = tid; i < take; i += kSelBlock) s_words[i] = mt_temper(mt[pos + i]);
-        __syncthreads();
+        const int pairs = take >> 1;
+        for (int i = tid; i < pairs; i += kSelBlock) {
+            const unsigned a = mt_temper(s_mt[cur][pos + 2 * i]), b = mt_temper(s_mt[cur][pos + 2 * i + 1]);
+            draws[produced + i] = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+        }
         if (take & 1) {
-            // odd number of words left before the twist: the last word pairs with the first of the
-            // next block; generate the next block now and complete the pair
-            const unsigned a = s_words[take - 1];
+            // an odd number of words was left before the twist: the last one pairs with the first word of the next state
+            const unsigned a = mt_temper(s_mt[cur][pos + take - 1]);
             __syncthreads();
-            mt_twist(mt, tid);
-            const unsigned b = mt_temper(mt[0]);
-            const int pairs = take >> 1;
-            for (int i = tid; i < pairs; i += kSelBlock)
-                draws[produced + i] = ((double)(s_words[2 * i] >> 5) * 67108864.0 + (double)(s_words[2 * i + 1] >> 6)) / 9007199254740992.0;
+            mt_twist_lds(s_mt[cur], s_mt[cur ^ 1], tid);
+            cur ^= 1;
             if (tid == 0) {
+                const unsigned b = mt_temper(s_mt[cur][0]);
                 draws[produced + pairs] = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
-                mt[624] = 1;
             }
+            pos = 1;
             produced += pairs + 1;
         } else {
-            const int pairs = take >> 1;
-            for (int i = tid; i < pairs; i += kSelBlock)
-                draws[produced + i] = ((double)(s_words[2 * i] >> 5) * 67108864.0 + (double)(s_words[2 * i + 1] >> 6)) / 9007199254740992.0;
-            if (tid == 0) mt[624] = (unsigned)(pos + take);
+            pos += take;
             produced += pairs;
         }
-        __syncthreads();
+        __syncthreads();       // the words just read may be overwritten by the next twist's other buffer only after everyone has read them
     }
+    for (int i = tid; i < 624; i += kSelBlock) mt[i] = s_mt[cur][i];
+    if (tid == 0) mt[624] = (unsigned)pos;
+    __syncthreads();
 }
 
 // ---- workgroup-wide helpers --------------------------------------------------------------------------
