@@ -107,8 +107,8 @@ def build_workload(args, rank, world, dev):
 
 def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16):
     """Upstream-equivalent mode, reference after reference as the pipeline runs it: aggregate kernel ->
-    on-device coverage sampling (M=10000) -> indexed kernel, including the per-reference synchronisation
-    the selection count needs.  Reported next to the headline (dense) number, not instead of it."""
+    on-device coverage sampling (M=10000) -> indexed kernels in one asynchronous call (lfd_triangulate_sampled),
+    then the read-back of the counts.  Reported next to the headline (dense) number, not instead of it."""
     H, W, wm, hm = dims
     params = hb.make_params(cfg)
     dens.seed_rng(cfg.seed)
@@ -119,10 +119,8 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pts = 0
-        for b in batches:
-            best, _ = dens.aggregate(b, params)
-            sel = dens.select_samples(best[0], cfg.matches_per_ref, cap=0.9, border=2, tiles=24)
-            out = dens.triangulate_indexed(b, params, sel, [0, int(sel.numel())])
+        for b in batches:       # what core/pipeline.py runs per reference: one fused call, one read-back
+            out = dens.triangulate_sampled(b, params, cfg.matches_per_ref, cap=0.9, border=2, tiles=24)
             pts += out.count
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0

@@ -82,6 +82,9 @@ def load_library() -> C.CDLL:
     lib.lfd_triangulate_indexed.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p,
                                             C.POINTER(C.c_int64), C.POINTER(lfd_points), C.c_void_p, C.c_void_p,
                                             C.c_void_p]
+    lib.lfd_triangulate_sampled.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_int32, C.c_float, C.c_int32,
+                                            C.c_int32, C.c_float, C.POINTER(lfd_points), C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
     lib.lfd_select_top_m.argtypes = [ctxp, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int64,
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.lfd_pack_ply.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -102,7 +105,7 @@ def load_library() -> C.CDLL:
     lib.lfd_host_eval_correspondence.argtypes = [fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                                  C.c_int32, C.POINTER(lfd_params), fptr]
     for name in ("lfd_create", "lfd_set_stream", "lfd_upload_cameras", "lfd_aggregate", "lfd_triangulate_dense",
-                 "lfd_triangulate_indexed", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
+                 "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
                  "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_identity_axis",
                  "lfd_host_fundamental",
                  "lfd_host_eval_correspondence"):
@@ -201,6 +204,7 @@ class TriangulationOutput:
     ref_offsets: np.ndarray      # (n_refs+1,) i64 host
     seg_counts: np.ndarray       # (n_refs,k) i32 host
     seg_order: Optional[np.ndarray] = None   # indexed mode: slot of the g-th emitted group, -1 = none
+    n_selected: Optional[int] = None         # sampled call: cells the selection stage picked
 
     @property
     def count(self) -> int:
@@ -274,6 +278,7 @@ class PreparedBatch:
 
 
 _tls = threading.local()
+_SELECT_ERRORS = {1: "probabilities contain NaN", 2: "probabilities are not non-negative", 3: "Fewer non-zero entries in p than size"}
 
 
 def _read_back_i32(t: torch.Tensor) -> np.ndarray:
@@ -307,19 +312,30 @@ class OutputBuffers:
         # the small integer outputs share ONE buffer so that collect() needs a single device-to-host copy:
         # [ref_offsets i64 x (R+1)] [seg_counts i32 x R*k] [seg_order i32 x R*k]
         n_off, n_seg = 2 * (n_refs + 1), n_refs * k
-        self._meta = torch.zeros((n_off + 2 * n_seg,), dtype=torch.int32, device=device)
-        self._meta[n_off + n_seg:].fill_(-1)
+        self._meta = torch.zeros((n_off + 2 * n_seg + 2,), dtype=torch.int32, device=device)
+        self._meta[n_off + n_seg:n_off + 2 * n_seg].fill_(-1)
         self.ref_offsets = self._meta[:n_off].view(torch.int64)
         self.seg_counts = self._meta[n_off:n_off + n_seg].view(n_refs, k)
-        self.seg_order = self._meta[n_off + n_seg:].view(n_refs, k)
+        self.seg_order = self._meta[n_off + n_seg:n_off + 2 * n_seg].view(n_refs, k)
+        self.sel_info = self._meta[n_off + 2 * n_seg:]           # lfd_triangulate_sampled: {cells selected, selection status}
         self._n_refs, self._k = n_refs, k
         self.c = lfd_points(xyz=self.xyz.data_ptr(), rgb=self.rgb.data_ptr(), err=self.err.data_ptr(),
                             cell=self.cell.data_ptr() if with_cell else None,
                             slot=self.slot.data_ptr() if with_cell else None, capacity=self.capacity)
 
-    def collect(self, indexed: bool = False) -> TriangulationOutput:
-        """Synchronise and trim to the number of survivors."""
+    def select_status(self, meta: np.ndarray) -> int:
+        return int(meta[2 * (self._n_refs + 1) + 2 * self._n_refs * self._k + 1])
+
+    def collect(self, indexed: bool = False, check_selection: bool = False) -> TriangulationOutput:
+        """Synchronise and trim to the number of survivors.  ``check_selection``: raise what upstream's sampling stage
+        would have raised if the fused call's selection refused its input."""
         meta = _read_back_i32(self._meta)                     # one copy through a cached pinned buffer (synchronises)
+        if check_selection:
+            st = self.select_status(meta)
+            if st in (1, 2, 3):
+                raise ValueError(_SELECT_ERRORS[st])
+            if st != 0:
+                raise HipBackendError(f"selection failed with status {st}")
         n_off, n_seg = 2 * (self._n_refs + 1), self._n_refs * self._k
         offs = meta[:n_off].view(np.int64).copy()
         n = int(offs[-1])
@@ -329,7 +345,9 @@ class OutputBuffers:
             xyz=self.xyz[:n], rgb=self.rgb[:n], err=self.err[:n],
             cell=self.cell[:n] if self.cell is not None else None, slot=self.slot[:n] if self.slot is not None else None,
             ref_offsets=offs, seg_counts=meta[n_off:n_off + n_seg].reshape(self._n_refs, self._k).copy(),
-            seg_order=meta[n_off + n_seg:].reshape(self._n_refs, self._k).copy() if indexed else None)
+            seg_order=meta[n_off + n_seg:n_off + 2 * n_seg].reshape(self._n_refs, self._k).copy() if indexed else None,
+            n_selected=int(meta[n_off + 2 * n_seg]))
+        
 
 
 class HipDensifier:
@@ -490,6 +508,23 @@ class HipDensifier:
                                                       offs, C.byref(out.c), out.ref_offsets.data_ptr(),
                                                       out.seg_counts.data_ptr(), out.seg_order.data_ptr()),
                     "lfd_triangulate_indexed")
+
+    def launch_sampled(self, batch: PreparedBatch, params: lfd_params, M: int, out: OutputBuffers, cap: float = 0.9,
+                       border: int = 2, tiles: int = 24, s_override: float = 0.0, sel_cells: Optional[torch.Tensor] = None) -> None:
+        """One reference view through aggregate -> selection -> indexed triangulation in one asynchronous call
+        (lfd_triangulate_sampled): no read-back in between, the selection count stays on the device."""
+        self._check(self._lib.lfd_triangulate_sampled(self._ctx, C.byref(batch.c), C.byref(params), int(M), C.c_float(cap), int(border),
+                                                      int(tiles), C.c_float(s_override), C.byref(out.c), out.ref_offsets.data_ptr(),
+                                                      out.seg_counts.data_ptr(), out.seg_order.data_ptr(), out.sel_info.data_ptr(),
+                                                      sel_cells.data_ptr() if sel_cells is not None else None),
+                    "lfd_triangulate_sampled")
+
+    def triangulate_sampled(self, batch: PreparedBatch, params: lfd_params, M: int, cap: float = 0.9, border: int = 2,
+                            tiles: int = 24, s_override: float = 0.0, with_cell: bool = True) -> TriangulationOutput:
+        out = OutputBuffers(int(M) + int(tiles) * int(tiles) + 64, 1, batch.k, self.device, with_cell)
+        self.launch_sampled(batch, params, M, out, cap, border, tiles, s_override)
+        self.check_launches()
+        return out.collect(indexed=True, check_selection=True)
 
     # -- convenience wrappers (synchronising) -------------------------------------------------------------
     def aggregate(self, batch: PreparedBatch, params: lfd_params):

@@ -255,14 +255,22 @@ class _HotPath:
             mask_a=torch.from_numpy(np.array(packed.mask_a, dtype=np.uint8, copy=True)).to(dev) if packed.mask_a is not None else None,
             mask_b=mask_b)
 
-    def sampled(self, ref: hb.ReferenceInputs, axes, rng, device_seed: Optional[int]
+    def sampled(self, ref: hb.ReferenceInputs, axes, rng, device_seed: Optional[int], need_best: bool = False
                 ) -> Tuple[Optional[hb.TriangulationOutput], Optional[torch.Tensor]]:
         """aggregate kernel -> coverage sampling -> indexed kernel.  The sampling stage runs on the
         device (lfd_select_samples consuming the context's MT19937 stream; lfd_select_top_m for
-        no_filter) unless the configuration asks for the host stage (core/sampling.py)."""
+        no_filter) unless the configuration asks for the host stage (core/sampling.py).  With the device
+        stage and no debug preview to feed (``need_best``), the three steps are ONE asynchronous call
+        (lfd_triangulate_sampled): the selection count never visits the host."""
         batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes)
-        best, _ = self.dens.aggregate(batch, self.params)
         on_device = self.config.selection_backend == "device"
+        fusable = on_device and (not self.config.no_filter or self.config.matches_per_ref <= self.dens.TOP_M_MAX)
+        if fusable and not need_best:
+            if device_seed is not None and not self.config.no_filter:
+                self.dens.seed_rng(device_seed)
+            out = self.dens.triangulate_sampled(batch, self.params, self.config.matches_per_ref, cap=self.sample_cap, border=2, tiles=24)
+            return (out if out.count else None), None
+        best, _ = self.dens.aggregate(batch, self.params)
         if on_device and self.config.no_filter and self.config.matches_per_ref <= self.dens.TOP_M_MAX:
             sel_t = self.dens.select_top_m(best[0], self.config.matches_per_ref, cap=self.sample_cap)
         elif on_device and not self.config.no_filter:
@@ -474,7 +482,7 @@ def run_dense_pipeline(
             try:
                 rng = _reference_rng(config.seed, packed.ref_uid) if per_ref_rng else stream_rng
                 dseed = _reference_seed(config.seed, packed.ref_uid) if per_ref_rng else None
-                out, best = hot.sampled(ref, axes, rng, dseed)
+                out, best = hot.sampled(ref, axes, rng, dseed, need_best=want_debug)
             except Exception as ex:
                 log.error(f"Triangulation error for ref {packed.ref_uid}: {ex}")
                 out = None

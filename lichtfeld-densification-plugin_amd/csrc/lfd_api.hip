@@ -69,7 +69,7 @@ struct lfd_context {
     bool consts_valid = false;
     int consts_wm = 0, consts_hm = 0;
     // indexed-mode scratch
-    DeviceBuffer scratch, codes, idx_tab;
+    DeviceBuffer scratch, codes, idx_tab, agg, sel_buf;
     // selection stage: legacy MT19937 stream (625 words) + scratch
     DeviceBuffer mt, sel_scratch;
     bool mt_seeded = false;
@@ -342,7 +342,7 @@ void lfd_destroy(lfd_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->mt, &ctx->sel_scratch})
+    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->mt, &ctx->sel_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
@@ -528,11 +528,12 @@ int lfd_rng_set_state(lfd_context* ctx, const uint32_t* key624, int32_t pos) {
     return LFD_OK;
 }
 
-static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
-                       int32_t border, int32_t tiles, float s_override, int64_t* sel_out, int64_t capacity,
-                       int32_t* n_sel_host, int32_t* status_host) {
+// launches the selection of one reference; *d_info = device {n_out, status}; nothing is read back here
+static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
+                         int32_t border, int32_t tiles, float s_override, int64_t* sel_out, int64_t capacity,
+                         long long* sel_offsets_dev, int** d_info, unsigned char** d_time) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
-    if (!best_cert || !sel_out || !n_sel_host || !status_host) return fail(ctx, LFD_ERR_INVALID, "null argument");
+    if (!best_cert || !sel_out) return fail(ctx, LFD_ERR_INVALID, "null argument");
     if (H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL || M < 0 || tiles <= 0 || border < 0 || capacity < 0)
         return fail(ctx, LFD_ERR_INVALID, "bad selection arguments");
     if (!topm && !ctx->mt_seeded) return fail(ctx, LFD_ERR_STATE, "lfd_rng_seed must be called before lfd_select_samples");
@@ -563,10 +564,14 @@ static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int3
     A.status = reinterpret_cast<int*>(base + o_out + 4);
     A.capacity = capacity;
     A.H = H; A.W = W; A.M = M; A.border = border; A.tiles = tiles; A.cap = cap; A.s_override = s_override;
+    A.sel_offsets_out = sel_offsets_dev;
+    *d_info = reinterpret_cast<int*>(base + o_out);
+    *d_time = nullptr;
     const bool timing = !topm && std::getenv("LFD_SELECT_TIMING") != nullptr;
     if (timing) {
         A.timing = reinterpret_cast<unsigned long long*>(base + o_time);
         LFD_HIP(ctx, hipMemsetAsync(base + o_time, 0, 256, ctx->stream));
+        *d_time = base + o_time;
     }
     if (topm) {
         static bool attr_set = false;
@@ -593,25 +598,106 @@ static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int3
         }
     }
     LFD_HIP(ctx, hipGetLastError());
+    return LFD_OK;
+}
+
+static const char* select_status_name(int st) {
+    static const char* names[] = {"ok", "probabilities contain NaN", "probabilities are not non-negative",
+                                  "Fewer non-zero entries in p than size", "weight below 2^-29: exact parallel cumsum not guaranteed",
+                                  "no progress", "too many coverage bins", "sel_out capacity too small"};
+    return names[std::min(std::max(st, 0), 7)];
+}
+
+static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
+                       int32_t border, int32_t tiles, float s_override, int64_t* sel_out, int64_t capacity,
+                       int32_t* n_sel_host, int32_t* status_host) {
+    if (ctx && (!n_sel_host || !status_host)) return fail(ctx, LFD_ERR_INVALID, "null argument");
+    int* d_info = nullptr;
+    unsigned char* d_time = nullptr;
+    int rc = select_launch(ctx, topm, best_cert, H, W, M, cap, border, tiles, s_override, sel_out, capacity, nullptr, &d_info, &d_time);
+    if (rc != LFD_OK) return rc;
     int* host = ctx->pinned_words + 4;
-    LFD_HIP(ctx, hipMemcpyAsync(host, base + o_out, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    LFD_HIP(ctx, hipMemcpyAsync(host, d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_sel_host = host[0];
     *status_host = host[1];
-    if (timing) {   // phase times of the filter kernel (100 MHz wall clock), profiling only
+    if (d_time) {   // phase times of the filter kernel (100 MHz wall clock), profiling only
         unsigned long long t[32];
-        LFD_HIP(ctx, hipMemcpy(t, base + o_time, sizeof(t), hipMemcpyDeviceToHost));
+        LFD_HIP(ctx, hipMemcpy(t, d_time, sizeof(t), hipMemcpyDeviceToHost));
         fprintf(stderr, "[lfd] select phases (us):");
         for (int i = 1; i < 32 && t[i]; ++i) fprintf(stderr, " %.1f", (double)(t[i] - t[i - 1]) * 0.01);
         fprintf(stderr, "\n");
     }
-    if (host[1] != LFD_SELECT_OK) {
-        static const char* names[] = {"ok", "probabilities contain NaN", "probabilities are not non-negative",
-                                      "Fewer non-zero entries in p than size", "weight below 2^-29: exact parallel cumsum not guaranteed",
-                                      "no progress", "too many coverage bins", "sel_out capacity too small"};
+    if (host[1] != LFD_SELECT_OK)
         return fail(ctx, host[1] == LFD_SELECT_CAPACITY ? LFD_ERR_CAPACITY : LFD_ERR_INVALID,
-                    std::string("selection: ") + names[std::min(host[1], 7)]);
+                    std::string("selection: ") + select_status_name(host[1]));
+    return LFD_OK;
+}
+
+int lfd_triangulate_sampled(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, int32_t M, float cap,
+                            int32_t border, int32_t tiles, float s_override, const lfd_points* out, int64_t* ref_offsets,
+                            int32_t* seg_counts, int32_t* seg_order, int32_t* sel_info, int64_t* sel_cells) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (!batch || !params || !sel_info) return fail(ctx, LFD_ERR_INVALID, "null argument");
+    if (batch->n_refs != 1) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_sampled takes one reference view per call");
+    if (M < 0 || tiles <= 0 || border < 0) return fail(ctx, LFD_ERR_INVALID, "bad selection arguments");
+    const bool topm = params->no_filter != 0;
+    if (topm && M > LFD_SELECT_TOPM_MAX) return fail(ctx, LFD_ERR_INVALID, "no_filter selection is limited to 16384 matches per reference");
+    LfdLaunch L;
+    int rc = prepare_launch(ctx, batch, params, nullptr, 0, L, nullptr);
+    if (rc != LFD_OK) return rc;
+    rc = check_points(ctx, out, reinterpret_cast<long long*>(ref_offsets));
+    if (rc != LFD_OK) return rc;
+    const long long HW = (long long)batch->H * batch->W;
+    const long long cap_sel = topm ? std::max<long long>(std::min<long long>(M, HW), 1) : (long long)M + (long long)tiles * tiles + 64;
+    if (out->capacity < cap_sel) return fail(ctx, LFD_ERR_CAPACITY, "output capacity below M + tiles*tiles + 64");
+    // P1 + F1
+    rc = ensure(ctx, ctx->agg, (size_t)HW * sizeof(float));
+    if (rc != LFD_OK) return rc;
+    float* best = static_cast<float*>(ctx->agg.ptr);
+    {
+        const int per_block = 256 * 4;
+        const int gx = (int)std::min<long long>((HW + per_block - 1) / per_block, 2048);
+        hipLaunchKernelGGL(lfd_aggregate_kernel, dim3((unsigned)gx, 1u, 1u), dim3(256), 0, ctx->stream, L, best, static_cast<uint8_t*>(nullptr));
+        LFD_HIP(ctx, hipGetLastError());
     }
+    // S: the count stays on the device ({0, n} in sel_offsets) for the kernels below
+    rc = ensure(ctx, ctx->sel_buf, 16 + (size_t)cap_sel * sizeof(long long));
+    if (rc != LFD_OK) return rc;
+    long long* sel_offsets = static_cast<long long*>(ctx->sel_buf.ptr);
+    long long* cells = sel_cells ? reinterpret_cast<long long*>(sel_cells) : sel_offsets + 2;
+    LFD_HIP(ctx, hipMemsetAsync(sel_offsets, 0, 16, ctx->stream));
+    int* d_info = nullptr;
+    unsigned char* d_time = nullptr;
+    rc = select_launch(ctx, topm, best, batch->H, batch->W, M, cap, topm ? 0 : border, topm ? 1 : tiles, topm ? 0.0f : s_override,
+                       reinterpret_cast<int64_t*>(cells), cap_sel, sel_offsets, &d_info, &d_time);
+    if (rc != LFD_OK) return rc;
+    LFD_HIP(ctx, hipMemcpyAsync(sel_info, d_info, 2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    // F2..F10 on the selected cells
+    rc = prepare_lookback(ctx, 1, 1, false, L);
+    if (rc != LFD_OK) return rc;
+    rc = ensure(ctx, ctx->scratch, (size_t)cap_sel * 8 * sizeof(float));
+    if (rc != LFD_OK) return rc;
+    rc = ensure(ctx, ctx->codes, (size_t)cap_sel);
+    if (rc != LFD_OK) return rc;
+    const size_t tab_bytes = (size_t)LFD_MAX_SLOTS * 2 * sizeof(unsigned);
+    rc = ensure(ctx, ctx->idx_tab, tab_bytes);
+    if (rc != LFD_OK) return rc;
+    unsigned* tab = static_cast<unsigned*>(ctx->idx_tab.ptr);
+    LFD_HIP(ctx, hipMemsetAsync(tab, 0, tab_bytes, ctx->stream));
+    L.xyz = out->xyz; L.rgb = out->rgb; L.err = out->err; L.cell = out->cell; L.slot = out->slot;
+    L.capacity = out->capacity;
+    L.ref_offsets = reinterpret_cast<long long*>(ref_offsets);
+    L.seg_counts = seg_counts;
+    const unsigned chunks = (unsigned)((cap_sel + LFD_INDEXED_EVAL_BLOCK - 1) / LFD_INDEXED_EVAL_BLOCK);
+    hipLaunchKernelGGL(lfd_indexed_eval_kernel, dim3(chunks, 1u), dim3(LFD_INDEXED_EVAL_BLOCK), 0, ctx->stream, L,
+                       static_cast<const long long*>(cells), static_cast<const long long*>(sel_offsets), static_cast<float*>(ctx->scratch.ptr),
+                       static_cast<uint8_t*>(ctx->codes.ptr), tab);
+    LFD_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(lfd_indexed_kernel, dim3(1u), dim3(LFD_INDEXED_BLOCK), 0, ctx->stream, L,
+                       static_cast<const long long*>(cells), static_cast<const long long*>(sel_offsets), static_cast<float*>(ctx->scratch.ptr),
+                       static_cast<uint8_t*>(ctx->codes.ptr), seg_order, static_cast<const unsigned*>(tab));
+    LFD_HIP(ctx, hipGetLastError());
     return LFD_OK;
 }
 

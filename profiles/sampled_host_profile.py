@@ -29,3 +29,10 @@ for rep in range(3):
         dens.check_launches(); t = tick("check_launches", t)
         out = ob.collect(indexed=True); t = tick("collect", t)
 print({k: round(v / len(batches) * 1e3, 4) for k, v in acc.items()}, "ms per reference; total", round(sum(acc.values()) / len(batches) * 1e3, 3))
+dens.seed_rng(0)
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for b in batches:
+        out = dens.triangulate_sampled(b, params, 10000, cap=0.9, border=2, tiles=24)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("fused lfd_triangulate_sampled + read-back: %.3f ms per reference" % (dt / len(batches) * 1e3))

@@ -165,3 +165,57 @@ def test_multi_workgroup_kernel_equals_single_workgroup_kernel(dens, monkeypatch
         dens.select_samples(torch.from_numpy(sparse).to(dens.device), M)
     after = dens.rng_state()
     assert before[1] == after[1] and np.array_equal(before[0], after[0])
+
+
+@pytest.mark.parametrize("no_filter", [False, True])
+def test_fused_sampled_call_equals_the_three_calls(dens, no_filter):
+    """lfd_triangulate_sampled (aggregate -> selection -> indexed in one asynchronous call, the count staying on the
+    device) returns exactly what lfd_aggregate + lfd_select_samples / lfd_select_top_m + lfd_triangulate_indexed return, and
+    leaves the MT19937 stream where they leave it; a refused input raises upstream's ValueError and emits nothing."""
+    import lichtfeld_densification_plugin_amd as lfd
+    from lichtfeld_densification_plugin_amd import synthetic
+    dev = dens.device
+    cams = synthetic.ring_cameras(40, seed=0)
+    dens.upload_cameras(cams)
+    H = W = 160
+    M = 3000
+    cfg = lfd.DensePipelineConfig(output_path="", matches_per_ref=M, no_filter=no_filter)
+    params = hb.make_params(cfg)
+    outs = {}
+    for mode in ("three", "fused"):
+        dens.seed_rng(5)
+        res = []
+        for ref in (3, 11):
+            nbrs = synthetic.ring_neighbours(40, ref, 3)
+            s = synthetic.synth_reference(cams, ref, nbrs, H, W, H, W, noise_px=0.4, outlier_frac=0.05, channels=2, seed=ref,
+                                          cert_mode="tiefree", device=dev)
+            r = hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=[s.cert[j] for j in range(3)], warp=[s.warp[j] for j in range(3)], image=s.image)
+            b = hb.PreparedBatch([r], W, H)
+            if mode == "three":
+                best, _ = dens.aggregate(b, params)
+                sel = dens.select_top_m(best[0], M, cap=0.9) if no_filter else dens.select_samples(best[0], M, cap=0.9, border=2, tiles=24)
+                out = dens.triangulate_indexed(b, params, sel, [0, int(sel.numel())])
+                n_sel = int(sel.numel())
+            else:
+                out = dens.triangulate_sampled(b, params, M, cap=0.9, border=2, tiles=24)
+                n_sel = out.n_selected
+            res.append((n_sel, out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy(), out.cell.cpu().numpy(),
+                        out.slot.cpu().numpy(), out.ref_offsets, out.seg_counts, out.seg_order))
+        outs[mode] = (res, dens.rng_state())
+    for a, b in zip(outs["three"][0], outs["fused"][0]):
+        assert a[0] == b[0] and a[0] > 1000
+        for x, y in zip(a[1:], b[1:]):
+            np.testing.assert_array_equal(x, y)
+    assert outs["three"][1][1] == outs["fused"][1][1]
+    np.testing.assert_array_equal(outs["three"][1][0], outs["fused"][1][0])
+    if not no_filter:       # fewer non-zero weights than draws: upstream raises, the stream is untouched, nothing is emitted
+        nbrs = synthetic.ring_neighbours(40, 3, 2)
+        s = synthetic.synth_reference(cams, 3, nbrs, H, W, H, W, noise_px=0.4, outlier_frac=0.0, channels=2, seed=1, cert_mode="tiefree", device=dev)
+        mask = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+        mask[80, :40] = 1
+        r = hb.ReferenceInputs(ref_cam=3, nbr_cams=nbrs, cert=[s.cert[j] for j in range(2)], warp=[s.warp[j] for j in range(2)], image=s.image, mask_a=mask)
+        before = dens.rng_state()
+        with pytest.raises(ValueError):
+            dens.triangulate_sampled(hb.PreparedBatch([r], W, H), params, M)
+        after = dens.rng_state()
+        assert before[1] == after[1] and np.array_equal(before[0], after[0])
