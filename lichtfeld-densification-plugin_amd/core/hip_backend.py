@@ -205,6 +205,18 @@ class TriangulationOutput:
     seg_counts: np.ndarray       # (n_refs,k) i32 host
     seg_order: Optional[np.ndarray] = None   # indexed mode: slot of the g-th emitted group, -1 = none
     n_selected: Optional[int] = None         # sampled call: cells the selection stage picked
+    _packed: Optional[torch.Tensor] = None   # the one float buffer xyz / rgb / err are views of
+    _cap: int = 0
+
+    def host_arrays(self):
+        """(xyz, rgb, err) as NumPy arrays.  When the buffers are small (sampled mode) the whole packed buffer crosses in
+        one copy instead of three."""
+        n = int(self.xyz.shape[0])
+        if self._packed is None or self._cap * 7 > (1 << 20) or n == 0:
+            return self.xyz.cpu().numpy(), self.rgb.cpu().numpy(), self.err.cpu().numpy()
+        h = self._packed.cpu().numpy()
+        c = self._cap
+        return h[:3 * c].reshape(c, 3)[:n].copy(), h[3 * c:6 * c].reshape(c, 3)[:n].copy(), h[6 * c:6 * c + n].copy()
 
     @property
     def count(self) -> int:
@@ -304,9 +316,12 @@ class OutputBuffers:
         self.capacity = int(capacity)
         self.with_segments = with_segments
         cap = max(self.capacity, 1)
-        self.xyz = torch.empty((cap, 3), dtype=torch.float32, device=device)
-        self.rgb = torch.empty((cap, 3), dtype=torch.float32, device=device)
-        self.err = torch.empty((cap,), dtype=torch.float32, device=device)
+        # one allocation for the three float outputs (views below): the sampled mode's few thousand points then reach the
+        # host in ONE copy (TriangulationOutput.host_arrays)
+        self._f = torch.empty((cap * 7,), dtype=torch.float32, device=device)
+        self.xyz = self._f[:cap * 3].view(cap, 3)
+        self.rgb = self._f[cap * 3:cap * 6].view(cap, 3)
+        self.err = self._f[cap * 6:]
         self.cell = torch.empty((cap,), dtype=torch.int32, device=device) if with_cell else None
         self.slot = torch.empty((cap,), dtype=torch.uint8, device=device) if with_cell else None
         # the small integer outputs share ONE buffer so that collect() needs a single device-to-host copy:
@@ -346,8 +361,8 @@ class OutputBuffers:
             cell=self.cell[:n] if self.cell is not None else None, slot=self.slot[:n] if self.slot is not None else None,
             ref_offsets=offs, seg_counts=meta[n_off:n_off + n_seg].reshape(self._n_refs, self._k).copy(),
             seg_order=meta[n_off + n_seg:n_off + 2 * n_seg].reshape(self._n_refs, self._k).copy() if indexed else None,
-            n_selected=int(meta[n_off + 2 * n_seg]))
-        
+            n_selected=int(meta[n_off + 2 * n_seg]), _packed=self._f, _cap=max(self.capacity, 1))
+
 
 
 class HipDensifier:

@@ -493,7 +493,8 @@ def run_dense_pipeline(
                 dbg = {"matches": hot.debug_matches(ref, out.cell, out.slot, axes, best),
                        "pair_index": {j: first_pair + j for j in range(len(certs))}}
             dev_parts.append((out.xyz, out.rgb, out.err))
-            emit(local_i, packed, out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy(), dbg)
+            hx, hc, he = out.host_arrays()
+            emit(local_i, packed, hx, hc, he, dbg)
         flush_dense()
     finally:
         if prefetch is not None:
