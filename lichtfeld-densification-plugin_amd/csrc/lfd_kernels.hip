@@ -212,6 +212,57 @@ __device__ __forceinline__ void cell_best(const LfdLaunch& L, const BlockShared&
     for (int j = 1; j < ns; ++j) argmax_step(cell_cert(L, S, j, cell, x, y, lfd_global(S.slot[j].cert)[cell], ma), j, best, bj);
 }
 
+// the same for four consecutive cells of one row when masks are present (W % 4 == 0): certainties and warps come in
+// 16-byte loads, the row / column arithmetic is shared; per cell the operations and their order are those of cell_cert
+__device__ __forceinline__ void cells4_best_masked(const LfdLaunch& L, const BlockShared& S, int cell0, int y, int x0,
+                                                   float best[4], int bj[4]) {
+    const float th = L.kp.certainty_thresh;
+    float ma[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    const bool has_a = S.ref.mask_a != nullptr;
+    if (has_a) {
+        const uint8_t LFD_GLOBAL_AS* row = lfd_global(S.ref.mask_a) + (size_t)lfd_nearest_src(y, L.mask_sy, L.h_match) * L.w_match;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ma[e] = (float)row[lfd_nearest_src(x0 + e, L.mask_sx, L.w_match)];
+    }
+    const int ns = S.ref.n_slots;
+    for (int j = 0; j < ns; ++j) {
+        const float4 c4 = load_f32x4(S.slot[j].cert + cell0);
+        float c[4] = {lfd_cert_floor(c4.x, th), lfd_cert_floor(c4.y, th), lfd_cert_floor(c4.z, th), lfd_cert_floor(c4.w, th)};
+        if (has_a) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[e] = c[e] * ma[e];
+        }
+        const uint8_t* mb = S.slot[j].mask_b;
+        if (mb) {
+            float wx[4], wy[4];
+            const float* wp = S.slot[j].warp;
+            if (L.warp_channels == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float4 v = load_f32x4(wp + (size_t)(unsigned)(cell0 + e) * 4); wx[e] = v.z; wy[e] = v.w; }
+            } else {
+                const float4 a = load_f32x4(wp + (size_t)(unsigned)cell0 * 2), b = load_f32x4(wp + (size_t)(unsigned)cell0 * 2 + 4);
+                wx[0] = a.x; wy[0] = a.y; wx[1] = a.z; wy[1] = a.w; wx[2] = b.x; wy[2] = b.y; wx[3] = b.z; wy[3] = b.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ix = lfd_grid_nearest(wx[e], L.W);
+                const int iy = lfd_grid_nearest(wy[e], L.H);
+                float m = 0.0f;
+                if (ix >= 0 && iy >= 0)
+                    m = (float)lfd_global(mb)[(size_t)lfd_nearest_src(iy, L.mask_sy, L.h_match) * L.w_match + lfd_nearest_src(ix, L.mask_sx, L.w_match)];
+                c[e] = c[e] * m;
+            }
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { best[e] = c[e]; bj[e] = 0; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) argmax_step(c[e], j, best[e], bj[e]);
+        }
+    }
+}
+
 // winner's warp -> normalised coordinates of the correspondence
 __device__ __forceinline__ void cell_coords(const LfdLaunch& L, const BlockShared& S, int cell, int bj, float& xan,
                                             float& yan, float& xbn, float& ybn) {
@@ -280,6 +331,16 @@ extern "C" __global__ void __launch_bounds__(256) lfd_aggregate_kernel(LfdLaunch
             *reinterpret_cast<float4*>(best_cert + (size_t)r * HW + base) = best;
             if (best_slot) {
                 const unsigned packed = (unsigned)b0 | ((unsigned)b1 << 8) | ((unsigned)b2 << 16) | ((unsigned)b3 << 24);
+                *reinterpret_cast<unsigned*>(best_slot + (size_t)r * HW + base) = packed;
+            }
+        } else if ((L.W & 3) == 0 && (HW & 3) == 0 && base + 3 < HW) {      // masks, four cells of one row at a time
+            int y, x0;
+            lfd_divmod(base, L.W, L.inv_w, y, x0);
+            float b4[4]; int j4[4];
+            cells4_best_masked(L, S, base, y, x0, b4, j4);
+            *reinterpret_cast<float4*>(best_cert + (size_t)r * HW + base) = make_float4(b4[0], b4[1], b4[2], b4[3]);
+            if (best_slot) {
+                const unsigned packed = (unsigned)j4[0] | ((unsigned)j4[1] << 8) | ((unsigned)j4[2] << 16) | ((unsigned)j4[3] << 24);
                 *reinterpret_cast<unsigned*>(best_slot + (size_t)r * HW + base) = packed;
             }
         } else {
@@ -402,6 +463,11 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
                 argmax_step(lfd_cert_floor(c.z, th), j, best.z, bj[2]);
                 argmax_step(lfd_cert_floor(c.w, th), j, best.w, bj[3]);
             }
+        } else if ((L.W & 3) == 0 && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW) {      // masks present
+            int dy, x0;
+            lfd_divmod_local(tile_x0 + tid * kCpt, L.W, L.inv_w, dy, x0);
+            float b4[4];
+            cells4_best_masked(L, S, cell0, tile_y0 + dy, x0, b4, bj);
         } else {
 #pragma unroll
             for (int e = 0; e < kCpt; ++e) {

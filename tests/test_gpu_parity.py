@@ -361,6 +361,48 @@ def test_indexed_batch_of_references_and_empty_selection(dev):
     dens.close()
 
 
+@pytest.mark.parametrize("channels", [2, 4])
+def test_dense_and_aggregate_with_masks_pick_the_oracle_winners(dev, channels):
+    """Masks on the reference and on every neighbour (certainty prologue, core/pipeline.py:405-430): the four-cells-at-a-time
+    masked path of the dense and aggregate kernels picks, cell for cell, the neighbour upstream's stack/max picks, and
+    the aggregated certainty is bit-identical."""
+    H, W, wm, hm = 96, 128, 128, 96
+    cams, refs, srefs = _synthetic_batch(dev, 2, [3, 2], H, W, wm, hm, seed=31, channels=channels, cert_mode="tiefree")
+    rs = np.random.RandomState(7)
+
+    def blob():
+        m = np.ones((hm, wm), np.uint8)
+        for _ in range(5):
+            y, x = rs.randint(0, hm - 30), rs.randint(0, wm - 30)
+            m[y:y + 25, x:x + 28] = 0
+        return m
+    masks = []
+    for r in refs:
+        ma = blob()
+        mbs = [blob() for _ in r.cert]
+        masks.append((ma, mbs))
+        r.mask_a = torch.from_numpy(ma).to(dev)
+        r.mask_b = [torch.from_numpy(m).to(dev) for m in mbs]
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    batch = hb.PreparedBatch(refs, wm, hm)
+    params = hb.make_params(lfd.DensePipelineConfig(output_path=""))
+    best, slot = dens.aggregate(batch, params)
+    out = dens.triangulate_dense(batch, params)
+    oparams = orc.OracleParams()
+    cells, slots = out.cell.cpu().numpy(), out.slot.cpu().numpy()
+    for i, s in enumerate(srefs):
+        k = len(s.nbr_indices)
+        bc, bk, _ = orc.prepare_reference([s.cert[j].numpy() for j in range(k)], [s.warp[j].numpy() for j in range(k)], oparams,
+                                          masks[i][0], masks[i][1])
+        np.testing.assert_array_equal(best[i].cpu().numpy(), bc)
+        np.testing.assert_array_equal(slot[i].cpu().numpy().astype(np.int64), bk.astype(np.int64))
+        lo, hi = int(out.ref_offsets[i]), int(out.ref_offsets[i + 1])
+        assert hi - lo > 1000
+        np.testing.assert_array_equal(slots[lo:hi].astype(np.int64), bk.reshape(-1)[cells[lo:hi]].astype(np.int64))
+    dens.close()
+
+
 def test_indexed_split_kernels_equal_the_single_kernel(dev, monkeypatch):
     """Indexed mode evaluates the selected cells chip-wide (lfd_indexed_eval_kernel) and orders them per reference;
     with LFD_INDEXED_SPLIT=0 one workgroup per reference does both.  Same bits either way, including an empty and a
