@@ -845,64 +845,138 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
 // Radix-select the M-th largest 64-bit key {value bits, ~index} (8 rounds of 8-bit histograms), gather
 // the M winners, bitonic-sort them in LDS.
 // =================================================================================================
+namespace {
+
+// order-preserving unsigned image of a capped certainty: larger = earlier in the output; NaN sorts last (NumPy)
+__device__ __forceinline__ unsigned topm_ord(float c, float cap) {
+    c = (c > cap) ? cap : c;
+    const unsigned u = __float_as_uint(c);
+    if (c != c) return 0u;                                               // NaN: last
+    unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);           // total order of finite floats
+    if (ord == 0u) ord = 1u;
+    return ord;
+}
+
+// workgroup-wide: the digit d (scanning bins from the top) at which the running count reaches `need`; returns d and
+// leaves in need_out what is still wanted inside that bin.  hist has n_bins (<= 2 * kSelBlock) entries.
+__device__ int topm_pick_bin(const unsigned* hist, int n_bins, unsigned need, int* s_i, int* s_pick, int tid, unsigned& need_out) {
+    const int b_hi = n_bins - 1 - 2 * tid, b_lo = b_hi - 1;               // this thread's two bins, higher first
+    const unsigned h_hi = b_hi >= 0 ? hist[b_hi] : 0u, h_lo = b_lo >= 0 ? hist[b_lo] : 0u;
+    int total;
+    const int excl = block_excl_scan_i32((int)(h_hi + h_lo), s_i, tid, total);
+    if ((unsigned)excl < need && need <= (unsigned)excl + h_hi + h_lo) {
+        if (need <= (unsigned)excl + h_hi) { s_pick[0] = b_hi; s_pick[1] = (int)(need - (unsigned)excl); }
+        else { s_pick[0] = b_lo; s_pick[1] = (int)(need - (unsigned)excl - h_hi); }
+    }
+    __syncthreads();
+    need_out = (unsigned)s_pick[1];
+    return s_pick[0];
+}
+
+}  // namespace
+
+// Three histogram passes over the certainty map itself (11 + 11 + 10 bits of the ordered value, 16-byte loads) find the
+// value of the M-th largest cell; ties at that value - the norm when many cells sit at the cap - are taken in index
+// order by an ordered count; the winners are then sorted in LDS.  (The first version materialised 64-bit keys and made
+// eight 8-bit passes over them: 19 MB through one CU instead of 4-5 MB.)
 extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_topm_kernel(LfdSelectArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];   // [LFD_SELECT_TOPM_MAX]
-    __shared__ unsigned s_hist[256];
-    __shared__ unsigned long long s_prefix;
-    __shared__ unsigned s_remaining, s_count;
+    __shared__ unsigned s_hist[2048];
+    __shared__ unsigned s_count;
     __shared__ int s_i[kSelBlock / 64];
+    __shared__ int s_pick[2];
+    __shared__ int s_wave_ties[kSelBlock / 64];
 
-    const int tid = (int)threadIdx.x;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = A.H * A.W;
     const int M = min(A.M, N);
     if (tid == 0) { *A.n_out = 0; *A.status = LFD_SELECT_OK; }
     if (M <= 0) return;
     if (M > LFD_SELECT_TOPM_MAX || (long long)M > A.capacity) { if (tid == 0) *A.status = LFD_SELECT_CAPACITY; return; }
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(A.cdf);     // [N] scratch
+    const float* cert = A.best_cert;
+    const float cap = A.cap;
+    const bool vec4 = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(cert) & 15u) == 0);
 
-    // key: larger = earlier in the output.  -NaN sorts last in NumPy -> key 0..; finite values map to
-    // an order-preserving unsigned (sign flip), ties resolved by lower index first.
+    // visit every cell: f(i, ord)
+    auto for_each_cell = [&](auto&& f) {
+        if (vec4) {
 #pragma unroll 4
-    for (int i = tid; i < N; i += kSelBlock) {
-        float c = A.best_cert[i];
-        c = (c > A.cap) ? A.cap : c;
-        unsigned u = __float_as_uint(c);
-        unsigned ord;
-        if (c != c) ord = 0u;                                              // NaN: last
-        else ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);            // total order of finite floats (+0 > -0 irrelevant)
-        if (ord == 0u && !(c != c)) ord = 1u;
-        keys[i] = ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
-    }
-    if (tid == 0) { s_prefix = 0ull; s_remaining = (unsigned)M; }
+            for (int g = tid; g < (N >> 2); g += kSelBlock) {
+                const float4 c4 = *reinterpret_cast<const float4*>(cert + 4 * g);
+                f(4 * g + 0, topm_ord(c4.x, cap)); f(4 * g + 1, topm_ord(c4.y, cap));
+                f(4 * g + 2, topm_ord(c4.z, cap)); f(4 * g + 3, topm_ord(c4.w, cap));
+            }
+        } else {
+#pragma unroll 4
+            for (int i = tid; i < N; i += kSelBlock) f(i, topm_ord(cert[i], cap));
+        }
+    };
+
+    // ---- the M-th largest value, 11 + 11 + 10 bits at a time -------------------------------------------------------
+    unsigned need = (unsigned)M;
+    for (int b = tid; b < 2048; b += kSelBlock) s_hist[b] = 0;
     __syncthreads();
-    // MSB-first radix select of the M-th largest key
-    for (int round = 7; round >= 0; --round) {
-        const int shift = round * 8;
-        for (int b = tid; b < 256; b += kSelBlock) s_hist[b] = 0;
-        __syncthreads();
-        const unsigned long long prefix = s_prefix;
-        const unsigned long long himask = (round == 7) ? 0ull : (~0ull << (shift + 8));
-#pragma unroll 4
-        for (int i = tid; i < N; i += kSelBlock) {
-            const unsigned long long kx = keys[i];
-            if ((kx & himask) == prefix) atomicAdd(&s_hist[(unsigned)(kx >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned need = s_remaining, acc = 0;
-            int b = 255;
-            for (; b >= 0; --b) { if (acc + s_hist[b] >= need) break; acc += s_hist[b]; }
-            s_remaining = need - acc;                     // still wanted inside bucket b
-            s_prefix = prefix | ((unsigned long long)(unsigned)b << shift);
-        }
-        __syncthreads();
-    }
-    const unsigned long long kth = s_prefix;               // exactly M keys are >= kth (keys are distinct)
+    for_each_cell([&](int, unsigned ord) { atomicAdd(&s_hist[ord >> 21], 1u); });
+    __syncthreads();
+    const unsigned d2 = (unsigned)topm_pick_bin(s_hist, 2048, need, s_i, s_pick, tid, need);
+    __syncthreads();
+    for (int b = tid; b < 2048; b += kSelBlock) s_hist[b] = 0;
+    __syncthreads();
+    for_each_cell([&](int, unsigned ord) { if ((ord >> 21) == d2) atomicAdd(&s_hist[(ord >> 10) & 0x7ffu], 1u); });
+    __syncthreads();
+    const unsigned d1 = (unsigned)topm_pick_bin(s_hist, 2048, need, s_i, s_pick, tid, need);
+    __syncthreads();
+    for (int b = tid; b < 2048; b += kSelBlock) s_hist[b] = 0;
+    __syncthreads();
+    const unsigned hi21 = (d2 << 11) | d1;
+    for_each_cell([&](int, unsigned ord) { if ((ord >> 10) == hi21) atomicAdd(&s_hist[ord & 0x3ffu], 1u); });
+    __syncthreads();
+    const unsigned d0 = (unsigned)topm_pick_bin(s_hist, 1024, need, s_i, s_pick, tid, need);
+    const unsigned ord_k = (hi21 << 10) | d0;            // value of the M-th largest cell
+    const unsigned ties = s_hist[d0];                    // cells holding exactly that value; `need` of them are wanted
+    __syncthreads();
+
+    // ---- gather: every cell above ord_k, and the `need` lowest-indexed cells at ord_k ---------------------------------------
     if (tid == 0) s_count = 0;
     __syncthreads();
-    for (int i = tid; i < N; i += kSelBlock) {
-        const unsigned long long kx = keys[i];
-        if (kx >= kth) { const unsigned pos = atomicAdd(&s_count, 1u); if (pos < (unsigned)LFD_SELECT_TOPM_MAX) s_keys[pos] = kx; }
+    if (need >= ties) {          // all of them: no order to respect
+        for_each_cell([&](int i, unsigned ord) {
+            if (ord >= ord_k) { const unsigned pos = atomicAdd(&s_count, 1u); if (pos < (unsigned)LFD_SELECT_TOPM_MAX) s_keys[pos] = ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned)i); }
+        });
+    } else {
+        // each wave owns one contiguous span; ties are ranked by (wave, step, lane, cell) = index order
+        constexpr int nwaves = kSelBlock / 64;
+        const int span = ((N + nwaves - 1) / nwaves + 255) & ~255;
+        const int w_lo = min(wave * span, N), w_hi = min(w_lo + span, N);
+        int my_ties = 0;
+#pragma unroll 4
+        for (int i = w_lo + 4 * lane; i < w_hi; i += 256)
+            for (int e = 0; e < 4 && i + e < w_hi; ++e) my_ties += topm_ord(cert[i + e], cap) == ord_k;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) my_ties += __shfl_xor(my_ties, off, 64);
+        if (lane == 0) s_wave_ties[wave] = my_ties;
+        __syncthreads();
+        unsigned rank_base = 0;
+        for (int w = 0; w < wave; ++w) rank_base += (unsigned)s_wave_ties[w];
+        for (int base = w_lo; base < w_hi; base += 256) {
+            const int i0 = base + 4 * lane;
+            unsigned ords[4];
+            int t = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ords[e] = (i0 + e < w_hi) ? topm_ord(cert[i0 + e], cap) : 0u; t += (i0 + e < w_hi) && ords[e] == ord_k; }
+            int incl = t;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int n = __shfl_up(incl, off, 64); if (lane >= off) incl += n; }
+            unsigned r = rank_base + (unsigned)(incl - t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (i0 + e >= w_hi) continue;
+                bool take = ords[e] > ord_k;
+                if (ords[e] == ord_k) { take = r < need; ++r; }
+                if (take) { const unsigned pos = atomicAdd(&s_count, 1u); if (pos < (unsigned)LFD_SELECT_TOPM_MAX) s_keys[pos] = ((unsigned long long)ords[e] << 32) | (unsigned long long)(0xffffffffu - (unsigned)(i0 + e)); }
+            }
+            rank_base += (unsigned)__shfl(incl, 63, 64);
+        }
     }
     __syncthreads();
     // pad to a power of two with 0 (sorts last), bitonic sort descending
@@ -925,7 +999,6 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_topm_k
     }
     for (int i = tid; i < M; i += kSelBlock) A.sel_out[i] = (long long)(0xffffffffu - (unsigned)(s_keys[i] & 0xffffffffull));
     if (tid == 0) { *A.n_out = M; if (A.sel_offsets_out) A.sel_offsets_out[1] = M; }
-    (void)s_i;
 }
 
 // seed exactly like np.random.seed(uint32): init_genrand
