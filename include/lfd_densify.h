@@ -123,9 +123,9 @@ int lfd_triangulate_indexed(lfd_context* ctx, const lfd_batch* batch, const lfd_
  * `_triangulate_ref`) in ONE stream-ordered call with nothing read back in between: lfd_aggregate -> selection (coverage
  * sampling on the context's MT19937 stream, or the top-M of the no_filter mode when params->no_filter) ->
  * lfd_triangulate_indexed on the cells selected.  Equivalent to the three calls, bit for bit.
- * out->capacity >= M + tiles*tiles + 64.  sel_info: device i32 [2] = {cells selected, selection status (0 = ok, else
- * the LFD_SELECT_* code upstream would have raised for)}; with a non-zero status or an empty selection no point is
- * emitted (ref_offsets = {0, 0}).  sel_cells: device i64 [M + tiles*tiles + 64] receiving the selected cells, or NULL. */
+ * out->capacity >= M + tiles*tiles + 64.  sel_info: device i32 [3] = {cells selected, selection status (0 = ok, else
+ * the LFD_SELECT_* code upstream would have raised for), launch status (what lfd_launch_status would report: 0 = ok)};
+ * with a non-zero selection status or an empty selection no point is emitted (ref_offsets = {0, 0}).  sel_cells: device i64 [M + tiles*tiles + 64] receiving the selected cells, or NULL. */
 int lfd_triangulate_sampled(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, int32_t M, float cap,
                             int32_t border, int32_t tiles, float s_override, const lfd_points* out, int64_t* ref_offsets,
                             int32_t* seg_counts, int32_t* seg_order, int32_t* sel_info, int64_t* sel_cells);

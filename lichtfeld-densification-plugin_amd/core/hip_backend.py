@@ -205,6 +205,7 @@ class TriangulationOutput:
     seg_counts: np.ndarray       # (n_refs,k) i32 host
     seg_order: Optional[np.ndarray] = None   # indexed mode: slot of the g-th emitted group, -1 = none
     n_selected: Optional[int] = None         # sampled call: cells the selection stage picked
+    launch_status: int = 0                   # sampled call: look-back status of the launch (0 = ok)
     _packed: Optional[torch.Tensor] = None   # the one float buffer xyz / rgb / err are views of
     _cap: int = 0
 
@@ -327,12 +328,12 @@ class OutputBuffers:
         # the small integer outputs share ONE buffer so that collect() needs a single device-to-host copy:
         # [ref_offsets i64 x (R+1)] [seg_counts i32 x R*k] [seg_order i32 x R*k]
         n_off, n_seg = 2 * (n_refs + 1), n_refs * k
-        self._meta = torch.zeros((n_off + 2 * n_seg + 2,), dtype=torch.int32, device=device)
+        self._meta = torch.zeros((n_off + 2 * n_seg + 3,), dtype=torch.int32, device=device)
         self._meta[n_off + n_seg:n_off + 2 * n_seg].fill_(-1)
         self.ref_offsets = self._meta[:n_off].view(torch.int64)
         self.seg_counts = self._meta[n_off:n_off + n_seg].view(n_refs, k)
         self.seg_order = self._meta[n_off + n_seg:n_off + 2 * n_seg].view(n_refs, k)
-        self.sel_info = self._meta[n_off + 2 * n_seg:]           # lfd_triangulate_sampled: {cells selected, selection status}
+        self.sel_info = self._meta[n_off + 2 * n_seg:]           # lfd_triangulate_sampled: {cells selected, selection status, launch status}
         self._n_refs, self._k = n_refs, k
         self.c = lfd_points(xyz=self.xyz.data_ptr(), rgb=self.rgb.data_ptr(), err=self.err.data_ptr(),
                             cell=self.cell.data_ptr() if with_cell else None,
@@ -361,7 +362,8 @@ class OutputBuffers:
             cell=self.cell[:n] if self.cell is not None else None, slot=self.slot[:n] if self.slot is not None else None,
             ref_offsets=offs, seg_counts=meta[n_off:n_off + n_seg].reshape(self._n_refs, self._k).copy(),
             seg_order=meta[n_off + n_seg:n_off + 2 * n_seg].reshape(self._n_refs, self._k).copy() if indexed else None,
-            n_selected=int(meta[n_off + 2 * n_seg]), _packed=self._f, _cap=max(self.capacity, 1))
+            n_selected=int(meta[n_off + 2 * n_seg]), launch_status=int(meta[n_off + 2 * n_seg + 2]), _packed=self._f,
+            _cap=max(self.capacity, 1))
 
 
 
@@ -538,8 +540,11 @@ class HipDensifier:
                             tiles: int = 24, s_override: float = 0.0, with_cell: bool = True) -> TriangulationOutput:
         out = OutputBuffers(int(M) + int(tiles) * int(tiles) + 64, 1, batch.k, self.device, with_cell)
         self.launch_sampled(batch, params, M, out, cap, border, tiles, s_override)
-        self.check_launches()
-        return out.collect(indexed=True, check_selection=True)
+        with torch.cuda.stream(self.stream):                       # the read-back is ordered after the launch on ITS stream
+            res = out.collect(indexed=True, check_selection=True)  # one copy: counts, selection status, launch status
+        if res.launch_status != 0:
+            self.check_launches()                                  # resets the device word and raises
+        return res
 
     # -- convenience wrappers (synchronising) -------------------------------------------------------------
     def aggregate(self, batch: PreparedBatch, params: lfd_params):

@@ -698,6 +698,8 @@ int lfd_triangulate_sampled(lfd_context* ctx, const lfd_batch* batch, const lfd_
                        static_cast<const long long*>(cells), static_cast<const long long*>(sel_offsets), static_cast<float*>(ctx->scratch.ptr),
                        static_cast<uint8_t*>(ctx->codes.ptr), seg_order, static_cast<const unsigned*>(tab));
     LFD_HIP(ctx, hipGetLastError());
+    // the look-back status word of this launch rides along with the counts: one read-back tells the caller everything
+    LFD_HIP(ctx, hipMemcpyAsync(sel_info + 2, static_cast<unsigned char*>(ctx->ws.ptr) + 8, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
     return LFD_OK;
 }
 
