@@ -588,7 +588,13 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
         int n_wg = LFD_SELECT_DEFAULT_WG;
         if (const char* e = std::getenv("LFD_SELECT_WORKGROUPS")) n_wg = std::atoi(e);
         n_wg = std::min(std::min(n_wg, (int)LFD_SELECT_MAX_WG), (int)(N / 8192));
-        if (n_wg >= 2 && !timing) {
+        {
+            const int tile = std::max(1, W / tiles);
+            const long long nbins = (long long)((W - 1) / tile + 1) * ((H - 1) / tile + 1);
+            if (nbins > LFD_SELECT_MAX_BINS) return fail(ctx, LFD_ERR_INVALID, "selection: too many coverage bins");
+        }
+        const bool timing_mw = timing && std::atoi(std::getenv("LFD_SELECT_TIMING")) == 2;     // 2: stamps of workgroup 0 of the multi-workgroup kernel
+        if (n_wg >= 2 && (!timing || timing_mw)) {
             A.coop = base + o_coop;
             A.n_wg = n_wg;
             LFD_HIP(ctx, hipMemsetAsync(base + o_coop, 0, 64, ctx->stream));       // barrier words and flags
@@ -625,7 +631,8 @@ static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int3
         unsigned long long t[32];
         LFD_HIP(ctx, hipMemcpy(t, d_time, sizeof(t), hipMemcpyDeviceToHost));
         fprintf(stderr, "[lfd] select phases (us):");
-        for (int i = 1; i < 32 && t[i]; ++i) fprintf(stderr, " %.1f", (double)(t[i] - t[i - 1]) * 0.01);
+        for (int i = 1; i < 30 && t[i]; ++i) fprintf(stderr, " %.1f", (double)(t[i] - t[i - 1]) * 0.01);
+        if (t[30]) fprintf(stderr, " | stream workgroup: start +%.1f, first draws ready +%.1f", (double)((long long)t[30] - (long long)t[0]) * 0.01, (double)((long long)t[31] - (long long)t[0]) * 0.01);
         fprintf(stderr, "\n");
     }
     if (host[1] != LFD_SELECT_OK)

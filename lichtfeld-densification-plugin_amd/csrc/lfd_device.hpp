@@ -97,6 +97,7 @@ struct LfdLaunch {              // kernel argument, passed by value
 // shared scratch of the multi-workgroup selection kernel (byte offsets)
 #define LFD_COOP_BAR 0               // u32 arrivals, u32 generation
 #define LFD_COOP_FLAGS 16            // i32 nz, inexact, negative, nan
+#define LFD_COOP_MSG 32              // u32 draws_ready (round whose draws are in place), u32 go (1 commit / 2 abort), u64 request {round << 32 | need}, round 0xffffffff = done
 #define LFD_COOP_PART 64             // f64 [MAX_WG] partial sums of the weights
 #define LFD_COOP_SPAN (LFD_COOP_PART + 8 * LFD_SELECT_MAX_WG)                       // f64 [MAX_WG * 16] span sums of the live p
 #define LFD_COOP_WGCNT (LFD_COOP_SPAN + 8 * 16 * LFD_SELECT_MAX_WG)                 // i32 [MAX_WG + 1] per-workgroup counts of an ordered compaction

@@ -466,7 +466,8 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         const unsigned long long mine = s_bin[b];
         if (mine == 0ull) continue;
         int rank = 0;
-        for (int o = 0; o < nbins; ++o) rank += (s_bin[o] > mine);  // keys are distinct (they embed the cell index)
+#pragma unroll 8
+        for (int o = 0; o < nbins; ++o) rank += (s_bin[o] > mine);  // keys are distinct (they embed the cell index); unrolled: the LDS reads overlap
         if (rank < budget) mark[0xffffffffu - (unsigned)(mine & 0xffffffffull)] = 1;
     }
     __syncthreads();
@@ -557,40 +558,92 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     __shared__ double s_chunk[kSelBlock];
     __shared__ unsigned long long s_bin[LFD_SELECT_MAX_BINS];
     __shared__ double s_tab[16 * LFD_SELECT_MAX_WG];       // span sums, fetched once per round
+    __shared__ unsigned long long s_msg;
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wg = (int)blockIdx.x, G = A.n_wg, T = (int)gridDim.x;          // T = G + 1
+    const int wg = (int)blockIdx.x, G = A.n_wg;                               // grid = G compute workgroups + 1
     const bool rng_wg = wg == G;
     const int H = A.H, W = A.W, N = H * W;
     const float* cert = A.best_cert;
     float* wbuf = A.weights;
     double* cdf = A.cdf;
-    unsigned char* mark = A.mark;
+    unsigned char* mark = A.mark;          // bit 0: drawn (p = 0 from now on), bit 1: coverage pick
     unsigned* bar = reinterpret_cast<unsigned*>(A.coop + LFD_COOP_BAR);
     int* flags = reinterpret_cast<int*>(A.coop + LFD_COOP_FLAGS);
+    unsigned* msg_ready = reinterpret_cast<unsigned*>(A.coop + LFD_COOP_MSG);
+    unsigned* msg_go = msg_ready + 1;
+    unsigned long long* msg_req = reinterpret_cast<unsigned long long*>(A.coop + LFD_COOP_MSG + 8);
     double* g_part = reinterpret_cast<double*>(A.coop + LFD_COOP_PART);
     double* g_span = reinterpret_cast<double*>(A.coop + LFD_COOP_SPAN);
     int* g_cnt = reinterpret_cast<int*>(A.coop + LFD_COOP_WGCNT);
     unsigned long long* g_bins = reinterpret_cast<unsigned long long*>(A.coop + LFD_COOP_BINS);
     unsigned* mt_spec = reinterpret_cast<unsigned*>(A.coop + LFD_COOP_MT);
-#define LFD_GRID_SYNC() do { if (!grid_barrier(bar, (unsigned)T)) { if (tid == 0) *A.status = LFD_SELECT_NO_PROGRESS; return; } } while (0)
-
-    if (wg == 0 && tid == 0) { *A.n_out = 0; *A.status = LFD_SELECT_OK; }
     const int size = min((int)((double)A.M * 0.85), N);           // int(M * 0.85), f64 product like Python
+
+    // ================= the workgroup on the MT19937 stream =================
+    // It never meets the others at a barrier: the first round's draws are generated on a copy of the state while the others
+    // stream the map; whether they count (upstream's argument checks) and what later rounds need arrives as messages.
+    if (rng_wg) {
+        if (A.timing && tid == 0) A.timing[30] = wall_clock64();
+        for (int i = tid; i < 625; i += kSelBlock) mt_spec[i] = A.mt[i];
+        __syncthreads();
+        mt_fill_doubles(mt_spec, A.draws, size, tid);
+        if (tid == 0) { __threadfence(); __hip_atomic_store(msg_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (A.timing && tid == 0) A.timing[31] = wall_clock64();
+        unsigned round_done = 1;
+        while (true) {
+            if (tid == 0) {
+                unsigned long long m = 0ull;
+                unsigned spins = 0;
+                while (true) {
+                    const unsigned go = __hip_atomic_load(msg_go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (go == 2u) { m = ~0ull; break; }                         // refused input: the stream stays where it was
+                    if (go == 1u) {
+                        m = __hip_atomic_load(msg_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(m >> 32) > round_done) break;          // a new round, or 0xffffffff = finished
+                    }
+                    if (++spins > (1u << 22)) { m = ~0ull - 1ull; break; }      // the others never spoke: give up without committing
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                __threadfence();
+                s_msg = m;
+            }
+            __syncthreads();
+            const unsigned long long m = s_msg;
+            __syncthreads();
+            if (m == ~0ull || m == ~0ull - 1ull) return;
+            const unsigned round = (unsigned)(m >> 32);
+            if (round == 0xffffffffu) break;
+            mt_fill_doubles(mt_spec, A.draws, (int)(unsigned)m, tid);
+            round_done = round;
+            if (tid == 0) { __threadfence(); __hip_atomic_store(msg_ready, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+        for (int i = tid; i < 625; i += kSelBlock) A.mt[i] = mt_spec[i];       // the draws were consumed: commit the stream
+        return;
+    }
+
+    // ================= the compute workgroups =================
+#define LFD_GRID_SYNC() do { if (!grid_barrier(bar, (unsigned)G)) { if (tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; } } while (0)
+#define LFD_TELL_RNG(round, need) do { if (wg == 0 && tid == 0) { __threadfence(); __hip_atomic_store(msg_req, ((unsigned long long)(unsigned)(round) << 32) | (unsigned long long)(unsigned)(need), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } } while (0)
+    if (wg == 0 && tid == 0) { *A.n_out = 0; *A.status = LFD_SELECT_OK; }
+    int t_slot = 0;
+#define LFD_MW_STAMP() do { if (A.timing && wg == 0 && tid == 0 && t_slot < 30) A.timing[t_slot] = wall_clock64(); ++t_slot; } while (0)
+    LFD_MW_STAMP();
     // wave spans: span index s = wg * 16 + wave covers [s * span, (s + 1) * span), a multiple of 256 cells
     constexpr int nwaves = kSelBlock / 64;
     const int n_spans = G * nwaves;
     const int span = ((N + n_spans - 1) / n_spans + 255) & ~255;
     const int sidx = wg * nwaves + wave;
-    const int w_lo = rng_wg ? N : min(sidx * span, N), w_hi = rng_wg ? N : min(w_lo + span, N);
+    const int w_lo = min(sidx * span, N), w_hi = min(w_lo + span, N);
     const bool cert16 = (reinterpret_cast<uintptr_t>(cert) & 15u) == 0;
+    const int tile = max(1, W / A.tiles);
+    const int nbx = (W - 1) / tile + 1, nby = (H - 1) / tile + 1;
+    const int nbins = nbx * nby;                                  // <= LFD_SELECT_MAX_BINS (checked by the host)
+    const int T = G * kSelBlock;                                  // compute threads
+    const int gt = wg * kSelBlock + tid;
 
-    // ---- weights, exact sum, NaN check | first round's draws on a copy of the stream -----------------------------------
-    if (rng_wg) {
-        for (int i = tid; i < 625; i += kSelBlock) mt_spec[i] = A.mt[i];
-        __syncthreads();
-        mt_fill_doubles(mt_spec, A.draws, size, tid);
-    } else {
+    // ---- weights, exact sum, NaN check ------------------------------------------------------------------------------
+    {
         double acc = 0.0;
         int bad = 0;
 #pragma unroll 4
@@ -618,20 +671,31 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         const double wsum = block_sum_f64(acc, s_d, tid);
         const int any_bad = block_sum_i32(bad, s_i, tid);
         if (tid == 0) { g_part[wg] = wsum; if (any_bad) atomicOr(&flags[3], 1); }
+        if (wg == 0) for (int b = tid; b < LFD_SELECT_MAX_BINS; b += kSelBlock) g_bins[b] = 0ull;
+        for (int b = tid; b < nbins; b += kSelBlock) s_bin[b] = 0ull;
     }
+    LFD_MW_STAMP();
     LFD_GRID_SYNC();
+    LFD_MW_STAMP();
 
     double s64 = 0.0;
     for (int g = 0; g < G; ++g) s64 += g_part[g];                  // same order in every workgroup
     const float s32 = (A.s_override > 0.0f) ? A.s_override : (float)s64;
-    if (__hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (wg == 0 && tid == 0) *A.status = LFD_SELECT_NAN; return; }
-    if (!(s32 > 0.0f)) return;                                     // upstream: `if s <= 0: return empty` (the stream is not touched)
+    if (__hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_NAN; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        return;
+    }
+    if (!(s32 > 0.0f)) {                                           // upstream: `if s <= 0: return empty` (the stream is not touched)
+        if (wg == 0 && tid == 0) __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
 
-    // ---- p = (weights / s) as f32; exactness precondition; non-zero count; span sums; marks cleared -----------------------
-    if (!rng_wg) {
+    // ---- p = (weights / s) as f32; exactness precondition; non-zero count; span sums; marks and first-occurrence words
+    //      initialised; coverage bins (best cell of every tile bin, by weight, ties: lower index) -----------------------------
+    {
         int nz = 0, inexact = 0, neg = 0;
         double part = 0.0;
-#pragma unroll 4
+#pragma unroll 2
         for (int i = w_lo + 4 * lane; i < w_hi; i += 256) {
             float pf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (i + 3 < w_hi) {
@@ -639,14 +703,27 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
                 pf[0] = w4.x / s32; pf[1] = w4.y / s32; pf[2] = w4.z / s32; pf[3] = w4.w / s32;
                 *reinterpret_cast<float4*>(wbuf + i) = make_float4(pf[0], pf[1], pf[2], pf[3]);
                 *reinterpret_cast<unsigned*>(mark + i) = 0u;
+                *reinterpret_cast<int4*>(A.first + i) = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
             } else {
-                for (int e = 0; e < 4 && i + e < w_hi; ++e) { pf[e] = wbuf[i + e] / s32; wbuf[i + e] = pf[e]; mark[i + e] = 0; }
+                for (int e = 0; e < 4 && i + e < w_hi; ++e) { pf[e] = wbuf[i + e] / s32; wbuf[i + e] = pf[e]; mark[i + e] = 0; A.first[i + e] = 0x7fffffff; }
             }
+            int cur_bin = -1;
+            unsigned long long cur_key = 0ull;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (pf[e] > 0.0f) { ++nz; if (pf[e] < 1.862645149230957e-09f) inexact = 1; }   // 2^-29
+                if (pf[e] > 0.0f) {
+                    ++nz;
+                    if (pf[e] < 1.862645149230957e-09f) inexact = 1;   // 2^-29
+                    const int ii = i + e;
+                    const int y = ii / W, x = ii - y * W;
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(pf[e]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)ii);
+                    const int b = (x / tile) * nby + (y / tile);
+                    if (b == cur_bin) { cur_key = key > cur_key ? key : cur_key; }     // positive floats order like their bit patterns
+                    else { if (cur_bin >= 0) atomicMax(&s_bin[cur_bin], cur_key); cur_bin = b; cur_key = key; }
+                }
                 if (pf[e] < 0.0f) neg = 1;
             }
+            if (cur_bin >= 0) atomicMax(&s_bin[cur_bin], cur_key);
             part += ((double)pf[0] + (double)pf[1]) + ((double)pf[2] + (double)pf[3]);
         }
 #pragma unroll
@@ -654,40 +731,38 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         if (lane == 0) g_span[sidx] = part;
         nz = block_sum_i32(nz, s_i, tid);
         inexact = block_sum_i32(inexact, s_i, tid);
-        neg = block_sum_i32(neg, s_i, tid);
+        neg = block_sum_i32(neg, s_i, tid);                       // (its barriers also complete the LDS bins)
         if (tid == 0) { atomicAdd(&flags[0], nz); if (inexact) atomicOr(&flags[1], 1); if (neg) atomicOr(&flags[2], 1); }
-        if (wg == 0) for (int b = tid; b < LFD_SELECT_MAX_BINS; b += kSelBlock) g_bins[b] = 0ull;
+        for (int b = tid; b < nbins; b += kSelBlock) if (s_bin[b]) atomicMax(&g_bins[b], s_bin[b]);
     }
+    LFD_MW_STAMP();
     LFD_GRID_SYNC();
+    LFD_MW_STAMP();
     {
         const int nz = __hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int inexact = __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int neg = __hip_atomic_load(&flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int st = LFD_SELECT_OK;
         if (neg) st = LFD_SELECT_NEGATIVE; else if (nz < size) st = LFD_SELECT_FEWER_NONZERO; else if (inexact) st = LFD_SELECT_INEXACT;
-        if (st != LFD_SELECT_OK) { if (wg == 0 && tid == 0) *A.status = st; return; }
+        if (st != LFD_SELECT_OK) {
+            if (wg == 0 && tid == 0) { *A.status = st; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            return;
+        }
     }
-    if (rng_wg) for (int i = tid; i < 625; i += kSelBlock) A.mt[i] = mt_spec[i];      // the checks passed: the draws are consumed
+    if (wg == 0 && tid == 0) {      // the checks passed: the draws count
+        __hip_atomic_store(msg_req, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(msg_go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // ---- legacy choice(replace=False, p) -----------------------------------------------------------------------
     const int per = (N + kSelBlock - 1) / kSelBlock;              // run length of the coarse search table
-    int n_uniq = 0, n_marked = 0, guard = 0;
+    int n_uniq = 0, guard = 0;
     while (n_uniq < size) {
-        if (++guard > 64) { if (wg == 0 && tid == 0) *A.status = LFD_SELECT_NO_PROGRESS; return; }
+        if (++guard > 60) { if (wg == 0 && tid == 0) *A.status = LFD_SELECT_NO_PROGRESS; LFD_TELL_RNG(0xffffffffu, 0); return; }
         const int need = size - n_uniq;
-        if (rng_wg) {
-            if (guard > 1) mt_fill_doubles(A.mt, A.draws, need, tid);
-        } else {
-            for (int j = n_marked + wg * kSelBlock + tid; j < n_uniq; j += G * kSelBlock) {      // p[found] = 0
-                const int c = A.found[j];
-                mark[c] = 1;
-                atomicAdd(&g_span[c / span], -(double)wbuf[c]);                                    // exact, hence order-independent
-            }
-        }
-        n_marked = n_uniq;
-        LFD_GRID_SYNC();
+        const unsigned tag = (unsigned)(64 - guard) << 24;        // later rounds win the atomicMin below over stale words
         // cdf = cumsum(p) / cdf[-1] over this wave's span; the carry comes from the table of span sums
-        if (!rng_wg) {
+        {
             for (int i = tid; i < n_spans; i += kSelBlock) s_tab[i] = g_span[i];
             __syncthreads();
             double carry = 0.0, total = 0.0;
@@ -707,12 +782,12 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
                 if (full) {
                     const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
                     const unsigned m4 = *reinterpret_cast<const unsigned*>(mark + i);
-                    v0 = (m4 & 0xffu) ? 0.0 : (double)w4.x; v1 = (m4 & 0xff00u) ? 0.0 : (double)w4.y;
-                    v2 = (m4 & 0xff0000u) ? 0.0 : (double)w4.z; v3 = (m4 & 0xff000000u) ? 0.0 : (double)w4.w;
+                    v0 = (m4 & 0x1u) ? 0.0 : (double)w4.x; v1 = (m4 & 0x100u) ? 0.0 : (double)w4.y;
+                    v2 = (m4 & 0x10000u) ? 0.0 : (double)w4.z; v3 = (m4 & 0x1000000u) ? 0.0 : (double)w4.w;
                 } else {
-                    if (i < w_hi) v0 = mark[i] ? 0.0 : (double)wbuf[i];
-                    if (i + 1 < w_hi) v1 = mark[i + 1] ? 0.0 : (double)wbuf[i + 1];
-                    if (i + 2 < w_hi) v2 = mark[i + 2] ? 0.0 : (double)wbuf[i + 2];
+                    if (i < w_hi) v0 = (mark[i] & 1) ? 0.0 : (double)wbuf[i];
+                    if (i + 1 < w_hi) v1 = (mark[i + 1] & 1) ? 0.0 : (double)wbuf[i + 1];
+                    if (i + 2 < w_hi) v2 = (mark[i + 2] & 1) ? 0.0 : (double)wbuf[i + 2];
                 }
                 v1 += v0; v2 += v1; v3 += v2;
                 double v = v3;
@@ -733,108 +808,126 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
                 carry += __shfl(v, 63, 64);
             }
         }
+        LFD_MW_STAMP();
         LFD_GRID_SYNC();
-        // new = searchsorted(cdf, x, side="right"): every workgroup takes a share of the draws
+        LFD_MW_STAMP();
+    LFD_MW_STAMP();
+        // the draws of this round must be in place
+        {
+            if (tid == 0) {
+                unsigned spins = 0;
+                int ok = 1;
+                while (__hip_atomic_load(msg_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)guard) {
+                    if (++spins > (1u << 22)) { ok = 0; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                __threadfence();
+                s_i[0] = ok;
+            }
+            __syncthreads();
+            const int ok = s_i[0];
+            __syncthreads();
+            if (!ok) { if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
+        }
+        // new = searchsorted(cdf, x, side="right"); the first occurrence of a value is found with an atomicMin of the draw index
         s_chunk[tid] = cdf[min((tid + 1) * per, N) - 1];
         __syncthreads();
-        for (int j = wg * kSelBlock + tid; j < need; j += T * kSelBlock) {
+        for (int j = gt; j < need; j += T) {
             const double x = A.draws[j];
             int lo = 0, len = kSelBlock;
             while (len > 0) { const int half = len >> 1, mid = lo + half; if (s_chunk[mid] <= x) { lo = mid + 1; len -= half + 1; } else len = half; }
             const int b = min(lo * per, N);
-            lo = b; len = min(b + per, N) - b;
-            while (len > 0) { const int half = len >> 1, mid = lo + half; if (cdf[mid] <= x) { lo = mid + 1; len -= half + 1; } else len = half; }
+            lo = b;
+            int hi = min(b + per, N);
+            while (hi - lo > 0) { const int half = (hi - lo) >> 1, mid = lo + half; if (cdf[mid] <= x) lo = mid + 1; else hi = mid; }
             A.cand[j] = lo;
-            A.first[lo] = 0x7fffffff;
+            atomicMin(&A.first[lo], (int)(tag | (unsigned)j));
         }
+        if (guard == 1) {
+            // the coverage picks (the `budget` heaviest bins) are flagged now - bit 1 of the mark, which the cumulative sum ignores
+            const int budget = max(A.M - size, 1);
+            for (int b = tid; b < nbins; b += kSelBlock) s_bin[b] = g_bins[b];
+            __syncthreads();
+            // rank of a bin = bins with a larger key (keys are distinct: they embed the cell index); 32 threads per bin share the
+            // comparisons (one thread per bin walked the whole table: ~30 us of dependent LDS reads)
+            const int bpw = (nbins + G - 1) / G, b0 = wg * bpw;
+            for (int bl0 = 0; bl0 < bpw; bl0 += kSelBlock / 32) {
+                const int bl = bl0 + (tid >> 5), b = b0 + bl, sub = tid & 31;
+                const bool valid = bl < bpw && b < nbins;
+                const unsigned long long mine = valid ? s_bin[b] : 0ull;
+                int rank = 0;
+                if (mine != 0ull) for (int o = sub; o < nbins; o += 32) rank += (s_bin[o] > mine);
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) rank += __shfl_xor(rank, off, 32);
+                if (mine != 0ull && sub == 0 && rank < budget) mark[0xffffffffu - (unsigned)(mine & 0xffffffffull)] = 2;
+            }
+        }
+        LFD_MW_STAMP();
         LFD_GRID_SYNC();
-        for (int j = wg * kSelBlock + tid; j < need; j += T * kSelBlock) atomicMin(&A.first[A.cand[j]], j);
-        LFD_GRID_SYNC();
-        // first occurrence of every distinct value, in draw order: thread (wg, tid) owns the draws [g*c, (g+1)*c), g = wg*1024 + tid
+        LFD_MW_STAMP();
+    LFD_MW_STAMP();
+        // first occurrence of every distinct value, in draw order: thread g owns the draws [g*c, (g+1)*c)
         {
-            const int c = (need + T * kSelBlock - 1) / (T * kSelBlock);
-            const int gt = wg * kSelBlock + tid;
+            const int c = (need + T - 1) / T;
             const long long jl = (long long)gt * c;
             const int j_lo = (int)(jl < need ? jl : need), j_hi = min(j_lo + c, need);
             int cnt = 0;
             for (int j = j_lo; j < j_hi; ++j)
-                cnt += __hip_atomic_load(&A.first[A.cand[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == j;
+                cnt += __hip_atomic_load(&A.first[A.cand[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)(tag | (unsigned)j);
             int total;
             int pos = block_excl_scan_i32(cnt, s_i, tid, total);
             if (tid == 0) g_cnt[wg] = total;
+            LFD_MW_STAMP();
             LFD_GRID_SYNC();
+            LFD_MW_STAMP();
+        LFD_MW_STAMP();
+    LFD_MW_STAMP();
             int base = 0, appended = 0;
-            for (int g = 0; g < T; ++g) { const int v = g_cnt[g]; if (g < wg) base += v; appended += v; }
-            for (int j = j_lo; j < j_hi; ++j)
-                if (__hip_atomic_load(&A.first[A.cand[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == j) A.found[n_uniq + base + pos++] = A.cand[j];
-            n_uniq += appended;
-        }
-        LFD_GRID_SYNC();
-    }
-
-    // ---- tile coverage: best cell of every tile bin, bins by descending weight (ties: lower index) ----------
-    const int tile = max(1, W / A.tiles);
-    const int nbx = (W - 1) / tile + 1, nby = (H - 1) / tile + 1;
-    const int nbins = nbx * nby;
-    if (nbins > LFD_SELECT_MAX_BINS) { if (wg == 0 && tid == 0) *A.status = LFD_SELECT_TOO_MANY_BINS; return; }
-    for (int b = tid; b < nbins; b += kSelBlock) s_bin[b] = 0ull;
-    __syncthreads();
-    if (!rng_wg) {
-#pragma unroll 2
-        for (int i = w_lo + 4 * lane; i < w_hi; i += 256) {
-            int cur_bin = -1;
-            unsigned long long cur_key = 0ull;
-            for (int e = 0; e < 4 && i + e < w_hi; ++e) {
-                const float wv = wbuf[i + e];
-                if (wv > 0.0f) {
-                    const int ii = i + e;
-                    const int y = ii / W, x = ii - y * W;
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(wv) << 32) | (unsigned long long)(0xffffffffu - (unsigned)ii);
-                    const int b = (x / tile) * nby + (y / tile);
-                    if (b == cur_bin) { cur_key = key > cur_key ? key : cur_key; }     // positive floats order like their bit patterns
-                    else { if (cur_bin >= 0) atomicMax(&s_bin[cur_bin], cur_key); cur_bin = b; cur_key = key; }
+            for (int g = 0; g < G; ++g) { const int v = g_cnt[g]; if (g < wg) base += v; appended += v; }
+            if (n_uniq + appended < size) LFD_TELL_RNG(guard + 1, size - n_uniq - appended);      // next round's draws can start now
+            for (int j = j_lo; j < j_hi; ++j) {
+                const int cell = A.cand[j];
+                if (__hip_atomic_load(&A.first[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)(tag | (unsigned)j)) {
+                    A.found[n_uniq + base + pos++] = cell;
+                    mark[cell] = (unsigned char)(mark[cell] | 1);                                // p[found] = 0 from now on ...
+                    atomicAdd(&g_span[cell / span], -(double)wbuf[cell]);                      // ... exact, hence order-independent
                 }
             }
-            if (cur_bin >= 0) atomicMax(&s_bin[cur_bin], cur_key);
+            n_uniq += appended;
         }
-        __syncthreads();
-        for (int b = tid; b < nbins; b += kSelBlock) if (s_bin[b]) atomicMax(&g_bins[b], s_bin[b]);
+        LFD_MW_STAMP();
+        LFD_GRID_SYNC();
+        LFD_MW_STAMP();
+    LFD_MW_STAMP();
     }
-    LFD_GRID_SYNC();
-    {
-        const int budget = max(A.M - size, 1);
-        for (int b = tid; b < nbins; b += kSelBlock) s_bin[b] = g_bins[b];
-        __syncthreads();
-        for (int b = wg * kSelBlock + tid; b < nbins; b += T * kSelBlock) {
-            const unsigned long long mine = s_bin[b];
-            if (mine == 0ull) continue;
-            int rank = 0;
-            for (int o = 0; o < nbins; ++o) rank += (s_bin[o] > mine);  // keys are distinct (they embed the cell index)
-            if (rank < budget) mark[0xffffffffu - (unsigned)(mine & 0xffffffffull)] = 1;
-        }
-        for (int j = n_marked + wg * kSelBlock + tid; j < size; j += T * kSelBlock) mark[A.found[j]] = 1;
-    }
-    LFD_GRID_SYNC();
+    LFD_TELL_RNG(0xffffffffu, 0);                                  // the stream is final: the other workgroup commits it
+
     // ---- np.unique(concat): marked cells in ascending order; thread (wg, wave, lane) owns span/64 consecutive cells ------------
     {
         const int per_lane = span >> 6;                             // multiple of 4
         const int lo = min(w_lo + lane * per_lane, w_hi), hi = min(lo + per_lane, w_hi);
         int cnt = 0;
         for (int i = lo; i < hi; i += 4) {
-            if (i + 3 < hi) cnt += __popc(*reinterpret_cast<const unsigned*>(mark + i));      // marks are 0 or 1
-            else for (int e = 0; i + e < hi; ++e) cnt += mark[i + e];
+            if (i + 3 < hi) { const unsigned m = *reinterpret_cast<const unsigned*>(mark + i); cnt += __popc((m | (m >> 1)) & 0x01010101u); }
+            else for (int e = 0; i + e < hi; ++e) cnt += mark[i + e] != 0;
         }
         int total;
         int pos = block_excl_scan_i32(cnt, s_i, tid, total);
         if (tid == 0) g_cnt[wg] = total;
+        LFD_MW_STAMP();
         LFD_GRID_SYNC();
+        LFD_MW_STAMP();
+    LFD_MW_STAMP();
         int base = 0, all = 0;
-        for (int g = 0; g < T; ++g) { const int v = g_cnt[g]; if (g < wg) base += v; all += v; }
+        for (int g = 0; g < G; ++g) { const int v = g_cnt[g]; if (g < wg) base += v; all += v; }
         if ((long long)all > A.capacity) { if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_CAPACITY; *A.n_out = all; } return; }
         pos += base;
         if (cnt) for (int i = lo; i < hi; ++i) if (mark[i]) A.sel_out[pos++] = (long long)i;
         if (wg == 0 && tid == 0) { *A.n_out = all; if (A.sel_offsets_out) A.sel_offsets_out[1] = all; }
     }
+    LFD_MW_STAMP();
+#undef LFD_MW_STAMP
+#undef LFD_TELL_RNG
 #undef LFD_GRID_SYNC
 }
 
