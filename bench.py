@@ -331,7 +331,7 @@ def main():
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         value = total_pts * args.steps / elapsed
         line = {
-            "metric": "triangulated points/sec (dense fused filter+triangulate kernel), MipNeRF360 garden @fast",
+            "metric": "triangulated points/sec + pairs/sec, MipNeRF360 garden @fast, 1/2/4/8 GPU",     # BASELINE.json's metric; value = points/s, pairs_per_s beside it
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (+f64 Sampson/DLT solve)", "data": "synthetic",
@@ -339,7 +339,7 @@ def main():
                                    f"{args.refs} reference views x {args.k} neighbours resident per GPU, "
                                    f"default thresholds (certainty 0.2 / sampson 5.0 / reproj 0.8 / parallax 0.5 deg), "
                                    f"noise {args.noise_px} px, {args.outliers:.0%} outliers",
-                       "mode": "dense", "refs_per_gpu": args.refs, "neighbours": args.k, "grid": [H, W],
+                       "kernel": "fused dense filter+triangulate kernel (lfd_dense_kernel)", "mode": "dense", "refs_per_gpu": args.refs, "neighbours": args.k, "grid": [H, W],
                        "sharding": f"references round-robin over {world} rank(s)"},
             "pairs_per_s": args.refs * world * args.k * args.steps / elapsed,
             "cells_per_s": cells * world * args.steps / elapsed,
