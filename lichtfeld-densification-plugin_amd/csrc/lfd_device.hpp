@@ -20,7 +20,7 @@
 #endif
 #define LFD_DENSE_CPT 4         // consecutive grid cells per thread (one 16-byte certainty load per slot)
 #ifndef LFD_DENSE_WAVES_PER_SIMD
-#define LFD_DENSE_WAVES_PER_SIMD 4       // register budget of the fused kernel: 512/4 -> <=128 VGPRs
+#define LFD_DENSE_WAVES_PER_SIMD 7       // register budget of the fused kernel: 512/7 -> <=72 VGPRs (it needs 69-72)
 #endif
 #define LFD_INDEXED_BLOCK 1024  // one workgroup (16 waves) per reference in the indexed kernel
 #define LFD_INDEXED_EVAL_BLOCK 256   // cells per workgroup of the indexed-mode evaluation kernel
