@@ -191,3 +191,31 @@ def test_null_vector_degenerate_inputs_terminate():
     _, _, Vt = np.linalg.svd(A.astype(np.float64))
     xn = x / np.linalg.norm(x)
     assert min(np.linalg.norm(xn - Vt[-1]), np.linalg.norm(xn + Vt[-1])) < 1e-9
+
+
+def test_markstein_quotient_is_the_correctly_rounded_division():
+    """The selection kernels normalise the cumulative sum with q' = RN(q + r (a - b q)), r = RN(1/b), q = RN(a r)
+    instead of 262144 IEEE divisions per pass (csrc/lfd_select.hip).  That quotient must BE RN(a / b) - NumPy's
+    ``cdf /= cdf[-1]`` - for the operands that occur there: 0 <= a <= b, b = a sum of f32 probabilities near 1 or
+    below.  Checked in exact rational arithmetic."""
+    import random
+    from fractions import Fraction as F
+    rnd = random.Random(7)
+
+    def total():
+        c = rnd.random()
+        if c < 0.3:
+            return 1.0 + rnd.randint(-2000, 2000) * 2.0 ** -52 * rnd.randint(1, 1 << 20)
+        if c < 0.6:
+            return rnd.uniform(0.5, 1.0)
+        return rnd.uniform(1e-3, 1.0)
+    for _ in range(20000):
+        b = total()
+        a = min(rnd.random() * b, b)
+        if rnd.random() < 0.2:
+            a = min(float(F(rnd.randint(0, 1 << 52), 1 << 52)) * b, b)
+        r = float(F(1) / F(b))                       # RN(1/b)
+        q = a * r                                    # RN(a r)
+        rem = float(F(a) - F(b) * F(q))              # fma(-b, q, a): exact
+        q2 = float(F(q) + F(rem) * F(r))             # fma(rem, r, q): one rounding
+        assert q2 == float(F(a) / F(b)), (a, b)
