@@ -1,9 +1,10 @@
 // S: coverage sampling of the aggregated certainty map, on the device
 // (upstream core/sampling.py:8-53 = torch clamp/sum + legacy numpy.random.choice + argsort walk).
 //
-// One 1024-thread workgroup per reference view runs the whole selection: the problem is ~260k
-// weights and ~9k draws, far too small to need the whole chip, and a single workgroup keeps every
-// phase ordered with plain barriers.
+// Two kernels with identical results: lfd_select_filter_kernel runs the whole selection in one 1024-thread workgroup
+// (small maps, profiling); lfd_select_filter_mw_kernel shares the streaming passes, the searches and the ordered compactions
+// out over several workgroups that meet at grid barriers, with one more workgroup on the (sequential) MT19937 stream.  The
+// problem is ~260k weights and ~9k draws: latency and one CU's memory pipeline bound it, not the chip's bandwidth.
 //
 // Restated third-party algorithms (absent from /root/reference; NumPy 2.2.6 numpy/random/mtrand.pyx
 // `RandomState.choice(a, size, replace=False, p)` and `_legacy_seeding`, randomkit's MT19937):
