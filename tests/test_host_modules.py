@@ -180,3 +180,27 @@ def test_debug_state_blocks_until_stepped():
     st.set_single_match_mode(True)
     st.next_match(5)
     assert st.visible_match_indices(5) == [1]
+
+
+def test_host_arrays_slices_the_packed_buffer_like_three_copies():
+    """TriangulationOutput.host_arrays: one copy of the packed float buffer must yield what three separate copies of the
+    xyz / rgb / err views yield (layout [xyz cap*3][rgb cap*3][err cap])."""
+    import numpy as np
+    import torch
+    from lichtfeld_densification_plugin_amd.core import hip_backend as hb
+    cap, n = 37, 21
+    packed = torch.arange(cap * 7, dtype=torch.float32)
+    xyz, rgb, err = packed[:cap * 3].view(cap, 3), packed[cap * 3:cap * 6].view(cap, 3), packed[cap * 6:]
+    out = hb.TriangulationOutput(xyz=xyz[:n], rgb=rgb[:n], err=err[:n], cell=None, slot=None,
+                                 ref_offsets=np.array([0, n], np.int64), seg_counts=np.zeros((1, 3), np.int32),
+                                 _packed=packed, _cap=cap)
+    hx, hc, he = out.host_arrays()
+    np.testing.assert_array_equal(hx, xyz[:n].numpy())
+    np.testing.assert_array_equal(hc, rgb[:n].numpy())
+    np.testing.assert_array_equal(he, err[:n].numpy())
+    assert hx.flags["C_CONTIGUOUS"] and hc.flags["C_CONTIGUOUS"] and out.count == n
+    # without the packed buffer (or when it is large) the three views are copied one by one
+    out2 = hb.TriangulationOutput(xyz=xyz[:n], rgb=rgb[:n], err=err[:n], cell=None, slot=None,
+                                  ref_offsets=np.array([0, n], np.int64), seg_counts=np.zeros((1, 3), np.int32))
+    for a, b in zip(out2.host_arrays(), (hx, hc, he)):
+        np.testing.assert_array_equal(a, b)
