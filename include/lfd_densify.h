@@ -16,8 +16,10 @@
  * error code and records a message retrievable with lfd_last_error(); nothing aborts.  A context is
  * bound to one HIP device and one stream; use one context per thread (no hidden globals).
  *
- * There is no CPU implementation behind this interface: every entry point that computes needs a
- * GPU and fails with LFD_ERR_HIP when none is present.
+ * Every entry point that computes needs a GPU and fails with LFD_ERR_HIP when none is present; nothing falls back to
+ * the host.  The CPU twin at the end of this header (lfd_create_host + the *_host entry points: the host build of
+ * the same per-cell source over host arrays) is a separate, explicitly chosen interface for upstream's CPU-only
+ * configuration, for timing a CPU baseline and for parity checks.
  */
 #ifndef LFD_DENSIFY_H
 #define LFD_DENSIFY_H
@@ -28,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LFD_ABI_VERSION 1
+#define LFD_ABI_VERSION 2
 #define LFD_MAX_SLOTS 16 /* neighbours per reference handled by one launch */
 
 enum lfd_status {
@@ -50,8 +52,14 @@ typedef struct lfd_params {
     float reproj_thresh;    /* px (core/pipeline.py:745)                                             */
     float min_parallax_deg; /* degrees; <= 0 disables (core/pipeline.py:748)                         */
     int32_t no_filter;      /* keep every finite point (core/pipeline.py:739-743)                    */
-    int32_t reserved;
+    int32_t flags;          /* LFD_FLAG_* below, 0 = defaults                                        */
 } lfd_params;
+
+/* lfd_triangulate_dense blends the four colour taps in f32 by default (same taps, weights and order as upstream
+ * core/pipeline.py:661-679, within 2.5e-7 of upstream's f64 blend).  With this flag it runs upstream's f64
+ * arithmetic: rgb is then bit-identical to upstream's, at ~6 % more kernel time.  The upstream-equivalent entry
+ * points (lfd_triangulate_indexed / _sampled) always use the f64 form. */
+#define LFD_FLAG_EXACT_COLOUR 1
 
 /* One launch = n_refs reference views, each with up to k neighbour slots (slots [0, n_slots[r]) are
  * valid, in the order upstream's `nn_ids` lists the loaded neighbours).  Arrays marked "host" are
@@ -73,6 +81,13 @@ typedef struct lfd_batch {
     const uint8_t* const* mask_b; /* NULL, or host [n_refs*k] -> device u8 {0,1} [h_match*w_match] or NULL */
     const float* axis_x;          /* device f32 [W]: A-grid x of column j (torch.linspace(-1+1/W,1-1/W,W)); */
     const float* axis_y;          /* device f32 [H]; both NULL -> lfd_identity_axis() values. Used when warp_channels==2 */
+    const float* fundamental;     /* NULL, or host f32 [n_refs*k*9]: F of every (reference, slot) pair as upstream's
+                                   * fundamental_from_world2cam returns it (core/geometry.py:122-130, row-major), used instead of
+                                   * the F the library derives from the camera table.  The library's own F is built with the
+                                   * closed-form inverse of K (exactly 1/fx, -cx/fx ...) where upstream calls np.linalg.inv
+                                   * (LAPACK sgetrf/sgetri); the two agree to ~2e-6 relative, not bit for bit, which moves a
+                                   * Sampson value next to the threshold by ~1e-5.  A caller that already holds upstream's F
+                                   * (integration path B in INTEGRATION.md) passes it here and gets upstream's Sampson decisions. */
 } lfd_batch;
 
 /* Survivors.  Capacity is in points.  cell / slot are optional (NULL to skip). */
@@ -163,6 +178,11 @@ int lfd_pack_points3d(lfd_context* ctx, const float* xyz, const float* rgb, cons
                       uint64_t id_base, uint8_t* out);
 int lfd_quantise_rgb(lfd_context* ctx, const float* rgb, int64_t n, uint8_t* out);
 
+/* Debug / test read-back: the f64-widened fundamental matrices the kernels of the LAST prepared batch used, one
+ * row-major 3x3 per (reference, slot) pair (n_pairs = n_refs * k of that batch; rows of unused slots are unspecified).
+ * Synchronises the stream. */
+int lfd_get_pair_fundamental(lfd_context* ctx, int32_t n_pairs, double* F_out_host);
+
 /* Synchronise the context's stream and report whether the last launches completed normally.
  * *status_out = 0, or 1 when a bounded look-back spin gave up (results invalid; returns LFD_ERR_HIP). */
 int lfd_launch_status(lfd_context* ctx, int32_t* status_out);
@@ -188,6 +208,24 @@ int lfd_host_null_vector(const float* A16, double* out4);
 int lfd_host_eval_correspondence(const float* cam1, const float* cam2, float xa_norm, float ya_norm,
                                  float xb_norm, float yb_norm, int32_t w_match, int32_t h_match,
                                  const lfd_params* params, float* out8);
+
+/* ---- CPU twin ------------------------------------------------------------------ */
+/* The same three steps on the host: EVERY pointer of lfd_batch / lfd_points / the arguments below is a HOST pointer.
+ * The per-cell arithmetic is the host build of the very source the kernels compile (csrc/lfd_geometry.hpp; IEEE
+ * division / square root where the device uses the 1-ulp v_rcp / v_sqrt), spread over n_threads std::threads
+ * (<= 0: all hardware threads).  A host context accepts lfd_upload_cameras, lfd_last_error, lfd_destroy and the
+ * three *_host calls; every device entry point refuses it with LFD_ERR_STATE, and the *_host calls refuse a device
+ * context: neither side ever stands in for the other.  Semantics (orders, counts, optional outputs, LFD_ERR_CAPACITY
+ * with valid counts) are those of lfd_aggregate / lfd_triangulate_dense / lfd_triangulate_indexed. */
+int lfd_create_host(int32_t n_threads, lfd_context** out);
+int lfd_host_threads(const lfd_context* ctx); /* threads a host context uses (0 for a device context) */
+int lfd_aggregate_host(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, float* best_cert,
+                       uint8_t* best_slot);
+int lfd_triangulate_dense_host(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params,
+                               const lfd_points* out, int64_t* ref_offsets, int32_t* seg_counts);
+int lfd_triangulate_indexed_host(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params,
+                                 const int64_t* sel_idx, const int64_t* sel_offsets, const lfd_points* out,
+                                 int64_t* ref_offsets, int32_t* seg_counts, int32_t* seg_order);
 
 #ifdef __cplusplus
 }

@@ -1,13 +1,24 @@
-"""Live match-preview store shared between the pipeline thread and the GUI (upstream
-core/debug_viz.py:12-161).  The pipeline only needs ``is_enabled / is_auto_step / set_total_pairs /
-submit_preview / release_waiters``; ``submit_preview`` blocks the pipeline thread while manual
-stepping is active."""
+"""What the pipeline needs from the host's match-debug object, and nothing else.
+
+Upstream's GUI owns a ``MatchDebugState`` (core/debug_viz.py:29-161 there) with list cursors, history and
+visibility controls for its panel; that is GUI state and out of scope here.
+``run_dense_pipeline`` only ever calls five methods on whatever object it is handed:
+
+    is_enabled()  is_auto_step()  set_total_pairs(n)  submit_preview(MatchPreview)  release_waiters()
+
+so the host's own object is accepted as it is (duck typing).  ``PreviewGate`` below is the small
+stand-alone implementation of those five calls for callers without a GUI (the tests, scripts): a
+one-slot mailbox with an optional turnstile - when manual stepping is on, ``submit_preview`` parks the
+producer until the consumer calls ``step_once()`` (upstream's panel does the same to the pipeline thread).
+
+``MatchPreview`` is the record handed over; its field names are what upstream's panel reads
+(core/debug_viz.py:12-26 there).
+"""
 from __future__ import annotations
 
 import threading
-from collections import deque
 from dataclasses import dataclass
-from typing import Deque, List, Optional
+from typing import Optional
 
 import numpy as np
 
@@ -27,121 +38,73 @@ class MatchPreview:
     total_pairs: int
 
 
-class MatchDebugState:
-    def __init__(self, max_history: int = 4) -> None:
-        self._lock = threading.Lock()
-        self._go = threading.Event()
-        self._go.set()
-        self._enabled = False
-        self._auto = True
-        self._latest: Optional[MatchPreview] = None
-        self._history: Deque[MatchPreview] = deque(maxlen=max_history)
-        self._total_pairs = 0
-        self._max_visible = 0
-        self._single = False
-        self._cursor = 0
+class PreviewGate:
+    """One-slot mailbox + turnstile.  Thread-safe; every wait is on one condition variable."""
 
-    # -- switches -------------------------------------------------------------------------------
-    def set_enabled(self, enabled: bool) -> None:
-        with self._lock:
-            self._enabled = bool(enabled)
-            if not enabled:
-                self._history.clear()
-                self._latest = None
-                self._auto = True
-                self._go.set()
+    def __init__(self) -> None:
+        self._cv = threading.Condition()
+        self._on = False
+        self._manual = False          # True: every submitted preview waits for a step
+        self._slot: Optional[MatchPreview] = None
+        self._pairs = 0
+        self._tickets = 0             # steps granted so far
+        self._open = False            # release_waiters(): nobody waits any more
 
+    # -- the five calls of the pipeline ---------------------------------------------------------------
     def is_enabled(self) -> bool:
-        with self._lock:
-            return self._enabled
-
-    def set_auto_step(self, auto: bool) -> None:
-        with self._lock:
-            self._auto = bool(auto)
-            if auto:
-                self._go.set()
+        with self._cv:
+            return self._on
 
     def is_auto_step(self) -> bool:
-        with self._lock:
-            return self._auto
+        with self._cv:
+            return not self._manual
 
     def set_total_pairs(self, total: int) -> None:
-        with self._lock:
-            self._total_pairs = max(0, int(total))
+        with self._cv:
+            self._pairs = int(total) if total > 0 else 0
 
-    def total_pairs(self) -> int:
-        with self._lock:
-            return self._total_pairs
-
-    # -- producer / consumer ------------------------------------------------------------------------
     def submit_preview(self, preview: MatchPreview) -> None:
-        with self._lock:
-            if not self._enabled:
+        with self._cv:
+            if not self._on:
                 return
-            self._latest = preview
-            self._history.append(preview)
-            auto = self._auto
-        if not auto:
-            self._go.clear()
-            self._go.wait()
-
-    def step_once(self) -> None:
-        self._go.set()
+            self._slot = preview
+            if not self._manual or self._open:
+                return
+            want = self._tickets + 1
+            self._cv.wait_for(lambda: self._tickets >= want or self._open or not self._manual or not self._on)
 
     def release_waiters(self) -> None:
-        self._go.set()
+        with self._cv:
+            self._open = True
+            self._cv.notify_all()
+
+    # -- consumer side --------------------------------------------------------------------------------
+    def set_enabled(self, enabled: bool) -> None:
+        with self._cv:
+            self._on = bool(enabled)
+            if not self._on:
+                self._slot = None
+                self._manual = False
+            self._cv.notify_all()
+
+    def set_auto_step(self, auto: bool) -> None:
+        with self._cv:
+            self._manual = not bool(auto)
+            self._cv.notify_all()
+
+    def step_once(self) -> None:
+        with self._cv:
+            self._tickets += 1
+            self._cv.notify_all()
 
     def latest(self) -> Optional[MatchPreview]:
-        with self._lock:
-            return self._latest
+        with self._cv:
+            return self._slot
 
-    def history(self) -> List[MatchPreview]:
-        with self._lock:
-            return list(self._history)
+    def total_pairs(self) -> int:
+        with self._cv:
+            return self._pairs
 
-    # -- which matches the panel draws ----------------------------------------------------------------
-    def set_max_visible_matches(self, n: int) -> None:
-        with self._lock:
-            self._max_visible = max(0, int(n))
 
-    def max_visible_matches(self) -> int:
-        with self._lock:
-            return self._max_visible
-
-    def set_single_match_mode(self, enabled: bool) -> None:
-        with self._lock:
-            self._single = bool(enabled)
-            if enabled:
-                self._cursor = 0
-
-    def is_single_match_mode(self) -> bool:
-        with self._lock:
-            return self._single
-
-    def current_match_index(self) -> int:
-        with self._lock:
-            return self._cursor
-
-    def set_current_match_index(self, idx: int) -> None:
-        with self._lock:
-            self._cursor = max(0, int(idx))
-
-    def next_match(self, total: int) -> None:
-        with self._lock:
-            if total > 0:
-                self._cursor = (self._cursor + 1) % total
-
-    def prev_match(self, total: int) -> None:
-        with self._lock:
-            if total > 0:
-                self._cursor = (self._cursor - 1) % total
-
-    def visible_match_indices(self, total: int) -> List[int]:
-        with self._lock:
-            if total <= 0:
-                return []
-            if self._single:
-                return [min(self._cursor, total - 1)]
-            if self._max_visible <= 0 or self._max_visible >= total:
-                return list(range(total))
-            return list(range(self._max_visible))
+# the name the upstream entry points use in their signatures (densify.py:148-153,248-255 there)
+MatchDebugState = PreviewGate

@@ -45,24 +45,48 @@ def _collective_device(t: torch.Tensor, dist, group=None) -> torch.device:
     return torch.device("cpu") if "gloo" in backend else t.device
 
 
+def _all_gather_rows(mine: torch.Tensor, world: int, dist, group=None) -> torch.Tensor:
+    """``[world, rows, cols]`` from every rank's ``[rows, cols]`` with ONE collective into ONE pre-sized buffer
+    (``all_gather_into_tensor``); backends without it take the list form."""
+    out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+    try:
+        dist.all_gather_into_tensor(out.view(-1), mine.reshape(-1), group=group)
+    except (RuntimeError, NotImplementedError, AttributeError):
+        dist.all_gather([out[r] for r in range(world)], mine, group=group)
+    return out
+
+
 def all_gather_points(xyz: torch.Tensor, rgb: torch.Tensor, err: torch.Tensor, dist, group=None
                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, List[int]]:
-    """Concatenate every rank's survivors in rank order.  Returns (xyz, rgb, err, counts)."""
+    """Concatenate every rank's survivors in rank order.  Returns (xyz, rgb, err, counts).
+
+    Two collectives: the counts (8 B per rank), then the survivors packed 28 B per point and padded to the largest
+    rank's count, gathered into one ``[world, rows, 7]`` buffer.  Under RCCL the tensors never leave the device."""
     world = dist.get_world_size(group)
     home = xyz.device
     dev = _collective_device(xyz, dist, group)
     xyz, rgb, err = xyz.to(dev), rgb.to(dev), err.to(dev)
     n_local = torch.tensor([xyz.shape[0]], dtype=torch.int64, device=dev)
-    counts_t = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts_t, n_local, group=group)
-    counts = [int(c.item()) for c in counts_t]
+    counts = [int(c) for c in _all_gather_rows(n_local, world, dist, group).reshape(-1).tolist()]
     rows = max(max(counts), 1)
-    mine = _pack(xyz, rgb, err, rows)
-    bufs = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(bufs, mine, group=group)
-    cat = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0) if sum(counts) else mine[:0]
+    gathered = _all_gather_rows(_pack(xyz, rgb, err, rows), world, dist, group)
+    cat = torch.cat([gathered[r, :c] for r, c in enumerate(counts)], dim=0) if sum(counts) else gathered[0, :0]
     cat = cat.to(home)
     return cat[:, 0:3].contiguous(), cat[:, 3:6].contiguous(), cat[:, 6].contiguous(), counts
+
+
+def agree_on_status(local_code: int, dist, device=None, group=None) -> int:
+    """MAX over the ranks of a small status code (0 = fine).  Called before the final exchange so that a rank that was
+    cancelled or failed does not leave the others blocked in the collective: every rank learns the worst status and
+    raises the same exception."""
+    try:
+        backend = str(dist.get_backend(group)).lower()
+    except Exception:
+        backend = "nccl"
+    dev = torch.device("cpu") if ("gloo" in backend or device is None) else device
+    t = torch.tensor([int(local_code)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
 
 
 def all_gather_by_reference(xyz: torch.Tensor, rgb: torch.Tensor, err: torch.Tensor,
@@ -86,9 +110,7 @@ def all_gather_by_reference(xyz: torch.Tensor, rgb: torch.Tensor, err: torch.Ten
         local[:len(ref_counts)] = torch.as_tensor(list(ref_counts), dtype=torch.int64, device=dev)
     if int(local.sum().item()) != xyz.shape[0]:
         raise ValueError("ref_counts do not add up to the number of local points")
-    tables = [torch.zeros_like(local) for _ in range(world)]
-    dist.all_gather(tables, local, group=group)
-    table = torch.stack(tables, 0).cpu().numpy()                  # [world, per_rank]
+    table = _all_gather_rows(local, world, dist, group).cpu().numpy()                  # [world, per_rank]
     gx, gc, ge, counts = all_gather_points(xyz, rgb, err, dist, group)
     rank_base = np.concatenate([[0], np.cumsum(counts)])[:-1]
     within = np.concatenate([np.zeros((world, 1), np.int64), np.cumsum(table, axis=1)], axis=1)

@@ -18,6 +18,8 @@ import torch
 from .types import CameraRecord, DensePipelineConfig
 
 LFD_MAX_SLOTS = 16
+LFD_ABI_VERSION = 2
+LFD_FLAG_EXACT_COLOUR = 1     # lfd_params.flags: dense mode blends colours with upstream's f64 arithmetic (bit-identical rgb)
 _LIB_NAME = "liblfd_densify.so"
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -26,10 +28,16 @@ class HipBackendError(RuntimeError):
     """Raised for any non-zero status of the HIP library (message from ``lfd_last_error``)."""
 
 
+class SelectionInexact(HipBackendError):
+    """The device selection met a normalised weight below 2^-29 (LFD_SELECT_INEXACT): its exact parallel cumulative sum
+    is not guaranteed for such input, so it refused - WITHOUT consuming the MT19937 stream.  The caller runs the host
+    stage (core/sampling.py) on the same map with the device's stream state instead (core/pipeline.py does)."""
+
+
 class lfd_params(C.Structure):
     _fields_ = [("sampson_thresh", C.c_double), ("certainty_thresh", C.c_float), ("sample_cap", C.c_float),
                 ("reproj_thresh", C.c_float), ("min_parallax_deg", C.c_float), ("no_filter", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("flags", C.c_int32)]
 
 
 class lfd_batch(C.Structure):
@@ -38,7 +46,7 @@ class lfd_batch(C.Structure):
                 ("ref_cam", C.POINTER(C.c_int32)), ("n_slots", C.POINTER(C.c_int32)), ("nbr_cam", C.POINTER(C.c_int32)),
                 ("cert", C.POINTER(C.c_void_p)), ("warp", C.POINTER(C.c_void_p)), ("image", C.POINTER(C.c_void_p)),
                 ("mask_a", C.POINTER(C.c_void_p)), ("mask_b", C.POINTER(C.c_void_p)),
-                ("axis_x", C.c_void_p), ("axis_y", C.c_void_p)]
+                ("axis_x", C.c_void_p), ("axis_y", C.c_void_p), ("fundamental", C.POINTER(C.c_float))]
 
 
 class lfd_points(C.Structure):
@@ -91,11 +99,20 @@ def load_library() -> C.CDLL:
     lib.lfd_pack_points3d.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]
     lib.lfd_quantise_rgb.argtypes = [ctxp, C.c_void_p, C.c_int64, C.c_void_p]
     lib.lfd_launch_status.argtypes = [ctxp, C.POINTER(C.c_int32)]
+    lib.lfd_get_pair_fundamental.argtypes = [ctxp, C.c_int32, C.POINTER(C.c_double)]
     lib.lfd_rng_seed.argtypes = [ctxp, C.c_uint32]
     lib.lfd_rng_get_state.argtypes = [ctxp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
     lib.lfd_rng_set_state.argtypes = [ctxp, C.POINTER(C.c_uint32), C.c_int32]
     lib.lfd_select_samples.argtypes = [ctxp, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32,
                                        C.c_float, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.lfd_create_host.argtypes = [C.c_int32, C.POINTER(ctxp)]
+    lib.lfd_host_threads.argtypes = [ctxp]
+    lib.lfd_host_threads.restype = C.c_int
+    lib.lfd_aggregate_host.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p, C.c_void_p]
+    lib.lfd_triangulate_dense_host.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.POINTER(lfd_points),
+                                               C.c_void_p, C.c_void_p]
+    lib.lfd_triangulate_indexed_host.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p,
+                                                 C.POINTER(C.c_int64), C.POINTER(lfd_points), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.lfd_identity_axis.argtypes = [C.c_int32, fptr]
     lib.lfd_parallax_dot_threshold.argtypes = [C.c_float]
     lib.lfd_parallax_dot_threshold.restype = C.c_float
@@ -107,18 +124,23 @@ def load_library() -> C.CDLL:
     for name in ("lfd_create", "lfd_set_stream", "lfd_upload_cameras", "lfd_aggregate", "lfd_triangulate_dense",
                  "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
                  "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_identity_axis",
-                 "lfd_host_fundamental",
+                 "lfd_host_fundamental", "lfd_get_pair_fundamental", "lfd_create_host", "lfd_aggregate_host",
+                 "lfd_triangulate_dense_host", "lfd_triangulate_indexed_host",
                  "lfd_host_eval_correspondence"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
 
 
-def make_params(config: DensePipelineConfig, sample_cap: float = 0.9) -> lfd_params:
+def make_params(config: DensePipelineConfig, sample_cap: float = 0.9, exact_colour: Optional[bool] = None) -> lfd_params:
+    """``exact_colour``: dense mode blends colours in f64 like upstream (bit-identical rgb) instead of f32 (within 2.5e-7);
+    default: the configuration's ``exact_colour`` field (False)."""
+    if exact_colour is None:
+        exact_colour = bool(getattr(config, "exact_colour", False))
     return lfd_params(sampson_thresh=float(config.sampson_thresh), certainty_thresh=float(config.certainty_thresh),
                       sample_cap=float(sample_cap), reproj_thresh=float(config.reproj_thresh),
                       min_parallax_deg=float(config.min_parallax_deg), no_filter=1 if config.no_filter else 0,
-                      reserved=0)
+                      flags=LFD_FLAG_EXACT_COLOUR if exact_colour else 0)
 
 
 def _f32(a) -> np.ndarray:
@@ -149,6 +171,20 @@ def host_fundamental(K1, R1, t1, K2, R2, t2) -> np.ndarray:
     if rc != 0:
         raise HipBackendError("lfd_host_fundamental failed")
     return out.reshape(3, 3)
+
+
+def fundamental_from_world2cam(K1, R1, t1, K2, R2, t2) -> np.ndarray:
+    """Upstream's ``fundamental_from_world2cam`` (core/geometry.py:122-130 with ``skew`` :53-55): the same NumPy
+    calls in the same order on the same f32 arrays (``np.linalg.inv`` is LAPACK sgetrf/sgetri), so the result is
+    upstream's F bit for bit on the same machine.  Handed to the kernels through ``lfd_batch.fundamental``."""
+    K1, R1, K2, R2 = (np.asarray(a, np.float32) for a in (K1, R1, K2, R2))
+    t1, t2 = np.asarray(t1, np.float32).reshape(3, 1), np.asarray(t2, np.float32).reshape(3, 1)
+    R = R2 @ R1.T
+    t = (t2 - R @ t1).reshape(3)
+    tx, ty, tz = t
+    cross = np.array([[0, -tz, ty], [tz, 0, -tx], [-ty, tx, 0]], dtype=np.float32)
+    E = cross @ R
+    return np.linalg.inv(K2).T @ E @ np.linalg.inv(K1)
 
 
 def host_null_vector(A) -> "tuple[np.ndarray, int]":
@@ -192,6 +228,7 @@ class ReferenceInputs:
     image: torch.Tensor                       # (h_match,w_match,3) u8
     mask_a: Optional[torch.Tensor] = None     # (h_match,w_match) u8 {0,1}
     mask_b: Optional[List[Optional[torch.Tensor]]] = None
+    fundamental: Optional[Sequence[np.ndarray]] = None   # per slot (3,3) f32: upstream's F for the pair (see PreparedBatch)
 
 
 @dataclasses.dataclass
@@ -228,7 +265,10 @@ class PreparedBatch:
     """ctypes view of a list of ReferenceInputs; keeps the tensors alive."""
 
     def __init__(self, refs: Sequence[ReferenceInputs], w_match: int, h_match: int,
-                 axes: Optional[Sequence[torch.Tensor]] = None):
+                 axes: Optional[Sequence[torch.Tensor]] = None, cameras: Optional[Sequence[CameraRecord]] = None):
+        """``cameras``: the run's camera records; when given, every pair's fundamental matrix is computed on the host
+        with upstream's own NumPy calls (``fundamental_from_world2cam``) and handed to the library, so the Sampson gate
+        sees upstream's F bit for bit.  A reference that carries its own ``fundamental`` list keeps it."""
         if not refs:
             raise ValueError("empty batch")
         self.refs = list(refs)
@@ -265,6 +305,20 @@ class PreparedBatch:
                 self.warp[s] = self._chk(r.warp[j], torch.float32, (H, W, ch), "warp").data_ptr()
                 if r.mask_b is not None and r.mask_b[j] is not None:
                     self.mask_b[s] = self._chk(r.mask_b[j], torch.uint8, (h_match, w_match), "mask_b").data_ptr()
+        self.fundamental = None
+        if cameras is not None or any(r.fundamental is not None for r in self.refs):
+            fund = np.zeros((n * k, 9), np.float32)
+            for i, r in enumerate(self.refs):
+                for j in range(len(r.cert)):
+                    if r.fundamental is not None:
+                        F = np.asarray(r.fundamental[j], np.float32)
+                    elif cameras is not None:
+                        a, b = cameras[int(r.ref_cam)], cameras[int(r.nbr_cams[j])]
+                        F = fundamental_from_world2cam(a.K, a.R, a.t, b.K, b.R, b.t)
+                    else:
+                        raise ValueError("fundamental matrices must be given for every reference of a batch or for none")
+                    fund[i * k + j] = np.asarray(F, np.float32).reshape(9)
+            self.fundamental = np.ascontiguousarray(fund)
         self.axes = None
         if axes is not None:
             ax = self._chk(axes[0], torch.float32, (W,), "axis_x")
@@ -273,6 +327,7 @@ class PreparedBatch:
         vp = C.POINTER(C.c_void_p)
         self.c = lfd_batch(
             n_refs=n, k=k, H=int(H), W=int(W), w_match=int(w_match), h_match=int(h_match), warp_channels=ch, reserved=0,
+            fundamental=self.fundamental.ctypes.data_as(C.POINTER(C.c_float)) if self.fundamental is not None else None,
             ref_cam=C.cast(self.ref_cam, C.POINTER(C.c_int32)), n_slots=C.cast(self.n_slots, C.POINTER(C.c_int32)),
             nbr_cam=C.cast(self.nbr_cam, C.POINTER(C.c_int32)), cert=C.cast(self.cert, vp), warp=C.cast(self.warp, vp),
             image=C.cast(self.image, vp), mask_a=C.cast(self.mask_a, vp) if self.mask_a is not None else None,
@@ -280,8 +335,9 @@ class PreparedBatch:
             axis_x=self.axes[0].data_ptr() if self.axes else None, axis_y=self.axes[1].data_ptr() if self.axes else None)
 
     def _chk(self, t: torch.Tensor, dtype, shape, what: str) -> torch.Tensor:
-        if not isinstance(t, torch.Tensor) or not t.is_cuda:
-            raise ValueError(f"{what} must be a device tensor (the HIP path consumes RoMa's outputs in place)")
+        if not isinstance(t, torch.Tensor) or t.device != self.device:
+            raise ValueError(f"{what} must be a tensor on {self.device} (the path consumes RoMa's outputs in place, "
+                             "all tensors of a batch on one device)")
         if t.dtype != dtype or tuple(t.shape) != tuple(shape):
             raise ValueError(f"{what}: expected {dtype} {tuple(shape)}, got {t.dtype} {tuple(t.shape)}")
         if not t.is_contiguous():
@@ -298,6 +354,8 @@ def _read_back_i32(t: torch.Tensor) -> np.ndarray:
     """Small int32 device tensor -> NumPy copy, staged through a per-thread pinned buffer (a pageable ``.cpu()`` costs
     ~2x as much and pinning a fresh buffer per call far more)."""
     n = int(t.numel())
+    if not t.is_cuda:
+        return t.numpy().copy()
     buf = getattr(_tls, "pinned_i32", None)
     if buf is None or buf.numel() < n:
         buf = torch.empty((max(n, 4096),), dtype=torch.int32).pin_memory()
@@ -350,6 +408,8 @@ class OutputBuffers:
             st = self.select_status(meta)
             if st in (1, 2, 3):
                 raise ValueError(_SELECT_ERRORS[st])
+            if st == 4:
+                raise SelectionInexact("selection: a weight is below 2^-29 (exact parallel cumsum not guaranteed)")
             if st != 0:
                 raise HipBackendError(f"selection failed with status {st}")
         n_off, n_seg = 2 * (self._n_refs + 1), self._n_refs * self._k
@@ -412,6 +472,13 @@ class HipDensifier:
         self._check(self._lib.lfd_upload_cameras(self._ctx, len(cams), _fp(K), _fp(R), _fp(t), _fp(P), _fp(Cc),
                                                  wh.ctypes.data_as(C.POINTER(C.c_int32))), "lfd_upload_cameras")
         self.n_cams = len(cams)
+
+    def pair_fundamentals(self, n_refs: int, k: int) -> np.ndarray:
+        """(n_refs, k, 3, 3) f64: the fundamental matrices the kernels of the last prepared batch used (debug read-back)."""
+        out = np.zeros((n_refs * k, 9), np.float64)
+        self._check(self._lib.lfd_get_pair_fundamental(self._ctx, n_refs * k, out.ctypes.data_as(C.POINTER(C.c_double))),
+                    "lfd_get_pair_fundamental")
+        return out.reshape(n_refs, k, 3, 3)
 
     def check_launches(self) -> None:
         """Synchronise and raise if a kernel reported a look-back timeout."""
@@ -486,6 +553,8 @@ class HipDensifier:
                                           C.c_float(s_override), out.data_ptr(), cap_n, C.byref(n), C.byref(st))
         if rc != 0 and st.value in (1, 2, 3):
             raise ValueError(self._lib.lfd_last_error(self._ctx).decode().replace("selection: ", ""))
+        if rc != 0 and st.value == 4:
+            raise SelectionInexact(self._lib.lfd_last_error(self._ctx).decode())
         self._check(rc, "lfd_select_samples")
         return out[:int(n.value)]
 
@@ -566,4 +635,56 @@ class HipDensifier:
         out = OutputBuffers(int(sel_offsets[-1]), batch.n_refs, batch.k, self.device, with_cell)
         self.launch_indexed(batch, params, sel_idx, sel_offsets, out)
         self.check_launches()
+        return out.collect(indexed=True)
+
+
+class HostDensifier:
+    """The CPU twin of :class:`HipDensifier` (``lfd_create_host`` + the ``*_host`` entry points of the C-ABI): the host
+    build of the kernels' per-cell source over CPU tensors, on ``n_threads`` threads.  Explicitly chosen - for upstream's
+    CPU-only configuration, for the CPU baseline of the benchmark and for parity checks - never a fallback: a
+    :class:`HipDensifier` does not turn into one when the GPU is missing."""
+
+    def __init__(self, n_threads: int = 0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        rc = self._lib.lfd_create_host(int(n_threads), C.byref(self._ctx))
+        if rc != 0:
+            raise HipBackendError(f"lfd_create_host failed ({rc}): {self._lib.lfd_last_error(None).decode()}")
+        self.device = torch.device("cpu")
+        self.n_threads = int(self._lib.lfd_host_threads(self._ctx))
+        self.n_cams = 0
+
+    close = HipDensifier.close
+    __del__ = HipDensifier.__del__
+    _check = HipDensifier._check
+    upload_cameras = HipDensifier.upload_cameras
+
+    def check_launches(self) -> None:
+        pass
+
+    def aggregate(self, batch: PreparedBatch, params: lfd_params):
+        best = torch.empty((batch.n_refs, batch.H, batch.W), dtype=torch.float32)
+        slot = torch.empty((batch.n_refs, batch.H, batch.W), dtype=torch.uint8)
+        self._check(self._lib.lfd_aggregate_host(self._ctx, C.byref(batch.c), C.byref(params), best.data_ptr(), slot.data_ptr()),
+                    "lfd_aggregate_host")
+        return best, slot
+
+    def triangulate_dense(self, batch: PreparedBatch, params: lfd_params, capacity: Optional[int] = None,
+                          with_cell: bool = True) -> TriangulationOutput:
+        cap = batch.n_refs * batch.H * batch.W if capacity is None else int(capacity)
+        out = OutputBuffers(cap, batch.n_refs, batch.k, self.device, with_cell)
+        self._check(self._lib.lfd_triangulate_dense_host(self._ctx, C.byref(batch.c), C.byref(params), C.byref(out.c),
+                                                         out.ref_offsets.data_ptr(), out.seg_counts.data_ptr()),
+                    "lfd_triangulate_dense_host")
+        return out.collect()
+
+    def triangulate_indexed(self, batch: PreparedBatch, params: lfd_params, sel_idx: torch.Tensor,
+                            sel_offsets: Sequence[int], with_cell: bool = True) -> TriangulationOutput:
+        if sel_idx.dtype != torch.int64 or sel_idx.is_cuda or not sel_idx.is_contiguous():
+            raise ValueError("sel_idx must be a contiguous int64 CPU tensor")
+        out = OutputBuffers(int(sel_offsets[-1]), batch.n_refs, batch.k, self.device, with_cell)
+        offs = (C.c_int64 * (batch.n_refs + 1))(*[int(v) for v in sel_offsets])
+        self._check(self._lib.lfd_triangulate_indexed_host(self._ctx, C.byref(batch.c), C.byref(params), sel_idx.data_ptr(), offs,
+                                                           C.byref(out.c), out.ref_offsets.data_ptr(), out.seg_counts.data_ptr(),
+                                                           out.seg_order.data_ptr()), "lfd_triangulate_indexed_host")
         return out.collect(indexed=True)

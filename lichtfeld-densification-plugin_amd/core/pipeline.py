@@ -236,6 +236,7 @@ class _HotPath:
         self.dens = densifier if densifier is not None else hb.HipDensifier(dev)
         self._own = densifier is None
         self.dens.upload_cameras(cams)
+        self.cams = list(cams) if bool(getattr(config, "upstream_fundamental", True)) else None
         self.params = hb.make_params(config, sample_cap)
 
     def close(self) -> None:
@@ -262,22 +263,38 @@ class _HotPath:
         no_filter) unless the configuration asks for the host stage (core/sampling.py).  With the device
         stage and no debug preview to feed (``need_best``), the three steps are ONE asynchronous call
         (lfd_triangulate_sampled): the selection count never visits the host."""
-        batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes)
+        batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes, cameras=self.cams)
         on_device = self.config.selection_backend == "device"
         fusable = on_device and (not self.config.no_filter or self.config.matches_per_ref <= self.dens.TOP_M_MAX)
         if fusable and not need_best:
             if device_seed is not None and not self.config.no_filter:
                 self.dens.seed_rng(device_seed)
-            out = self.dens.triangulate_sampled(batch, self.params, self.config.matches_per_ref, cap=self.sample_cap, border=2, tiles=24)
-            return (out if out.count else None), None
+            try:
+                out = self.dens.triangulate_sampled(batch, self.params, self.config.matches_per_ref, cap=self.sample_cap, border=2, tiles=24)
+                return (out if out.count else None), None
+            except hb.SelectionInexact:
+                pass         # weights below 2^-29 (certainty_thresh ~ 0): the host stage below, on the device's RNG stream
         best, _ = self.dens.aggregate(batch, self.params)
+        sel_t = None
         if on_device and self.config.no_filter and self.config.matches_per_ref <= self.dens.TOP_M_MAX:
             sel_t = self.dens.select_top_m(best[0], self.config.matches_per_ref, cap=self.sample_cap)
         elif on_device and not self.config.no_filter:
             if device_seed is not None:
                 self.dens.seed_rng(device_seed)
-            sel_t = self.dens.select_samples(best[0], self.config.matches_per_ref, cap=self.sample_cap, border=2, tiles=24)
-        else:
+            try:
+                sel_t = self.dens.select_samples(best[0], self.config.matches_per_ref, cap=self.sample_cap, border=2, tiles=24)
+            except hb.SelectionInexact:
+                # upstream handles such maps normally (core/sampling.py:27-32): run its host stage on the stream the device
+                # holds (the refused call consumed nothing) and hand the advanced stream back
+                key, pos = self.dens.rng_state()
+                rs = np.random.RandomState()
+                rs.set_state(("MT19937", key, pos, 0, 0.0))
+                sel = select_samples_with_coverage(best[0], self.config.matches_per_ref, cap=self.sample_cap, border=2,
+                                                   tiles=24, no_filter=False, rng=rs)
+                st = rs.get_state()
+                self.dens.set_rng_state(st[1], int(st[2]))
+                sel_t = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int64)).to(self.dev)
+        if sel_t is None:        # host stage by configuration (selection_backend="host", or no_filter beyond the device's top-M limit)
             sel = select_samples_with_coverage(best[0], self.config.matches_per_ref, cap=self.sample_cap, border=2,
                                                tiles=24, no_filter=self.config.no_filter, rng=rng)
             sel_t = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int64)).to(self.dev)
@@ -287,7 +304,7 @@ class _HotPath:
         return (out if out.count else None), best[0]
 
     def dense(self, refs: List[hb.ReferenceInputs], axes) -> hb.TriangulationOutput:
-        batch = hb.PreparedBatch(refs, self.w_match, self.h_match, axes=axes)
+        batch = hb.PreparedBatch(refs, self.w_match, self.h_match, axes=axes, cameras=self.cams)
         return self.dens.triangulate_dense(batch, self.params)
 
     def debug_matches(self, ref: hb.ReferenceInputs, out_cell: torch.Tensor, out_slot: torch.Tensor, axes,
@@ -371,6 +388,8 @@ def run_dense_pipeline(
     prefetch: Optional[_OrderedPrefetcher] = None
     hot: Optional[_HotPath] = None
 
+    rank_status = 0          # 0 fine, 1 cancelled, 2 failed: agreed on by all ranks before the exchange step (core/distributed.py)
+    rank_error: Optional[BaseException] = None
     try:
         cached = has_cached_romav2_weights() if own_matcher else True
         msg = "Initializing RoMa v2 model..." if cached else "Installing model weights..."
@@ -440,8 +459,8 @@ def run_dense_pipeline(
             xyz, rgb, err = out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy()
             for bi, (local_i, packed, ref, _axes) in enumerate(pending):
                 lo, hi = int(offs[bi]), int(offs[bi + 1])
-                if hi > lo:
-                    dev_parts.append((out.xyz[lo:hi], out.rgb[lo:hi], out.err[lo:hi]))
+                if hi > lo:     # trimmed copies: a slice would pin the whole capacity-sized buffer of this flush until the run ends
+                    dev_parts.append((out.xyz[lo:hi].clone(), out.rgb[lo:hi].clone(), out.err[lo:hi].clone()))
                     emit(local_i, packed, xyz[lo:hi], rgb[lo:hi], err[lo:hi], None)
             pending.clear()
 
@@ -492,10 +511,16 @@ def run_dense_pipeline(
             if want_debug:
                 dbg = {"matches": hot.debug_matches(ref, out.cell, out.slot, axes, best),
                        "pair_index": {j: first_pair + j for j in range(len(certs))}}
-            dev_parts.append((out.xyz, out.rgb, out.err))
+            dev_parts.append((out.xyz.clone(), out.rgb.clone(), out.err.clone()))
             hx, hc, he = out.host_arrays()
             emit(local_i, packed, hx, hc, he, dbg)
         flush_dense()
+    except BaseException as exc:
+        if world == 1:
+            raise
+        # sharded run: the other ranks are heading for the collectives below; tell them instead of leaving them blocked
+        rank_status = 1 if isinstance(exc, PipelineCancelled) else 2
+        rank_error = exc
     finally:
         if prefetch is not None:
             prefetch.close()
@@ -512,7 +537,16 @@ def run_dense_pipeline(
         if torch.cuda.is_available():
             torch.cuda.empty_cache()
 
-    _raise_if_cancelled(cancel_requested)
+    if world > 1:
+        if rank_status == 0 and _cancelled(cancel_requested):
+            rank_status = 1
+        worst = lfd_dist.agree_on_status(rank_status, dist, dev)
+        if worst:
+            if rank_error is not None:
+                raise rank_error
+            raise PipelineCancelled("Cancelled") if worst == 1 else RuntimeError("dense pipeline failed on another rank")
+    else:
+        _raise_if_cancelled(cancel_requested)
     if progress_callback:
         progress_callback(90.0, "Finalizing triangulation...")
 
@@ -525,10 +559,12 @@ def run_dense_pipeline(
     if world == 1 and dev_parts:
         device_points = (torch.cat([p[0] for p in dev_parts], 0), torch.cat([p[1] for p in dev_parts], 0),
                          torch.cat([p[2] for p in dev_parts], 0))
-    if world > 1:       # the one exchange step: ordered all-gather of the survivors over RCCL
-        gx, gc_, ge, counts = lfd_dist.all_gather_by_reference(
-            torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev), torch.from_numpy(err).to(dev),
-            counts_local, len(refs_local), dist)
+    if world > 1:       # the one exchange step: ordered all-gather of the survivors over RCCL, from where they already are (HBM)
+        if dev_parts:
+            lx, lc, le = (torch.cat([p[i] for p in dev_parts], 0) for i in range(3))
+        else:
+            lx, lc, le = (torch.zeros((0, 3), device=dev), torch.zeros((0, 3), device=dev), torch.zeros((0,), device=dev))
+        gx, gc_, ge, counts = lfd_dist.all_gather_by_reference(lx, lc, le, counts_local, len(refs_local), dist)
         xyz, rgb, err = gx.cpu().numpy(), gc_.cpu().numpy(), ge.cpu().numpy()
         device_points = (gx, gc_, ge)
         t = torch.tensor([refs_with_points, pair_counter], dtype=torch.int64,

@@ -50,6 +50,11 @@ class DensePipelineConfig:
     # whole per-reference path stays on the GPU) or "host" (core/sampling.py: the library calls
     # upstream makes, including torch's own f32 sum as the normaliser).
     selection_backend: str = "device"
+    # dense mode only: blend colours with upstream's f64 arithmetic (bit-identical rgb) instead of f32 (within 2.5e-7)
+    exact_colour: bool = False
+    # hand upstream's own fundamental matrices (np.linalg.inv products, computed on the host exactly as upstream computes
+    # them) to the kernels instead of the closed-form F the library derives from the camera table
+    upstream_fundamental: bool = True
 
     def __post_init__(self) -> None:
         if self.triangulation_mode not in TRIANGULATION_MODES:

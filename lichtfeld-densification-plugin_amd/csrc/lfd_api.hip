@@ -7,14 +7,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
-#include "../../include/lfd_densify.h"
-#include "lfd_device.hpp"
+#include "lfd_context.hpp"
 
 extern "C" __global__ void lfd_aggregate_kernel(LfdLaunch L, float* best_cert, uint8_t* best_slot);
 extern "C" __global__ void lfd_dense_kernel(LfdLaunch L);
+extern "C" __global__ void lfd_dense_exact_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* ref_out, LfdPairConst* pair_out);
 extern "C" __global__ void lfd_select_filter_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_pack_ply_kernel(const float* xyz, const float* rgb, long long n, unsigned char* out);
@@ -31,56 +32,17 @@ extern "C" __global__ void lfd_indexed_kernel(LfdLaunch L, const long long* sel_
 
 namespace {
 
+// the one piece of process-wide state: the message of the last lfd_create() that failed (there is no context to hold it).
+// Written under a mutex; lfd_last_error(NULL) hands out a per-thread copy, so concurrent creators cannot tear it.
+std::mutex g_create_mutex;
 std::string g_create_error;
-
-struct DeviceBuffer {
-    void* ptr = nullptr;
-    size_t bytes = 0;
-};
+thread_local std::string t_create_error_copy;
 
 }  // namespace
 
-struct lfd_context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    // camera table
-    DeviceBuffer cams;
-    int32_t n_cams = 0;
-    // descriptor tables: refs | slots | sel_offsets, staged through pinned memory
-    DeviceBuffer desc;
-    void* pinned = nullptr;
-    size_t pinned_bytes = 0;
-    hipEvent_t pinned_free = nullptr;
-    bool pinned_in_flight = false;
-    int* pinned_words = nullptr;   // 16 pinned ints: landing place of the small synchronous read-backs (status, selection count)
-    std::vector<unsigned char> desc_cache;   // what the device table currently holds
-    // look-back workspace: [0] u64 ticket counter, [1..] tile states
-    DeviceBuffer ws;
-    unsigned long long tickets_issued = 0;   // host mirror of the device ticket counter (indexed kernel)
-    unsigned long long lane_issued[LFD_TICKET_LANES] = {};   // host mirrors of the dense kernel's ticket sequences
-    unsigned epoch = 0;
-    int n_cus = 0;                 // compute units of the device
-    // default A-grid axes
-    DeviceBuffer axes;
-    int axes_w = 0, axes_h = 0;
-    // per-pair constants of the current batch (valid while the descriptor tables are unchanged)
-    DeviceBuffer consts;
-    bool consts_valid = false;
-    int consts_wm = 0, consts_hm = 0;
-    // indexed-mode scratch
-    DeviceBuffer scratch, codes, idx_tab, agg, sel_buf;
-    // selection stage: legacy MT19937 stream (625 words) + scratch
-    DeviceBuffer mt, sel_scratch;
-    bool mt_seeded = false;
-};
-
 namespace {
 
-int fail(lfd_context* ctx, int code, const std::string& msg) {
-    if (ctx) ctx->err = msg; else g_create_error = msg;
-    return code;
-}
+int fail(lfd_context* ctx, int code, const std::string& msg) { return lfd_fail(ctx, code, msg); }
 
 #define LFD_HIP(ctx, expr)                                                                         \
     do {                                                                                           \
@@ -106,6 +68,7 @@ int ensure(lfd_context* ctx, DeviceBuffer& b, size_t bytes, bool zero = false) {
 
 int validate_batch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "this context was made by lfd_create_host: it serves the *_host entry points only");
     if (!b || !p) return fail(ctx, LFD_ERR_INVALID, "null batch/params");
     if (ctx->n_cams <= 0) return fail(ctx, LFD_ERR_STATE, "lfd_upload_cameras must be called first");
     if (b->n_refs <= 0) return fail(ctx, LFD_ERR_INVALID, "n_refs must be > 0");
@@ -133,11 +96,12 @@ int validate_batch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p) {
 
 // Build refs|slots|extra into one blob, upload only when it differs from what the device holds.
 int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, size_t n_extra,
-                  const LfdRefDesc** d_refs, const LfdSlotDesc** d_slots, const long long** d_extra) {
+                  const LfdRefDesc** d_refs, const LfdSlotDesc** d_slots, const long long** d_extra, const float** d_fund) {
     const size_t nr = (size_t)b->n_refs, ns = nr * (size_t)b->k;
     const size_t off_slots = (nr * sizeof(LfdRefDesc) + 15) & ~size_t(15);
     const size_t off_extra = (off_slots + ns * sizeof(LfdSlotDesc) + 15) & ~size_t(15);
-    const size_t total = off_extra + n_extra * sizeof(long long);
+    const size_t off_fund = (off_extra + n_extra * sizeof(long long) + 15) & ~size_t(15);
+    const size_t total = off_fund + (b->fundamental ? ns * 9 * sizeof(float) : 0);
     std::vector<unsigned char> blob(total, 0);
     LfdRefDesc* refs = reinterpret_cast<LfdRefDesc*>(blob.data());
     LfdSlotDesc* slots = reinterpret_cast<LfdSlotDesc*>(blob.data() + off_slots);
@@ -157,6 +121,7 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
         }
     }
     if (n_extra) std::memcpy(blob.data() + off_extra, extra, n_extra * sizeof(long long));
+    if (b->fundamental) std::memcpy(blob.data() + off_fund, b->fundamental, ns * 9 * sizeof(float));
     int rc = ensure(ctx, ctx->desc, total);
     if (rc != LFD_OK) return rc;
     if (blob != ctx->desc_cache) {
@@ -178,6 +143,7 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
     *d_refs = reinterpret_cast<const LfdRefDesc*>(ctx->desc.ptr);
     *d_slots = reinterpret_cast<const LfdSlotDesc*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_slots);
     if (d_extra) *d_extra = reinterpret_cast<const long long*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_extra);
+    *d_fund = b->fundamental ? reinterpret_cast<const float*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_fund) : nullptr;
     return LFD_OK;
 }
 
@@ -197,11 +163,14 @@ int default_axes(lfd_context* ctx, int W, int H, const float** ax, const float**
     return LFD_OK;
 }
 
-void fill_kernel_params(const lfd_batch* b, const lfd_params* p, LfdKernelParams& kp) {
+}  // namespace
+
+void lfd_fill_kernel_params(const lfd_batch* b, const lfd_params* p, LfdKernelParams& kp) {
     kp.sampson_thresh = p->sampson_thresh;
     kp.certainty_thresh = p->certainty_thresh;
     kp.reproj_thresh = p->reproj_thresh;
     kp.no_filter = p->no_filter ? 1 : 0;
+    (void)LFD_FLAG_EXACT_COLOUR;     // consumed by lfd_triangulate_dense (kernel choice), not by the per-cell routine
     kp.use_sampson = (!p->no_filter && p->sampson_thresh > 0.0) ? 1 : 0;
     kp.use_parallax = (!p->no_filter && p->min_parallax_deg > 0.0f) ? 1 : 0;
     kp.dot_thresh = kp.use_parallax ? lfd_parallax_dot_threshold(p->min_parallax_deg) : 2.0f;
@@ -209,13 +178,15 @@ void fill_kernel_params(const lfd_batch* b, const lfd_params* p, LfdKernelParams
     kp.hm1 = (float)(b->h_match - 1);
 }
 
+namespace {
+
 int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, const long long* extra, size_t n_extra,
                    LfdLaunch& L, const long long** d_extra) {
     int rc = validate_batch(ctx, b, p);
     if (rc != LFD_OK) return rc;
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     std::memset(&L, 0, sizeof(L));
-    rc = upload_tables(ctx, b, extra, n_extra, &L.refs, &L.slots, d_extra);
+    rc = upload_tables(ctx, b, extra, n_extra, &L.refs, &L.slots, d_extra, &L.fund_override);
     if (rc != LFD_OK) return rc;
     L.cams = static_cast<const LfdCam*>(ctx->cams.ptr);
     if (b->axis_x) { L.axis_x = b->axis_x; L.axis_y = b->axis_y; }
@@ -234,7 +205,7 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
     L.mask_sx = (float)b->w_match / (float)b->W;
     L.mask_sy = (float)b->h_match / (float)b->H;
     L.inv_w = 1.0f / (float)b->W;
-    fill_kernel_params(b, p, L.kp);
+    lfd_fill_kernel_params(b, p, L.kp);
     // per-pair constants: (re)derive when the batch tables, the cameras or the match size changed
     const size_t ref_bytes = ((size_t)b->n_refs * sizeof(LfdRefConst) + 15) & ~size_t(15);
     const size_t need = ref_bytes + (size_t)b->n_refs * b->k * sizeof(LfdPairConst);
@@ -250,6 +221,7 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
         hipLaunchKernelGGL(lfd_pair_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, L, d_rc, d_pc);
         LFD_HIP(ctx, hipGetLastError());
         ctx->consts_valid = true;
+        ctx->consts_refs = b->n_refs; ctx->consts_k = b->k;
         ctx->consts_wm = b->w_match;
         ctx->consts_hm = b->h_match;
     }
@@ -307,12 +279,23 @@ int check_points(lfd_context* ctx, const lfd_points* out, const long long* ref_o
 
 }  // namespace
 
+int lfd_fail(lfd_context* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    else { std::lock_guard<std::mutex> lock(g_create_mutex); g_create_error = msg; }
+    return code;
+}
+
 // =================================================================================================
 extern "C" {
 
 int lfd_abi_version(void) { return LFD_ABI_VERSION; }
 
-const char* lfd_last_error(const lfd_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char* lfd_last_error(const lfd_context* ctx) {
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lock(g_create_mutex);
+    t_create_error_copy = g_create_error;
+    return t_create_error_copy.c_str();
+}
 
 int lfd_create(int device_index, void* hip_stream, lfd_context** out) {
     if (!out) return fail(nullptr, LFD_ERR_INVALID, "out is null");
@@ -340,6 +323,7 @@ int lfd_create(int device_index, void* hip_stream, lfd_context** out) {
 
 void lfd_destroy(lfd_context* ctx) {
     if (!ctx) return;
+    if (ctx->is_host) { delete ctx; return; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->mt, &ctx->sel_scratch})
@@ -352,6 +336,7 @@ void lfd_destroy(lfd_context* ctx) {
 
 int lfd_set_stream(lfd_context* ctx, void* hip_stream) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = static_cast<hipStream_t>(hip_stream);
@@ -361,6 +346,7 @@ int lfd_set_stream(lfd_context* ctx, void* hip_stream) {
 int lfd_launch_status(lfd_context* ctx, int32_t* status_out) {
     if (!ctx || !status_out) return fail(ctx, LFD_ERR_INVALID, "null argument");
     *status_out = 0;
+    if (ctx->is_host) return LFD_OK;
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->ws.ptr) { LFD_HIP(ctx, hipStreamSynchronize(ctx->stream)); return LFD_OK; }
     LFD_HIP(ctx, hipMemcpyAsync(ctx->pinned_words, static_cast<unsigned char*>(ctx->ws.ptr) + 8, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
@@ -371,6 +357,22 @@ int lfd_launch_status(lfd_context* ctx, int32_t* status_out) {
         *status_out = (int32_t)st;
         return fail(ctx, LFD_ERR_HIP, "a look-back spin timed out (workgroups of the persistent grid were not co-resident); results of the last launch are invalid");
     }
+    return LFD_OK;
+}
+
+int lfd_get_pair_fundamental(lfd_context* ctx, int32_t n_pairs, double* F_out_host) {
+    if (!ctx || !F_out_host || n_pairs <= 0) return fail(ctx, LFD_ERR_INVALID, "bad arguments");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
+    if (!ctx->consts_valid || !ctx->consts.ptr) return fail(ctx, LFD_ERR_STATE, "no batch has been prepared on this context yet");
+    if (n_pairs != ctx->consts_refs * ctx->consts_k) return fail(ctx, LFD_ERR_INVALID, "n_pairs must be n_refs * k of the last batch");
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ref_bytes = ((size_t)ctx->consts_refs * sizeof(LfdRefConst) + 15) & ~size_t(15);
+    std::vector<LfdPairConst> host((size_t)n_pairs);
+    LFD_HIP(ctx, hipMemcpyAsync(host.data(), static_cast<unsigned char*>(ctx->consts.ptr) + ref_bytes, host.size() * sizeof(LfdPairConst),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_pairs; ++i)
+        for (int j = 0; j < 9; ++j) F_out_host[(size_t)i * 9 + j] = host[(size_t)i].F[j];
     return LFD_OK;
 }
 
@@ -390,6 +392,7 @@ int lfd_upload_cameras(lfd_context* ctx, int32_t n, const float* K, const float*
         c.pad[0] = c.pad[1] = 0;
         if (c.w <= 0 || c.h <= 0) return fail(ctx, LFD_ERR_INVALID, "camera width/height must be positive");
     }
+    if (ctx->is_host) { ctx->host_cams.swap(cams); ctx->n_cams = n; return LFD_OK; }
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure(ctx, ctx->cams, cams.size() * sizeof(LfdCam));
     if (rc != LFD_OK) return rc;
@@ -432,7 +435,10 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
     L.seg_counts = seg_counts;                // zeroed inside the kernel (tile 0), no memset launch
     size_t extra_lds = 0;                     // profiling switch: dynamic LDS lowers the number of resident workgroups
     if (const char* e = std::getenv("LFD_DENSE_EXTRA_LDS")) extra_lds = (size_t)std::atol(e);
-    hipLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), extra_lds, ctx->stream, L);
+    if (params->flags & LFD_FLAG_EXACT_COLOUR)
+        hipLaunchKernelGGL(lfd_dense_exact_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), extra_lds, ctx->stream, L);
+    else
+        hipLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), extra_lds, ctx->stream, L);
     LFD_HIP(ctx, hipGetLastError());
     return LFD_OK;
 }
@@ -493,6 +499,7 @@ int lfd_triangulate_indexed(lfd_context* ctx, const lfd_batch* batch, const lfd_
 // ---- S: selection ---------------------------------------------------------------------------------
 int lfd_rng_seed(lfd_context* ctx, uint32_t seed) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure(ctx, ctx->mt, 625 * sizeof(unsigned));
     if (rc != LFD_OK) return rc;
@@ -504,6 +511,7 @@ int lfd_rng_seed(lfd_context* ctx, uint32_t seed) {
 
 int lfd_rng_get_state(lfd_context* ctx, uint32_t* key624, int32_t* pos) {
     if (!ctx || !key624 || !pos) return fail(ctx, LFD_ERR_INVALID, "null argument");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
     if (!ctx->mt_seeded) return fail(ctx, LFD_ERR_STATE, "lfd_rng_seed / lfd_rng_set_state must be called first");
     unsigned host[625];
     LFD_HIP(ctx, hipSetDevice(ctx->device));
@@ -516,6 +524,7 @@ int lfd_rng_get_state(lfd_context* ctx, uint32_t* key624, int32_t* pos) {
 
 int lfd_rng_set_state(lfd_context* ctx, const uint32_t* key624, int32_t pos) {
     if (!ctx || !key624 || pos < 0 || pos > 624) return fail(ctx, LFD_ERR_INVALID, "bad MT19937 state");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure(ctx, ctx->mt, 625 * sizeof(unsigned));
     if (rc != LFD_OK) return rc;
@@ -534,6 +543,7 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
                          long long* sel_offsets_dev, int** d_info, unsigned char** d_time) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
     if (!best_cert || !sel_out) return fail(ctx, LFD_ERR_INVALID, "null argument");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
     if (H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL || M < 0 || tiles <= 0 || border < 0 || capacity < 0)
         return fail(ctx, LFD_ERR_INVALID, "bad selection arguments");
     if (!topm && !ctx->mt_seeded) return fail(ctx, LFD_ERR_STATE, "lfd_rng_seed must be called before lfd_select_samples");
@@ -574,12 +584,11 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
         *d_time = base + o_time;
     }
     if (topm) {
-        static bool attr_set = false;
         const size_t lds = (size_t)LFD_SELECT_TOPM_MAX * sizeof(unsigned long long);
-        if (!attr_set) {
+        if (!ctx->topm_lds_attr_set) {     // after hipSetDevice(ctx->device) above: the attribute belongs to this context's device
             LFD_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lfd_select_topm_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
+            ctx->topm_lds_attr_set = true;
         }
         hipLaunchKernelGGL(lfd_select_topm_kernel, dim3(1), dim3(LFD_SELECT_BLOCK), lds, ctx->stream, A);
     } else {
@@ -645,6 +654,7 @@ int lfd_triangulate_sampled(lfd_context* ctx, const lfd_batch* batch, const lfd_
                             int32_t border, int32_t tiles, float s_override, const lfd_points* out, int64_t* ref_offsets,
                             int32_t* seg_counts, int32_t* seg_order, int32_t* sel_info, int64_t* sel_cells) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
     if (!batch || !params || !sel_info) return fail(ctx, LFD_ERR_INVALID, "null argument");
     if (batch->n_refs != 1) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_sampled takes one reference view per call");
     if (M < 0 || tiles <= 0 || border < 0) return fail(ctx, LFD_ERR_INVALID, "bad selection arguments");
@@ -724,6 +734,7 @@ int lfd_select_top_m(lfd_context* ctx, const float* best_cert, int32_t H, int32_
 // ---- N1: writers ----------------------------------------------------------------------------------
 int lfd_pack_ply(lfd_context* ctx, const float* xyz, const float* rgb, int64_t n, uint8_t* out) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
     if (n < 0 || (n > 0 && (!xyz || !rgb || !out))) return fail(ctx, LFD_ERR_INVALID, "bad arguments");
     if (reinterpret_cast<uintptr_t>(out) & 3u) return fail(ctx, LFD_ERR_INVALID, "out must be 4-byte aligned");
     if (n == 0) return LFD_OK;
@@ -737,6 +748,7 @@ int lfd_pack_ply(lfd_context* ctx, const float* xyz, const float* rgb, int64_t n
 int lfd_pack_points3d(lfd_context* ctx, const float* xyz, const float* rgb, const float* err, int64_t n, uint64_t id_base,
                       uint8_t* out) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
     if (n < 0 || (n > 0 && (!xyz || !rgb || !out))) return fail(ctx, LFD_ERR_INVALID, "bad arguments");
     if (reinterpret_cast<uintptr_t>(out) & 3u) return fail(ctx, LFD_ERR_INVALID, "out must be 4-byte aligned");
     if (n == 0) return LFD_OK;
@@ -750,6 +762,7 @@ int lfd_pack_points3d(lfd_context* ctx, const float* xyz, const float* rgb, cons
 
 int lfd_quantise_rgb(lfd_context* ctx, const float* rgb, int64_t n, uint8_t* out) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
     if (n < 0 || (n > 0 && (!rgb || !out))) return fail(ctx, LFD_ERR_INVALID, "bad arguments");
     if (n == 0) return LFD_OK;
     LFD_HIP(ctx, hipSetDevice(ctx->device));
@@ -814,7 +827,7 @@ int lfd_host_eval_correspondence(const float* cam1, const float* cam2, float xa_
     lfd_batch bb; std::memset(&bb, 0, sizeof(bb));
     bb.w_match = w_match; bb.h_match = h_match;
     LfdKernelParams kp;
-    fill_kernel_params(&bb, params, kp);
+    lfd_fill_kernel_params(&bb, params, kp);
     LfdCellResult res;
     lfd_eval_correspondence(rc, pc, xa_norm, ya_norm, xb_norm, yb_norm, kp, res);
     out8[0] = res.x; out8[1] = res.y; out8[2] = res.z; out8[3] = 0.0f; out8[4] = 0.0f; out8[5] = 0.0f;

@@ -1,0 +1,60 @@
+// The context behind the opaque `lfd_context` of include/lfd_densify.h, shared by the device entry points (lfd_api.hip)
+// and the CPU twin (lfd_host.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lfd_densify.h"
+#include "lfd_device.hpp"
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct lfd_context {
+    // a context made by lfd_create_host() never touches HIP: it serves the *_host entry points only
+    bool is_host = false;
+    int host_threads = 1;
+    std::vector<LfdCam> host_cams;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // camera table
+    DeviceBuffer cams;
+    int32_t n_cams = 0;
+    // descriptor tables: refs | slots | sel_offsets, staged through pinned memory
+    DeviceBuffer desc;
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    hipEvent_t pinned_free = nullptr;
+    bool pinned_in_flight = false;
+    int* pinned_words = nullptr;   // 16 pinned ints: landing place of the small synchronous read-backs (status, selection count)
+    std::vector<unsigned char> desc_cache;   // what the device table currently holds
+    // look-back workspace: [0] u64 ticket counter, [1..] tile states
+    DeviceBuffer ws;
+    unsigned long long tickets_issued = 0;   // host mirror of the device ticket counter (indexed kernel)
+    unsigned long long lane_issued[LFD_TICKET_LANES] = {};   // host mirrors of the dense kernel's ticket sequences
+    unsigned epoch = 0;
+    int n_cus = 0;                 // compute units of the device
+    // default A-grid axes
+    DeviceBuffer axes;
+    int axes_w = 0, axes_h = 0;
+    // per-pair constants of the current batch (valid while the descriptor tables are unchanged)
+    DeviceBuffer consts;
+    bool consts_valid = false;
+    int consts_wm = 0, consts_hm = 0;
+    int consts_refs = 0, consts_k = 0;
+    // indexed-mode scratch
+    DeviceBuffer scratch, codes, idx_tab, agg, sel_buf;
+    // selection stage: legacy MT19937 stream (625 words) + scratch
+    DeviceBuffer mt, sel_scratch;
+    bool mt_seeded = false;
+    bool topm_lds_attr_set = false;   // hipFuncSetAttribute is per device: remembered per context, not per process
+};
+
+// records `msg` on the context (or as the creation error when ctx is null) and returns `code`
+int lfd_fail(lfd_context* ctx, int code, const std::string& msg);

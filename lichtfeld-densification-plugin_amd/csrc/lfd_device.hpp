@@ -57,6 +57,7 @@ struct LfdLaunch {              // kernel argument, passed by value
     const LfdPairConst* pair_const;  // [n_refs*k]
     const float* axis_x;        // [W]
     const float* axis_y;        // [H]
+    const float* fund_override; // [n_refs*k*9] f32 fundamental matrices handed over by the caller (lfd_batch.fundamental), or null
     int32_t n_refs, k, H, W, w_match, h_match, warp_channels, tiles_per_ref;
     float mask_sx, mask_sy;     // (float)w_match/(float)W, (float)h_match/(float)H  (nearest resize)
     float inv_w;                // 1.0f / W (cell -> row estimate)

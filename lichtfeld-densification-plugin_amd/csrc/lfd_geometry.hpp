@@ -526,6 +526,44 @@ LFD_HD void lfd_bilinear_rgb(const uint8_t* img, int wi, int hi, float xa_px, fl
     }
 }
 
+// The four-tap blend in f32 (dense mode's default; LFD_FLAG_EXACT_COLOUR selects the f64 form above): same taps, same
+// weights (x1-x)(y1-y) ... and the same association order as upstream, every operation rounded to f32 instead of f64,
+// so the result is within 4 x 255 x 2^-24 of upstream's blend before the division, i.e. within 2.5e-7 of upstream's
+// rgb - the parity tests allow 1/(255*4) = 9.8e-4 and the writers quantise to 1/255.  A clamped column (x1 == x0)
+// reads one texel with both weights upstream; here the weights are folded instead (the sum is the same expression).
+LFD_HD void lfd_blend4_f32(const float* a, const float* b, const float* c, const float* d, int wi, int hi, float xa_px,
+                           float ya_px, float* rgb) {
+    const float x0 = fminf(fmaxf(floorf(xa_px), 0.0f), (float)(wi - 1));
+    const float y0 = fminf(fmaxf(floorf(ya_px), 0.0f), (float)(hi - 1));
+    const float x1 = fminf(x0 + 1.0f, (float)(wi - 1));
+    const float y1 = fminf(y0 + 1.0f, (float)(hi - 1));
+    const float ax = x1 - xa_px, bx = xa_px - x0, ay = y1 - ya_px, by = ya_px - y0;
+    float wa = ax * ay, wb = bx * ay, wc = ax * by, wd = bx * by;
+    if (x1 == x0) {
+        wa = wa + wb; wb = 0.0f;
+        wc = wc + wd; wd = 0.0f;
+    }
+    for (int ch = 0; ch < 3; ++ch) {
+        const float s = fmaf(d[ch], wd, fmaf(c[ch], wc, fmaf(b[ch], wb, a[ch] * wa)));
+        rgb[ch] = s * 0.00392156862745098f;       // RN(1/255): one more ulp, instead of the ~10-instruction IEEE division
+    }
+}
+
+// byte-addressed form (CPU twin, indexed kernels): the taps upstream reads, blended by lfd_blend4_f32
+LFD_HD void lfd_bilinear_rgb_f32(const uint8_t* img, int wi, int hi, float xa_px, float ya_px, float* rgb) {
+    const int x0 = (int)fminf(fmaxf(floorf(xa_px), 0.0f), (float)(wi - 1));
+    const int y0 = (int)fminf(fmaxf(floorf(ya_px), 0.0f), (float)(hi - 1));
+    const int x1 = lfd_clampi(x0 + 1, 0, wi - 1);
+    const int y1 = lfd_clampi(y0 + 1, 0, hi - 1);
+    const uint8_t* pa = img + ((size_t)y0 * (size_t)wi + (size_t)x0) * 3u;
+    const uint8_t* pb = img + ((size_t)y0 * (size_t)wi + (size_t)x1) * 3u;
+    const uint8_t* pc = img + ((size_t)y1 * (size_t)wi + (size_t)x0) * 3u;
+    const uint8_t* pd = img + ((size_t)y1 * (size_t)wi + (size_t)x1) * 3u;
+    const float a[3] = {(float)pa[0], (float)pa[1], (float)pa[2]}, b[3] = {(float)pb[0], (float)pb[1], (float)pb[2]};
+    const float c[3] = {(float)pc[0], (float)pc[1], (float)pc[2]}, d[3] = {(float)pd[0], (float)pd[1], (float)pd[2]};
+    lfd_blend4_f32(a, b, c, d, wi, hi, xa_px, ya_px, rgb);
+}
+
 #if defined(__HIPCC__)
 // Same arithmetic as lfd_bilinear_rgb, fewer memory instructions: the two taps of a row are 6
 // consecutive bytes, fetched with ONE unaligned 8-byte load per row (2 loads per point instead of 12),
@@ -579,6 +617,19 @@ __device__ __forceinline__ void lfd_bilinear_eval(LfdTapRows t, unsigned sh0, un
         const double s = fma(pd, wd, fma(pc, wc, fma(pb, wb, pa * wa)));
         rgb[c] = (float)lfd_div_by_recip(s, 255.0, 1.0 / 255.0);   // == s / 255.0, correctly rounded
     }
+}
+
+// lfd_blend4_f32 on the two 8-byte windows of lfd_bilinear_fetch: the taps come straight out of the windows with
+// v_cvt_f32_ubyteN (no mask / shift per tap).  Bit-identical to lfd_bilinear_rgb_f32.
+__device__ __forceinline__ void lfd_bilinear_eval_f32(LfdTapRows t, unsigned sh0, unsigned sh1, int wi, int hi, float xa_px, float ya_px, float* rgb) {
+    const unsigned long long r0 = t.r0 >> sh0, r1 = t.r1 >> sh1;
+    const unsigned lo0 = (unsigned)r0, hi0 = (unsigned)(r0 >> 32), lo1 = (unsigned)r1, hi1 = (unsigned)(r1 >> 32);
+    // bytes of a window: a.r a.g a.b b.r | b.g b.b   (with x1 == x0 the b taps are not upstream's, but their weight is 0)
+    const float a[3] = {(float)(lo0 & 0xffu), (float)((lo0 >> 8) & 0xffu), (float)((lo0 >> 16) & 0xffu)};
+    const float b[3] = {(float)(lo0 >> 24), (float)(hi0 & 0xffu), (float)((hi0 >> 8) & 0xffu)};
+    const float c[3] = {(float)(lo1 & 0xffu), (float)((lo1 >> 8) & 0xffu), (float)((lo1 >> 16) & 0xffu)};
+    const float d[3] = {(float)(lo1 >> 24), (float)(hi1 & 0xffu), (float)((hi1 >> 8) & 0xffu)};
+    lfd_blend4_f32(a, b, c, d, wi, hi, xa_px, ya_px, rgb);
 }
 #endif
 

@@ -290,8 +290,11 @@ extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* __res
     const int n_pairs = L.n_refs * L.k;
     if (i < n_pairs) {
         const int r = i / L.k, j = i - r * L.k;
-        if (j < L.refs[r].n_slots)
+        if (j < L.refs[r].n_slots) {
             lfd_make_pair_const(L.cams[L.refs[r].cam], L.cams[L.slots[i].cam], L.slots[i].cam, L.w_match, L.h_match, pair_out[i]);
+            if (L.fund_override)       // the caller's F (upstream's fundamental_from_world2cam result) replaces the one derived here
+                for (int e = 0; e < 9; ++e) pair_out[i].F[e] = (double)L.fund_override[(size_t)i * 9 + e];
+        }
     } else if (i < n_pairs + L.n_refs) {
         const int r = i - n_pairs;
         lfd_make_ref_const(L.cams[L.refs[r].cam], L.w_match, L.h_match, ref_out[r]);
@@ -387,7 +390,12 @@ struct DenseStage {                // per-tile results, indexed by the cell's sl
 
 struct __attribute__((packed, aligned(4))) LfdF3 { float a, b, c; };
 
-extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_kernel(LfdLaunch L) {
+// records a thread of the copy-out waves handles: the tile's survivors are shared out over the waves that do NOT run the look-back
+constexpr int kCopyThreads = kBlock - 64;
+constexpr int kCopyRecords = (kTile + kCopyThreads - 1) / kCopyThreads;
+
+template <bool kExactColour>
+__device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
     __shared__ BlockShared S;
     __shared__ DenseStage stage;
     __shared__ unsigned s_ticket;
@@ -406,7 +414,6 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
     // a running workgroup, as with a single counter; the 8 classes also match the round-robin dealing of
     // workgroups to the 8 XCDs.
     const unsigned seq = blockIdx.x % LFD_TICKET_LANES;
-    const unsigned seg_ready_early = L.seg_counts ? __hip_atomic_load(L.seg_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     if (tid == 0) {
         const unsigned long long k = atomicAdd(L.ticket_lanes + (size_t)seq * 16, 1ull) - L.ticket_base_lane[seq];
         s_ticket = (unsigned)k * LFD_TICKET_LANES + seq;
@@ -585,6 +592,31 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
             for (int e = 0; e < kCpt; ++e)
                 if ((keep_bits >> e) & 1u) stage.order[lpos++] = (unsigned short)(tid * kCpt + e);
         }
+        __syncthreads();                          // stage.order complete
+        if (L.seg_counts && tid < ns && s_slot_cnt[tid]) {
+            // the workgroup of tile 0 zeroed the array and raised seg_ready when the launch began (no memset launch)
+            // (only the first few workgroups of a launch ever have to poll.  The counters are only touched by device-scope
+            // atomics, so a relaxed read of the flag is enough.)
+            unsigned spins = 0;
+            unsigned ready = __hip_atomic_load(L.seg_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (ready != L.epoch) {
+                if (++spins > LFD_SPIN_LIMIT) { atomicExch(L.status, LFD_LAUNCH_TIMEOUT); break; }
+                __builtin_amdgcn_s_sleep(8);
+                ready = __hip_atomic_load(L.seg_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            atomicAdd(&L.seg_counts[(size_t)r * L.k + tid], (int)s_slot_cnt[tid]);
+        }
+
+        // ---- stage 5: ordered retirement.  Wave 0 runs the look-back (it publishes the tile's count at once and then
+        //      waits for its predecessors' counts); MEANWHILE waves 1..3 evaluate the colours of the tile's survivors
+        //      into registers - that work needs the tile-local order only, not the global offset - so the wait of the
+        //      look-back is covered by the workgroup's own arithmetic instead of idling all four waves.  After the
+        //      barrier the same three waves write their records: consecutive threads write consecutive records, so
+        //      every wave-wide store covers one contiguous span of the output arrays. -----------------------------
+        float rgb[kCopyRecords][3];
+        int ctid = (int)threadIdx.x;               // thread index among the copy-out waves; taken from the hardware register again
+        asm volatile("" : "+v"(ctid));             // here, so that no copy of it occupies a register across the geometry loop
+        ctid -= 64;
         if (wave == 0) {
 #if defined(LFD_ABLATE_LOOKBACK)
             const u64 excl = (u64)tile * kTile;
@@ -596,88 +628,88 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
                 if (tile_in_ref == 0) L.ref_offsets[r] = (long long)excl;
                 if (tile == n_tiles - 1u) L.ref_offsets[L.n_refs] = (long long)(excl + block_total);
             }
-        }
-        __syncthreads();                          // staging complete, prefix known
-        if (L.seg_counts && tid < ns && s_slot_cnt[tid]) {
-            // the workgroup of tile 0 zeroed the array and raised seg_ready when the launch began (no memset launch)
-            // (sampled when the workgroup started; only the first few workgroups of a launch ever have to poll.  The
-            // counters are only touched by device-scope atomics, so a relaxed read of the flag is enough.)
-            unsigned spins = 0;
-            unsigned ready = seg_ready_early;
-            while (ready != L.epoch) {
-                if (++spins > LFD_SPIN_LIMIT) { atomicExch(L.status, LFD_LAUNCH_TIMEOUT); break; }
-                __builtin_amdgcn_s_sleep(8);
-                ready = __hip_atomic_load(L.seg_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+#if !defined(LFD_ABLATE_STORES)
+            const uint8_t* image = S.ref.image;
+            const int n_loc = (int)block_total;
+#pragma unroll
+            for (int u0 = 0; u0 < kCopyRecords; u0 += LFD_COPY_UNROLL) {
+                // LFD_COPY_UNROLL records per step: their image rows are in flight before the first colour is evaluated
+                float px[LFD_COPY_UNROLL], py[LFD_COPY_UNROLL];
+                LfdTapRows taps[LFD_COPY_UNROLL];
+                unsigned sh0[LFD_COPY_UNROLL], sh1[LFD_COPY_UNROLL];
+                if (ctid + u0 * kCopyThreads < n_loc) {       // wave-uniform except in the tile's last partial wave
+#pragma unroll
+                    for (int v = 0; v < LFD_COPY_UNROLL; ++v) {
+                        if (u0 + v >= kCopyRecords) break;
+                        const int i = ctid + (u0 + v) * kCopyThreads;
+                        const int sl = (int)stage.order[i < n_loc ? i : n_loc - 1];
+                        {   // reference position in match pixels, from the A-grid coordinates of the cell (not staged: LDS is
+                            // one of the two things that limit the number of resident workgroups)
+                            const int cell = tile_cell0 + sl;
+                            float xan, yan;
+                            if (L.warp_channels == 4) {
+                                const float2 w2 = load_f32x2(S.slot[stage.slot[sl]].warp + (size_t)cell * 4);
+                                xan = w2.x; yan = w2.y;
+                            } else {
+                                int dy, x;
+                                lfd_divmod_local(tile_x0 + sl, L.W, L.inv_w, dy, x);
+                                const int y = tile_y0 + dy;
+                                if (L.axis_identity) { xan = lfd_axis_value(L.ax, x); yan = lfd_axis_value(L.ay, y); }
+                                else { xan = lfd_global(L.axis_x)[x]; yan = lfd_global(L.axis_y)[y]; }
+                            }
+                            px[v] = lfd_match_px(xan, L.kp.wm1); py[v] = lfd_match_px(yan, L.kp.hm1);
+                        }
+                        taps[v] = lfd_bilinear_fetch(image, L.w_match, L.h_match, px[v], py[v], sh0[v], sh1[v]);
+                    }
+#pragma unroll
+                    for (int v = 0; v < LFD_COPY_UNROLL; ++v) {
+                        if (u0 + v >= kCopyRecords) break;
+#if defined(LFD_ABLATE_COLOUR)
+                        rgb[u0 + v][0] = px[v]; rgb[u0 + v][1] = py[v]; rgb[u0 + v][2] = (float)(taps[v].r0 + taps[v].r1 + sh0[v] + sh1[v]);
+#else
+                        if (kExactColour) lfd_bilinear_eval(taps[v], sh0[v], sh1[v], L.w_match, L.h_match, px[v], py[v], rgb[u0 + v]);
+                        else lfd_bilinear_eval_f32(taps[v], sh0[v], sh1[v], L.w_match, L.h_match, px[v], py[v], rgb[u0 + v]);
+#endif
+                    }
+                }
             }
-            atomicAdd(&L.seg_counts[(size_t)r * L.k + tid], (int)s_slot_cnt[tid]);
+#endif
         }
+        __syncthreads();                          // prefix known, colours in registers
 
-        // ---- stage 5: coalesced copy-out ----------------------------------------------------------------
-        {
+#if !defined(LFD_ABLATE_STORES)
+        if (wave != 0) {
             const long long base = (long long)s_tile_excl;
             long long room = L.capacity - base;          // beyond capacity: counted, not written
             int n = (int)block_total;
             if (room < (long long)n) n = room > 0 ? (int)room : 0;
-#if !defined(LFD_ABLATE_STORES)
-            // one survivor record per thread: consecutive threads write consecutive records, so every
-            // wave-wide store covers one contiguous span of the output arrays
             LfdF3* gx = reinterpret_cast<LfdF3*>(L.xyz + 3 * base);
             LfdF3* gc = reinterpret_cast<LfdF3*>(L.rgb + 3 * base);
             float* ge = L.err + base;
-            // LFD_COPY_UNROLL records per thread per step: their image rows are in flight before the first colour is evaluated
-            const uint8_t* image = S.ref.image;
-            for (int i0 = tid; i0 < n; i0 += LFD_COPY_UNROLL * kBlock) {
-                int sl[LFD_COPY_UNROLL];
-                float px[LFD_COPY_UNROLL], py[LFD_COPY_UNROLL];
-                LfdTapRows taps[LFD_COPY_UNROLL];
-                unsigned sh0[LFD_COPY_UNROLL], sh1[LFD_COPY_UNROLL];
 #pragma unroll
-                for (int u = 0; u < LFD_COPY_UNROLL; ++u) {
-                    const int i = i0 + u * kBlock;
-                    sl[u] = (int)stage.order[i < n ? i : n - 1];
-                    {   // reference position in match pixels, from the A-grid coordinates of the cell (not staged: LDS is
-                        // one of the two things that limit the number of resident workgroups)
-                        const int cell = tile_cell0 + sl[u];
-                        float xan, yan;
-                        if (L.warp_channels == 4) {
-                            const float2 v = load_f32x2(S.slot[stage.slot[sl[u]]].warp + (size_t)cell * 4);
-                            xan = v.x; yan = v.y;
-                        } else {
-                            int dy, x;
-                            lfd_divmod_local(tile_x0 + sl[u], L.W, L.inv_w, dy, x);
-                            const int y = tile_y0 + dy;
-                            if (L.axis_identity) { xan = lfd_axis_value(L.ax, x); yan = lfd_axis_value(L.ay, y); }
-                            else { xan = lfd_global(L.axis_x)[x]; yan = lfd_global(L.axis_y)[y]; }
-                        }
-                        px[u] = lfd_match_px(xan, L.kp.wm1); py[u] = lfd_match_px(yan, L.kp.hm1);
-                    }
-                    taps[u] = lfd_bilinear_fetch(image, L.w_match, L.h_match, px[u], py[u], sh0[u], sh1[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < LFD_COPY_UNROLL; ++u) {
-                    const int i = i0 + u * kBlock;
-                    float rgb[3];
-#if defined(LFD_ABLATE_COLOUR)
-                    rgb[0] = px[u]; rgb[1] = py[u]; rgb[2] = (float)(taps[u].r0 + taps[u].r1 + sh0[u] + sh1[u]);
-#else
-                    lfd_bilinear_eval(taps[u], sh0[u], sh1[u], L.w_match, L.h_match, px[u], py[u], rgb);
-#endif
-                    if (i < n) {
-                        LfdF3 p, c;
-                        p.a = stage.xyz[3 * sl[u] + 0]; p.b = stage.xyz[3 * sl[u] + 1]; p.c = stage.xyz[3 * sl[u] + 2];
-                        c.a = rgb[0]; c.b = rgb[1]; c.c = rgb[2];
-                        gx[i] = p;
-                        gc[i] = c;
-                        ge[i] = stage.err[sl[u]];
-                        if (L.cell) L.cell[base + i] = tile_cell0 + sl[u];
-                        if (L.slot) L.slot[base + i] = stage.slot[sl[u]];
-                    }
+            for (int u = 0; u < kCopyRecords; ++u) {
+                const int i = ctid + u * kCopyThreads;
+                if (i < n) {
+                    const int sl = (int)stage.order[i];
+                    LfdF3 p, c;
+                    p.a = stage.xyz[3 * sl + 0]; p.b = stage.xyz[3 * sl + 1]; p.c = stage.xyz[3 * sl + 2];
+                    c.a = rgb[u][0]; c.b = rgb[u][1]; c.c = rgb[u][2];
+                    gx[i] = p;
+                    gc[i] = c;
+                    ge[i] = stage.err[sl];
+                    if (L.cell) L.cell[base + i] = tile_cell0 + sl;
+                    if (L.slot) L.slot[base + i] = stage.slot[sl];
                 }
             }
-#endif
         }
+#endif
     }
 }
+
+extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_kernel(LfdLaunch L) { lfd_dense_body<false>(L); }
+// the same kernel with upstream's f64 colour arithmetic (bit-identical rgb; lfd_params.flags & LFD_FLAG_EXACT_COLOUR)
+extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_exact_kernel(LfdLaunch L) { lfd_dense_body<true>(L); }
 
 // =================================================================================================
 // indexed mode, pass A on the whole chip: every selected cell is evaluated by its own thread (256 cells per workgroup,

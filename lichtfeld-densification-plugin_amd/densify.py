@@ -136,10 +136,21 @@ def _voxel_downsample(xyz: np.ndarray, rgb: np.ndarray, voxel_size: float) -> Tu
         return (p / cnt[:, None]).astype(np.float32), (c / cnt[:, None]).astype(np.float32)
 
 
+def _is_writer_rank() -> bool:
+    """True unless this process is a non-zero rank of an initialised torch.distributed job."""
+    try:
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+    except Exception:
+        return True
+
+
 def _write_output(path: str, xyz, rgb, err, device_points=None) -> None:
     """``.ply`` -> upstream's PLY, anything else -> upstream's points3D.bin (densify.py:129-135).  When
     the points are still on the GPU the records are quantised and packed there (lfd_pack_*) and only
     the final bytes are copied to the host; the files are byte-identical either way."""
+    if not _is_writer_rank():        # sharded run: every rank holds the gathered cloud, rank 0 alone writes the file
+        return
     d = os.path.dirname(path)
     if d:
         os.makedirs(d, exist_ok=True)
@@ -281,7 +292,8 @@ def dense_init_from_lfs(camera_nodes, config: DensePipelineConfig,
         d = os.path.dirname(config.output_path)
         if d:
             os.makedirs(d, exist_ok=True)
-        write_ply(config.output_path, xyz, to_uint8_rgb(rgb))
+        if _is_writer_rank():
+            write_ply(config.output_path, xyz, to_uint8_rgb(rgb))
     else:
         _write_output(config.output_path, xyz, rgb, err, dev_pts)
     log.info(f"Dense point cloud saved to {config.output_path} ({xyz.shape[0]:,} points)")

@@ -90,8 +90,15 @@ def synth_image(h: int, w: int, seed: int, device="cpu") -> torch.Tensor:
 def synth_reference(cams: Sequence[CameraRecord], ref_index: int, nbr_indices: Sequence[int],
                     H: int, W: int, w_match: int, h_match: int, *, noise_px: float = 0.3,
                     outlier_frac: float = 0.0, channels: int = 2, seed: int = 0,
-                    cert_mode: str = "smooth", device="cpu", far_depth: float = 25.0) -> SyntheticReference:
+                    cert_mode: str = "smooth", device="cpu", far_depth: float = 25.0,
+                    low_parallax_patch: Optional[Sequence[float]] = None,
+                    patch_depths: Sequence[float] = (6.0, 60.0)) -> SyntheticReference:
     """Dense warp + certainty of ``ref_index`` into each neighbour.
+
+    low_parallax_patch: (y0, y1, x0, x1) as fractions of the grid.  Inside it the surface is replaced by a ramp of
+    depths ``patch_depths[0] .. patch_depths[1]`` along x (distance from the reference camera), so that the angle
+    between the two viewing rays falls through the min-parallax threshold (0.5 degrees by default) inside the patch:
+    SURVEY 8d config 3 asks for "a patch with sub-0.5 degree parallax" to exercise that reject reason.
 
     cert_mode: "smooth"  - low-frequency overlap-like field + 2 % jitter (coherent best-neighbour regions)
                "tiefree" - distinct uniform values in (0.2, 0.9) (no ties under floor/cap clamps)
@@ -118,6 +125,12 @@ def synth_reference(cams: Sequence[CameraRecord], ref_index: int, nbr_indices: S
     Xw = CA.view(1, 1, 3) + s.unsqueeze(-1) * dirs_w
     relief = 0.08 * torch.sin(2.1 * Xw[..., 0] + 0.3) * torch.cos(1.7 * Xw[..., 1] - 0.2)
     s = s * (1.0 - relief / CA[2].clamp(min=0.5))
+    if low_parallax_patch is not None:
+        fy0, fy1, fx0, fx1 = [float(v) for v in low_parallax_patch]
+        iy0, iy1, ix0, ix1 = int(fy0 * H), max(int(fy1 * H), int(fy0 * H) + 1), int(fx0 * W), max(int(fx1 * W), int(fx0 * W) + 1)
+        ramp = torch.linspace(float(patch_depths[0]), float(patch_depths[1]), ix1 - ix0, dtype=torch.float64, device=dev)
+        s = s.clone()
+        s[iy0:iy1, ix0:ix1] = ramp.view(1, -1).expand(iy1 - iy0, ix1 - ix0) / dirs_w[iy0:iy1, ix0:ix1].norm(dim=-1)
     Xw = CA.view(1, 1, 3) + s.unsqueeze(-1) * dirs_w
 
     warps, certs = [], []

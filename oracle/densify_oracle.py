@@ -40,7 +40,8 @@ __all__ = [
     "aggregate_best", "select_samples", "fundamental_matrix", "sampson_error",
     "dlt_triangulate", "reprojection_error", "depth_positive", "parallax_ok",
     "bilinear_colour", "match_pixels", "triangulate_selected", "triangulate_reference",
-    "triangulate_dense", "cell_diagnostics", "to_uint8_rgb", "ply_bytes", "points3d_bin_bytes",
+    "triangulate_dense", "cell_diagnostics", "cell_diagnostics_exact", "classify_flips", "FLIP_REASONS",
+    "to_uint8_rgb", "ply_bytes", "points3d_bin_bytes",
 ]
 
 
@@ -592,6 +593,113 @@ def cell_diagnostics(cells: np.ndarray, best_k: np.ndarray, agg: np.ndarray, cam
             ang[pos] = parallax_angle_deg(cam_a.C, cb.C, X)
     return {"sampson": se, "err": err, "z1": z1, "z2": z2, "parallax_deg": ang, "sv_ratio": sv_gap,
             "err_noise": noise}
+
+
+def cell_diagnostics_exact(cells: np.ndarray, best_k: np.ndarray, agg: np.ndarray, cam_a: OracleCamera,
+                           cams_b: Sequence[OracleCamera], w_match: int, h_match: int, axes=None) -> Dict[str, np.ndarray]:
+    """The same decision variables as ``cell_diagnostics`` evaluated WITHOUT upstream's f32 rounding noise downstream
+    of the DLT matrix: the f32 matrix A is upstream's (core/geometry.py:63-75), its smallest right singular vector
+    comes from an f64 SVD, the point is rounded to f32 once (upstream's X is f32), and reprojection / depth / parallax
+    are then evaluated in f64 on that f32 point.  ``cell_diagnostics`` (upstream's arithmetic) and this function
+    bracket what ANY correct evaluation of upstream's formulas on the same inputs can return; a cell whose threshold
+    lies between the two is decided by rounding, not by the algorithm (see ``classify_flips``)."""
+    cells = np.asarray(cells, np.int64)
+    h, w = best_k.shape
+    if agg.shape[1] == 2:
+        ax, ay = axes if axes is not None else (identity_axis(w), identity_axis(h))
+        agg = np.concatenate([ax[np.arange(h * w) % w, None], ay[np.arange(h * w) // w, None], agg], axis=1).astype(np.float32)
+    n = cells.size
+    out = {k: np.full(n, np.nan) for k in ("err", "z1", "z2", "parallax_deg", "z1_noise", "z2_noise")}
+    sel = agg[cells]
+    xA = match_pixels(sel[:, 0], w_match)
+    yA = match_pixels(sel[:, 1], h_match)
+    uvA_all = np.stack([xA * (cam_a.width / float(w_match)), yA * (cam_a.height / float(h_match))], axis=1)
+    kk_all = best_k.reshape(-1)[cells]
+    eps = np.float64(np.finfo(np.float32).eps)
+    for kk in np.unique(kk_all):
+        pos = np.nonzero(kk_all == kk)[0]
+        cb = cams_b[int(kk)]
+        xB = match_pixels(sel[pos, 2], w_match)
+        yB = match_pixels(sel[pos, 3], h_match)
+        uvB = np.stack([xB * (cb.width / float(w_match)), yB * (cb.height / float(h_match))], axis=1)
+        uvA = uvA_all[pos]
+        with np.errstate(all="ignore"):
+            A = dlt_rows(cam_a.P, cb.P, uvA, uvB).astype(np.float64)
+            Vt = np.linalg.svd(A)[2]
+            Xh = Vt[:, -1, :]
+            wv = np.where(np.abs(Xh[:, 3:4]) < 1e-12, 1e-12, Xh[:, 3:4])
+            X = (Xh / wv).astype(np.float32).astype(np.float64)          # upstream's point is f32
+            e = []
+            for P, uv, zk in ((cam_a.P, uvA, "z1"), (cb.P, uvB, "z2")):
+                pr = X @ P.astype(np.float64).T
+                z = np.maximum(pr[:, 2], 1e-12)
+                e.append(np.hypot(pr[:, 0] / z - uv[:, 0].astype(np.float64), pr[:, 1] / z - uv[:, 1].astype(np.float64)))
+                out[zk][pos] = pr[:, 2]
+                out[zk + "_noise"][pos] = 4.0 * eps * (np.abs(X) @ np.abs(P[2].astype(np.float64)))
+            out["err"][pos] = np.maximum(e[0], e[1])
+            v1 = X[:, :3] - cam_a.C.astype(np.float64).reshape(1, 3)
+            v2 = X[:, :3] - cb.C.astype(np.float64).reshape(1, 3)
+            v1 = v1 / (np.linalg.norm(v1, axis=1, keepdims=True) + 1e-12)
+            v2 = v2 / (np.linalg.norm(v2, axis=1, keepdims=True) + 1e-12)
+            out["parallax_deg"][pos] = np.degrees(np.arccos(np.clip(np.sum(v1 * v2, axis=1), -1.0, 1.0)))
+    return out
+
+
+FLIP_REASONS = ("sampson", "reproj", "cheirality", "parallax", "non_finite")
+
+
+def classify_flips(cells: np.ndarray, best_k: np.ndarray, agg: np.ndarray, cam_a: OracleCamera,
+                   cams_b: Sequence[OracleCamera], w_match: int, h_match: int, params: OracleParams, axes=None,
+                   sampson_rel: float = 1e-12):
+    """For cells that another implementation decided differently from this oracle: which threshold explains each one.
+
+    Noise model (stated, per reject reason; eps = 2^-23):
+      sampson     upstream evaluates the test in f64 from f32 inputs.  An implementation that is handed upstream's F may
+                  differ by the association order of ~20 f64 operations: |se - thr| <= sampson_rel * max(1, thr) with
+                  sampson_rel = 1e-12.  (Without upstream's F - the closed-form K^-1 instead of np.linalg.inv - F moves
+                  by ~2e-6 relative and the caller passes sampson_rel = 1e-5.)
+      reproj      the threshold lies between upstream's f32 value (LAPACK sgesdd + f32 reprojection) and the value of
+                  the same formulas free of f32 rounding noise (f64 SVD of the same f32 matrix, f64 reprojection),
+                  widened by the first-order bound on the f32 rounding of ONE reprojection, ``_reproj_noise``
+                  (4 eps sum|terms| / z): that is what any f32 evaluation of the formula may add.
+      cheirality  zero lies between upstream's f32 depth and the f64 depth, widened by 4 eps sum|terms| of the depth row.
+      parallax    the threshold lies between upstream's f32 angle and the f64 angle, widened by the f32 rounding of the
+                  normalised dot product seen through arccos: 4 eps / sin(theta_min) radians.
+      non_finite  upstream's value is NaN / Inf (w -> 0 guard, overflow): not reproducible by construction.
+    Returns ``(reason (n,) array of indices into FLIP_REASONS, -1 = out of band, details dict)``."""
+    cells = np.asarray(cells, np.int64)
+    n = cells.size
+    reason = np.full(n, -1, np.int64)
+    if n == 0:
+        return reason, {}
+    with np.errstate(all="ignore"):
+        up = cell_diagnostics(cells, best_k, agg, cam_a, cams_b, w_match, h_match, axes=axes)
+        ex = cell_diagnostics_exact(cells, best_k, agg, cam_a, cams_b, w_match, h_match, axes=axes)
+    eps = float(np.finfo(np.float32).eps)
+
+    def between(a, b, thr, pad):
+        lo, hi = np.minimum(a, b) - pad, np.maximum(a, b) + pad
+        return (thr >= lo) & (thr <= hi)
+
+    with np.errstate(all="ignore"):
+        if not params.no_filter:
+            thr_r = float(np.float32(params.reproj_thresh))
+            in_par = np.zeros(n, bool)
+            if params.min_parallax_deg > 0:
+                pad_par = np.degrees(4.0 * eps / np.sin(np.radians(max(float(params.min_parallax_deg), 1e-3))))
+                in_par = between(up["parallax_deg"].astype(np.float64), ex["parallax_deg"], float(params.min_parallax_deg), pad_par)
+            in_z = between(up["z1"].astype(np.float64), ex["z1"], 0.0, ex["z1_noise"]) | \
+                between(up["z2"].astype(np.float64), ex["z2"], 0.0, ex["z2_noise"])
+            in_rep = between(up["err"].astype(np.float64), ex["err"], thr_r, up["err_noise"].astype(np.float64))
+            in_sam = np.zeros(n, bool)
+            if params.sampson_thresh > 0:
+                in_sam = np.abs(up["sampson"] - params.sampson_thresh) <= sampson_rel * max(1.0, params.sampson_thresh)
+            bad = ~np.isfinite(up["err"].astype(np.float64)) | ~np.isfinite(ex["err"])
+            for idx, m in ((3, in_par), (2, in_z), (1, in_rep), (0, in_sam), (4, bad)):     # later entries take precedence
+                reason[m] = idx
+        else:
+            reason[~np.isfinite(up["err"].astype(np.float64)) | ~np.isfinite(ex["err"])] = 4
+    return reason, {"upstream": up, "exact": ex}
 
 
 # --------------------------------------------------------------------------------------------

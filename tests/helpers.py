@@ -60,3 +60,38 @@ def guard_band_ok(diag, params, eps_sampson=1e-6, eps_err=2e-3, eps_par=5e-3, ep
         near |= ~np.isfinite(diag["err"])
         ok &= ~(near & passed_s)
     return ok
+
+
+def oracle_cam(c):
+    return orc.OracleCamera(K=c.K, R=c.R, t=c.t, P=c.P, C=c.C, width=c.width, height=c.height)
+
+
+def flip_report(kept_cells, sref, cams, w_match, h_match, params, axes, sample=None, sampson_rel=1e-12, seed=0):
+    """Cells of one reference that an implementation (``kept_cells`` = the grid cells it kept, dense mode) decides
+    differently from the oracle, each classified by the threshold that explains it (``orc.classify_flips``: the band of
+    every reject reason is derived from a stated rounding-noise model, see its docstring).
+
+    ``sample``: compare on that many random cells only (the oracle's LAPACK path costs ~4 us per cell).
+    Returns dict(cells=compared, flipped=n, out_of_band=n, by_reason={reason: n}, oob_cells=[...], oracle=...)."""
+    k = len(sref.nbr_indices)
+    H, W = sref.cert.shape[1:]
+    certs = [sref.cert[j].cpu().numpy() for j in range(k)]
+    warps = [sref.warp[j].cpu().numpy() for j in range(k)]
+    ca, cbs = oracle_cam(cams[sref.ref_index]), [oracle_cam(cams[n]) for n in sref.nbr_indices]
+    with np.errstate(all="ignore"):
+        best_cert, best_k, agg = orc.prepare_reference(certs, warps, params)
+        if sample is None or sample >= H * W:
+            cells = np.arange(H * W, dtype=np.int64)
+        else:
+            cells = np.sort(np.random.RandomState(seed).choice(H * W, size=int(sample), replace=False)).astype(np.int64)
+        res = orc.triangulate_selected(cells, best_cert, best_k, agg, sref.image.cpu().numpy(), ca, cbs, w_match, h_match,
+                                       params, axes=axes)
+    keep_orc = np.zeros(H * W, bool)
+    keep_orc[res.cell] = True
+    keep_impl = np.zeros(H * W, bool)
+    keep_impl[np.asarray(kept_cells, np.int64)] = True
+    flipped = cells[keep_orc[cells] != keep_impl[cells]]
+    reason, _ = orc.classify_flips(flipped, best_k, agg, ca, cbs, w_match, h_match, params, axes=axes, sampson_rel=sampson_rel)
+    by = {name: int((reason == i).sum()) for i, name in enumerate(orc.FLIP_REASONS)}
+    return dict(cells=int(cells.size), flipped=int(flipped.size), out_of_band=int((reason < 0).sum()), by_reason=by,
+                oob_cells=flipped[reason < 0].tolist(), oracle=res, compared=cells)

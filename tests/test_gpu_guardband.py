@@ -1,0 +1,171 @@
+"""Every count flip against the oracle is explained, cell by cell, by a rounding-noise band - at FULL size on the shapes
+of the BASELINE configurations.  Run on the MI355X box with ``pytest -m gpu``.
+
+north_star asks for "surviving-point counts bit-identical under fixed thresholds".  Upstream's decision variables carry
+f32 rounding noise of its own (LAPACK sgesdd on an f32 4x4 matrix, f32 reprojection, f32 arccos), so a cell whose value
+sits within that noise of a threshold is decided by rounding in upstream itself: nobody - including upstream on another
+BLAS build - reproduces it.  What CAN be proved, and is proved here for every cell the HIP dense kernel decides
+differently from the oracle (= upstream's arithmetic on this machine):
+
+    the threshold of (at least) one test lies between upstream's f32 value and the value the same formulas give without
+    f32 rounding noise (f64 SVD of the same f32 matrix, f64 reprojection / depth / angle), widened by the first-order
+    bound of ONE f32 evaluation of that formula  (oracle.classify_flips states the band per reject reason).
+
+Zero flips outside the band are allowed, on any shape; the flip RATE is also bounded at 2x what was measured.
+The kernels receive upstream's own fundamental matrices (lfd_batch.fundamental), so the Sampson gate has no band at all
+beyond f64 association order (1e-12).
+"""
+import numpy as np
+import pytest
+import torch
+
+import lichtfeld_densification_plugin_amd as lfd
+from lichtfeld_densification_plugin_amd import synthetic
+from lichtfeld_densification_plugin_amd.core import hip_backend as hb
+from helpers import flip_report, oracle_cams, orc
+
+pytestmark = pytest.mark.gpu
+
+# name: cameras (n, w, h, focal), grid (H, W, w_match, h_match), k, references, noise px, outliers, low-parallax patch,
+#       thresholds (reproj), cells compared per reference (None = all), allowed flip rate
+SHAPES = {
+    # BASELINE config 2, GUI defaults: fast 512^2, k=3, reproj 0.8
+    "fast_k3_gui": dict(cams=(185, 1297, 840, 960.0), grid=(512, 512, 512, 512), k=3, refs=(0, 60), noise=0.5, outl=0.05,
+                        patch=None, reproj=0.8, sample=None, rate=3e-4),
+    # BASELINE config 2, CLI defaults: k=4, reproj 1.5 (densify.py:318-415)
+    "fast_k4_cli": dict(cams=(185, 1297, 840, 960.0), grid=(512, 512, 512, 512), k=4, refs=(30,), noise=1.0, outl=0.05,
+                        patch=None, reproj=1.5, sample=None, rate=3e-4),
+    # BASELINE config 3: `high` = 960^2 grid over 640-px match images, bicycle-sized cameras, 10 % gross outliers and a
+    # patch whose parallax falls through 0.5 degrees
+    "high_k3_patch": dict(cams=(194, 1237, 822, 915.0), grid=(960, 960, 640, 640), k=3, refs=(10,), noise=1.0, outl=0.10,
+                          patch=(0.3, 0.6, 0.2, 0.8), reproj=0.8, sample=None, rate=4e-4),
+    # BASELINE config 4, one rank's shape: fast, 8 neighbours, several references in one launch
+    "fast_k8_multi": dict(cams=(185, 1297, 840, 960.0), grid=(512, 512, 512, 512), k=8, refs=(5, 90, 150), noise=0.5, outl=0.05,
+                          patch=None, reproj=0.8, sample=120000, rate=3e-4),
+    # BASELINE config 5: `precise` = 1280^2 grid over 800-px match images, 8 neighbours, ROI subset of 12 cameras
+    "precise_k8_roi": dict(cams=(12, 1297, 840, 960.0), grid=(1280, 1280, 800, 800), k=8, refs=(5,), noise=0.5, outl=0.05,
+                           patch=None, reproj=0.8, sample=300000, rate=3e-4),
+}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _scene(spec, dev):
+    n, w, h, f = spec["cams"]
+    H, W, wm, hm = spec["grid"]
+    cams = synthetic.ring_cameras(n, width=w, height=h, focal=f, seed=0, arc=1.2 if n <= 16 else 2.0 * np.pi)
+    srefs, refs = [], []
+    for ref in spec["refs"]:
+        nbrs = synthetic.ring_neighbours(n, ref, spec["k"])
+        s = synthetic.synth_reference(cams, ref, nbrs, H, W, wm, hm, noise_px=spec["noise"], outlier_frac=spec["outl"],
+                                      channels=2, seed=1000 + ref, cert_mode="smooth", low_parallax_patch=spec["patch"])
+        srefs.append(s)
+        refs.append(hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=[s.cert[j].to(dev) for j in range(spec["k"])],
+                                       warp=[s.warp[j].contiguous().to(dev) for j in range(spec["k"])], image=s.image.to(dev)))
+    return cams, srefs, refs
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_every_flip_is_inside_the_derived_band(dev, name):
+    spec = SHAPES[name]
+    H, W, wm, hm = spec["grid"]
+    cams, srefs, refs = _scene(spec, dev)
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    cfg = lfd.DensePipelineConfig(output_path="", reproj_thresh=spec["reproj"], nns_per_ref=spec["k"])
+    params = orc.OracleParams(reproj_thresh=spec["reproj"])
+    batch = hb.PreparedBatch(refs, wm, hm, cameras=cams)          # upstream's F handed to the kernels
+    out = dens.triangulate_dense(batch, hb.make_params(cfg))
+    cell = out.cell.cpu().numpy().astype(np.int64)
+    axes = (orc.identity_axis_scalar(W), orc.identity_axis_scalar(H))
+    total = dict(cells=0, flipped=0, out_of_band=0)
+    by = {r: 0 for r in orc.FLIP_REASONS}
+    xyz, rgb, err = out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy()
+    for r, s in enumerate(srefs):
+        lo, hi = int(out.ref_offsets[r]), int(out.ref_offsets[r + 1])
+        rep = flip_report(cell[lo:hi], s, cams, wm, hm, params, axes, sample=spec["sample"], seed=r)
+        assert rep["out_of_band"] == 0, f"{name} ref {r}: cells {rep['oob_cells'][:8]} flip outside every band ({rep})"
+        for key in total:
+            total[key] += rep[key]
+        for k_, v in rep["by_reason"].items():
+            by[k_] += v
+        # the common survivors carry upstream's values
+        res = rep["oracle"]
+        common = np.intersect1d(cell[lo:hi], res.cell)
+        ph = np.searchsorted(cell[lo:hi], common) + lo
+        order_o = np.argsort(res.cell, kind="stable")
+        po = order_o[np.searchsorted(res.cell[order_o], common)]
+        np.testing.assert_allclose(xyz[ph], res.xyz[po], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rgb[ph], res.rgb[po], rtol=0, atol=1.0 / 255.0 / 4.0)
+        assert np.abs(err[ph] - res.err[po]).max() < 5e-2        # per-point bound incl. upstream's own noise: test_gpu_parity
+    assert total["flipped"] <= spec["rate"] * total["cells"] + 4, (name, total, by)
+    print(f"[guard band] {name}: {total} by reason {by}")
+    # every reject reason of the stack is exercised by the config-3 shape
+    if spec["patch"] is not None:
+        res = rep["oracle"]
+        assert res.count < 0.9 * rep["cells"]
+    dens.close()
+
+
+def test_exact_colour_flag_is_bit_identical_and_default_is_within_tolerance(dev):
+    """lfd_params.flags & LFD_FLAG_EXACT_COLOUR: dense-mode rgb equals the oracle's bit for bit; the default f32 blend stays
+    within 2.5e-7 of it (the stated tolerance is 1/1020) and changes nothing else."""
+    spec = dict(SHAPES["fast_k3_gui"], refs=(20,))
+    H, W, wm, hm = spec["grid"]
+    cams, srefs, refs = _scene(spec, dev)
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    cfg = lfd.DensePipelineConfig(output_path="")
+    batch = hb.PreparedBatch(refs, wm, hm, cameras=cams)
+    fast = dens.triangulate_dense(batch, hb.make_params(cfg))
+    exact = dens.triangulate_dense(batch, hb.make_params(cfg, exact_colour=True))
+    assert fast.count == exact.count and torch.equal(fast.xyz, exact.xyz) and torch.equal(fast.err, exact.err)
+    assert torch.equal(fast.cell, exact.cell)
+    assert (fast.rgb - exact.rgb).abs().max().item() <= 2.5e-7
+    axes = (orc.identity_axis_scalar(W), orc.identity_axis_scalar(H))
+    rep = flip_report(exact.cell.cpu().numpy(), srefs[0], cams, wm, hm, orc.OracleParams(), axes)
+    res = rep["oracle"]
+    cell = exact.cell.cpu().numpy().astype(np.int64)
+    common = np.intersect1d(cell, res.cell)
+    order_o = np.argsort(res.cell, kind="stable")
+    po = order_o[np.searchsorted(res.cell[order_o], common)]
+    np.testing.assert_array_equal(exact.rgb.cpu().numpy()[np.searchsorted(cell, common)], res.rgb[po])
+    dens.close()
+
+
+def test_fundamental_read_back_override_is_bit_equal_and_own_f_is_bounded(dev, g1):
+    """Row F5: the F the kernels use, read back from the device.  With lfd_batch.fundamental it IS upstream's
+    fundamental_from_world2cam result (golden g1, bit for bit); without it the library's closed-form-K^-1 F agrees to
+    2e-6 relative (np.linalg.inv's LU rounds differently), which is why callers that hold upstream's F pass it."""
+    cams, pairs = [], []
+    for pi in range(int(g1["n_pairs"])):
+        ca, cb = oracle_cams(g1, f"p{pi}_cam_")
+        for c in (ca, cb):
+            cams.append(lfd.CameraRecord(uid=len(cams), image_path="", width=c.width, height=c.height, K=c.K, R=c.R, t=c.t, P=c.P, C=c.C))
+        pairs.append((len(cams) - 2, len(cams) - 1, g1[f"p{pi}_F"]))
+        # the Python mirror's host routine is upstream's own NumPy call sequence: bit-equal to the captured F
+        np.testing.assert_array_equal(hb.fundamental_from_world2cam(ca.K, ca.R, ca.t, cb.K, cb.R, cb.t), g1[f"p{pi}_F"])
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    H = W = 32
+    z = torch.zeros((H, W), device=dev)
+    wp = torch.zeros((H, W, 2), device=dev)
+    img = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    cfg = lfd.DensePipelineConfig(output_path="")
+    for with_override in (True, False):
+        refs = [hb.ReferenceInputs(ref_cam=a, nbr_cams=[b], cert=[z], warp=[wp], image=img) for a, b, _ in pairs]
+        batch = hb.PreparedBatch(refs, W, H, cameras=cams if with_override else None)
+        dens.aggregate(batch, hb.make_params(cfg))
+        F = dens.pair_fundamentals(len(pairs), 1)[:, 0]
+        for (a, b, F_up), F_dev in zip(pairs, F):
+            if with_override:
+                np.testing.assert_array_equal(F_dev.astype(np.float32), np.asarray(F_up, np.float32))
+                np.testing.assert_array_equal(F_dev, np.asarray(F_up, np.float32).astype(np.float64))
+            else:
+                scale = np.abs(F_up).max()
+                assert np.abs(F_dev - F_up).max() <= 4e-6 * scale
+    dens.close()

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert len(names) >= 12
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/lfd_densify.h but not exported"
-    assert lib.lfd_abi_version() == 1
+    assert lib.lfd_abi_version() == hb.LFD_ABI_VERSION == 2
     assert ctypes.sizeof(hb.lfd_params) == 32
 
 
@@ -82,6 +82,16 @@ def test_fundamental_matches_numpy(g1):
 
 def _cam_record(oc, uid=0):
     return lfd.CameraRecord(uid=uid, image_path="", width=oc.width, height=oc.height, K=oc.K, R=oc.R, t=oc.t, P=oc.P, C=oc.C)
+
+
+def test_python_fundamental_is_upstream_bit_for_bit(g1):
+    """core.hip_backend.fundamental_from_world2cam repeats upstream's NumPy calls (core/geometry.py:122-130): on the same
+    machine it returns the captured F bit for bit; it is what PreparedBatch(cameras=...) hands to the kernels."""
+    for pi in range(int(g1["n_pairs"])):
+        ca, cb = oracle_cams(g1, f"p{pi}_cam_")
+        F = hb.fundamental_from_world2cam(ca.K, ca.R, ca.t, cb.K, cb.R, cb.t)
+        assert F.dtype == np.float32
+        np.testing.assert_array_equal(F, g1[f"p{pi}_F"])
 
 
 def test_host_eval_matches_golden_geometry(g1):

@@ -161,25 +161,34 @@ def test_point_cap_and_voxel_filter():
 
 
 def test_debug_state_blocks_until_stepped():
+    """The five calls run_dense_pipeline makes on the host's debug object (core/debug_viz.py here documents them)."""
     import threading
     st = MatchDebugState()
     pv = MatchPreview(1, 2, "a", "b", np.zeros((2, 2, 3), np.uint8), np.zeros((2, 2, 3), np.uint8),
                       np.zeros((1, 4), np.float32), np.zeros(1, np.float32), 1, 1, 1)
     st.submit_preview(pv)
-    assert st.latest() is None                       # disabled: dropped
+    assert st.latest() is None and not st.is_enabled()      # disabled: dropped
     st.set_enabled(True)
+    st.set_total_pairs(7)
+    assert st.is_auto_step() and st.total_pairs() == 7
+    st.submit_preview(pv)                                      # auto stepping: returns at once
     st.set_auto_step(False)
     done = threading.Event()
     th = threading.Thread(target=lambda: (st.submit_preview(pv), done.set()))
     th.start()
-    assert not done.wait(0.2)
+    assert not done.wait(0.2)                                  # manual stepping parks the producer ...
     st.step_once()
+    assert done.wait(2.0)                                      # ... until the consumer steps
+    th.join()
+    assert st.latest() is pv
+    done.clear()
+    th = threading.Thread(target=lambda: (st.submit_preview(pv), done.set()))
+    th.start()
+    assert not done.wait(0.2)
+    st.release_waiters()                                       # the pipeline's `finally`: nobody stays parked
     assert done.wait(2.0)
     th.join()
-    assert st.latest() is pv and st.visible_match_indices(5) == [0, 1, 2, 3, 4]
-    st.set_single_match_mode(True)
-    st.next_match(5)
-    assert st.visible_match_indices(5) == [1]
+    st.submit_preview(pv)                                      # and nobody parks afterwards
 
 
 def test_host_arrays_slices_the_packed_buffer_like_three_copies():
