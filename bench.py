@@ -9,19 +9,26 @@ synthetic RoMa outputs that is already resident in HBM: R reference views x k ne
 `fast` preset's 512x512 grid (MipNeRF360 `garden` geometry: 185 cameras on a ring, 1297x840 images),
 default filter thresholds.  Metric: triangulated (surviving) points per second, whole job.
 
-For N > 1 the references are dealt round-robin to the ranks (one process per GPU, no data-path
+For N > 1 the references are dealt round-robin to the ranks (one process per GPU over RCCL, no data-path
 collective inside the timed region: the path shards by reference view) and the survivors are
-all-gathered once after the timed region as a correctness check of the multi-GPU path.
+all-gathered once after the timed region - the one exchange step of the path, timed separately
+(`allgather_ms`).  `python bench.py --gpus N` without a launcher starts the N ranks itself (fresh child
+processes, before this process touches the GPU); under `torch.distributed.run` it is one of the ranks.
 
-Prints ONE JSON line on rank 0 (see the contract in the task description) with two extra objects:
-`roofline` (HBM roofline of the fused kernel, measured live with HIP events) and `cpu_baseline` (the
-NumPy oracle = a faithful port of the upstream CPU path, timed on a bounded sample).
+Prints ONE JSON line on rank 0 (see the contract in the task description) with extra objects:
+`roofline` (HBM roofline of the fused kernel, measured live with HIP events), `cpu_baseline` (this build's
+own C++ restatement - the CPU twin of the C-ABI, host build of the kernels' source - on 1 thread and on all
+host threads, the NumPy oracle and upstream's probed Python time quoted beside it) and `parity` (cells of
+the timed workload the kernel decides differently from the oracle, each checked against the derived
+rounding band).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -49,8 +56,10 @@ def parse_args():
     ap.add_argument("--noise-px", type=float, default=0.5)
     ap.add_argument("--outliers", type=float, default=0.05)
     ap.add_argument("--cpu-sample-refs", type=int, default=24,
-                    help="references timed on the CPU oracle, ~0.5 s each (0 = skip)")
+                    help="references of the workload timed on the CPU twin (0 = skip the cpu_baseline leg)")
     ap.add_argument("--spinup-s", type=float, default=0.25, help="untimed spin-up (launch + sync in a loop) before the warm-up steps")
+    ap.add_argument("--light", action="store_true", help="headline only: skip the secondary legs (profiling passes)")
+    ap.add_argument("--parity-refs", type=int, default=2, help="references of the workload checked cell by cell against the oracle (0 = skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc run of this same command (profiles/)")
     return ap.parse_args()
@@ -210,58 +219,176 @@ def d2h_inclusive_rate(dens, batch, params, out, dev, reps=3):
     return {"points_per_s": n / best, "ms": best * 1e3, "bytes_to_host": n * 28}
 
 
+def _oracle_cam(c):
+    from oracle import densify_oracle as orc     # checker / baseline only
+    return orc.OracleCamera(K=c.K, R=c.R, t=c.t, P=c.P, C=c.C, width=c.width, height=c.height)
+
+
 def cpu_baseline(args, cams, srefs, dims, cfg):
-    """The oracle (NumPy restatement of upstream's CPU path: same LAPACK batched f32 SVD, same dtype
-    ladder) on every cell of a few references of this very workload, single-threaded."""
+    """CPU numbers for the same workload, on this box's host cores (bounded sample, ~10-20 s in all):
+      * `value`: the CPU twin of the C-ABI (lfd_triangulate_dense_host: the HOST build of the kernels' per-cell source,
+        csrc/lfd_geometry.hpp, on std::threads) over every cell of the sample, all host threads - the same mode as the
+        GPU headline; `one_thread` the same on 1 thread;
+      * `sampled_mode`: upstream's own mode (aggregate -> coverage sampling M=10000 -> triangulate the ~9k selected cells)
+        on the twin + the host sampling stage, per reference - what upstream's `_triangulate_ref` does in 0.3-0.7 s;
+      * `oracle_numpy`: the NumPy oracle (upstream's arithmetic incl. the batched LAPACK f32 SVD), 1 thread, dense;
+      * `reference_python`: upstream's own Python timed in the development container (its files do
+        not travel to the GPU box)."""
     if args.cpu_sample_refs <= 0:
         return None
+    from lichtfeld_densification_plugin_amd.core.sampling import select_samples_with_coverage
+    H, W, wm, hm = dims
+    sample = srefs[:args.cpu_sample_refs]
+    host_refs = [hb.ReferenceInputs(ref_cam=s.ref_index, nbr_cams=list(s.nbr_indices), cert=[s.cert[j].cpu() for j in range(args.k)],
+                                    warp=[s.warp[j].cpu().contiguous() for j in range(args.k)], image=s.image.cpu()) for s in sample]
+    batch = hb.PreparedBatch(host_refs, wm, hm, cameras=cams)
+    params = hb.make_params(cfg)
+    out = {}
+    n_hw = os.cpu_count() or 1
+    for label, threads in (("all", 0), ("one", 1)):
+        twin = hb.HostDensifier(threads)
+        twin.upload_cameras(cams)
+        refs_used = len(host_refs) if threads != 1 else max(1, len(host_refs) // 4)
+        b = batch if refs_used == len(host_refs) else hb.PreparedBatch(host_refs[:refs_used], wm, hm, cameras=cams)
+        twin.triangulate_dense(b, params)                       # warm (page faults of the output buffers)
+        t0 = time.perf_counter()
+        res = twin.triangulate_dense(b, params)
+        dt = time.perf_counter() - t0
+        out[label] = dict(points_per_s=res.count / dt, cells_per_s=refs_used * H * W / dt, pairs_per_s=refs_used * args.k / dt,
+                          seconds=dt, references=refs_used, threads=twin.n_threads)
+        if threads == 0:     # upstream's own mode on the twin, reference after reference
+            rng = np.random.RandomState(cfg.seed)
+            t0 = time.perf_counter()
+            pts = 0
+            n_s = min(8, len(host_refs))
+            for r in host_refs[:n_s]:
+                b1 = hb.PreparedBatch([r], wm, hm, cameras=cams)
+                best, _ = twin.aggregate(b1, params)
+                sel = select_samples_with_coverage(best[0], cfg.matches_per_ref, cap=0.9, border=2, tiles=24, rng=rng)
+                pts += twin.triangulate_indexed(b1, params, torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int64)), [0, int(sel.size)]).count
+            dts = time.perf_counter() - t0
+            out["sampled"] = dict(ms_per_reference=dts / n_s * 1e3, points_per_s=pts / dts, pairs_per_s=n_s * args.k / dts,
+                                  references=n_s, matches_per_ref=cfg.matches_per_ref, threads=twin.n_threads,
+                                  note="CPU twin (aggregate + indexed) + host coverage sampling (core/sampling.py)")
+        twin.close()
+    # the NumPy oracle on a few references (1 BLAS thread), as in round 1
     from oracle import densify_oracle as orc     # checker / baseline only
     try:
         from threadpoolctl import threadpool_limits
     except Exception:                              # pragma: no cover
         threadpool_limits = None
-    H, W, wm, hm = dims
-    params = orc.OracleParams(certainty_thresh=cfg.certainty_thresh, reproj_thresh=cfg.reproj_thresh,
-                              sampson_thresh=cfg.sampson_thresh, min_parallax_deg=cfg.min_parallax_deg)
+    oparams = orc.OracleParams(certainty_thresh=cfg.certainty_thresh, reproj_thresh=cfg.reproj_thresh,
+                               sampson_thresh=cfg.sampson_thresh, min_parallax_deg=cfg.min_parallax_deg)
     axes = (orc.identity_axis_scalar(W), orc.identity_axis_scalar(H))
-
-    def oc(c):
-        return orc.OracleCamera(K=c.K, R=c.R, t=c.t, P=c.P, C=c.C, width=c.width, height=c.height)
-
-    sample = srefs[:args.cpu_sample_refs]
-    host = [([s.cert[j].cpu().numpy() for j in range(args.k)], [s.warp[j].cpu().numpy() for j in range(args.k)],
-             s.image.cpu().numpy(), oc(cams[s.ref_index]), [oc(cams[n]) for n in s.nbr_indices]) for s in sample]
-    pts = 0
+    n_o = min(4, len(sample))
     ctx = threadpool_limits(limits=1) if threadpool_limits else None
     t0 = time.perf_counter()
+    opts = 0
     with np.errstate(all="ignore"):
-        for certs, warps, img, ca, cbs in host:
-            pts += orc.triangulate_dense(certs, warps, img, ca, cbs, wm, hm, params, axes=axes)["xyz"].shape[0]
-    dt = time.perf_counter() - t0
-    if ctx is not None:
-        ctx.restore_original_limits() if hasattr(ctx, "restore_original_limits") else None
-    return {"value": pts / dt, "unit": "points/s", "cores": 1, "kind": "port",
-            "sample": f"{len(sample)} reference views x {args.k} neighbours x {H}x{W} cells of this workload "
-                      f"({pts} survivors in {dt:.1f} s, NumPy oracle, BLAS threads limited to 1)",
-            "pairs_per_s": len(sample) * args.k / dt}
+        for s in sample[:n_o]:
+            opts += orc.triangulate_dense([s.cert[j].cpu().numpy() for j in range(args.k)], [s.warp[j].cpu().numpy() for j in range(args.k)],
+                                          s.image.cpu().numpy(), _oracle_cam(cams[s.ref_index]), [_oracle_cam(cams[n]) for n in s.nbr_indices],
+                                          wm, hm, oparams, axes=axes)["xyz"].shape[0]
+    dto = time.perf_counter() - t0
+    if ctx is not None and hasattr(ctx, "restore_original_limits"):
+        ctx.restore_original_limits()
+    a = out["all"]
+    return {"value": a["points_per_s"], "unit": "points/s", "cores": a["threads"], "kind": "port",
+            "sample": f"{a['references']} reference views x {args.k} neighbours x {H}x{W} cells of this workload, dense mode "
+                      f"({a['seconds']:.2f} s on {a['threads']} threads of {n_hw} host CPUs; CPU twin of the C-ABI = host build of the kernels' source)",
+            "pairs_per_s": a["pairs_per_s"], "cells_per_s": a["cells_per_s"],
+            "one_thread": {"value": out["one"]["points_per_s"], "cores": 1, "pairs_per_s": out["one"]["pairs_per_s"],
+                           "sample": f"{out['one']['references']} references, {out['one']['seconds']:.2f} s"},
+            "sampled_mode": out["sampled"],
+            "oracle_numpy": {"value": opts / dto, "cores": 1, "pairs_per_s": n_o * args.k / dto,
+                             "sample": f"{n_o} references dense, {dto:.1f} s, BLAS threads limited to 1 (upstream's arithmetic: batched LAPACK f32 SVD)"},
+            "reference_python": {"ms_per_reference": [300, 700], "points_per_s": [15000, 30000], "cores": 8,
+                                 "note": "upstream core/pipeline.py::_triangulate_ref (sampled mode, 512^2, k=3, M=10000) probed in the development "
+                                         "container, BASELINE.md section 2; not runnable on the GPU box"}}
+
+
+def parity_report(args, dens, cams, refs, srefs, dims, cfg):
+    """"the bench reports near-threshold counts separately".  The first --parity-refs references of the
+    timed workload through the dense kernel (with cell indices) against the oracle, every differing cell classified by
+    the threshold whose derived rounding band explains it (oracle.classify_flips); `flipped_out_of_band` must be 0."""
+    if args.parity_refs <= 0:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import flip_report          # tests/helpers.py: oracle-based checker
+    from oracle import densify_oracle as orc
+    H, W, wm, hm = dims
+    n = min(args.parity_refs, len(refs))
+    batch = hb.PreparedBatch(refs[:n], wm, hm, cameras=cams)
+    out = dens.triangulate_dense(batch, hb.make_params(cfg))
+    cell = out.cell.cpu().numpy().astype(np.int64)
+    oparams = orc.OracleParams(certainty_thresh=cfg.certainty_thresh, reproj_thresh=cfg.reproj_thresh,
+                               sampson_thresh=cfg.sampson_thresh, min_parallax_deg=cfg.min_parallax_deg)
+    axes = (orc.identity_axis_scalar(W), orc.identity_axis_scalar(H))
+    tot = {"cells": 0, "flipped": 0, "flipped_out_of_band": 0, "by_reason": {r: 0 for r in orc.FLIP_REASONS}}
+    for r in range(n):
+        lo, hi = int(out.ref_offsets[r]), int(out.ref_offsets[r + 1])
+        rep = flip_report(cell[lo:hi], srefs[r], cams, wm, hm, oparams, axes)
+        tot["cells"] += rep["cells"]; tot["flipped"] += rep["flipped"]; tot["flipped_out_of_band"] += rep["out_of_band"]
+        for k_, v in rep["by_reason"].items():
+            tot["by_reason"][k_] += v
+    tot["references"] = n
+    tot["survivors_kernel"] = int(out.count)
+    tot["note"] = ("cells kept by exactly one of {HIP dense kernel, oracle = upstream's f32 arithmetic}; in band = the threshold lies between "
+                   "upstream's f32 value and the rounding-free value of the same formula (+ one f32 evaluation's bound)")
+    return tot
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes - this parent has not touched
+    the GPU and never will - wait for them, pass rank 0's JSON line through."""
+    n_dev = torch.cuda.device_count()          # does not initialise the GPU runtime on this image
+    share = int(os.environ.get("LFD_BENCH_RANKS_PER_GPU", "1"))
+    if n_dev * share < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but only {n_dev} GPU(s) visible"
+                         + (" (LFD_BENCH_RANKS_PER_GPU lets several ranks share one for a functional check)" if share == 1 else ""))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank // share if share > 1 else rank), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"rank exit codes {codes}")
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)                 # before anything here touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start {args.gpus} ranks (or run `python bench.py --gpus {args.gpus}` "
+                         "without a launcher, which starts them itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    shared_gpu = int(os.environ.get("LFD_BENCH_RANKS_PER_GPU", "1")) > 1     # functional check: several ranks on one GPU -> gloo
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    backend = None
     if world > 1 or os.environ.get("LFD_BENCH_FORCE_DIST"):     # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = "gloo" if shared_gpu else "nccl"
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cams, refs, srefs, dims, mine = build_workload(args, rank, world, dev)
     H, W, wm, hm = dims
@@ -269,7 +396,7 @@ def main():
     params = hb.make_params(cfg)
     dens = hb.HipDensifier(dev)
     dens.upload_cameras(cams)
-    batch = hb.PreparedBatch(refs, wm, hm)
+    batch = hb.PreparedBatch(refs, wm, hm, cameras=cams)      # the pipeline's default: upstream's own F handed to the kernels
     out = hb.OutputBuffers(len(refs) * H * W, len(refs), args.k, dev, with_cell=False, with_segments=False)   # upstream emits xyz, rgb, err only
 
     def barrier():
@@ -301,6 +428,8 @@ def main():
         print(f"[rank {rank}] enqueue done at {t_enq * 1e3:.2f} ms, first 5 host stamps {[round(x * 1e3, 2) for x in host_t[:5]]}", file=sys.stderr)
     per_launch = [a.elapsed_time(b) for a, b in ev]
     kernel_ms = float(np.mean(per_launch))
+    kernel_pct = {"p50": float(np.percentile(per_launch, 50)), "p95": float(np.percentile(per_launch, 95)),
+                  "min": float(np.min(per_launch)), "max": float(np.max(per_launch))}
     if os.environ.get("LFD_BENCH_DEBUG"):
         print(f"[rank {rank}] per-launch ms: min {min(per_launch):.3f} max {max(per_launch):.3f} mean {kernel_ms:.3f}; "
               f"wall {elapsed * 1e3:.2f} ms for {args.steps} steps", file=sys.stderr)
@@ -308,7 +437,9 @@ def main():
     res = out.collect()
     n_pts = res.count
 
-    stats = torch.tensor([elapsed, float(n_pts), kernel_ms], dtype=torch.float64, device=dev)
+    cdev = dev if backend != "gloo" else torch.device("cpu")
+    stats = torch.tensor([elapsed, float(n_pts), kernel_ms], dtype=torch.float64, device=cdev)
+    allgather = None
     if dist is not None:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -316,10 +447,21 @@ def main():
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0].item())
         total_pts = float(tsum[1].item())
-        # the one exchange step of the path: ordered all-gather of the survivors (outside the timed region)
+        # the one exchange step of the path: ordered all-gather of the survivors from HBM (outside the timed region, timed on its own)
         from lichtfeld_densification_plugin_amd.core import distributed as lfd_dist
-        gathered = lfd_dist.all_gather_points(res.xyz, res.rgb, res.err, dist)
+        offs = res.ref_offsets
+        counts_local = [int(offs[i + 1] - offs[i]) for i in range(len(refs))]
+        gathered = lfd_dist.all_gather_by_reference(res.xyz, res.rgb, res.err, counts_local, args.refs * world, dist)   # warm
+        barrier()
+        t_ag = time.perf_counter()
+        gathered = lfd_dist.all_gather_by_reference(res.xyz, res.rgb, res.err, counts_local, args.refs * world, dist)
+        barrier()
+        ag = torch.tensor([time.perf_counter() - t_ag], dtype=torch.float64, device=cdev)
+        dist.all_reduce(ag, op=dist.ReduceOp.MAX)
         assert gathered[0].shape[0] == int(total_pts), (gathered[0].shape, total_pts)
+        assert int(gathered[3].sum()) == int(total_pts) and gathered[3].shape[0] == args.refs * world
+        allgather = {"allgather_ms": float(ag[0].item()) * 1e3, "bytes_gathered": int(total_pts) * 28, "backend": backend,
+                     "points": int(total_pts), "order": "global reference position (1-GPU sequence)"}
     else:
         total_pts = float(n_pts)
 
@@ -332,7 +474,7 @@ def main():
         value = total_pts * args.steps / elapsed
         line = {
             "metric": "triangulated points/sec + pairs/sec, MipNeRF360 garden @fast, 1/2/4/8 GPU",     # BASELINE.json's metric; value = points/s, pairs_per_s beside it
-            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "points/s", "n_gpus": world, "rccl_ranks": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (+f64 Sampson/DLT solve)", "data": "synthetic",
             "config": {"workload": f"garden-like ring of 185 cameras 1297x840, `{args.preset}` grid {H}x{W}, "
@@ -347,17 +489,23 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic_bytes(args),
-                         "kernel": "lfd_dense_kernel", "kernel_ms": kernel_ms,
+                         "kernel": "lfd_dense_kernel", "kernel_ms": kernel_ms, "kernel_ms_percentiles": kernel_pct,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_cell": bytes_per_cell},
         }
         line["roofline"]["valu_busy_frac"] = valu_busy_frac(args)     # the f64 geometry makes the kernel vector-ALU-bound, not HBM-bound
         line["roofline"]["traffic_over_algorithmic"] = (line["roofline"]["traffic"] / algo_bytes) if line["roofline"]["traffic"] else None
-        line["with_d2h"] = d2h_inclusive_rate(dens, batch, params, out, dev)
-        line["sampled_mode"] = sampled_mode_rate(args, dens, refs, dims, cfg)
-        line["secondary_kernels"] = secondary_kernels(args, dens, batch, refs, dims, cfg, res)
-        base = cpu_baseline(args, cams, srefs, dims, cfg)
-        if base is not None:
-            line["cpu_baseline"] = base
+        if allgather is not None:
+            line["exchange"] = allgather
+        if not args.light:
+            line["with_d2h"] = d2h_inclusive_rate(dens, batch, params, out, dev)
+            line["sampled_mode"] = sampled_mode_rate(args, dens, refs, dims, cfg)
+            line["secondary_kernels"] = secondary_kernels(args, dens, batch, refs, dims, cfg, res)
+            par = parity_report(args, dens, cams, refs, srefs, dims, cfg)
+            if par is not None:
+                line["parity"] = par
+            base = cpu_baseline(args, cams, srefs, dims, cfg)
+            if base is not None:
+                line["cpu_baseline"] = base
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

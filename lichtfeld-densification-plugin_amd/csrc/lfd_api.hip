@@ -96,11 +96,13 @@ int validate_batch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p) {
 
 // Build refs|slots|extra into one blob, upload only when it differs from what the device holds.
 int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, size_t n_extra,
-                  const LfdRefDesc** d_refs, const LfdSlotDesc** d_slots, const long long** d_extra, const float** d_fund) {
+                  const LfdRefDesc** d_refs, const LfdSlotDesc** d_slots, const long long** d_extra, const float** d_fund,
+                  const float* const** d_cert_ptrs) {
     const size_t nr = (size_t)b->n_refs, ns = nr * (size_t)b->k;
     const size_t off_slots = (nr * sizeof(LfdRefDesc) + 15) & ~size_t(15);
     const size_t off_extra = (off_slots + ns * sizeof(LfdSlotDesc) + 15) & ~size_t(15);
-    const size_t off_fund = (off_extra + n_extra * sizeof(long long) + 15) & ~size_t(15);
+    const size_t off_cptr = (off_extra + n_extra * sizeof(long long) + 31) & ~size_t(31);
+    const size_t off_fund = (off_cptr + (ns + 4) * sizeof(const float*) + 15) & ~size_t(15);
     const size_t total = off_fund + (b->fundamental ? ns * 9 * sizeof(float) : 0);
     std::vector<unsigned char> blob(total, 0);
     LfdRefDesc* refs = reinterpret_cast<LfdRefDesc*>(blob.data());
@@ -110,6 +112,8 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
         refs[r].mask_a = b->mask_a ? b->mask_a[r] : nullptr;
         refs[r].cam = b->ref_cam[r];
         refs[r].n_slots = b->n_slots[r];
+        refs[r].any_mask = refs[r].mask_a ? 1 : 0;
+        refs[r].pad = 0;
         for (int j = 0; j < b->k; ++j) {
             LfdSlotDesc& s = slots[r * b->k + j];
             const bool valid = j < b->n_slots[r];
@@ -118,6 +122,8 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
             s.mask_b = (valid && b->mask_b) ? b->mask_b[r * b->k + j] : nullptr;
             s.cam = valid ? b->nbr_cam[r * b->k + j] : 0;
             s.pad = 0;
+            if (s.mask_b) refs[r].any_mask = 1;
+            reinterpret_cast<const float**>(blob.data() + off_cptr)[r * b->k + j] = s.cert;
         }
     }
     if (n_extra) std::memcpy(blob.data() + off_extra, extra, n_extra * sizeof(long long));
@@ -144,6 +150,7 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
     *d_slots = reinterpret_cast<const LfdSlotDesc*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_slots);
     if (d_extra) *d_extra = reinterpret_cast<const long long*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_extra);
     *d_fund = b->fundamental ? reinterpret_cast<const float*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_fund) : nullptr;
+    *d_cert_ptrs = reinterpret_cast<const float* const*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_cptr);
     return LFD_OK;
 }
 
@@ -186,7 +193,7 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
     if (rc != LFD_OK) return rc;
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     std::memset(&L, 0, sizeof(L));
-    rc = upload_tables(ctx, b, extra, n_extra, &L.refs, &L.slots, d_extra, &L.fund_override);
+    rc = upload_tables(ctx, b, extra, n_extra, &L.refs, &L.slots, d_extra, &L.fund_override, &L.cert_ptrs);
     if (rc != LFD_OK) return rc;
     L.cams = static_cast<const LfdCam*>(ctx->cams.ptr);
     if (b->axis_x) { L.axis_x = b->axis_x; L.axis_y = b->axis_y; }
@@ -326,7 +333,7 @@ void lfd_destroy(lfd_context* ctx) {
     if (ctx->is_host) { delete ctx; return; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->mt, &ctx->sel_scratch})
+    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->mt, &ctx->sel_scratch, &ctx->stamps})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
@@ -435,11 +442,33 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
     L.seg_counts = seg_counts;                // zeroed inside the kernel (tile 0), no memset launch
     size_t extra_lds = 0;                     // profiling switch: dynamic LDS lowers the number of resident workgroups
     if (const char* e = std::getenv("LFD_DENSE_EXTRA_LDS")) extra_lds = (size_t)std::atol(e);
-    if (params->flags & LFD_FLAG_EXACT_COLOUR)
+#if defined(LFD_DENSE_TIMING)            // profiling builds: per-tile phase stamps, dumped to the file named by LFD_DENSE_TIMING
+    const char* stamp_path = std::getenv("LFD_DENSE_TIMING");
+    if (stamp_path) {
+        rc = ensure(ctx, ctx->stamps, n_tiles * 2 * 12 * sizeof(unsigned long long));
+        if (rc != LFD_OK) return rc;
+        LFD_HIP(ctx, hipMemsetAsync(ctx->stamps.ptr, 0, n_tiles * 2 * 12 * sizeof(unsigned long long), ctx->stream));
+        L.phase_stamps = static_cast<unsigned long long*>(ctx->stamps.ptr);
+    }
+#endif
+#if defined(LFD_FORCE_EXACT_COLOUR)      // profiling builds: what the f64 colour costs on the bench workload
+    const bool exact_colour = true;
+#else
+    const bool exact_colour = (params->flags & LFD_FLAG_EXACT_COLOUR) != 0;
+#endif
+    if (exact_colour)
         hipLaunchKernelGGL(lfd_dense_exact_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), extra_lds, ctx->stream, L);
     else
         hipLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), extra_lds, ctx->stream, L);
     LFD_HIP(ctx, hipGetLastError());
+#if defined(LFD_DENSE_TIMING)
+    if (stamp_path) {
+        std::vector<unsigned long long> host(n_tiles * 2 * 12);
+        LFD_HIP(ctx, hipMemcpyAsync(host.data(), ctx->stamps.ptr, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (FILE* f = std::fopen(stamp_path, "wb")) { std::fwrite(host.data(), sizeof(unsigned long long), host.size(), f); std::fclose(f); }
+    }
+#endif
     return LFD_OK;
 }
 

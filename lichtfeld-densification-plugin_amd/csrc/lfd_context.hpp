@@ -52,6 +52,7 @@ struct lfd_context {
     DeviceBuffer scratch, codes, idx_tab, agg, sel_buf;
     // selection stage: legacy MT19937 stream (625 words) + scratch
     DeviceBuffer mt, sel_scratch;
+    DeviceBuffer stamps;           // profiling builds: phase stamps of the dense kernel
     bool mt_seeded = false;
     bool topm_lds_attr_set = false;   // hipFuncSetAttribute is per device: remembered per context, not per process
 };

@@ -22,6 +22,11 @@
 #ifndef LFD_DENSE_WAVES_PER_SIMD
 #define LFD_DENSE_WAVES_PER_SIMD 7       // register budget of the fused kernel: 512/7 -> <=72 VGPRs (it needs 69-72)
 #endif
+#ifndef LFD_FRONT_PRIO
+#define LFD_FRONT_PRIO 1        // s_setprio of a dense-kernel wave until its geometry loop starts (0 = off): the handful of instructions between the
+                                // front end's memory requests then go ahead of older waves' f64 streams instead of waiting for a free slot
+                                // (profiles/r2/ablation.txt: 0.331 -> 0.318 ms)
+#endif
 #define LFD_INDEXED_BLOCK 1024  // one workgroup (16 waves) per reference in the indexed kernel
 #define LFD_INDEXED_EVAL_BLOCK 256   // cells per workgroup of the indexed-mode evaluation kernel
 
@@ -39,6 +44,8 @@ struct LfdRefDesc {             // one per reference of a launch (device table)
     const uint8_t* mask_a;      // u8 {0,1} [h_match][w_match] or null
     int32_t cam;                // row of the camera table
     int32_t n_slots;            // valid neighbour slots
+    int32_t any_mask;           // 1 if mask_a or any mask_b of the reference is set (one word decides the kernels' plain path)
+    int32_t pad;
 };
 
 struct LfdSlotDesc {            // one per (reference, slot)
@@ -57,6 +64,7 @@ struct LfdLaunch {              // kernel argument, passed by value
     const LfdPairConst* pair_const;  // [n_refs*k]
     const float* axis_x;        // [W]
     const float* axis_y;        // [H]
+    const float* const* cert_ptrs;   // [n_refs*k + 4] the slots' certainty planes again, contiguous (four pointers = one scalar load)
     const float* fund_override; // [n_refs*k*9] f32 fundamental matrices handed over by the caller (lfd_batch.fundamental), or null
     int32_t n_refs, k, H, W, w_match, h_match, warp_channels, tiles_per_ref;
     float mask_sx, mask_sy;     // (float)w_match/(float)W, (float)h_match/(float)H  (nearest resize)
@@ -85,6 +93,7 @@ struct LfdLaunch {              // kernel argument, passed by value
     unsigned int pad0;
     unsigned int* status;         // 0 = ok, LFD_LAUNCH_TIMEOUT if a look-back spin gave up
     unsigned int* seg_ready;      // == epoch once the workgroup of tile 0 has zeroed seg_counts
+    unsigned long long* phase_stamps;   // profiling builds (-DLFD_DENSE_TIMING) with LFD_DENSE_TIMING set in the environment: [n_tiles][16] clock stamps, else null
 };
 
 // ---- S: on-device coverage sampling (lfd_select.hip) ---------------------------------------------

@@ -186,7 +186,11 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
 // Two solves are always made; more follow only while the growth factor has not settled (bad
 // conditioning: sigma4/sigma3 not small).
 #ifndef LFD_NULLVEC_TOL
-#define LFD_NULLVEC_TOL 1e-6      /* direction change (relative, on x_i/x_3) of the last solve that counts as settled */
+/* direction change (relative, on x_i/x_3) of the last solve that counts as settled.  The change measures the error of the
+ * PREVIOUS iterate; the one returned is q = (sigma4/sigma3)^2 times closer: within 1e-8 of v4 for sigma4/sigma3 <= 0.1.
+ * (1e-5 instead would save 0.35 solves per cell - a wave iterates until its slowest lane has settled - for 1 % of the dense
+ * kernel's time and ten times the error: measured, not taken, profiles/r2/ablation.txt.) */
+#define LFD_NULLVEC_TOL 1e-6
 #endif
 #ifndef LFD_NULLVEC_MAXIT
 #define LFD_NULLVEC_MAXIT 8       /* solves per pass */

@@ -128,6 +128,46 @@ struct BlockShared {
     LfdRefDesc ref;
 };
 
+// the same in two halves, so that the loads can be in flight while something else (the ticket atomic) is issued:
+// prologue_issue requests this thread's words of the four blocks, prologue_commit parks them in LDS (no barrier)
+struct PrologueRegs { unsigned pw[(LFD_MAX_SLOTS * sizeof(LfdPairConst) / 4 + LFD_DENSE_BLOCK - 1) / LFD_DENSE_BLOCK]; unsigned sw, rw; int k; };
+
+__device__ __forceinline__ void prologue_issue(const LfdLaunch& L, int r, PrologueRegs& P) {
+    // every load is unconditional (clamped index): straight-line code that the compiler cannot sink below the ticket atomic
+    // into the guarded LDS stores of prologue_commit
+    const int tid = (int)threadIdx.x;
+    constexpr int kPw = (int)(sizeof(P.pw) / sizeof(P.pw[0]));
+    const unsigned LFD_GLOBAL_AS* src = lfd_global(reinterpret_cast<const unsigned*>(L.pair_const + (size_t)r * L.k));
+    const int nw = L.k * (int)(sizeof(LfdPairConst) / 4);
+#pragma unroll
+    for (int q = 0; q < kPw; ++q) { const int i = tid + q * (int)blockDim.x; P.pw[q] = src[i < nw ? i : nw - 1]; }
+    const unsigned LFD_GLOBAL_AS* ssrc = lfd_global(reinterpret_cast<const unsigned*>(L.slots + (size_t)r * L.k));
+    const int nsw = L.k * (int)(sizeof(LfdSlotDesc) / 4);
+    P.sw = ssrc[tid < nsw ? tid : nsw - 1];
+    // reference constants (18 words) by threads 0..17, reference descriptor (8 words) by threads 64..71: one load per thread
+    const unsigned LFD_GLOBAL_AS* rsrc = lfd_global(reinterpret_cast<const unsigned*>(L.ref_const + r));
+    const unsigned LFD_GLOBAL_AS* dsrc = lfd_global(reinterpret_cast<const unsigned*>(L.refs + r));
+    constexpr int kRc = (int)(sizeof(LfdRefConst) / 4), kRd = (int)(sizeof(LfdRefDesc) / 4);
+    const bool second = tid >= 64;
+    const int i2 = second ? (tid - 64 < kRd ? tid - 64 : kRd - 1) : (tid < kRc ? tid : kRc - 1);
+    P.rw = (second ? dsrc : rsrc)[i2];
+    P.k = L.k;
+    __builtin_amdgcn_sched_barrier(0);         // the requests are out before anything below is issued (and nothing waits for them here)
+}
+
+__device__ __forceinline__ void prologue_commit(const LfdLaunch& L, const PrologueRegs& P, BlockShared& S) {
+    const int tid = (int)threadIdx.x;
+    constexpr int kPw = (int)(sizeof(P.pw) / sizeof(P.pw[0]));
+    unsigned* dst = reinterpret_cast<unsigned*>(S.pc);
+    const int nw = L.k * (int)(sizeof(LfdPairConst) / 4);
+#pragma unroll
+    for (int q = 0; q < kPw; ++q) { const int i = tid + q * (int)blockDim.x; if (i < nw) dst[i] = P.pw[q]; }
+    const int nsw = L.k * (int)(sizeof(LfdSlotDesc) / 4);
+    if (tid < nsw) reinterpret_cast<unsigned*>(S.slot)[tid] = P.sw;
+    if (tid < (int)(sizeof(LfdRefConst) / 4)) reinterpret_cast<unsigned*>(&S.rc)[tid] = P.rw;
+    if (tid >= 64 && tid < 64 + (int)(sizeof(LfdRefDesc) / 4)) reinterpret_cast<unsigned*>(&S.ref)[tid - 64] = P.rw;
+}
+
 __device__ __forceinline__ void block_prologue(const LfdLaunch& L, int r, BlockShared& S) {
     // One level of global loads, then one barrier: the descriptors and the per-pair constants of all k
     // slots of reference r are fetched together (rows of unused slots are never read afterwards).
@@ -394,6 +434,14 @@ struct __attribute__((packed, aligned(4))) LfdF3 { float a, b, c; };
 constexpr int kCopyThreads = kBlock - 64;
 constexpr int kCopyRecords = (kTile + kCopyThreads - 1) / kCopyThreads;
 
+// phase stamps of the dense kernel (profiling builds only): lane 0 of waves 0 and 1 record the shader clock at the phase
+// boundaries of their tile; profiles/dense_phases.py turns them into a per-phase latency table
+#if defined(LFD_DENSE_TIMING)
+#define LFD_STAMP(i) do { if (L.phase_stamps && lane == 0 && wave < 2) stamps[(i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LFD_STAMP(i) do { } while (0)
+#endif
+
 template <bool kExactColour>
 __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
     __shared__ BlockShared S;
@@ -405,6 +453,10 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+#if defined(LFD_DENSE_TIMING)
+    unsigned long long stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    LFD_STAMP(0);
     // Tickets: a workgroup learns its tile from an atomic counter, so every tile a look-back can wait for is
     // already being worked on.  Returning atomics on ONE address complete at ~12 ns each on MI355X
     // (profiles/microbench/latency.hip: 16384 tickets = 0.2 ms), so the counter is split in LFD_TICKET_LANES
@@ -414,14 +466,31 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
     // a running workgroup, as with a single counter; the 8 classes also match the round-robin dealing of
     // workgroups to the 8 XCDs.
     const unsigned seq = blockIdx.x % LFD_TICKET_LANES;
+    const unsigned n_tiles = (unsigned)L.n_refs * (unsigned)L.tiles_per_ref;
+    const int HW = L.H * L.W;
+
+    // ---- front end: ONE memory round trip for the ticket and the constants ---------------------------------------------
+    // Workgroup b nearly always draws a ticket of the same reference as tile b (tickets and workgroup indices run in step to
+    // within a few tiles; a reference has hundreds of tiles), so the constants of THAT reference are requested before the
+    // ticket is known, together with the ticket atomic, instead of after it.  If the ticket belongs to another reference
+    // the block is fetched again the plain way: results never depend on the guess.  (Requesting the certainty planes of
+    // tile b the same way does not pay: measured, only 7 % of the workgroups draw exactly ticket b.)
+    const unsigned tile_guess = blockIdx.x;
+    const int r_guess = __builtin_amdgcn_readfirstlane((int)(tile_guess / (unsigned)L.tiles_per_ref));
+#if LFD_FRONT_PRIO > 0
+    __builtin_amdgcn_s_setprio(LFD_FRONT_PRIO);     // the few instructions between the front end's memory requests go ahead of other waves' arithmetic
+#endif
+    PrologueRegs pro;
+    if (tile_guess < n_tiles) prologue_issue(L, r_guess, pro);        // constants of the guessed reference: loads in flight
     if (tid == 0) {
         const unsigned long long k = atomicAdd(L.ticket_lanes + (size_t)seq * 16, 1ull) - L.ticket_base_lane[seq];
         s_ticket = (unsigned)k * LFD_TICKET_LANES + seq;
     }
+    if (tid < LFD_MAX_SLOTS) s_slot_cnt[tid] = 0;
+    if (tile_guess < n_tiles) prologue_commit(L, pro, S);             // ... and into LDS
     __syncthreads();
+    LFD_STAMP(1);
     const unsigned tile = s_ticket;
-    const unsigned n_tiles = (unsigned)L.n_refs * (unsigned)L.tiles_per_ref;
-    const int HW = L.H * L.W;
     if (tile == 0 && L.seg_counts) {         // zero the per-(reference, slot) counters for this launch, then raise the flag
         for (int i = tid; i < L.n_refs * L.k; i += kBlock) L.seg_counts[i] = 0;
         __threadfence();
@@ -441,11 +510,16 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
             for (int i = 0; i < 3; ++i) rc.C[i] = rcp->C[i];
             rc.sx = rcp->sx; rc.sy = rcp->sy; rc.pad = 0.0f;
         }
-        if (tid < LFD_MAX_SLOTS) s_slot_cnt[tid] = 0;
-        block_prologue(L, r, S);                 // ends with a barrier (also covers s_slot_cnt)
+        if (r != r_guess || tile_guess >= n_tiles) {      // the guess was wrong: this tile's constants the plain way (uniform branch)
+            __syncthreads();                 // nobody reads the guessed block any more
+            block_prologue(L, r, S);         // ends with a barrier
+        }
+        LFD_STAMP(2);
+#if defined(LFD_DENSE_TIMING)
+        stamps[0] = (stamps[0] & ~3ull) | (r == r_guess ? 1ull : 0ull) | (tile == tile_guess ? 2ull : 0ull);     // did the guess hold?
+#endif
         const int ns = S.ref.n_slots;
-        bool any_mask = S.ref.mask_a != nullptr;
-        for (int j = 0; j < ns; ++j) any_mask |= (S.slot[j].mask_b != nullptr);
+        const bool any_mask = S.ref.any_mask != 0;
         const int tile_cell0 = tile_in_ref * kTile;
         const int cell0 = tile_cell0 + tid * kCpt;
         int tile_y0, tile_x0;                    // (row, column) of the tile's first cell: uniform, kept in SGPRs
@@ -459,16 +533,28 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
         int bj[kCpt];
         if (!any_mask && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW) {
             const float th = L.kp.certainty_thresh;
-            float4 best = load_f32x4(S.slot[0].cert + cell0);
-            best.x = lfd_cert_floor(best.x, th); best.y = lfd_cert_floor(best.y, th);
-            best.z = lfd_cert_floor(best.z, th); best.w = lfd_cert_floor(best.w, th);
+            float4 best;
             bj[0] = bj[1] = bj[2] = bj[3] = 0;
-            for (int j = 1; j < ns; ++j) {
-                const float4 c = load_f32x4(S.slot[j].cert + cell0);
-                argmax_step(lfd_cert_floor(c.x, th), j, best.x, bj[0]);
-                argmax_step(lfd_cert_floor(c.y, th), j, best.y, bj[1]);
-                argmax_step(lfd_cert_floor(c.z, th), j, best.z, bj[2]);
-                argmax_step(lfd_cert_floor(c.w, th), j, best.w, bj[3]);
+            {                                    // four planes in flight at a time: ONE dependent round trip per four neighbours (a
+                                                 // load-then-compare loop over the slots costs one round trip per neighbour)
+                best = load_f32x4(S.slot[0].cert + cell0);
+                best.x = lfd_cert_floor(best.x, th); best.y = lfd_cert_floor(best.y, th);
+                best.z = lfd_cert_floor(best.z, th); best.w = lfd_cert_floor(best.w, th);
+                for (int j0 = 1; j0 < ns; j0 += 4) {
+                    float4 c[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (j0 + u < ns) c[u] = load_f32x4(S.slot[j0 + u].cert + cell0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (j0 + u < ns) {
+                            argmax_step(lfd_cert_floor(c[u].x, th), j0 + u, best.x, bj[0]);
+                            argmax_step(lfd_cert_floor(c[u].y, th), j0 + u, best.y, bj[1]);
+                            argmax_step(lfd_cert_floor(c[u].z, th), j0 + u, best.z, bj[2]);
+                            argmax_step(lfd_cert_floor(c[u].w, th), j0 + u, best.w, bj[3]);
+                        }
+                    }
+                }
             }
         } else if ((L.W & 3) == 0 && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW) {      // masks present
             int dy, x0;
@@ -483,6 +569,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
             }
         }
 
+        LFD_STAMP(3);
         // ---- stage 2: winner's warp (8 or 16 B per cell), all four loads in flight together; the
         //      coordinates are parked in this thread's own LDS slots (the slots later receive the cell's
         //      outputs), so the geometry loop below carries no per-cell register arrays ------------------
@@ -533,6 +620,10 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
         }
         *reinterpret_cast<unsigned*>(&stage.slot[tid * kCpt]) = bj_packed;
 
+        LFD_STAMP(4);
+#if LFD_FRONT_PRIO > 0
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- stage 3: per-correspondence geometry + colour; survivors overwrite their slot -------------
         unsigned keep_bits = 0;
 #pragma unroll 1
@@ -556,6 +647,10 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
                 keep_bits |= 1u << e;
             }
         }
+        LFD_STAMP(5);
+#if defined(LFD_BACK_PRIO)
+        __builtin_amdgcn_s_setprio(LFD_BACK_PRIO);
+#endif
         // survivors per neighbour slot (outside the divergent loop): ballots over the kept cells of each slot
         if (L.seg_counts) {
             for (int j = 0; j < ns; ++j) {
@@ -580,6 +675,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
         const unsigned incl = before + my_cnt;
         if (lane == 0) s_wave_cnt[wave] = wave_total;
         __syncthreads();                          // s_wave_cnt written
+        LFD_STAMP(6);
         unsigned wave_off = 0, block_total = 0;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; ++w) {
@@ -593,6 +689,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
                 if ((keep_bits >> e) & 1u) stage.order[lpos++] = (unsigned short)(tid * kCpt + e);
         }
         __syncthreads();                          // stage.order complete
+        LFD_STAMP(7);
         if (L.seg_counts && tid < ns && s_slot_cnt[tid]) {
             // the workgroup of tile 0 zeroed the array and raised seg_ready when the launch began (no memset launch)
             // (only the first few workgroups of a launch ever have to poll.  The counters are only touched by device-scope
@@ -676,7 +773,9 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
             }
 #endif
         }
+        LFD_STAMP(8);
         __syncthreads();                          // prefix known, colours in registers
+        LFD_STAMP(9);
 
 #if !defined(LFD_ABLATE_STORES)
         if (wave != 0) {
@@ -702,6 +801,14 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
                     if (L.slot) L.slot[base + i] = stage.slot[sl];
                 }
             }
+        }
+#endif
+#if defined(LFD_DENSE_TIMING)
+        LFD_STAMP(10);
+        if (L.phase_stamps && lane == 0 && wave < 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores retired: the wave could end here
+            stamps[11] = __builtin_readcyclecounter();
+            for (int i = 0; i < 12; ++i) L.phase_stamps[((size_t)tile * 2 + wave) * 12 + i] = stamps[i];
         }
 #endif
     }

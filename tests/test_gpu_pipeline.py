@@ -203,3 +203,31 @@ def test_two_ranks_reproduce_the_single_process_sequence(g4, tmp_path, mode):
         np.testing.assert_array_equal(rgb, single.rgb)
         np.testing.assert_array_equal(err, single.err)
         assert n_refs == single.pairs_processed and n_pairs == single.pairs_matched
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher starts two fresh rank processes itself (here both on the one GPU of
+    the test box, LFD_BENCH_RANKS_PER_GPU=2, host collectives) and prints ONE line with n_gpus = 2, the whole-job value and
+    the separately timed ordered all-gather; with fewer GPUs than ranks and no sharing it refuses instead of silently
+    running one rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LFD_BENCH_RANKS_PER_GPU="2")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--refs", "4", "--preset", "turbo",
+           "--light", "--spinup-s", "0.05"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["exchange"]["points"] > 0 and d["exchange"]["allgather_ms"] > 0 and d["exchange"]["bytes_gathered"] == 28 * d["exchange"]["points"]
+    if torch.cuda.device_count() < 2:
+        env2 = dict(os.environ)
+        env2.pop("WORLD_SIZE", None)
+        env2.pop("LFD_BENCH_RANKS_PER_GPU", None)
+        res2 = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=120)
+        assert res2.returncode != 0 and "GPU(s) visible" in (res2.stderr + res2.stdout)

@@ -219,3 +219,45 @@ def test_fused_sampled_call_equals_the_three_calls(dens, no_filter):
             dens.triangulate_sampled(hb.PreparedBatch([r], W, H), params, M)
         after = dens.rng_state()
         assert before[1] == after[1] and np.array_equal(before[0], after[0])
+
+
+def test_tiny_weights_fall_back_to_the_host_stage_on_the_same_stream(dens):
+    """certainty_thresh = 0 leaves raw certainties like 1e-12 in the map: a normalised weight below 2^-29 makes the device
+    selection refuse (LFD_SELECT_INEXACT) WITHOUT consuming its MT19937 stream; upstream handles such maps normally, and so
+    does the pipeline's hot path, by running the host stage (core/sampling.py) on the device's stream and handing the
+    advanced stream back: same cells as upstream's own selection, stream positioned where upstream's would be."""
+    import lichtfeld_densification_plugin_amd as lfd
+    from lichtfeld_densification_plugin_amd import synthetic
+    from lichtfeld_densification_plugin_amd.core import pipeline as pl
+    from lichtfeld_densification_plugin_amd.core.sampling import select_samples_with_coverage
+    dev = torch.device("cuda:0")
+    H = W = 96
+    cams = synthetic.ring_cameras(40, seed=0)
+    nbrs = synthetic.ring_neighbours(40, 7, 2)
+    s = synthetic.synth_reference(cams, 7, nbrs, H, W, W, H, noise_px=0.3, channels=2, seed=3, cert_mode="tiefree")
+    cert = [c.clone() for c in s.cert]
+    for c in cert:
+        c[10:40, 10:40] = 1e-12                       # far below 2^-29 of the sum once normalised
+    ref = hb.ReferenceInputs(ref_cam=7, nbr_cams=nbrs, cert=[c.to(dev) for c in cert], warp=[w.contiguous().to(dev) for w in s.warp],
+                             image=s.image.to(dev))
+    cfg = lfd.DensePipelineConfig(output_path="", certainty_thresh=0.0, matches_per_ref=1500, seed=11)
+    batch = hb.PreparedBatch([ref], W, H, cameras=cams)
+    d2 = hb.HipDensifier(dev)
+    d2.upload_cameras(cams)
+    d2.seed_rng(cfg.seed)
+    best, _ = d2.aggregate(batch, hb.make_params(cfg))
+    with pytest.raises(hb.SelectionInexact):
+        d2.select_samples(best[0], cfg.matches_per_ref)
+    key0, pos0 = d2.rng_state()
+    rs0 = np.random.RandomState(cfg.seed)
+    assert pos0 == rs0.get_state()[2] and np.array_equal(key0, rs0.get_state()[1])        # the refused call consumed nothing
+    hot = pl._HotPath(cams, cfg, 0.9, W, H, dev, d2)
+    d2.seed_rng(cfg.seed)
+    out, _ = hot.sampled(ref, None, None, None)
+    expect = select_samples_with_coverage(best[0].cpu(), cfg.matches_per_ref, cap=0.9, border=2, tiles=24, rng=rs0)
+    idx = d2.triangulate_indexed(batch, hb.make_params(cfg), torch.from_numpy(expect.astype(np.int64)).to(dev), [0, int(expect.size)])
+    assert out is not None and out.count == idx.count > 500
+    assert torch.equal(out.xyz, idx.xyz) and torch.equal(out.cell, idx.cell)
+    key1, pos1 = d2.rng_state()
+    assert pos1 == rs0.get_state()[2] and np.array_equal(key1, rs0.get_state()[1])        # stream handed back advanced
+    d2.close()
