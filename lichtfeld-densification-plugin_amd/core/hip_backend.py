@@ -397,13 +397,33 @@ class OutputBuffers:
                             cell=self.cell.data_ptr() if with_cell else None,
                             slot=self.slot.data_ptr() if with_cell else None, capacity=self.capacity)
 
+    def begin_collect(self, stream: Optional["torch.cuda.Stream"] = None) -> None:
+        """Enqueue the read-back of the small integer outputs (counts, selection / launch status) into this buffer's own pinned
+        landing area and record an event behind it: ``collect`` then waits for THAT event only, not for whatever has been
+        launched on the stream since (the next reference's kernels)."""
+        if not self._meta.is_cuda:
+            return
+        if getattr(self, "_pinned_meta", None) is None:
+            self._pinned_meta = torch.empty((int(self._meta.numel()),), dtype=torch.int32).pin_memory()
+            self._meta_event = torch.cuda.Event()
+        st = stream if stream is not None else torch.cuda.current_stream(self._meta.device)
+        with torch.cuda.stream(st):
+            self._pinned_meta.copy_(self._meta, non_blocking=True)
+            self._meta_event.record(st)
+        self._meta_pending = True
+
     def select_status(self, meta: np.ndarray) -> int:
         return int(meta[2 * (self._n_refs + 1) + 2 * self._n_refs * self._k + 1])
 
     def collect(self, indexed: bool = False, check_selection: bool = False) -> TriangulationOutput:
         """Synchronise and trim to the number of survivors.  ``check_selection``: raise what upstream's sampling stage
         would have raised if the fused call's selection refused its input."""
-        meta = _read_back_i32(self._meta)                     # one copy through a cached pinned buffer (synchronises)
+        if getattr(self, "_meta_pending", False):             # begin_collect() was called: wait for that copy alone
+            self._meta_event.synchronize()
+            self._meta_pending = False
+            meta = self._pinned_meta.numpy().copy()
+        else:
+            meta = _read_back_i32(self._meta)                 # one copy through a cached pinned buffer (synchronises)
         if check_selection:
             st = self.select_status(meta)
             if st in (1, 2, 3):

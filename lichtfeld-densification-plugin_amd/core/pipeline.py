@@ -42,7 +42,7 @@ from .image_io import black_out, load_mask01, load_rgb_u8, to_uint8_rgb
 from .matcher import RomaMatcher, has_cached_romav2_weights, romav2_cached_weights_paths
 from .sampling import select_samples_with_coverage
 from .types import CameraRecord, DensePipelineConfig
-from .writers import ensure_dir, write_ply
+from .writers import CumulativePlyBody, StreamedPlyWriter, ensure_dir, write_ply
 
 _DEBUG_PREVIEW_INTERVAL = 3      # upstream core/pipeline.py:34
 _PREVIEW_MAX_MATCHES = 10000     # upstream core/pipeline.py:50
@@ -59,6 +59,7 @@ class PipelineResult:
     pairs_matched: int = 0          # actual (reference, neighbour) pairs matched
     points_per_reference: Optional[np.ndarray] = None
     device_points: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None   # same points, still on the GPU
+    streamed_path: Optional[str] = None   # config.stream_output: the PLY already written while the run proceeded (complete, header patched)
 
 
 class PipelineCancelled(RuntimeError):
@@ -303,6 +304,39 @@ class _HotPath:
         out = self.dens.triangulate_indexed(batch, self.params, sel_t, [0, int(sel_t.numel())])
         return (out if out.count else None), best[0]
 
+    def can_launch_ahead(self, need_best: bool, per_ref_rng: bool, H: int, W: int) -> bool:
+        """The fused sampled call of reference i+1 may be launched before reference i is read back when nothing on the host
+        depends on i's result: the selection runs on the device, no debug preview wants the aggregated map, and the device
+        selection cannot refuse its input (every weight >= 2^-29 or 0, i.e. certainty_thresh >= 2^-29 * H*W*cap; a refused
+        call consumes no random numbers and falls back to the host stage, which would then see the stream AFTER i+1's draws) -
+        or every reference has its own stream anyway."""
+        cfg = self.config
+        fusable = cfg.selection_backend == "device" and (not cfg.no_filter or cfg.matches_per_ref <= self.dens.TOP_M_MAX)
+        exact_ok = cfg.no_filter or per_ref_rng or float(cfg.certainty_thresh) >= 2.0 ** -29 * H * W * max(self.sample_cap, 1e-6)
+        return fusable and not need_best and exact_ok
+
+    def launch_sampled(self, ref: hb.ReferenceInputs, axes, device_seed: Optional[int]):
+        """Enqueue one reference's fused call and the read-back of its counts; returns what ``finish_sampled`` needs."""
+        batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes, cameras=self.cams)
+        if device_seed is not None and not self.config.no_filter:
+            self.dens.seed_rng(device_seed)
+        M = self.config.matches_per_ref
+        out = hb.OutputBuffers(int(M) + 24 * 24 + 64, 1, batch.k, self.dev)
+        self.dens.launch_sampled(batch, self.params, M, out, cap=self.sample_cap, border=2, tiles=24)
+        out.begin_collect(self.dens.stream)
+        return batch, out
+
+    def finish_sampled(self, handle) -> Optional[hb.TriangulationOutput]:
+        _batch, out = handle
+        res = out.collect(indexed=True, check_selection=True)
+        if res.launch_status != 0:
+            self.dens.check_launches()
+        return res if res.count else None
+
+    def pack_ply_bytes(self, xyz: torch.Tensor, rgb: torch.Tensor) -> bytes:
+        """The survivors' 15-byte PLY records, quantised and packed on the device (only file payload crosses PCIe)."""
+        return self.dens.pack_ply(xyz, rgb).cpu().numpy().tobytes()
+
     def dense(self, refs: List[hb.ReferenceInputs], axes) -> hb.TriangulationOutput:
         batch = hb.PreparedBatch(refs, self.w_match, self.h_match, axes=axes, cameras=self.cams)
         return self.dens.triangulate_dense(batch, self.params)
@@ -330,10 +364,12 @@ class _HotPath:
                              ((xbn + 1.0) * 0.5 * wm1).clamp(0.0, wm1), ((ybn + 1.0) * 0.5 * hm1).clamp(0.0, hm1)], dim=1)
             denom = self.sample_cap if self.sample_cap > 1e-6 else 1.0
             if best_cert is not None:
-                cn = (best_cert.reshape(-1)[sel] / denom).clamp(0.0, 1.0)
+                # gathered on the device, divided on the host with NumPy like upstream (core/pipeline.py:766-768): the GPU's f32
+                # division may differ from IEEE by an ulp, and these few thousand values are a preview, not a hot path
+                cn = np.clip(best_cert.reshape(-1)[sel].cpu().numpy() / denom, 0.0, 1.0).astype(np.float32)
             else:
-                cn = torch.ones(sel.numel(), device=self.dev)
-            res[j] = (m.cpu().numpy().astype(np.float32), cn.cpu().numpy().astype(np.float32))
+                cn = np.ones(int(sel.numel()), np.float32)
+            res[j] = (m.cpu().numpy().astype(np.float32), cn)
         return res
 
 
@@ -385,6 +421,8 @@ def run_dense_pipeline(
     pair_counter = 0
     t0 = time.time()
     own_matcher = matcher is None
+    cum_body: Optional[CumulativePlyBody] = None          # bytes of the cloud so far, for the intermediate previews
+    stream_writer: Optional[StreamedPlyWriter] = None     # config.stream_output: the output file grows while the run proceeds
     prefetch: Optional[_OrderedPrefetcher] = None
     hot: Optional[_HotPath] = None
 
@@ -413,14 +451,31 @@ def run_dense_pipeline(
                                       window=int(getattr(config, "prefetch_packages", 8)))
         total_refs = len(my_positions)
         pending: List[Tuple[int, _PackedReference, hb.ReferenceInputs, object]] = []   # dense mode batching
+        inflight: List[Tuple[int, _PackedReference, object]] = []                       # sampled mode: launched, not yet read back
+        if on_sequential_viz and viz_interval > 0 and intermediate_base:
+            cum_body = CumulativePlyBody()
+        if (bool(getattr(config, "stream_output", False)) and world == 1 and str(config.output_path).lower().endswith(".ply")
+                and int(config.max_points) <= 0 and float(config.voxel_size) <= 0.0):
+            stream_writer = StreamedPlyWriter(config.output_path)
 
-        def emit(local_i: int, packed: _PackedReference, xyz, rgb, err, dbg) -> None:
+        def emit(local_i: int, packed: _PackedReference, xyz, rgb, err, dbg, dev_pts=None) -> None:
             nonlocal refs_with_points
             xyz_parts.append(xyz)
             rgb_parts.append(rgb)
             err_parts.append(err)
             counts_local[local_i] = int(xyz.shape[0])
             refs_with_points += 1
+            if cum_body is not None or stream_writer is not None:
+                # this reference's PLY records, packed once (on the device when the points are there): the previews and the
+                # streamed output are made of these bytes, nothing is re-concatenated or re-quantised later
+                body = hot.pack_ply_bytes(dev_pts[0], dev_pts[1]) if dev_pts is not None else None
+                for sink in (cum_body, stream_writer):
+                    if sink is None:
+                        continue
+                    if body is not None:
+                        sink.append_packed(body)
+                    else:
+                        sink.append(xyz, to_uint8_rgb(rgb))
             if dbg is not None and debug_state is not None:
                 total_val = total_pairs_est if total_pairs_est > 0 else max(pair_counter, 1)
                 for slot, (m, cn) in dbg["matches"].items():
@@ -439,8 +494,8 @@ def run_dense_pipeline(
                 _raise_if_cancelled(cancel_requested)
                 try:
                     path = f"{intermediate_base}_{refs_with_points}.ply"
-                    write_ply(path, np.concatenate(xyz_parts, 0), to_uint8_rgb(np.concatenate(rgb_parts, 0)))
-                    log.debug(f"Live update: {sum(p.shape[0] for p in xyz_parts):,} points after {refs_with_points} refs")
+                    cum_body.snapshot(path)
+                    log.debug(f"Live update: {cum_body.count:,} points after {refs_with_points} refs")
                     on_sequential_viz(path)
                 except Exception as exc:
                     log.warn(f"Failed to emit intermediate PLY: {exc}")
@@ -461,8 +516,22 @@ def run_dense_pipeline(
                 lo, hi = int(offs[bi]), int(offs[bi + 1])
                 if hi > lo:     # trimmed copies: a slice would pin the whole capacity-sized buffer of this flush until the run ends
                     dev_parts.append((out.xyz[lo:hi].clone(), out.rgb[lo:hi].clone(), out.err[lo:hi].clone()))
-                    emit(local_i, packed, xyz[lo:hi], rgb[lo:hi], err[lo:hi], None)
+                    emit(local_i, packed, xyz[lo:hi], rgb[lo:hi], err[lo:hi], None, dev_parts[-1])
             pending.clear()
+
+        def finish_one() -> None:
+            """Collect the oldest launched reference (sampled mode) and emit it: references are emitted in launch order."""
+            li, pk, handle = inflight.pop(0)
+            try:
+                res = hot.finish_sampled(handle)
+            except Exception as ex:
+                log.error(f"Triangulation error for ref {pk.ref_uid}: {ex}")
+                return
+            if res is None:
+                return
+            dev_parts.append((res.xyz.clone(), res.rgb.clone(), res.err.clone()))
+            hx, hc, he = res.host_arrays()
+            emit(li, pk, hx, hc, he, None, dev_parts[-1])
 
         for local_i, packed in enumerate(prefetch):
             _raise_if_cancelled(cancel_requested)
@@ -498,9 +567,21 @@ def run_dense_pipeline(
                     flush_dense()
                 continue
 
+            rng = _reference_rng(config.seed, packed.ref_uid) if per_ref_rng else stream_rng
+            dseed = _reference_seed(config.seed, packed.ref_uid) if per_ref_rng else None
+            if hot.can_launch_ahead(want_debug, per_ref_rng, int(H), int(W)):
+                # reference i is launched (asynchronously, counts read back behind an event) BEFORE reference i-1 is collected:
+                # the host side of one reference - packing, descriptor upload, Python - runs under the kernels of the other
+                try:
+                    inflight.append((local_i, packed, hot.launch_sampled(ref, axes, dseed)))
+                except Exception as ex:
+                    log.error(f"Triangulation error for ref {packed.ref_uid}: {ex}")
+                while len(inflight) > 1:
+                    finish_one()
+                continue
+            while inflight:
+                finish_one()
             try:
-                rng = _reference_rng(config.seed, packed.ref_uid) if per_ref_rng else stream_rng
-                dseed = _reference_seed(config.seed, packed.ref_uid) if per_ref_rng else None
                 out, best = hot.sampled(ref, axes, rng, dseed, need_best=want_debug)
             except Exception as ex:
                 log.error(f"Triangulation error for ref {packed.ref_uid}: {ex}")
@@ -513,7 +594,9 @@ def run_dense_pipeline(
                        "pair_index": {j: first_pair + j for j in range(len(certs))}}
             dev_parts.append((out.xyz.clone(), out.rgb.clone(), out.err.clone()))
             hx, hc, he = out.host_arrays()
-            emit(local_i, packed, hx, hc, he, dbg)
+            emit(local_i, packed, hx, hc, he, dbg, dev_parts[-1])
+        while inflight:
+            finish_one()
         flush_dense()
     except BaseException as exc:
         if world == 1:
@@ -529,6 +612,11 @@ def run_dense_pipeline(
                 matcher.close()
             except Exception as exc:
                 log.warn(f"Matcher cleanup failed: {exc}")
+        if stream_writer is not None:
+            try:
+                stream_writer.close()         # patches the vertex count into the header
+            except Exception as exc:
+                log.warn(f"Closing the streamed output failed: {exc}")
         if hot is not None:
             hot.close()
         if debug_state:
@@ -576,4 +664,5 @@ def run_dense_pipeline(
         raise RuntimeError("No points triangulated. Try adjusting parameters.")
     return PipelineResult(xyz=xyz, rgb=rgb, err=err, elapsed_seconds=time.time() - t0,
                           pairs_processed=refs_with_points, pairs_matched=pair_counter, points_per_reference=counts,
-                          device_points=device_points)
+                          device_points=device_points,
+                          streamed_path=config.output_path if stream_writer is not None else None)

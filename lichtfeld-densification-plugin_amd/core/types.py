@@ -55,6 +55,10 @@ class DensePipelineConfig:
     # hand upstream's own fundamental matrices (np.linalg.inv products, computed on the host exactly as upstream computes
     # them) to the kernels instead of the closed-form F the library derives from the camera table
     upstream_fundamental: bool = True
+    # write the output PLY while the run proceeds: every completed reference's survivors are packed on the device
+    # (lfd_pack_ply, 15 B per point across PCIe) and appended to ``output_path``; the vertex count in the header is patched at
+    # the end.  Honoured when the output is a .ply and neither a point cap nor a voxel filter has to see the whole cloud first.
+    stream_output: bool = False
 
     def __post_init__(self) -> None:
         if self.triangulation_mode not in TRIANGULATION_MODES:

@@ -82,6 +82,13 @@ class StreamedPlyWriter:
         ply_records(xyz, rgb_uint8).tofile(self._f)
         self._n += int(xyz.shape[0])
 
+    def append_packed(self, body: bytes) -> None:
+        """15-byte records as the device packs them (HipDensifier.pack_ply)."""
+        if len(body) % 15:
+            raise ValueError("PLY body must be 15 bytes per vertex")
+        self._f.write(body)
+        self._n += len(body) // 15
+
     @property
     def count(self) -> int:
         return self._n
@@ -116,3 +123,33 @@ def write_points3D_bin_packed(path_out: str, n: int, body: bytes) -> None:
     with open(path_out, "wb") as f:
         f.write(np.uint64(n).tobytes())
         f.write(body)
+
+
+class CumulativePlyBody:
+    """The PLY body of everything emitted so far, kept as bytes: upstream re-concatenates, re-quantises and re-packs the WHOLE cloud
+    for every intermediate preview (core/pipeline.py:508-532 there); here each reference's 15-byte records are packed once (on the
+    device when the points are there) and a preview is header + the bytes so far."""
+
+    def __init__(self) -> None:
+        self._chunks = []
+        self._n = 0
+
+    def append_packed(self, body: bytes) -> None:
+        if len(body) % 15:
+            raise ValueError("PLY body must be 15 bytes per vertex")
+        self._chunks.append(bytes(body))
+        self._n += len(body) // 15
+
+    def append(self, xyz: np.ndarray, rgb_uint8: np.ndarray) -> None:
+        self.append_packed(ply_records(xyz, rgb_uint8).tobytes())
+
+    @property
+    def count(self) -> int:
+        return self._n
+
+    def snapshot(self, path_out: str) -> None:
+        """A complete PLY of the points so far (what upstream's intermediate previews contain)."""
+        with open(path_out, "wb") as f:
+            f.write(ply_header(self._n))
+            for c in self._chunks:
+                f.write(c)

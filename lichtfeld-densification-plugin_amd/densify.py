@@ -237,7 +237,8 @@ def dense_init(args, progress_callback: Optional[Callable[[float, str], None]] =
     dev_pts = _cap_device_points(result.device_points, result.xyz.shape[0], args.max_points, args.seed)
     if progress_callback:
         progress_callback(95.0, "Writing output...")
-    _write_output(config.output_path, xyz, rgb, err, dev_pts)
+    if getattr(result, "streamed_path", None) != config.output_path:      # config.stream_output: the file is already complete
+        _write_output(config.output_path, xyz, rgb, err, dev_pts)
     log.info(f"Dense reconstruction finished: {xyz.shape[0]:,} points -> {config.output_path}")
     if progress_callback:
         progress_callback(100.0, f"Done! {xyz.shape[0]:,} points")
@@ -294,7 +295,7 @@ def dense_init_from_lfs(camera_nodes, config: DensePipelineConfig,
             os.makedirs(d, exist_ok=True)
         if _is_writer_rank():
             write_ply(config.output_path, xyz, to_uint8_rgb(rgb))
-    else:
+    elif getattr(result, "streamed_path", None) != config.output_path:    # config.stream_output: the file is already complete
         _write_output(config.output_path, xyz, rgb, err, dev_pts)
     log.info(f"Dense point cloud saved to {config.output_path} ({xyz.shape[0]:,} points)")
     if progress_callback:

@@ -520,3 +520,29 @@ def test_non_finite_inputs_are_rejected_not_fatal(dev):
     best, bslot = dens.aggregate(hb.PreparedBatch(refs, 64, 64), hb.make_params(lfd.DensePipelineConfig(output_path="")))
     assert torch.isnan(best[0, 41, 41]) and int(bslot[0, 41, 41]) == 1
     dens.close()
+
+
+@pytest.mark.parametrize("name", ["a_filter_k3", "c_rect_k3", "d_hires_k2", "e_masks_k3", "f_nosampson_k4"])
+def test_debug_matches_of_the_product_path_equal_upstream_golden(g3, dev, name):
+    """F10 debug output (upstream core/pipeline.py:761-769): per neighbour group the clipped [xA,yA,xB,yB] in match pixels and
+    clip(cert/cap, 0, 1) of the survivors.  The pipeline's hot path gathers them on the GPU from the maps the kernels consumed
+    (core/pipeline.py::_HotPath.debug_matches); concatenated in upstream's group order they are upstream's arrays, bit for bit."""
+    from lichtfeld_densification_plugin_amd.core import pipeline as pl
+    ocams = oracle_cams(g3)
+    case = g3_case(g3, name)
+    cfg = _config(case["params"])
+    dens = hb.HipDensifier(dev)
+    hot = pl._HotPath(_records(ocams), cfg, 0.9, case["w_match"], case["h_match"], dev, dens)
+    ref = _ref_inputs(case, dev)
+    batch = hb.PreparedBatch([ref], case["w_match"], case["h_match"], cameras=_records(ocams))
+    sel = torch.from_numpy(case["sel"]).to(dev)
+    out = dens.triangulate_indexed(batch, hot.params, sel, [0, sel.numel()])
+    best, _ = dens.aggregate(batch, hot.params)
+    dbg = hot.debug_matches(ref, out.cell, out.slot, None, best[0])
+    order = [int(s) for s in out.seg_order[0] if s >= 0]
+    got_m = np.concatenate([dbg[s][0] for s in order], 0)
+    got_c = np.concatenate([dbg[s][1] for s in order], 0)
+    assert got_m.shape == case["dbg_matches"].shape
+    np.testing.assert_array_equal(got_m, case["dbg_matches"])
+    np.testing.assert_array_equal(got_c, case["dbg_cert"])
+    dens.close()

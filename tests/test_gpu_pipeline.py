@@ -231,3 +231,61 @@ def test_bench_starts_its_own_ranks(tmp_path):
         env2.pop("LFD_BENCH_RANKS_PER_GPU", None)
         res2 = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=120)
         assert res2.returncode != 0 and "GPU(s) visible" in (res2.stderr + res2.stdout)
+
+
+@pytest.mark.parametrize("mode", ["sampled", "dense"])
+def test_streamed_output_and_previews_are_the_host_writer_bytes(g4, tmp_path, mode):
+    """config.stream_output: the PLY grows while the run proceeds (records packed on the device, appended per reference, vertex
+    count patched into the header at the end) and equals upstream's write_ply of the final result byte for byte behind the
+    header; every intermediate preview is a complete PLY of the points so far (upstream core/pipeline.py:508-532)."""
+    from lichtfeld_densification_plugin_amd.core import writers
+    from lichtfeld_densification_plugin_amd.core.image_io import to_uint8_rgb
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+    out_path = os.path.join(str(tmp_path), "s", "streamed.ply")
+    cfg = lfd.DensePipelineConfig(output_path=out_path, nns_per_ref=2, seed=5, viz_interval=1, matches_per_ref=1200,
+                                  triangulation_mode=mode, stream_output=True)
+    previews = []
+    res = pl.run_dense_pipeline(cams, refs, nn, cfg, matcher=FakeMatcher(64, 64, table),
+                                on_sequential_viz=lambda p: previews.append(open(p, "rb").read()))
+    assert res.streamed_path == out_path and res.xyz.shape[0] > 500
+    raw = open(out_path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    ref_path = os.path.join(str(tmp_path), "ref.ply")
+    writers.write_ply(ref_path, res.xyz, to_uint8_rgb(res.rgb))
+    ref_head, ref_body = open(ref_path, "rb").read().split(b"end_header\n", 1)
+    assert body == ref_body
+    lines = [l for l in head.decode("ascii").split("\n") if l and not l.startswith("comment")]
+    assert lines == [l for l in ref_head.decode("ascii").split("\n") if l]           # same header once the padding comment is dropped
+    # previews: one per reference with points, each the complete cloud so far
+    counts = np.cumsum([c for c in res.points_per_reference if c > 0])
+    assert len(previews) == len(counts)
+    for n, blob in zip(counts, previews):
+        p = os.path.join(str(tmp_path), "prefix.ply")
+        writers.write_ply(p, res.xyz[:n], to_uint8_rgb(res.rgb[:n]))
+        assert blob == open(p, "rb").read()
+
+
+@pytest.mark.parametrize("per_ref", [False, True])
+def test_launch_ahead_equals_the_synchronous_loop(g4, tmp_path, per_ref, monkeypatch):
+    """Sampled mode launches reference i+1 before it reads reference i back (the device's MT19937 stream advances in stream order,
+    the counts come back behind an event): same points, same order, same per-reference counts as the one-at-a-time loop."""
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+    kw = dict(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=2, seed=5, viz_interval=0, matches_per_ref=1200,
+              per_reference_rng=per_ref)
+    ahead = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**kw), matcher=FakeMatcher(64, 64, table))
+    calls = {"n": 0}
+    orig = pl._HotPath.launch_sampled
+
+    def counted(self, *a, **k):
+        calls["n"] += 1
+        return orig(self, *a, **k)
+    monkeypatch.setattr(pl._HotPath, "launch_sampled", counted)
+    again = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**kw), matcher=FakeMatcher(64, 64, table))
+    assert calls["n"] == len(refs)                                   # the launch-ahead path is the one that ran
+    monkeypatch.setattr(pl._HotPath, "can_launch_ahead", lambda self, *a, **k: False)
+    sync = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**kw), matcher=FakeMatcher(64, 64, table))
+    for r in (ahead, again):
+        np.testing.assert_array_equal(r.xyz, sync.xyz)
+        np.testing.assert_array_equal(r.rgb, sync.rgb)
+        np.testing.assert_array_equal(r.err, sync.err)
+        np.testing.assert_array_equal(r.points_per_reference, sync.points_per_reference)
