@@ -183,6 +183,24 @@ int lfd_quantise_rgb(lfd_context* ctx, const float* rgb, int64_t n, uint8_t* out
  * Synchronises the stream. */
 int lfd_get_pair_fundamental(lfd_context* ctx, int32_t n_pairs, double* F_out_host);
 
+/* ---- N3: image preparation on the device (core/image_utils.py:40-91, core/pipeline.py:163-171) ------------------- */
+/* Decoding stays on the host (PIL); the decoded u8 arrays are uploaded and prepared here, bit for bit like Pillow 12:
+ * lfd_prepare_image:  dst = Image.resize((w_out, h_out), BILINEAR) of the (h_in, w_in, 3) u8 image src (8-bit two-pass
+ *                     fixed-point convolution, horizontal first), then masked pixels black (mask01: device u8 {0,1}
+ *                     [h_out*w_out] or NULL) as apply_mask_to_rgb does.  dst: device u8 [h_out*w_out*3].
+ * lfd_prepare_mask:   dst01 = load_mask_resized_np after the "L" conversion: Image.resize(NEAREST) of the (h_in, w_in) u8
+ *                     mask, then (v / 255 as f32) > threshold, optionally inverted; dst01: device u8 {0,1} [h_out*w_out].
+ * Asynchronous on the context's stream (the tables of a new size pair are built on the host and uploaded first). */
+int lfd_prepare_image(lfd_context* ctx, const uint8_t* src_rgb, int32_t w_in, int32_t h_in, int32_t w_out, int32_t h_out,
+                      const uint8_t* mask01, uint8_t* dst_rgb);
+int lfd_prepare_mask(lfd_context* ctx, const uint8_t* src_l, int32_t w_in, int32_t h_in, int32_t w_out, int32_t h_out,
+                     float threshold, int32_t invert, uint8_t* dst01);
+/* host helpers (CPU tests): the resampling tables exactly as the kernels use them.  bounds: [out_size*2] = {first, count};
+ * kk: [out_size * *ksize_out] 22-bit fixed-point coefficients (LFD_ERR_CAPACITY if kk_capacity is too small, *ksize_out is
+ * still set); idx: [out_size] NEAREST source indices. */
+int lfd_host_resize_tables(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* kk, int32_t kk_capacity, int32_t* ksize_out);
+int lfd_host_nearest_indices(int32_t in_size, int32_t out_size, int32_t* idx);
+
 /* Synchronise the context's stream and report whether the last launches completed normally.
  * *status_out = 0, or 1 when a bounded look-back spin gave up (results invalid; returns LFD_ERR_HIP). */
 int lfd_launch_status(lfd_context* ctx, int32_t* status_out);

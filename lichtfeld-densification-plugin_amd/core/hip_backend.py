@@ -113,6 +113,10 @@ def load_library() -> C.CDLL:
                                                C.c_void_p, C.c_void_p]
     lib.lfd_triangulate_indexed_host.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p,
                                                  C.POINTER(C.c_int64), C.POINTER(lfd_points), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.lfd_prepare_image.argtypes = [ctxp, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.lfd_prepare_mask.argtypes = [ctxp, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
+    lib.lfd_host_resize_tables.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]
+    lib.lfd_host_nearest_indices.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     lib.lfd_identity_axis.argtypes = [C.c_int32, fptr]
     lib.lfd_parallax_dot_threshold.argtypes = [C.c_float]
     lib.lfd_parallax_dot_threshold.restype = C.c_float
@@ -125,7 +129,8 @@ def load_library() -> C.CDLL:
                  "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
                  "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_identity_axis",
                  "lfd_host_fundamental", "lfd_get_pair_fundamental", "lfd_create_host", "lfd_aggregate_host",
-                 "lfd_triangulate_dense_host", "lfd_triangulate_indexed_host",
+                 "lfd_triangulate_dense_host", "lfd_triangulate_indexed_host", "lfd_prepare_image", "lfd_prepare_mask",
+                 "lfd_host_resize_tables", "lfd_host_nearest_indices",
                  "lfd_host_eval_correspondence"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
@@ -171,6 +176,28 @@ def host_fundamental(K1, R1, t1, K2, R2, t2) -> np.ndarray:
     if rc != 0:
         raise HipBackendError("lfd_host_fundamental failed")
     return out.reshape(3, 3)
+
+
+def host_resize_tables(in_size: int, out_size: int):
+    """(bounds (out,2), kk (out,ksize)) of the BILINEAR resampling exactly as the device kernel uses them (Pillow's tables)."""
+    lib = load_library()
+    ks = C.c_int32(0)
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((1,), np.int32)
+    lib.lfd_host_resize_tables(in_size, out_size, bounds.ctypes.data_as(C.POINTER(C.c_int32)), kk.ctypes.data_as(C.POINTER(C.c_int32)), 0, C.byref(ks))
+    kk = np.zeros((out_size, int(ks.value)), np.int32)
+    rc = lib.lfd_host_resize_tables(in_size, out_size, bounds.ctypes.data_as(C.POINTER(C.c_int32)), kk.ctypes.data_as(C.POINTER(C.c_int32)),
+                                    int(kk.size), C.byref(ks))
+    if rc != 0:
+        raise HipBackendError("lfd_host_resize_tables failed")
+    return bounds, kk
+
+
+def host_nearest_indices(in_size: int, out_size: int) -> np.ndarray:
+    idx = np.zeros((out_size,), np.int32)
+    if load_library().lfd_host_nearest_indices(in_size, out_size, idx.ctypes.data_as(C.POINTER(C.c_int32))) != 0:
+        raise HipBackendError("lfd_host_nearest_indices failed")
+    return idx
 
 
 def fundamental_from_world2cam(K1, R1, t1, K2, R2, t2) -> np.ndarray:
@@ -538,6 +565,34 @@ class HipDensifier:
         rgb = self._pts(rgb, 3, "rgb")
         out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
         self._check(self._lib.lfd_quantise_rgb(self._ctx, rgb.data_ptr(), int(rgb.shape[0]), out.data_ptr()), "lfd_quantise_rgb")
+        return out
+
+    # -- N3: image preparation on the device -----------------------------------------------------------------
+    def prepare_image(self, rgb: torch.Tensor, size_wh, mask01: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``Image.resize(size_wh, BILINEAR)`` of a decoded (h, w, 3) u8 device image, then masked pixels black
+        (upstream core/image_utils.py:69-91), bit for bit like Pillow.  Returns a (h_out, w_out, 3) u8 device tensor."""
+        if rgb.dtype != torch.uint8 or not rgb.is_cuda or rgb.dim() != 3 or rgb.shape[2] != 3:
+            raise ValueError("rgb must be a (h, w, 3) uint8 device tensor")
+        rgb = rgb.contiguous()
+        w_out, h_out = int(size_wh[0]), int(size_wh[1])
+        if mask01 is not None:
+            if mask01.dtype != torch.uint8 or not mask01.is_cuda or tuple(mask01.shape) != (h_out, w_out):
+                raise ValueError("mask01 must be a (h_out, w_out) uint8 device tensor")
+            mask01 = mask01.contiguous()
+        out = torch.empty((h_out, w_out, 3), dtype=torch.uint8, device=rgb.device)
+        self._check(self._lib.lfd_prepare_image(self._ctx, rgb.data_ptr(), int(rgb.shape[1]), int(rgb.shape[0]), w_out, h_out,
+                                                mask01.data_ptr() if mask01 is not None else None, out.data_ptr()), "lfd_prepare_image")
+        return out
+
+    def prepare_mask(self, mask_l: torch.Tensor, size_wh, threshold: float = 0.5, invert: bool = False) -> torch.Tensor:
+        """``load_mask_resized_np`` after the "L" conversion: NEAREST resize + threshold (core/image_utils.py:40-66)."""
+        if mask_l.dtype != torch.uint8 or not mask_l.is_cuda or mask_l.dim() != 2:
+            raise ValueError("mask_l must be a (h, w) uint8 device tensor")
+        mask_l = mask_l.contiguous()
+        w_out, h_out = int(size_wh[0]), int(size_wh[1])
+        out = torch.empty((h_out, w_out), dtype=torch.uint8, device=mask_l.device)
+        self._check(self._lib.lfd_prepare_mask(self._ctx, mask_l.data_ptr(), int(mask_l.shape[1]), int(mask_l.shape[0]), w_out, h_out,
+                                               C.c_float(threshold), 1 if invert else 0, out.data_ptr()), "lfd_prepare_mask")
         return out
 
     # -- S: selection stage on the device ----------------------------------------------------------------

@@ -64,6 +64,26 @@ def load_mask01(path: str, size: Tuple[int, int], invert: bool = False, threshol
     return out
 
 
+@lru_cache(maxsize=512)
+def decode_rgb_u8(path: str) -> np.ndarray:
+    """(h, w, 3) u8 array of ``path`` as decoded (no resize): input of the device image preparation (lfd_prepare_image)."""
+    from PIL import Image
+    arr = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
+    arr.setflags(write=False)
+    return arr
+
+
+@lru_cache(maxsize=512)
+def decode_mask_l(path: str) -> np.ndarray:
+    """(h, w) u8 "L" conversion of a mask file as decoded (no resize, no threshold): input of lfd_prepare_mask."""
+    from PIL import Image
+    if not os.path.isfile(path):
+        raise FileNotFoundError(path)
+    arr = np.asarray(Image.open(path).convert("L"), dtype=np.uint8)
+    arr.setflags(write=False)
+    return arr
+
+
 def black_out(rgb: np.ndarray, mask01: np.ndarray) -> np.ndarray:
     """Masked pixels become black before matching (upstream core/image_utils.py:69-82)."""
     if mask01.ndim != 2 or mask01.shape != rgb.shape[:2]:

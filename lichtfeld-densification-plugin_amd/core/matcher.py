@@ -67,8 +67,18 @@ def _import_romav2():
             "RoMaV2/src next to this package; the dense-initialisation kernels only consume its outputs.") from exc
 
 
+def _model_image(im):
+    """What RoMaV2._load_image takes: PIL images / paths / arrays as they are; an (h, w, 3) u8 DEVICE tensor (the output of the
+    device image preparation) as the (1, 3, h, w) tensor the model expects - no host round trip."""
+    if isinstance(im, torch.Tensor) and im.dim() == 3 and im.shape[-1] == 3:
+        return im.permute(2, 0, 1).unsqueeze(0)
+    return im
+
+
 class RomaMatcher:
     """Dense matcher with the reference image's features cached across its neighbours."""
+
+    accepts_device_images = True      # match_grids_batch takes (h, w, 3) u8 device tensors as well as PIL images
 
     def __init__(self, device: str = "cuda", mode: str = "outdoor", setting: str = "fast", two_channel: bool = True):
         del mode
@@ -105,7 +115,7 @@ class RomaMatcher:
             return []
         torch.set_float32_matmul_precision("highest")
         model = self.model
-        img_a = model._load_image(imA)
+        img_a = model._load_image(_model_image(imA))
         kw = dict(mode="bicubic", align_corners=False, antialias=True)
         a_lr = F.interpolate(img_a, size=(int(model.H_lr), int(model.W_lr)), **kw)
         a_hr = None
@@ -114,7 +124,7 @@ class RomaMatcher:
         feats_a = model.f(a_lr)                    # DINOv3 features of the reference: once per reference
         out: List[Tuple[torch.Tensor, torch.Tensor]] = []
         for im_b in imB_list:
-            pred = model.match_from_features(f_list_A=feats_a, img_A_lr=a_lr, imB=im_b, img_A_hr=a_hr)
+            pred = model.match_from_features(f_list_A=feats_a, img_A_lr=a_lr, imB=_model_image(im_b), img_A_hr=a_hr)
             warp_ab = pred["warp_AB"][0]
             cert = pred["overlap_AB"][0].squeeze(-1).contiguous()
             H, W = cert.shape

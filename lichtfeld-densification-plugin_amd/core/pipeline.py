@@ -38,7 +38,7 @@ from . import distributed as lfd_dist
 from . import hip_backend as hb
 from .debug_viz import MatchDebugState, MatchPreview
 from .hostlog import log
-from .image_io import black_out, load_mask01, load_rgb_u8, to_uint8_rgb
+from .image_io import black_out, decode_mask_l, decode_rgb_u8, load_mask01, load_rgb_u8, to_uint8_rgb
 from .matcher import RomaMatcher, has_cached_romav2_weights, romav2_cached_weights_paths
 from .sampling import select_samples_with_coverage
 from .types import CameraRecord, DensePipelineConfig
@@ -76,6 +76,10 @@ class _PackedReference:
     nbr_indices: List[int]
     nbr_images: List[np.ndarray]
     nbr_masks: List[Optional[np.ndarray]]
+    # device_image_prep: ``image`` / ``nbr_images`` / masks above hold the DECODED arrays (any size, masks as "L") until
+    # _HotPath.prepare_on_device has resized them on the GPU; ``dev`` then holds the prepared device tensors
+    raw: bool = False
+    dev: Optional[dict] = None
 
 
 def _cancelled(cb: Optional[Callable[[], bool]]) -> bool:
@@ -98,10 +102,13 @@ def _estimate_total_pairs(refs_local, nn_table, uids, nns_per_ref) -> int:
 
 
 def _pack_reference(position: int, ref_index: int, cams: Sequence[CameraRecord], nn_table, nns_per_ref: int,
-                    size_wh: Tuple[int, int], cancel) -> Optional[_PackedReference]:
-    """Load and pre-process one reference and its neighbours (upstream core/pipeline.py:132-227)."""
+                    size_wh: Tuple[int, int], cancel, raw: bool = False) -> Optional[_PackedReference]:
+    """Load and pre-process one reference and its neighbours (upstream core/pipeline.py:132-227).  ``raw``: decode only; the
+    resize / mask / black-out steps then run on the GPU (``_HotPath.prepare_on_device``)."""
     if _cancelled(cancel):
         return None
+    if raw:
+        return _pack_reference_raw(position, ref_index, cams, nn_table, nns_per_ref, cancel)
     cam = cams[ref_index]
     try:
         img_a = load_rgb_u8(cam.image_path, size_wh)
@@ -147,6 +154,51 @@ def _pack_reference(position: int, ref_index: int, cams: Sequence[CameraRecord],
     return _PackedReference(position=position, ref_index=ref_index, ref_uid=int(cam.uid),
                             image=np.asarray(img_a, dtype=np.uint8), mask_a=mask_a, nbr_indices=nbr_indices,
                             nbr_images=nbr_images, nbr_masks=nbr_masks)
+
+
+def _pack_reference_raw(position: int, ref_index: int, cams: Sequence[CameraRecord], nn_table, nns_per_ref: int,
+                        cancel) -> Optional[_PackedReference]:
+    """The decode half of _pack_reference: same skip / warn rules, images and masks left as decoded."""
+    cam = cams[ref_index]
+    try:
+        img_a = decode_rgb_u8(cam.image_path)
+    except Exception as exc:
+        log.warn(f"Failed to load reference {cam.image_path}: {exc}")
+        return None
+    mask_a = None
+    if getattr(cam, "mask_path", None):
+        try:
+            mask_a = decode_mask_l(cam.mask_path)
+        except Exception as exc:
+            log.warn(f"Failed to load/apply mask for reference {cam.uid}: {exc}")
+    local = nn_table[ref_index][:nns_per_ref]
+    if len(local) == 0:
+        return None
+    nbr_indices, nbr_images, nbr_masks = [], [], []
+    for n in local:
+        n = int(n)
+        if _cancelled(cancel):
+            return None
+        nb = cams[n]
+        if nb.uid == cam.uid:
+            continue
+        try:
+            img_b = decode_rgb_u8(nb.image_path)
+            mask_b = None
+            if getattr(nb, "mask_path", None):
+                try:
+                    mask_b = decode_mask_l(nb.mask_path)
+                except Exception as exc:
+                    log.warn(f"Failed to load/apply mask for neighbor {nb.uid}: {exc}")
+            nbr_indices.append(n)
+            nbr_images.append(img_b)
+            nbr_masks.append(mask_b)
+        except Exception as exc:
+            log.warn(f"Failed to load neighbor {nb.uid}: {exc}")
+    if not nbr_images:
+        return None
+    return _PackedReference(position=position, ref_index=ref_index, ref_uid=int(cam.uid), image=img_a, mask_a=mask_a,
+                            nbr_indices=nbr_indices, nbr_images=nbr_images, nbr_masks=nbr_masks, raw=True)
 
 
 class _OrderedPrefetcher:
@@ -244,8 +296,40 @@ class _HotPath:
         if self._own:
             self.dens.close()
 
+    def prepare_on_device(self, packed: _PackedReference, size_wh: Tuple[int, int], need_host: bool) -> _PackedReference:
+        """device_image_prep: the decoded arrays of ``packed`` are uploaded and resized / thresholded / blacked out by
+        lfd_prepare_mask + lfd_prepare_image (Pillow's arithmetic, bit for bit); the result replaces the host-prepared arrays
+        (``need_host``: also as NumPy copies, for a matcher that wants PIL images or for debug previews)."""
+        dev = self.dev
+
+        def up(a):
+            return torch.from_numpy(np.array(a, dtype=np.uint8, copy=True)).to(dev)      # the decode cache hands out read-only arrays
+
+        def one(img, mask_l):
+            m01 = self.dens.prepare_mask(up(mask_l), size_wh) if mask_l is not None else None
+            return self.dens.prepare_image(up(img), size_wh, m01), m01
+
+        img_a, mask_a = one(packed.image, packed.mask_a)
+        nbrs = [one(im, mk) for im, mk in zip(packed.nbr_images, packed.nbr_masks)]
+        out = dataclasses.replace(packed, raw=False, dev={"image": img_a, "mask_a": mask_a, "nbr_images": [n[0] for n in nbrs],
+                                                          "nbr_masks": [n[1] for n in nbrs]})
+        if need_host:
+            out.image = img_a.cpu().numpy()
+            out.mask_a = mask_a.cpu().numpy() if mask_a is not None else None
+            out.nbr_images = [n[0].cpu().numpy() for n in nbrs]
+            out.nbr_masks = [n[1].cpu().numpy() if n[1] is not None else None for n in nbrs]
+        else:
+            out.mask_a = True if mask_a is not None else None           # only "is there a mask" is asked of these below
+            out.nbr_masks = [True if n[1] is not None else None for n in nbrs]
+        return out
+
     def inputs(self, packed: _PackedReference, warps, certs) -> hb.ReferenceInputs:
         dev = self.dev
+        if packed.dev is not None:                 # prepared on the device: nothing to upload
+            d = packed.dev
+            use_masks = d["mask_a"] is not None or any(m is not None for m in d["nbr_masks"])
+            return hb.ReferenceInputs(ref_cam=packed.ref_index, nbr_cams=list(packed.nbr_indices), cert=certs, warp=warps,
+                                      image=d["image"], mask_a=d["mask_a"], mask_b=list(d["nbr_masks"]) if use_masks else None)
         use_masks = packed.mask_a is not None or any(m is not None for m in packed.nbr_masks)
         mask_b = None
         if use_masks:
@@ -445,8 +529,9 @@ def run_dense_pipeline(
         w_match, h_match = int(matcher.w_resized), int(matcher.h_resized)
         hot = _HotPath(camera_records, config, float(matcher.sample_thresh), w_match, h_match, dev, densifier)
         hot.dens.seed_rng(int(config.seed))      # upstream: np.random.seed(config.seed) (core/pipeline.py:793)
+        device_prep = bool(getattr(config, "device_image_prep", False))
         jobs = [(lambda p=p: _pack_reference(p, refs_local[p], camera_records, nn_table, config.nns_per_ref,
-                                             (w_match, h_match), cancel_requested)) for p in my_positions]
+                                             (w_match, h_match), cancel_requested, raw=device_prep)) for p in my_positions]
         prefetch = _OrderedPrefetcher(jobs, workers=int(getattr(config, "pack_workers", 4)),
                                       window=int(getattr(config, "prefetch_packages", 8)))
         total_refs = len(my_positions)
@@ -543,8 +628,15 @@ def run_dense_pipeline(
                 continue
             _raise_if_cancelled(cancel_requested)
             from PIL import Image
-            results = matcher.match_grids_batch(Image.fromarray(np.ascontiguousarray(packed.image)),
-                                                [Image.fromarray(np.ascontiguousarray(a)) for a in packed.nbr_images])
+            want_debug = debug_state is not None and debug_state.is_enabled()
+            dev_images = bool(getattr(matcher, "accepts_device_images", False))
+            if packed.raw:
+                packed = hot.prepare_on_device(packed, (w_match, h_match), need_host=want_debug or not dev_images)
+            if packed.dev is not None and dev_images:
+                results = matcher.match_grids_batch(packed.dev["image"], list(packed.dev["nbr_images"]))
+            else:
+                results = matcher.match_grids_batch(Image.fromarray(np.ascontiguousarray(packed.image)),
+                                                    [Image.fromarray(np.ascontiguousarray(a)) for a in packed.nbr_images])
             _raise_if_cancelled(cancel_requested)
             if not results:
                 continue
@@ -559,7 +651,6 @@ def run_dense_pipeline(
                     a0, a1 = ax(H, W)
                     axes = (torch.as_tensor(a0).to(dev, torch.float32).contiguous(), torch.as_tensor(a1).to(dev, torch.float32).contiguous())
             ref = hot.inputs(packed, warps, certs)
-            want_debug = debug_state is not None and debug_state.is_enabled()
 
             if config.triangulation_mode == "dense":
                 pending.append((local_i, packed, ref, axes))

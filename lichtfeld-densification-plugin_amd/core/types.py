@@ -59,6 +59,9 @@ class DensePipelineConfig:
     # (lfd_pack_ply, 15 B per point across PCIe) and appended to ``output_path``; the vertex count in the header is patched at
     # the end.  Honoured when the output is a .ply and neither a point cap nor a voxel filter has to see the whole cloud first.
     stream_output: bool = False
+    # resize / mask / black-out the decoded images on the GPU (lfd_prepare_image / lfd_prepare_mask: Pillow's BILINEAR and
+    # NEAREST arithmetic, bit for bit) instead of with PIL on the host pack threads; decoding stays on the host
+    device_image_prep: bool = False
 
     def __post_init__(self) -> None:
         if self.triangulation_mode not in TRIANGULATION_MODES:

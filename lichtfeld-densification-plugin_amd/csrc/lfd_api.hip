@@ -333,7 +333,7 @@ void lfd_destroy(lfd_context* ctx) {
     if (ctx->is_host) { delete ctx; return; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->mt, &ctx->sel_scratch, &ctx->stamps})
+    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->mt, &ctx->sel_scratch, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);

@@ -53,6 +53,11 @@ struct lfd_context {
     // selection stage: legacy MT19937 stream (625 words) + scratch
     DeviceBuffer mt, sel_scratch;
     DeviceBuffer stamps;           // profiling builds: phase stamps of the dense kernel
+    // N3 image preparation: coefficient / index tables of the last size pair
+    DeviceBuffer img_tab, msk_tab;
+    int img_key[4] = {0, 0, 0, 0}, img_ks[2] = {0, 0};
+    int msk_key[4] = {0, 0, 0, 0}, msk_inv = 0;
+    float msk_thr = -1.0f;
     bool mt_seeded = false;
     bool topm_lds_attr_set = false;   // hipFuncSetAttribute is per device: remembered per context, not per process
 };

@@ -12,7 +12,7 @@ if [ "$1" = "build" ]; then
     name=${spec%%:*}; flags=${spec#*:}
     [ "$flags" = "$spec" ] && flags=""
     ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fno-fast-math -Wno-unused-function -mllvm -amdgpu-sched-strategy=max-ilp $flags \
-        -pthread $SRC/lfd_api.hip $SRC/lfd_kernels.hip $SRC/lfd_select.hip $SRC/lfd_writer.hip $SRC/lfd_host.hip -o $VD/$name.so || echo "BUILD FAILED $name" ) &
+        -pthread $SRC/lfd_api.hip $SRC/lfd_kernels.hip $SRC/lfd_select.hip $SRC/lfd_writer.hip $SRC/lfd_host.hip $SRC/lfd_image.hip -o $VD/$name.so || echo "BUILD FAILED $name" ) &
     while [ $(jobs -r | wc -l) -ge 6 ]; do sleep 0.5; done
   done
   wait

@@ -358,8 +358,43 @@ def g6_selection_tables():
     save("g6_selection_tables.npz", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# G7: image preparation (core/image_utils.py:40-91, core/pipeline.py:163-171): decoded arrays -> what upstream feeds the matcher
+# ---------------------------------------------------------------------------------------------
+def g7_image_prep():
+    import tempfile
+    from PIL import Image
+    import PIL
+    rs = np.random.RandomState(7)
+    out = {"pillow_version": np.array(PIL.__version__)}
+    cases = [("down", 61, 97, 64, 48), ("downup", 84, 130, 51, 96), ("up", 40, 50, 80, 64), ("same", 48, 64, 64, 48),
+             ("wonly", 48, 64, 40, 48), ("honly", 33, 77, 77, 20), ("garden", 210, 324, 128, 128)]
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, h, w, wo, ho in cases:
+            yy, xx = np.mgrid[0:h, 0:w]
+            base = np.stack([127 + 120 * np.sin(xx / 7.0 + yy / 11.0), 127 + 120 * np.cos(xx / 5.0 - yy / 13.0), (xx * 3 + yy * 5) % 256], -1)
+            img = np.clip(base + rs.randint(-20, 21, size=(h, w, 3)), 0, 255).astype(np.uint8)
+            mask = (rs.randint(0, 256, size=(h, w)) * (np.hypot(xx - w / 2, yy - h / 2) < 0.45 * min(h, w))).astype(np.uint8)
+            ip, mp = os.path.join(tmp, name + ".png"), os.path.join(tmp, name + "_mask.png")
+            Image.fromarray(img).save(ip)
+            Image.fromarray(mask, mode="L").save(mp)
+            rgb = ns.image_utils.load_rgb_resized(ip, (wo, ho))
+            m01 = ns.image_utils.load_mask_resized_np(mp, (wo, ho))
+            m01_inv = ns.image_utils.load_mask_resized_np(mp, (wo, ho), invert=True, threshold=0.3)
+            blk = ns.image_utils.apply_mask_to_rgb(rgb, m01)
+            pre = name + "_"
+            out[pre + "image"], out[pre + "mask"] = img, mask
+            out[pre + "size"] = np.array([wo, ho], np.int64)
+            out[pre + "rgb"] = np.asarray(rgb, dtype=np.uint8)
+            out[pre + "mask01"], out[pre + "mask01_inv03"] = m01, m01_inv
+            out[pre + "blacked"] = np.asarray(blk, dtype=np.uint8)
+            print(f"  g7 {name}: {h}x{w} -> {ho}x{wo}, kept {int(m01.sum())} mask pixels")
+    out["names"] = np.array([c[0] for c in cases])
+    save("g7_image_prep.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     for w in which:
         {"g1": g1_geometry, "g2": g2_selection, "g3": g3_triangulate, "g4": g4_pipeline, "g5": g5_writers,
-         "g6": g6_selection_tables}[w]()
+         "g6": g6_selection_tables, "g7": g7_image_prep}[w]()

@@ -289,3 +289,47 @@ def test_launch_ahead_equals_the_synchronous_loop(g4, tmp_path, per_ref, monkeyp
         np.testing.assert_array_equal(r.rgb, sync.rgb)
         np.testing.assert_array_equal(r.err, sync.err)
         np.testing.assert_array_equal(r.points_per_reference, sync.points_per_reference)
+
+
+@pytest.mark.parametrize("device_matcher", [False, True])
+def test_device_image_prep_gives_the_host_prepared_run(g4, tmp_path, device_matcher):
+    """config.device_image_prep: decoded images (97x130, not the match size) and "L" masks are resized / thresholded / blacked
+    out on the GPU with Pillow's arithmetic instead of by PIL on the pack threads; the run is identical, whether the matcher
+    takes the prepared images as device tensors or as PIL images."""
+    from PIL import Image
+    ocams = oracle_cams(g4)
+    rs = np.random.RandomState(2)
+    cams = []
+    for i, c in enumerate(ocams):
+        ip, mp = os.path.join(str(tmp_path), f"big{i:02d}.png"), os.path.join(str(tmp_path), f"big{i:02d}_mask.png")
+        Image.fromarray(rs.randint(0, 256, (97, 130, 3)).astype(np.uint8)).save(ip)
+        m = np.full((97, 130), 255, np.uint8)
+        m[10 + i:40 + i, 20:70] = 0
+        m[60:80, 90 + i:120] = 100                      # below the threshold
+        Image.fromarray(m, mode="L").save(mp)
+        cam = lfd.CameraRecord(uid=int(g4["cam_uid"][i]), image_path=ip, width=c.width, height=c.height, K=c.K, R=c.R, t=c.t, P=c.P, C=c.C)
+        cam.mask_path = mp
+        cams.append(cam)
+    refs = [int(r) for r in g4["refs_local"]]
+    table = [[(torch.from_numpy(g4[f"ref{r}_warp"][j]), torch.from_numpy(g4[f"ref{r}_cert"][j])) for j in range(2)] for r in refs]
+    seen = []
+
+    class DevMatcher(FakeMatcher):
+        accepts_device_images = True
+
+        def match_grids_batch(self, imA, imB_list):
+            seen.append((isinstance(imA, torch.Tensor) and imA.is_cuda and tuple(imA.shape) == (64, 64, 3),
+                         all(isinstance(b, torch.Tensor) and b.is_cuda for b in imB_list)))
+            return super().match_grids_batch(imA, imB_list)
+
+    kw = dict(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=2, seed=5, viz_interval=0, matches_per_ref=1200)
+    host = pl.run_dense_pipeline(cams, refs, g4["nn_table"], lfd.DensePipelineConfig(**kw), matcher=FakeMatcher(64, 64, table))
+    mk = DevMatcher if device_matcher else FakeMatcher
+    devr = pl.run_dense_pipeline(cams, refs, g4["nn_table"], lfd.DensePipelineConfig(device_image_prep=True, **kw), matcher=mk(64, 64, table))
+    assert host.xyz.shape[0] > 300
+    np.testing.assert_array_equal(devr.xyz, host.xyz)
+    np.testing.assert_array_equal(devr.rgb, host.rgb)
+    np.testing.assert_array_equal(devr.err, host.err)
+    np.testing.assert_array_equal(devr.points_per_reference, host.points_per_reference)
+    if device_matcher:
+        assert seen and all(a and b for a, b in seen)
