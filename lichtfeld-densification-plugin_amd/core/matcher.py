@@ -79,6 +79,7 @@ class RomaMatcher:
     """Dense matcher with the reference image's features cached across its neighbours."""
 
     accepts_device_images = True      # match_grids_batch takes (h, w, 3) u8 device tensors as well as PIL images
+    supports_feature_keys = True      # match_grids_batch(..., keys=(ref_key, [nbr_keys])) shares backbone features between references
 
     def __init__(self, device: str = "cuda", mode: str = "outdoor", setting: str = "fast", two_channel: bool = True):
         del mode
@@ -107,24 +108,46 @@ class RomaMatcher:
                                torch.linspace(-1 + 1 / H, 1 - 1 / H, H, device=self.device))
         return self._axes[key]
 
+    def set_feature_cache(self, cache) -> None:
+        """A core.scheduler.FeatureCache: backbone features (``model.f`` of the low-resolution image) are then computed once per
+        camera key instead of once per (reference, neighbour) pair.  The vendored model is not modified: its ``f`` is wrapped
+        for the duration of a keyed call."""
+        self._feature_cache = cache
+
+    def _keyed_f(self, key):
+        """``model.f`` memoised under ``key`` (None: plain)."""
+        plain = self._plain_f
+        cache = getattr(self, "_feature_cache", None)
+        if key is None or cache is None:
+            return plain
+        return lambda img: cache.get_or_compute(key, lambda: plain(img))
+
     @torch.inference_mode()
-    def match_grids_batch(self, imA, imB_list: Sequence) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+    def match_grids_batch(self, imA, imB_list: Sequence, keys=None) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+        """``keys`` = (reference key, [neighbour keys]): camera identities for the feature cache (core/scheduler.py)."""
         if self.model is None:
             raise RuntimeError("RoMaV2 model has been released; create a new matcher before matching.")
         if not imB_list:
             return []
         torch.set_float32_matmul_precision("highest")
         model = self.model
+        if not hasattr(self, "_plain_f"):
+            self._plain_f = model.f
+        ref_key, nbr_keys = keys if keys is not None else (None, [None] * len(imB_list))
         img_a = model._load_image(_model_image(imA))
         kw = dict(mode="bicubic", align_corners=False, antialias=True)
         a_lr = F.interpolate(img_a, size=(int(model.H_lr), int(model.W_lr)), **kw)
         a_hr = None
         if model.H_hr is not None and model.W_hr is not None:
             a_hr = F.interpolate(img_a, size=(int(model.H_hr), int(model.W_hr)), **kw)
-        feats_a = model.f(a_lr)                    # DINOv3 features of the reference: once per reference
+        feats_a = self._keyed_f(ref_key)(a_lr)     # DINOv3 features of the reference: once per reference (once per RUN with keys)
         out: List[Tuple[torch.Tensor, torch.Tensor]] = []
-        for im_b in imB_list:
-            pred = model.match_from_features(f_list_A=feats_a, img_A_lr=a_lr, imB=_model_image(im_b), img_A_hr=a_hr)
+        for im_b, key_b in zip(imB_list, nbr_keys):
+            model.f = self._keyed_f(key_b)         # the neighbour's features: looked up instead of recomputed when seen before
+            try:
+                pred = model.match_from_features(f_list_A=feats_a, img_A_lr=a_lr, imB=_model_image(im_b), img_A_hr=a_hr)
+            finally:
+                model.f = self._plain_f
             warp_ab = pred["warp_AB"][0]
             cert = pred["overlap_AB"][0].squeeze(-1).contiguous()
             H, W = cert.shape

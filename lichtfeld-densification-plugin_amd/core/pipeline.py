@@ -41,6 +41,7 @@ from .hostlog import log
 from .image_io import black_out, decode_mask_l, decode_rgb_u8, load_mask01, load_rgb_u8, to_uint8_rgb
 from .matcher import RomaMatcher, has_cached_romav2_weights, romav2_cached_weights_paths
 from .sampling import select_samples_with_coverage
+from .scheduler import FeatureCache, PairSchedule
 from .types import CameraRecord, DensePipelineConfig
 from .writers import CumulativePlyBody, StreamedPlyWriter, ensure_dir, write_ply
 
@@ -529,6 +530,12 @@ def run_dense_pipeline(
         w_match, h_match = int(matcher.w_resized), int(matcher.h_resized)
         hot = _HotPath(camera_records, config, float(matcher.sample_thresh), w_match, h_match, dev, densifier)
         hot.dens.seed_rng(int(config.seed))      # upstream: np.random.seed(config.seed) (core/pipeline.py:793)
+        # N4: every camera's backbone features once per run, kept exactly until their last use (core/scheduler.py)
+        schedule = PairSchedule(refs_local, nn_table, uids, config.nns_per_ref, positions=my_positions)
+        feat_cache = None
+        if bool(getattr(matcher, "supports_feature_keys", False)) and bool(getattr(config, "share_features", True)):
+            feat_cache = FeatureCache(schedule.last_use)
+            matcher.set_feature_cache(feat_cache)
         device_prep = bool(getattr(config, "device_image_prep", False))
         jobs = [(lambda p=p: _pack_reference(p, refs_local[p], camera_records, nn_table, config.nns_per_ref,
                                              (w_match, h_match), cancel_requested, raw=device_prep)) for p in my_positions]
@@ -632,11 +639,14 @@ def run_dense_pipeline(
             dev_images = bool(getattr(matcher, "accepts_device_images", False))
             if packed.raw:
                 packed = hot.prepare_on_device(packed, (w_match, h_match), need_host=want_debug or not dev_images)
+            kw_keys = {"keys": (packed.ref_index, list(packed.nbr_indices))} if feat_cache is not None else {}
             if packed.dev is not None and dev_images:
-                results = matcher.match_grids_batch(packed.dev["image"], list(packed.dev["nbr_images"]))
+                results = matcher.match_grids_batch(packed.dev["image"], list(packed.dev["nbr_images"]), **kw_keys)
             else:
                 results = matcher.match_grids_batch(Image.fromarray(np.ascontiguousarray(packed.image)),
-                                                    [Image.fromarray(np.ascontiguousarray(a)) for a in packed.nbr_images])
+                                                    [Image.fromarray(np.ascontiguousarray(a)) for a in packed.nbr_images], **kw_keys)
+            if feat_cache is not None:
+                feat_cache.advance(local_i)
             _raise_if_cancelled(cancel_requested)
             if not results:
                 continue

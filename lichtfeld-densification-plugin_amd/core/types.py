@@ -62,6 +62,9 @@ class DensePipelineConfig:
     # resize / mask / black-out the decoded images on the GPU (lfd_prepare_image / lfd_prepare_mask: Pillow's BILINEAR and
     # NEAREST arithmetic, bit for bit) instead of with PIL on the host pack threads; decoding stays on the host
     device_image_prep: bool = False
+    # compute every camera's backbone (DINOv3) features once per run and share them between the references that list the camera
+    # (core/scheduler.py); upstream recomputes a neighbour's features for every reference
+    share_features: bool = True
 
     def __post_init__(self) -> None:
         if self.triangulation_mode not in TRIANGULATION_MODES:
