@@ -145,6 +145,18 @@ int lfd_triangulate_sampled(lfd_context* ctx, const lfd_batch* batch, const lfd_
                             int32_t border, int32_t tiles, float s_override, const lfd_points* out, int64_t* ref_offsets,
                             int32_t* seg_counts, int32_t* seg_order, int32_t* sel_info, int64_t* sel_cells);
 
+/* The same for SEVERAL reference views per call, each drawing from its own MT19937 stream seeded with seeds[r] (host u32
+ * [n_refs]) like np.random.seed(seeds[r]) - the per-reference streams of the multi-GPU / per_reference_rng mode, where no
+ * reference depends on another one's draws.  One aggregate launch and one pair of indexed launches serve the whole batch; the
+ * selections run one after the other.  out->capacity >= n_refs * (M + tiles*tiles + 64).  sel_info: device i32 [2*n_refs + 1] =
+ * {cells selected, selection status} per reference, then the launch status.  sel_cells: device i64 [n_refs * (M + tiles*tiles +
+ * 64)] (reference r's cells start at r * (M + tiles*tiles + 64)) or NULL.  The context's own stream is left seeded with the last
+ * reference's seed. */
+int lfd_triangulate_sampled_multi(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, int32_t M, float cap,
+                                  int32_t border, int32_t tiles, const uint32_t* seeds, const lfd_points* out,
+                                  int64_t* ref_offsets, int32_t* seg_counts, int32_t* seg_order, int32_t* sel_info,
+                                  int64_t* sel_cells);
+
 /* S: coverage sampling on the device (core/sampling.py:8-53, filter mode).  The context owns a legacy
  * MT19937 stream seeded like np.random.seed(seed); every call consumes it exactly as upstream's
  * np.random.choice does, so successive references see the same stream upstream would.

@@ -93,6 +93,9 @@ def load_library() -> C.CDLL:
     lib.lfd_triangulate_sampled.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_int32, C.c_float, C.c_int32,
                                             C.c_int32, C.c_float, C.POINTER(lfd_points), C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
+    lib.lfd_triangulate_sampled_multi.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_int32, C.c_float, C.c_int32,
+                                                  C.c_int32, C.POINTER(C.c_uint32), C.POINTER(lfd_points), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p]
     lib.lfd_select_top_m.argtypes = [ctxp, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int64,
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.lfd_pack_ply.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -126,7 +129,7 @@ def load_library() -> C.CDLL:
     lib.lfd_host_eval_correspondence.argtypes = [fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                                  C.c_int32, C.POINTER(lfd_params), fptr]
     for name in ("lfd_create", "lfd_set_stream", "lfd_upload_cameras", "lfd_aggregate", "lfd_triangulate_dense",
-                 "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
+                 "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_triangulate_sampled_multi", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
                  "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_identity_axis",
                  "lfd_host_fundamental", "lfd_get_pair_fundamental", "lfd_create_host", "lfd_aggregate_host",
                  "lfd_triangulate_dense_host", "lfd_triangulate_indexed_host", "lfd_prepare_image", "lfd_prepare_mask",
@@ -413,12 +416,12 @@ class OutputBuffers:
         # the small integer outputs share ONE buffer so that collect() needs a single device-to-host copy:
         # [ref_offsets i64 x (R+1)] [seg_counts i32 x R*k] [seg_order i32 x R*k]
         n_off, n_seg = 2 * (n_refs + 1), n_refs * k
-        self._meta = torch.zeros((n_off + 2 * n_seg + 3,), dtype=torch.int32, device=device)
+        self._meta = torch.zeros((n_off + 2 * n_seg + 2 * n_refs + 1,), dtype=torch.int32, device=device)
         self._meta[n_off + n_seg:n_off + 2 * n_seg].fill_(-1)
         self.ref_offsets = self._meta[:n_off].view(torch.int64)
         self.seg_counts = self._meta[n_off:n_off + n_seg].view(n_refs, k)
         self.seg_order = self._meta[n_off + n_seg:n_off + 2 * n_seg].view(n_refs, k)
-        self.sel_info = self._meta[n_off + 2 * n_seg:]           # lfd_triangulate_sampled: {cells selected, selection status, launch status}
+        self.sel_info = self._meta[n_off + 2 * n_seg:]           # lfd_triangulate_sampled[_multi]: {cells selected, selection status} per reference, then the launch status
         self._n_refs, self._k = n_refs, k
         self.c = lfd_points(xyz=self.xyz.data_ptr(), rgb=self.rgb.data_ptr(), err=self.err.data_ptr(),
                             cell=self.cell.data_ptr() if with_cell else None,
@@ -440,7 +443,11 @@ class OutputBuffers:
         self._meta_pending = True
 
     def select_status(self, meta: np.ndarray) -> int:
-        return int(meta[2 * (self._n_refs + 1) + 2 * self._n_refs * self._k + 1])
+        """Worst selection status over the references of a fused sampled call (0 = every selection went through)."""
+        base = 2 * (self._n_refs + 1) + 2 * self._n_refs * self._k
+        st = meta[base + 1:base + 2 * self._n_refs:2]
+        bad = st[st != 0]
+        return int(bad[0]) if bad.size else 0
 
     def collect(self, indexed: bool = False, check_selection: bool = False) -> TriangulationOutput:
         """Synchronise and trim to the number of survivors.  ``check_selection``: raise what upstream's sampling stage
@@ -469,7 +476,8 @@ class OutputBuffers:
             cell=self.cell[:n] if self.cell is not None else None, slot=self.slot[:n] if self.slot is not None else None,
             ref_offsets=offs, seg_counts=meta[n_off:n_off + n_seg].reshape(self._n_refs, self._k).copy(),
             seg_order=meta[n_off + n_seg:n_off + 2 * n_seg].reshape(self._n_refs, self._k).copy() if indexed else None,
-            n_selected=int(meta[n_off + 2 * n_seg]), launch_status=int(meta[n_off + 2 * n_seg + 2]), _packed=self._f,
+            n_selected=int(meta[n_off + 2 * n_seg:n_off + 2 * n_seg + 2 * self._n_refs:2].sum()),
+            launch_status=int(meta[n_off + 2 * n_seg + 2 * self._n_refs]), _packed=self._f,
             _cap=max(self.capacity, 1))
 
 
@@ -679,6 +687,18 @@ class HipDensifier:
                                                       out.seg_counts.data_ptr(), out.seg_order.data_ptr(), out.sel_info.data_ptr(),
                                                       sel_cells.data_ptr() if sel_cells is not None else None),
                     "lfd_triangulate_sampled")
+
+    def launch_sampled_multi(self, batch: PreparedBatch, params: lfd_params, M: int, out: OutputBuffers, seeds: Sequence[int],
+                             cap: float = 0.9, border: int = 2, tiles: int = 24) -> None:
+        """Several reference views through the fused call at once, each on its own MT19937 stream (``seeds[r]``, like
+        ``np.random.seed``): lfd_triangulate_sampled_multi.  ``out`` needs capacity n_refs * (M + tiles*tiles + 64)."""
+        if len(seeds) != batch.n_refs:
+            raise ValueError("one seed per reference")
+        arr = (C.c_uint32 * batch.n_refs)(*[int(v) & 0xFFFFFFFF for v in seeds])
+        self._check(self._lib.lfd_triangulate_sampled_multi(self._ctx, C.byref(batch.c), C.byref(params), int(M), C.c_float(cap), int(border),
+                                                            int(tiles), arr, C.byref(out.c), out.ref_offsets.data_ptr(),
+                                                            out.seg_counts.data_ptr(), out.seg_order.data_ptr(), out.sel_info.data_ptr(), None),
+                    "lfd_triangulate_sampled_multi")
 
     def triangulate_sampled(self, batch: PreparedBatch, params: lfd_params, M: int, cap: float = 0.9, border: int = 2,
                             tiles: int = 24, s_override: float = 0.0, with_cell: bool = True) -> TriangulationOutput:

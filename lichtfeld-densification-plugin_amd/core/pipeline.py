@@ -411,6 +411,15 @@ class _HotPath:
         out.begin_collect(self.dens.stream)
         return batch, out
 
+    def launch_sampled_multi(self, refs: List[hb.ReferenceInputs], axes, seeds: List[int]):
+        """``refs_per_launch`` references through ONE fused call, each on its own stream (per_reference_rng)."""
+        batch = hb.PreparedBatch(refs, self.w_match, self.h_match, axes=axes, cameras=self.cams)
+        M = self.config.matches_per_ref
+        out = hb.OutputBuffers(len(refs) * (int(M) + 24 * 24 + 64), len(refs), batch.k, self.dev)
+        self.dens.launch_sampled_multi(batch, self.params, M, out, seeds, cap=self.sample_cap, border=2, tiles=24)
+        out.begin_collect(self.dens.stream)
+        return batch, out
+
     def finish_sampled(self, handle) -> Optional[hb.TriangulationOutput]:
         _batch, out = handle
         res = out.collect(indexed=True, check_selection=True)
@@ -611,6 +620,40 @@ def run_dense_pipeline(
                     emit(local_i, packed, xyz[lo:hi], rgb[lo:hi], err[lo:hi], None, dev_parts[-1])
             pending.clear()
 
+        group: List[Tuple[int, _PackedReference, hb.ReferenceInputs, object, int]] = []     # sampled mode, several references per call
+
+        def flush_group() -> None:
+            if not group:
+                return
+            items = list(group)
+            group.clear()
+            try:
+                handle = hot.launch_sampled_multi([g[2] for g in items], items[0][3], [g[4] for g in items])
+                res = hot.finish_sampled(handle)
+            except Exception as ex:
+                # upstream isolates failures per reference (core/pipeline.py:874-879): redo the group one reference at a time,
+                # so that only the reference that cannot be processed is dropped
+                log.warn(f"Grouped triangulation of refs {[g[1].ref_uid for g in items]} failed ({ex}); retrying one by one")
+                for li, pk, rf, ax_, sd in items:
+                    try:
+                        one = hot.finish_sampled(hot.launch_sampled(rf, ax_, sd))
+                    except Exception as ex1:
+                        log.error(f"Triangulation error for ref {pk.ref_uid}: {ex1}")
+                        continue
+                    if one is not None:
+                        dev_parts.append((one.xyz.clone(), one.rgb.clone(), one.err.clone()))
+                        h1 = one.host_arrays()
+                        emit(li, pk, h1[0], h1[1], h1[2], None, dev_parts[-1])
+                return
+            if res is None:
+                return
+            hx, hc, he = res.xyz.cpu().numpy(), res.rgb.cpu().numpy(), res.err.cpu().numpy()
+            for bi, (li, pk, _ref, _axes, _seed) in enumerate(items):
+                lo, hi = int(res.ref_offsets[bi]), int(res.ref_offsets[bi + 1])
+                if hi > lo:
+                    dev_parts.append((res.xyz[lo:hi].clone(), res.rgb[lo:hi].clone(), res.err[lo:hi].clone()))
+                    emit(li, pk, hx[lo:hi], hc[lo:hi], he[lo:hi], None, dev_parts[-1])
+
         def finish_one() -> None:
             """Collect the oldest launched reference (sampled mode) and emit it: references are emitted in launch order."""
             li, pk, handle = inflight.pop(0)
@@ -639,7 +682,8 @@ def run_dense_pipeline(
             dev_images = bool(getattr(matcher, "accepts_device_images", False))
             if packed.raw:
                 packed = hot.prepare_on_device(packed, (w_match, h_match), need_host=want_debug or not dev_images)
-            kw_keys = {"keys": (packed.ref_index, list(packed.nbr_indices))} if feat_cache is not None else {}
+            kw_keys = ({"keys": (packed.ref_index, list(packed.nbr_indices))}
+                       if bool(getattr(matcher, "supports_feature_keys", False)) else {})
             if packed.dev is not None and dev_images:
                 results = matcher.match_grids_batch(packed.dev["image"], list(packed.dev["nbr_images"]), **kw_keys)
             else:
@@ -670,6 +714,13 @@ def run_dense_pipeline(
 
             rng = _reference_rng(config.seed, packed.ref_uid) if per_ref_rng else stream_rng
             dseed = _reference_seed(config.seed, packed.ref_uid) if per_ref_rng else None
+            if per_ref_rng and int(config.refs_per_launch) > 1 and hot.can_launch_ahead(want_debug, True, int(H), int(W)):
+                # every reference has its own stream: refs_per_launch of them share one fused call (lfd_triangulate_sampled_multi)
+                group.append((local_i, packed, ref, axes, dseed))
+                if len(group) >= int(config.refs_per_launch):
+                    flush_group()
+                continue
+            flush_group()
             if hot.can_launch_ahead(want_debug, per_ref_rng, int(H), int(W)):
                 # reference i is launched (asynchronously, counts read back behind an event) BEFORE reference i-1 is collected:
                 # the host side of one reference - packing, descriptor upload, Python - runs under the kernels of the other
@@ -696,6 +747,7 @@ def run_dense_pipeline(
             dev_parts.append((out.xyz.clone(), out.rgb.clone(), out.err.clone()))
             hx, hc, he = out.host_arrays()
             emit(local_i, packed, hx, hc, he, dbg, dev_parts[-1])
+        flush_group()
         while inflight:
             finish_one()
         flush_dense()

@@ -26,9 +26,9 @@ extern "C" __global__ void lfd_select_topm_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_select_filter_mw_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_mt_seed_kernel(unsigned* mt, unsigned seed);
 extern "C" __global__ void lfd_indexed_eval_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets, float* scratch,
-                                                   uint8_t* codes, unsigned* tab);
+                                                   uint8_t* codes, unsigned* tab, int off_pairs);
 extern "C" __global__ void lfd_indexed_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets,
-                                              float* scratch, uint8_t* codes, int32_t* seg_order, const unsigned* tab);
+                                              float* scratch, uint8_t* codes, int32_t* seg_order, const unsigned* tab, int off_pairs);
 
 namespace {
 
@@ -515,12 +515,12 @@ int lfd_triangulate_indexed(lfd_context* ctx, const lfd_batch* batch, const lfd_
         const unsigned chunks = (unsigned)((max_sel + LFD_INDEXED_EVAL_BLOCK - 1) / LFD_INDEXED_EVAL_BLOCK);
         hipLaunchKernelGGL(lfd_indexed_eval_kernel, dim3(chunks, (unsigned)batch->n_refs), dim3(LFD_INDEXED_EVAL_BLOCK), 0, ctx->stream, L,
                            reinterpret_cast<const long long*>(sel_idx), d_off, static_cast<float*>(ctx->scratch.ptr),
-                           static_cast<uint8_t*>(ctx->codes.ptr), tab);
+                           static_cast<uint8_t*>(ctx->codes.ptr), tab, 0);
         LFD_HIP(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(lfd_indexed_kernel, dim3((unsigned)batch->n_refs), dim3(LFD_INDEXED_BLOCK), 0, ctx->stream, L,
                        reinterpret_cast<const long long*>(sel_idx), d_off, static_cast<float*>(ctx->scratch.ptr),
-                       static_cast<uint8_t*>(ctx->codes.ptr), seg_order, static_cast<const unsigned*>(tab));
+                       static_cast<uint8_t*>(ctx->codes.ptr), seg_order, static_cast<const unsigned*>(tab), 0);
     LFD_HIP(ctx, hipGetLastError());
     return LFD_OK;
 }
@@ -679,13 +679,14 @@ static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int3
     return LFD_OK;
 }
 
-int lfd_triangulate_sampled(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, int32_t M, float cap,
-                            int32_t border, int32_t tiles, float s_override, const lfd_points* out, int64_t* ref_offsets,
-                            int32_t* seg_counts, int32_t* seg_order, int32_t* sel_info, int64_t* sel_cells) {
+static int sampled_impl(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, int32_t M, float cap, int32_t border, int32_t tiles,
+                        float s_override, const uint32_t* seeds, const lfd_points* out, int64_t* ref_offsets, int32_t* seg_counts,
+                        int32_t* seg_order, int32_t* sel_info, int64_t* sel_cells) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
     if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
     if (!batch || !params || !sel_info) return fail(ctx, LFD_ERR_INVALID, "null argument");
-    if (batch->n_refs != 1) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_sampled takes one reference view per call");
+    const int R = batch->n_refs;
+    if (R != 1 && !seeds) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_sampled takes one reference view per call (several need per-reference seeds: lfd_triangulate_sampled_multi)");
     if (M < 0 || tiles <= 0 || border < 0) return fail(ctx, LFD_ERR_INVALID, "bad selection arguments");
     const bool topm = params->no_filter != 0;
     if (topm && M > LFD_SELECT_TOPM_MAX) return fail(ctx, LFD_ERR_INVALID, "no_filter selection is limited to 16384 matches per reference");
@@ -696,37 +697,51 @@ int lfd_triangulate_sampled(lfd_context* ctx, const lfd_batch* batch, const lfd_
     if (rc != LFD_OK) return rc;
     const long long HW = (long long)batch->H * batch->W;
     const long long cap_sel = topm ? std::max<long long>(std::min<long long>(M, HW), 1) : (long long)M + (long long)tiles * tiles + 64;
-    if (out->capacity < cap_sel) return fail(ctx, LFD_ERR_CAPACITY, "output capacity below M + tiles*tiles + 64");
-    // P1 + F1
-    rc = ensure(ctx, ctx->agg, (size_t)HW * sizeof(float));
+    if (out->capacity < cap_sel * R) return fail(ctx, LFD_ERR_CAPACITY, "output capacity below (M + tiles*tiles + 64) per reference");
+    // P1 + F1 for every reference of the batch in one launch
+    rc = ensure(ctx, ctx->agg, (size_t)HW * (size_t)R * sizeof(float));
     if (rc != LFD_OK) return rc;
     float* best = static_cast<float*>(ctx->agg.ptr);
     {
         const int per_block = 256 * 4;
         const int gx = (int)std::min<long long>((HW + per_block - 1) / per_block, 2048);
-        hipLaunchKernelGGL(lfd_aggregate_kernel, dim3((unsigned)gx, 1u, 1u), dim3(256), 0, ctx->stream, L, best, static_cast<uint8_t*>(nullptr));
+        hipLaunchKernelGGL(lfd_aggregate_kernel, dim3((unsigned)gx, (unsigned)R, 1u), dim3(256), 0, ctx->stream, L, best, static_cast<uint8_t*>(nullptr));
         LFD_HIP(ctx, hipGetLastError());
     }
-    // S: the count stays on the device ({0, n} in sel_offsets) for the kernels below
-    rc = ensure(ctx, ctx->sel_buf, 16 + (size_t)cap_sel * sizeof(long long));
+    // S, reference after reference (the selection kernels share one scratch area): the counts stay on the device as {begin, end}
+    // pairs for the kernels below; every reference's cells sit at a fixed stride
+    rc = ensure(ctx, ctx->sel_buf, (size_t)R * 16 + (size_t)cap_sel * (size_t)R * sizeof(long long));
     if (rc != LFD_OK) return rc;
-    long long* sel_offsets = static_cast<long long*>(ctx->sel_buf.ptr);
-    long long* cells = sel_cells ? reinterpret_cast<long long*>(sel_cells) : sel_offsets + 2;
-    LFD_HIP(ctx, hipMemsetAsync(sel_offsets, 0, 16, ctx->stream));
-    int* d_info = nullptr;
-    unsigned char* d_time = nullptr;
-    rc = select_launch(ctx, topm, best, batch->H, batch->W, M, cap, topm ? 0 : border, topm ? 1 : tiles, topm ? 0.0f : s_override,
-                       reinterpret_cast<int64_t*>(cells), cap_sel, sel_offsets, &d_info, &d_time);
+    long long* sel_pairs = static_cast<long long*>(ctx->sel_buf.ptr);
+    long long* cells = sel_cells ? reinterpret_cast<long long*>(sel_cells) : sel_pairs + 2 * (size_t)R;
+    if (R == 1) {
+        LFD_HIP(ctx, hipMemsetAsync(sel_pairs, 0, 16, ctx->stream));
+    } else {
+        std::vector<long long> begins(2 * (size_t)R);
+        for (int r = 0; r < R; ++r) begins[2 * (size_t)r] = begins[2 * (size_t)r + 1] = (long long)r * cap_sel;
+        LFD_HIP(ctx, hipMemcpyAsync(sel_pairs, begins.data(), begins.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+        LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));       // the host vector goes out of scope
+    }
+    for (int r = 0; r < R; ++r) {
+        if (seeds && !topm) {
+            rc = lfd_rng_seed(ctx, seeds[r]);
+            if (rc != LFD_OK) return rc;
+        }
+        int* d_info = nullptr;
+        unsigned char* d_time = nullptr;
+        rc = select_launch(ctx, topm, best + (size_t)r * HW, batch->H, batch->W, M, cap, topm ? 0 : border, topm ? 1 : tiles, topm ? 0.0f : s_override,
+                           reinterpret_cast<int64_t*>(cells + (size_t)r * cap_sel), cap_sel, sel_pairs + 2 * (size_t)r, &d_info, &d_time);
+        if (rc != LFD_OK) return rc;
+        LFD_HIP(ctx, hipMemcpyAsync(sel_info + 2 * (size_t)r, d_info, 2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    // F2..F10 on the selected cells of all references
+    rc = prepare_lookback(ctx, (size_t)R, (size_t)R, false, L);
     if (rc != LFD_OK) return rc;
-    LFD_HIP(ctx, hipMemcpyAsync(sel_info, d_info, 2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-    // F2..F10 on the selected cells
-    rc = prepare_lookback(ctx, 1, 1, false, L);
+    rc = ensure(ctx, ctx->scratch, (size_t)cap_sel * (size_t)R * 8 * sizeof(float));
     if (rc != LFD_OK) return rc;
-    rc = ensure(ctx, ctx->scratch, (size_t)cap_sel * 8 * sizeof(float));
+    rc = ensure(ctx, ctx->codes, (size_t)cap_sel * (size_t)R);
     if (rc != LFD_OK) return rc;
-    rc = ensure(ctx, ctx->codes, (size_t)cap_sel);
-    if (rc != LFD_OK) return rc;
-    const size_t tab_bytes = (size_t)LFD_MAX_SLOTS * 2 * sizeof(unsigned);
+    const size_t tab_bytes = (size_t)R * LFD_MAX_SLOTS * 2 * sizeof(unsigned);
     rc = ensure(ctx, ctx->idx_tab, tab_bytes);
     if (rc != LFD_OK) return rc;
     unsigned* tab = static_cast<unsigned*>(ctx->idx_tab.ptr);
@@ -736,17 +751,31 @@ int lfd_triangulate_sampled(lfd_context* ctx, const lfd_batch* batch, const lfd_
     L.ref_offsets = reinterpret_cast<long long*>(ref_offsets);
     L.seg_counts = seg_counts;
     const unsigned chunks = (unsigned)((cap_sel + LFD_INDEXED_EVAL_BLOCK - 1) / LFD_INDEXED_EVAL_BLOCK);
-    hipLaunchKernelGGL(lfd_indexed_eval_kernel, dim3(chunks, 1u), dim3(LFD_INDEXED_EVAL_BLOCK), 0, ctx->stream, L,
-                       static_cast<const long long*>(cells), static_cast<const long long*>(sel_offsets), static_cast<float*>(ctx->scratch.ptr),
-                       static_cast<uint8_t*>(ctx->codes.ptr), tab);
+    hipLaunchKernelGGL(lfd_indexed_eval_kernel, dim3(chunks, (unsigned)R), dim3(LFD_INDEXED_EVAL_BLOCK), 0, ctx->stream, L,
+                       static_cast<const long long*>(cells), static_cast<const long long*>(sel_pairs), static_cast<float*>(ctx->scratch.ptr),
+                       static_cast<uint8_t*>(ctx->codes.ptr), tab, 1);
     LFD_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(lfd_indexed_kernel, dim3(1u), dim3(LFD_INDEXED_BLOCK), 0, ctx->stream, L,
-                       static_cast<const long long*>(cells), static_cast<const long long*>(sel_offsets), static_cast<float*>(ctx->scratch.ptr),
-                       static_cast<uint8_t*>(ctx->codes.ptr), seg_order, static_cast<const unsigned*>(tab));
+    hipLaunchKernelGGL(lfd_indexed_kernel, dim3((unsigned)R), dim3(LFD_INDEXED_BLOCK), 0, ctx->stream, L,
+                       static_cast<const long long*>(cells), static_cast<const long long*>(sel_pairs), static_cast<float*>(ctx->scratch.ptr),
+                       static_cast<uint8_t*>(ctx->codes.ptr), seg_order, static_cast<const unsigned*>(tab), 1);
     LFD_HIP(ctx, hipGetLastError());
     // the look-back status word of this launch rides along with the counts: one read-back tells the caller everything
-    LFD_HIP(ctx, hipMemcpyAsync(sel_info + 2, static_cast<unsigned char*>(ctx->ws.ptr) + 8, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    LFD_HIP(ctx, hipMemcpyAsync(sel_info + 2 * (size_t)R, static_cast<unsigned char*>(ctx->ws.ptr) + 8, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
     return LFD_OK;
+}
+
+int lfd_triangulate_sampled(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, int32_t M, float cap,
+                            int32_t border, int32_t tiles, float s_override, const lfd_points* out, int64_t* ref_offsets,
+                            int32_t* seg_counts, int32_t* seg_order, int32_t* sel_info, int64_t* sel_cells) {
+    if (ctx && batch && batch->n_refs != 1) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_sampled takes one reference view per call");
+    return sampled_impl(ctx, batch, params, M, cap, border, tiles, s_override, nullptr, out, ref_offsets, seg_counts, seg_order, sel_info, sel_cells);
+}
+
+int lfd_triangulate_sampled_multi(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, int32_t M, float cap,
+                                  int32_t border, int32_t tiles, const uint32_t* seeds, const lfd_points* out, int64_t* ref_offsets,
+                                  int32_t* seg_counts, int32_t* seg_order, int32_t* sel_info, int64_t* sel_cells) {
+    if (ctx && !seeds) return fail(ctx, LFD_ERR_INVALID, "seeds is required: every reference draws from its own MT19937 stream");
+    return sampled_impl(ctx, batch, params, M, cap, border, tiles, 0.0f, seeds, out, ref_offsets, seg_counts, seg_order, sel_info, sel_cells);
 }
 
 int lfd_select_samples(lfd_context* ctx, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,

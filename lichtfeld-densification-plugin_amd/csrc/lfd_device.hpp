@@ -144,5 +144,5 @@ struct LfdSelectArgs {
     unsigned long long* timing;   // profiling: wall_clock64() at the phase boundaries of the filter kernel, or null
     unsigned char* coop;          // multi-workgroup kernel: shared scratch (LFD_SELECT_COOP_BYTES, header zeroed before the launch)
     int n_wg;                     // multi-workgroup kernel: compute workgroups (the grid has one more, which runs the MT19937 stream)
-    long long* sel_offsets_out;   // optional device i64 [2]: {0, n_out} for the indexed kernels that follow in the same stream (zeroed by the host)
+    long long* sel_offsets_out;   // optional device i64 [2]: {begin, begin + n_out} for the indexed kernels that follow in the same stream ([0] = [1] = begin set by the host)
 };

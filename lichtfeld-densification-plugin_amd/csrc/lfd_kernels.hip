@@ -824,16 +824,18 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
 // ([ref][slot]{count, 0xffffffff - first}, zeroed before the launch) for lfd_indexed_kernel, which then only orders and
 // scatters.
 // =================================================================================================
+// sel_offsets: [n_refs + 1] (reference r owns [off[r], off[r+1])) or, with off_pairs, [2 * n_refs] = {begin, end} per reference
+// (the fused multi-reference call: every reference's selection sits at a fixed stride, its length known only on the device)
 extern "C" __global__ void __launch_bounds__(LFD_INDEXED_EVAL_BLOCK) lfd_indexed_eval_kernel(LfdLaunch L, const long long* __restrict__ sel_idx,
                                                                                              const long long* __restrict__ sel_offsets,
                                                                                              float* __restrict__ scratch, uint8_t* __restrict__ codes,
-                                                                                             unsigned* __restrict__ tab) {
+                                                                                             unsigned* __restrict__ tab, int off_pairs) {
     __shared__ BlockShared S;
     __shared__ unsigned s_cnt[LFD_MAX_SLOTS];
     __shared__ unsigned s_first[LFD_MAX_SLOTS];
     const int tid = (int)threadIdx.x;
     const int r = (int)blockIdx.y;
-    const long long sel_begin = sel_offsets[r], sel_end = sel_offsets[r + 1];
+    const long long sel_begin = off_pairs ? sel_offsets[2 * r] : sel_offsets[r], sel_end = off_pairs ? sel_offsets[2 * r + 1] : sel_offsets[r + 1];
     const int n_sel = (int)(sel_end - sel_begin);
     const int i = (int)blockIdx.x * LFD_INDEXED_EVAL_BLOCK + tid;
     if ((int)blockIdx.x * LFD_INDEXED_EVAL_BLOCK >= n_sel) return;
@@ -881,7 +883,7 @@ extern "C" __global__ void __launch_bounds__(LFD_INDEXED_EVAL_BLOCK) lfd_indexed
 extern "C" __global__ void __launch_bounds__(LFD_INDEXED_BLOCK) lfd_indexed_kernel(LfdLaunch L, const long long* __restrict__ sel_idx,
                                                                                    const long long* __restrict__ sel_offsets,
                                                                                    float* __restrict__ scratch, uint8_t* __restrict__ codes,
-                                                                                   int32_t* __restrict__ seg_order, const unsigned* __restrict__ tab) {
+                                                                                   int32_t* __restrict__ seg_order, const unsigned* __restrict__ tab, int off_pairs) {
     __shared__ BlockShared S;
     __shared__ unsigned s_ticket;
     __shared__ unsigned s_cnt[LFD_MAX_SLOTS];          // survivors per slot
@@ -900,7 +902,7 @@ extern "C" __global__ void __launch_bounds__(LFD_INDEXED_BLOCK) lfd_indexed_kern
     const int r = (int)s_ticket;
     block_prologue(L, r, S);
     const int ns = S.ref.n_slots;
-    const long long sel_begin = sel_offsets[r], sel_end = sel_offsets[r + 1];
+    const long long sel_begin = off_pairs ? sel_offsets[2 * r] : sel_offsets[r], sel_end = off_pairs ? sel_offsets[2 * r + 1] : sel_offsets[r + 1];
     const int n_sel = (int)(sel_end - sel_begin);
     const int HW = L.H * L.W;
 

@@ -509,7 +509,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         } else {
             for (int i = lo; i < hi; ++i) if (mark[i]) A.sel_out[pos++] = (long long)i;
         }
-        if (tid == 0) { *A.n_out = total; if (A.sel_offsets_out) A.sel_offsets_out[1] = total; }
+        if (tid == 0) { *A.n_out = total; if (A.sel_offsets_out) A.sel_offsets_out[1] = A.sel_offsets_out[0] + total; }
     }
     LFD_SEL_STAMP();      // unique
 #undef LFD_SEL_STAMP
@@ -924,7 +924,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         if ((long long)all > A.capacity) { if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_CAPACITY; *A.n_out = all; } return; }
         pos += base;
         if (cnt) for (int i = lo; i < hi; ++i) if (mark[i]) A.sel_out[pos++] = (long long)i;
-        if (wg == 0 && tid == 0) { *A.n_out = all; if (A.sel_offsets_out) A.sel_offsets_out[1] = all; }
+        if (wg == 0 && tid == 0) { *A.n_out = all; if (A.sel_offsets_out) A.sel_offsets_out[1] = A.sel_offsets_out[0] + all; }
     }
     LFD_MW_STAMP();
 #undef LFD_MW_STAMP
@@ -1092,7 +1092,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_topm_k
         }
     }
     for (int i = tid; i < M; i += kSelBlock) A.sel_out[i] = (long long)(0xffffffffu - (unsigned)(s_keys[i] & 0xffffffffull));
-    if (tid == 0) { *A.n_out = M; if (A.sel_offsets_out) A.sel_offsets_out[1] = M; }
+    if (tid == 0) { *A.n_out = M; if (A.sel_offsets_out) A.sel_offsets_out[1] = A.sel_offsets_out[0] + M; }
 }
 
 // seed exactly like np.random.seed(uint32): init_genrand

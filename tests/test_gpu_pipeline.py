@@ -333,3 +333,20 @@ def test_device_image_prep_gives_the_host_prepared_run(g4, tmp_path, device_matc
     np.testing.assert_array_equal(devr.points_per_reference, host.points_per_reference)
     if device_matcher:
         assert seen and all(a and b for a, b in seen)
+
+
+def test_grouped_sampled_launches_equal_single_launches(g4, tmp_path):
+    """per_reference_rng + refs_per_launch = 3: three references share one fused call (lfd_triangulate_sampled_multi: one aggregate
+    launch, three selections each on its own MT19937 stream, one pair of indexed launches); same points, order and counts as one
+    call per reference."""
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+    kw = dict(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=2, seed=5, viz_interval=0, matches_per_ref=1200,
+              per_reference_rng=True)
+    single = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(refs_per_launch=1, **kw), matcher=FakeMatcher(64, 64, table))
+    for n in (2, 3):
+        grouped = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(refs_per_launch=n, **kw), matcher=FakeMatcher(64, 64, table))
+        np.testing.assert_array_equal(grouped.xyz, single.xyz)
+        np.testing.assert_array_equal(grouped.rgb, single.rgb)
+        np.testing.assert_array_equal(grouped.err, single.err)
+        np.testing.assert_array_equal(grouped.points_per_reference, single.points_per_reference)
+    assert single.xyz.shape[0] > 1000

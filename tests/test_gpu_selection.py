@@ -261,3 +261,41 @@ def test_tiny_weights_fall_back_to_the_host_stage_on_the_same_stream(dens):
     key1, pos1 = d2.rng_state()
     assert pos1 == rs0.get_state()[2] and np.array_equal(key1, rs0.get_state()[1])        # stream handed back advanced
     d2.close()
+
+
+def test_sampled_mode_cli_defaults_full_size(dens):
+    """BASELINE config 2 as the CLI runs it (densify.py:318-415): fast 512^2, k=4, M=12000, reproj 1.5, upstream's own mode.  The
+    fused device call selects exactly the cells the oracle selects when given the device's normaliser, and emits the oracle's
+    survivors of those cells, group by group, in upstream's order."""
+    import lichtfeld_densification_plugin_amd as lfd
+    from lichtfeld_densification_plugin_amd import synthetic
+    from helpers import oracle_cam
+    dev = dens.device
+    H = W = 512
+    cams = synthetic.ring_cameras(185, seed=0)
+    dens.upload_cameras(cams)
+    ref, k, M = 42, 4, 12000
+    nbrs = synthetic.ring_neighbours(185, ref, k)
+    # tie-free certainties: with ties (floor / cap clamps) upstream's coverage pass depends on NumPy's unspecified argsort order
+    s = synthetic.synth_reference(cams, ref, nbrs, H, W, W, H, noise_px=1.0, outlier_frac=0.05, channels=2, seed=77, cert_mode="tiefree")
+    r = hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=[s.cert[j].to(dev) for j in range(k)], warp=[s.warp[j].contiguous().to(dev) for j in range(k)],
+                           image=s.image.to(dev))
+    cfg = lfd.DensePipelineConfig(output_path="", matches_per_ref=M, reproj_thresh=1.5, nns_per_ref=k)
+    batch = hb.PreparedBatch([r], W, H, cameras=cams)
+    dens.seed_rng(0)
+    out = dens.triangulate_sampled(batch, hb.make_params(cfg), M, cap=0.9, border=2, tiles=24)
+    params = orc.OracleParams(reproj_thresh=1.5, matches_per_ref=M)
+    axes = (orc.identity_axis_scalar(W), orc.identity_axis_scalar(H))
+    certs, warps = [s.cert[j].numpy() for j in range(k)], [s.warp[j].numpy() for j in range(k)]
+    with np.errstate(all="ignore"):
+        best, bk, agg = orc.prepare_reference(certs, warps, params)
+        sel = orc.select_samples(best, M, rng=np.random.RandomState(0), s_override=float(_exact_s(best)))
+        res = orc.triangulate_selected(sel, best, bk, agg, s.image.numpy(), oracle_cam(cams[ref]), [oracle_cam(cams[n]) for n in nbrs], W, H, params, axes=axes)
+    assert out.n_selected == sel.size and 0.85 * M < sel.size <= M + 24 * 24
+    assert abs(out.count - res.count) <= 3                 # a cell within upstream's rounding noise of a threshold may differ (test_gpu_guardband)
+    common, ih, io_ = np.intersect1d(out.cell.cpu().numpy(), res.cell, return_indices=True)
+    assert common.size >= res.count - 3
+    np.testing.assert_allclose(out.xyz.cpu().numpy()[ih], res.xyz[io_], rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(out.rgb.cpu().numpy()[ih], res.rgb[io_])
+    if out.count == res.count and common.size == res.count:
+        np.testing.assert_array_equal(out.cell.cpu().numpy(), res.cell)          # upstream's group order
