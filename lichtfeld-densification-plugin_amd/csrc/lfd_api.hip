@@ -96,13 +96,11 @@ int validate_batch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p) {
 
 // Build refs|slots|extra into one blob, upload only when it differs from what the device holds.
 int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, size_t n_extra,
-                  const LfdRefDesc** d_refs, const LfdSlotDesc** d_slots, const long long** d_extra, const float** d_fund,
-                  const float* const** d_cert_ptrs) {
+                  const LfdRefDesc** d_refs, const LfdSlotDesc** d_slots, const long long** d_extra, const float** d_fund) {
     const size_t nr = (size_t)b->n_refs, ns = nr * (size_t)b->k;
     const size_t off_slots = (nr * sizeof(LfdRefDesc) + 15) & ~size_t(15);
     const size_t off_extra = (off_slots + ns * sizeof(LfdSlotDesc) + 15) & ~size_t(15);
-    const size_t off_cptr = (off_extra + n_extra * sizeof(long long) + 31) & ~size_t(31);
-    const size_t off_fund = (off_cptr + (ns + 4) * sizeof(const float*) + 15) & ~size_t(15);
+    const size_t off_fund = (off_extra + n_extra * sizeof(long long) + 15) & ~size_t(15);
     const size_t total = off_fund + (b->fundamental ? ns * 9 * sizeof(float) : 0);
     std::vector<unsigned char> blob(total, 0);
     LfdRefDesc* refs = reinterpret_cast<LfdRefDesc*>(blob.data());
@@ -123,7 +121,6 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
             s.cam = valid ? b->nbr_cam[r * b->k + j] : 0;
             s.pad = 0;
             if (s.mask_b) refs[r].any_mask = 1;
-            reinterpret_cast<const float**>(blob.data() + off_cptr)[r * b->k + j] = s.cert;
         }
     }
     if (n_extra) std::memcpy(blob.data() + off_extra, extra, n_extra * sizeof(long long));
@@ -150,7 +147,6 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
     *d_slots = reinterpret_cast<const LfdSlotDesc*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_slots);
     if (d_extra) *d_extra = reinterpret_cast<const long long*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_extra);
     *d_fund = b->fundamental ? reinterpret_cast<const float*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_fund) : nullptr;
-    *d_cert_ptrs = reinterpret_cast<const float* const*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_cptr);
     return LFD_OK;
 }
 
@@ -193,7 +189,7 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
     if (rc != LFD_OK) return rc;
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     std::memset(&L, 0, sizeof(L));
-    rc = upload_tables(ctx, b, extra, n_extra, &L.refs, &L.slots, d_extra, &L.fund_override, &L.cert_ptrs);
+    rc = upload_tables(ctx, b, extra, n_extra, &L.refs, &L.slots, d_extra, &L.fund_override);
     if (rc != LFD_OK) return rc;
     L.cams = static_cast<const LfdCam*>(ctx->cams.ptr);
     if (b->axis_x) { L.axis_x = b->axis_x; L.axis_y = b->axis_y; }

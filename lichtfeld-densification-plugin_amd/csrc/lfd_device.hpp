@@ -22,6 +22,12 @@
 #ifndef LFD_DENSE_WAVES_PER_SIMD
 #define LFD_DENSE_WAVES_PER_SIMD 7       // register budget of the fused kernel: 512/7 -> <=72 VGPRs (it needs 69-72)
 #endif
+#ifndef LFD_DENSE_ALL_WARPS
+#define LFD_DENSE_ALL_WARPS 0   // 1: dense kernel, k <= 4: the warps of ALL slots ride along with the certainty planes (one memory round trip less, 8 (k-1) B
+                                // per cell more traffic).  Measured (profiles/r2/ablation.txt): the winner's-warp phase falls from 7.5 to 2.3 us per tile but
+                                // the kernel only from 0.317 to 0.310 ms at k = 3 and gets SLOWER at k = 4 (0.356 -> 0.372): with that latency gone the
+                                // vector ALU is the limit.  Off: not worth 1.4 x the HBM traffic.
+#endif
 #ifndef LFD_FRONT_PRIO
 #define LFD_FRONT_PRIO 1        // s_setprio of a dense-kernel wave until its geometry loop starts (0 = off): the handful of instructions between the
                                 // front end's memory requests then go ahead of older waves' f64 streams instead of waiting for a free slot
@@ -64,7 +70,6 @@ struct LfdLaunch {              // kernel argument, passed by value
     const LfdPairConst* pair_const;  // [n_refs*k]
     const float* axis_x;        // [W]
     const float* axis_y;        // [H]
-    const float* const* cert_ptrs;   // [n_refs*k + 4] the slots' certainty planes again, contiguous (four pointers = one scalar load)
     const float* fund_override; // [n_refs*k*9] f32 fundamental matrices handed over by the caller (lfd_batch.fundamental), or null
     int32_t n_refs, k, H, W, w_match, h_match, warp_channels, tiles_per_ref;
     float mask_sx, mask_sy;     // (float)w_match/(float)W, (float)h_match/(float)H  (nearest resize)

@@ -531,6 +531,43 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
 
         // ---- stage 1: certainty floor + arg-max over the neighbour slots (coalesced 16-B loads) -----
         int bj[kCpt];
+#if LFD_DENSE_ALL_WARPS
+        // Up to four neighbours, two-channel warps, no masks: the warps of ALL slots are requested together with the certainty
+        // planes (dense 16-byte loads) and the winner's is picked in registers, instead of a second, dependent round trip for the
+        // winner's warp alone (8-byte loads at a 32-byte stride).  Costs 8 (k - 1) more bytes per cell of HBM traffic - the
+        // kernel is bound by its chain of memory round trips, not by bandwidth (profiles/r2/phases_*.txt).
+        float spec_xb[4] = {0.0f, 0.0f, 0.0f, 0.0f}, spec_yb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        bool have_warps = false;
+        if (!any_mask && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW && ns <= 4 && L.warp_channels == 2) {
+            const float th = L.kp.certainty_thresh;
+            float4 c[4], wa[4], wb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < ns) {
+                    c[j] = load_f32x4(S.slot[j].cert + cell0);
+                    wa[j] = load_f32x4(S.slot[j].warp + (size_t)(unsigned)cell0 * 2);           // cells 0, 1: xB yB xB yB
+                    wb[j] = load_f32x4(S.slot[j].warp + (size_t)(unsigned)cell0 * 2 + 4);       // cells 2, 3
+                }
+            }
+            float4 best = c[0];
+            best.x = lfd_cert_floor(best.x, th); best.y = lfd_cert_floor(best.y, th);
+            best.z = lfd_cert_floor(best.z, th); best.w = lfd_cert_floor(best.w, th);
+            bj[0] = bj[1] = bj[2] = bj[3] = 0;
+            spec_xb[0] = wa[0].x; spec_yb[0] = wa[0].y; spec_xb[1] = wa[0].z; spec_yb[1] = wa[0].w;
+            spec_xb[2] = wb[0].x; spec_yb[2] = wb[0].y; spec_xb[3] = wb[0].z; spec_yb[3] = wb[0].w;
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+                if (j < ns) {
+                    int t;
+                    t = bj[0]; argmax_step(lfd_cert_floor(c[j].x, th), j, best.x, bj[0]); if (bj[0] != t) { spec_xb[0] = wa[j].x; spec_yb[0] = wa[j].y; }
+                    t = bj[1]; argmax_step(lfd_cert_floor(c[j].y, th), j, best.y, bj[1]); if (bj[1] != t) { spec_xb[1] = wa[j].z; spec_yb[1] = wa[j].w; }
+                    t = bj[2]; argmax_step(lfd_cert_floor(c[j].z, th), j, best.z, bj[2]); if (bj[2] != t) { spec_xb[2] = wb[j].x; spec_yb[2] = wb[j].y; }
+                    t = bj[3]; argmax_step(lfd_cert_floor(c[j].w, th), j, best.w, bj[3]); if (bj[3] != t) { spec_xb[3] = wb[j].z; spec_yb[3] = wb[j].w; }
+                }
+            }
+            have_warps = true;
+        } else
+#endif
         if (!any_mask && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW) {
             const float th = L.kp.certainty_thresh;
             float4 best;
@@ -598,6 +635,10 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
                 if (L.warp_channels == 4) {
                     const float4 v = load_f32x4(wp + (size_t)(unsigned)(cell0 + e) * 4);
                     xan = v.x; yan = v.y; xbn = v.z; ybn = v.w;
+#if LFD_DENSE_ALL_WARPS
+                } else if (have_warps) {
+                    xan = xa[e]; yan = ya; xbn = spec_xb[e]; ybn = spec_yb[e];
+#endif
                 } else {
                     const float2 v = load_f32x2(wp + (size_t)(unsigned)(cell0 + e) * 2);
                     xan = xa[e]; yan = ya; xbn = v.x; ybn = v.y;

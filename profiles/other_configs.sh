@@ -2,7 +2,7 @@
 # dense kernel on the other BASELINE.json configurations (synthetic stand-ins, same generator as bench.py)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 run() {
-  python $REPO/bench.py --cpu-sample-refs 0 --steps 30 "$@" 2>&1 | python -c "
+  python $REPO/bench.py --light --steps 30 "$@" 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

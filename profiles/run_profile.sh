@@ -8,9 +8,9 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --cpu-sample-refs 0 $*"
+ARGS="--steps 10 --warmup 2 --light $*"
 # the kernel-trace pass times what bench.py times: many back-to-back launches, short spin-up
-TRACE_ARGS="--steps 400 --warmup 5 --spinup-s 0.02 --cpu-sample-refs 0 $*"
+TRACE_ARGS="--steps 400 --warmup 5 --spinup-s 0.02 --light $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $REPO/bench.py $TRACE_ARGS > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -o sq -- python3 $REPO/bench.py $ARGS > $OUT/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $REPO/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
