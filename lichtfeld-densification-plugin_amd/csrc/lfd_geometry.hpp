@@ -39,8 +39,11 @@ struct LfdCam {       // one row of the uploaded camera table (CameraRecord, f32
     int32_t pad[2];   // 40 words = 160 B
 };
 
+// Projection matrices in the two constant blocks are stored with rows 0 and 1 interleaved: Pi[2c] = P[0][c], Pi[2c+1] = P[1][c],
+// Pi[8+c] = P[2][c].  Everything the path computes with P comes in (row 0, row 1) pairs that share row 2's entry - the two DLT
+// rows of a view, the x and y of a reprojection - so a pair is one 8-byte operand of a packed f32 instruction.
 struct LfdRefConst {  // per reference view, staged in LDS
-    float P[12];
+    float P[12];      // interleaved (see above)
     float C[3];
     float sx, sy;     // camera px per match px: (float)(w_cam / (double)w_match)
     float pad;
@@ -48,7 +51,7 @@ struct LfdRefConst {  // per reference view, staged in LDS
 
 struct LfdPairConst { // per (reference, neighbour slot), staged in LDS
     double F[9];      // fundamental matrix: f32 values, widened for the f64 Sampson expression
-    float P[12];
+    float P[12];      // interleaved (see above)
     float C[3];
     float sx, sy;
     int32_t cam;
@@ -150,8 +153,12 @@ LFD_HD void lfd_fundamental(const float* K1, const float* R1, const float* t1, c
             F[i * 3 + j] = lfd_dot3_chain(T[i * 3 + 0], K1i[0 + j], T[i * 3 + 1], K1i[3 + j], T[i * 3 + 2], K1i[6 + j]);
 }
 
+LFD_HD void lfd_interleave_p(const float* P, float* Pi) {
+    for (int c = 0; c < 4; ++c) { Pi[2 * c] = P[c]; Pi[2 * c + 1] = P[4 + c]; Pi[8 + c] = P[8 + c]; }
+}
+
 LFD_HD void lfd_make_ref_const(const LfdCam& c, int w_match, int h_match, LfdRefConst& o) {
-    for (int i = 0; i < 12; ++i) o.P[i] = c.P[i];
+    lfd_interleave_p(c.P, o.P);
     for (int i = 0; i < 3; ++i) o.C[i] = c.C[i];
     o.sx = (float)((double)c.w / (double)w_match);
     o.sy = (float)((double)c.h / (double)h_match);
@@ -163,7 +170,7 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
     float F[9];
     lfd_fundamental(a.K, a.R, a.t, b.K, b.R, b.t, F);
     for (int i = 0; i < 9; ++i) o.F[i] = (double)F[i];
-    for (int i = 0; i < 12; ++i) o.P[i] = b.P[i];
+    lfd_interleave_p(b.P, o.P);
     for (int i = 0; i < 3; ++i) o.C[i] = b.C[i];
     o.sx = (float)((double)b.w / (double)w_match);
     o.sy = (float)((double)b.h / (double)h_match);
@@ -185,6 +192,9 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
 //     perturb L by its error times sigma1^2, far above sigma4^2.
 // Two solves are always made; more follow only while the growth factor has not settled (bad
 // conditioning: sigma4/sigma3 not small).
+#ifndef LFD_PACK_ROWS
+#define LFD_PACK_ROWS 0     /* bit 0: the reference view's DLT rows as packed f32 operations, bit 1: the neighbour's.  Measured: the packed forms need 2-6 registers more than the geometry loop has (scratch in the loop: 0.333-0.384 ms against 0.315), profiles/r2/ablation.txt */
+#endif
 #ifndef LFD_NULLVEC_TOL
 /* direction change (relative, on x_i/x_3) of the last solve that counts as settled.  The change measures the error of the
  * PREVIOUS iterate; the one returned is q = (sigma4/sigma3)^2 times closer: within 1e-8 of v4 for sigma4/sigma3 <= 0.1.
@@ -360,10 +370,10 @@ LFD_HD float lfd_div_by_recip_f32(float a, float b, float r) {
     return fmaf(fmaf(-b, q, a), r, q);
 }
 
-LFD_HD float lfd_proj_row(const float* P, int row, float X0, float X1, float X2, float X3) {
-    // (X @ P.T)[row] as sgemm accumulates it: forward FMA chain over the 4 terms
-    const float* p = P + row * 4;
-    return fmaf(X3, p[3], fmaf(X2, p[2], fmaf(X1, p[1], X0 * p[0])));
+LFD_HD float lfd_proj_row(const float* Pi, int row, float X0, float X1, float X2, float X3) {
+    // (X @ P.T)[row] as sgemm accumulates it: forward FMA chain over the 4 terms (Pi: the interleaved layout of the constant blocks)
+    if (row == 2) return fmaf(X3, Pi[11], fmaf(X2, Pi[10], fmaf(X1, Pi[9], X0 * Pi[8])));
+    return fmaf(X3, Pi[6 + row], fmaf(X2, Pi[4 + row], fmaf(X1, Pi[2 + row], X0 * Pi[row])));
 }
 
 // 1-ulp reciprocal / square root of the vector ALU on the device (v_rcp_f32, v_sqrt_f32: one instruction each
@@ -433,11 +443,29 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
         LFD_HD void operator()(float* A) const {
             float u1 = ua, v1 = va, u2 = ub, v2 = vb;
             LFD_OPAQUE4(u1, v1, u2, v2);
+            // the two rows of a view together (one packed multiply and one packed subtract per column on the device; element
+            // by element the same f32 multiply-then-subtract as upstream)
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const v2f uv1 = {u1, v1}, uv2 = {u2, v2};
             for (int c = 0; c < 4; ++c) {
-                A[0 + c] = u1 * rc.P[8 + c] - rc.P[0 + c];
-                A[4 + c] = v1 * rc.P[8 + c] - rc.P[4 + c];
-                A[8 + c] = u2 * pc.P[8 + c] - pc.P[0 + c];
-                A[12 + c] = v2 * pc.P[8 + c] - pc.P[4 + c];
+#if LFD_PACK_ROWS & 1
+                const v2f p1 = {rc.P[2 * c], rc.P[2 * c + 1]};
+                const v2f m1 = uv1 * rc.P[8 + c];
+                const v2f r1 = m1 - p1;
+                A[0 + c] = r1.x; A[4 + c] = r1.y;
+#else
+                A[0 + c] = u1 * rc.P[8 + c] - rc.P[2 * c];
+                A[4 + c] = v1 * rc.P[8 + c] - rc.P[2 * c + 1];
+#endif
+#if LFD_PACK_ROWS & 2
+                const v2f p2 = {pc.P[2 * c], pc.P[2 * c + 1]};
+                const v2f m2 = uv2 * pc.P[8 + c];
+                const v2f r2 = m2 - p2;
+                A[8 + c] = r2.x; A[12 + c] = r2.y;
+#else
+                A[8 + c] = u2 * pc.P[8 + c] - pc.P[2 * c];
+                A[12 + c] = v2 * pc.P[8 + c] - pc.P[2 * c + 1];
+#endif
             }
         }
     };
