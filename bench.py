@@ -153,6 +153,26 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16):
         dt2 = time.perf_counter() - t0
     assert pts2 == pts, (pts2, pts)
     res["pipelined_ms_per_reference"] = dt2 / len(todo) * 1e3
+    # several references per fused call (lfd_triangulate_sampled_multi), every reference on its own MT19937 stream - what sharded
+    # runs use (core/pipeline.py, per_reference_rng): one aggregate launch, the selections of the group side by side in one
+    # launch (a selection occupies 17 of the 256 CUs), one pair of indexed launches, one read-back
+    G = len(todo)
+    outg = hb.OutputBuffers(cap * G, G, args.k, dens.device)
+    bg = hb.PreparedBatch(todo, wm, hm)
+    seeds = [(cfg.seed * 2654435761 + i) & 0xFFFFFFFF for i in range(G)]
+    reps = 4
+    for warm in (True, False):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ptsg = 0
+        for _ in range(reps):
+            dens.launch_sampled_multi(bg, params, cfg.matches_per_ref, outg, seeds, cap=0.9, border=2, tiles=24)
+            ptsg += outg.collect(indexed=True, check_selection=True).count
+        torch.cuda.synchronize()
+        dtg = time.perf_counter() - t0
+    res["grouped"] = {"references_per_call": G, "ms_per_reference": dtg / (reps * G) * 1e3, "refs_per_s": reps * G / dtg,
+                      "pairs_per_s": reps * G * args.k / dtg, "points_per_s": ptsg / dtg,
+                      "note": "per-reference MT19937 streams (sharded runs): the group's selections run side by side"}
     return res
 
 

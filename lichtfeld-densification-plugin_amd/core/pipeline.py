@@ -561,10 +561,11 @@ def run_dense_pipeline(
 
         def emit(local_i: int, packed: _PackedReference, xyz, rgb, err, dbg, dev_pts=None) -> None:
             nonlocal refs_with_points
+            # (dense mode hands over the device tensors only: the host arrays of the result are one copy at the end of the run)
             xyz_parts.append(xyz)
             rgb_parts.append(rgb)
             err_parts.append(err)
-            counts_local[local_i] = int(xyz.shape[0])
+            counts_local[local_i] = int(xyz.shape[0]) if xyz is not None else int(dev_pts[0].shape[0])
             refs_with_points += 1
             if cum_body is not None or stream_writer is not None:
                 # this reference's PLY records, packed once (on the device when the points are there): the previews and the
@@ -611,13 +612,12 @@ def run_dense_pipeline(
                 log.error(f"Triangulation error for refs {[p[1].ref_uid for p in pending]}: {ex}")
                 pending.clear()
                 return
-            offs = out.ref_offsets
-            xyz, rgb, err = out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy()
+            offs = out.ref_offsets          # the only read-back of a flush: R + 1 offsets
             for bi, (local_i, packed, ref, _axes) in enumerate(pending):
                 lo, hi = int(offs[bi]), int(offs[bi + 1])
                 if hi > lo:     # trimmed copies: a slice would pin the whole capacity-sized buffer of this flush until the run ends
                     dev_parts.append((out.xyz[lo:hi].clone(), out.rgb[lo:hi].clone(), out.err[lo:hi].clone()))
-                    emit(local_i, packed, xyz[lo:hi], rgb[lo:hi], err[lo:hi], None, dev_parts[-1])
+                    emit(local_i, packed, None, None, None, None, dev_parts[-1])
             pending.clear()
 
         group: List[Tuple[int, _PackedReference, hb.ReferenceInputs, object, int]] = []     # sampled mode, several references per call
@@ -791,15 +791,17 @@ def run_dense_pipeline(
     if progress_callback:
         progress_callback(90.0, "Finalizing triangulation...")
 
-    if xyz_parts:
-        xyz, rgb, err = np.concatenate(xyz_parts, 0), np.concatenate(rgb_parts, 0), np.concatenate(err_parts, 0)
-    else:
-        xyz, rgb, err = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0,), np.float32)
     counts = np.asarray(counts_local, np.int64)
     device_points = None
     if world == 1 and dev_parts:
         device_points = (torch.cat([p[0] for p in dev_parts], 0), torch.cat([p[1] for p in dev_parts], 0),
                          torch.cat([p[2] for p in dev_parts], 0))
+    if xyz_parts and all(x is not None for x in xyz_parts):
+        xyz, rgb, err = np.concatenate(xyz_parts, 0), np.concatenate(rgb_parts, 0), np.concatenate(err_parts, 0)
+    elif xyz_parts and device_points is not None:      # dense mode: the survivors cross PCIe once, here
+        xyz, rgb, err = (t.cpu().numpy() for t in device_points)
+    else:
+        xyz, rgb, err = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0,), np.float32)
     if world > 1:       # the one exchange step: ordered all-gather of the survivors over RCCL, from where they already are (HBM)
         if dev_parts:
             lx, lc, le = (torch.cat([p[i] for p in dev_parts], 0) for i in range(3))

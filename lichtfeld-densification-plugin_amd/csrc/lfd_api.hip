@@ -25,6 +25,7 @@ extern "C" __global__ void lfd_quantise_rgb_kernel(const float* rgb, long long n
 extern "C" __global__ void lfd_select_topm_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_select_filter_mw_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_mt_seed_kernel(unsigned* mt, unsigned seed);
+extern "C" __global__ void lfd_mt_seed_batch_kernel(unsigned* mt_base, LfdSeedBatch seeds);
 extern "C" __global__ void lfd_indexed_eval_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets, float* scratch,
                                                    uint8_t* codes, unsigned* tab, int off_pairs);
 extern "C" __global__ void lfd_indexed_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets,
@@ -329,7 +330,7 @@ void lfd_destroy(lfd_context* ctx) {
     if (ctx->is_host) { delete ctx; return; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->mt, &ctx->sel_scratch, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab})
+    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->mt, &ctx->mt_batch, &ctx->sel_scratch, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
@@ -562,16 +563,22 @@ int lfd_rng_set_state(lfd_context* ctx, const uint32_t* key624, int32_t pos) {
     return LFD_OK;
 }
 
-// launches the selection of one reference; *d_info = device {n_out, status}; nothing is read back here
+// launches the selection of one reference; *d_info = device {n_out, status}; nothing is read back here.
+// n_batch > 1 (or info_batch set): n_batch references in ONE launch (blockIdx.y = reference) - maps best_cert + r*H*W, cells
+// sel_out + r*capacity, {begin, end} pairs sel_offsets_dev + 2r, MT19937 states mt_batch + r*LFD_MT_STATE_STRIDE, results at
+// info_batch + 2r; every reference has its own scratch block and barrier words, so they run side by side (a selection
+// occupies 17 of the 256 CUs).
 static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
                          int32_t border, int32_t tiles, float s_override, int64_t* sel_out, int64_t capacity,
-                         long long* sel_offsets_dev, int** d_info, unsigned char** d_time) {
+                         long long* sel_offsets_dev, int** d_info, unsigned char** d_time, int n_batch = 1,
+                         unsigned* mt_batch = nullptr, int* info_batch = nullptr) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
     if (!best_cert || !sel_out) return fail(ctx, LFD_ERR_INVALID, "null argument");
     if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
     if (H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL || M < 0 || tiles <= 0 || border < 0 || capacity < 0)
         return fail(ctx, LFD_ERR_INVALID, "bad selection arguments");
-    if (!topm && !ctx->mt_seeded) return fail(ctx, LFD_ERR_STATE, "lfd_rng_seed must be called before lfd_select_samples");
+    if (!topm && !mt_batch && !ctx->mt_seeded) return fail(ctx, LFD_ERR_STATE, "lfd_rng_seed must be called before lfd_select_samples");
+    if (n_batch < 1 || n_batch > LFD_SELECT_BATCH_MAX) return fail(ctx, LFD_ERR_INVALID, "bad selection batch");
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->mt.ptr) { int rc0 = ensure(ctx, ctx->mt, 625 * sizeof(unsigned)); if (rc0 != LFD_OK) return rc0; }
     const size_t N = (size_t)H * W, Mz = (size_t)std::max(M, 1);
@@ -579,7 +586,7 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
     const size_t o_w = 0, o_p = o_w + up(N * 4), o_cdf = o_p + up(N * 8), o_first = o_cdf + up(N * 8), o_mark = o_first + up(N * 4),
                  o_draws = o_mark + up(N), o_cand = o_draws + up(Mz * 8), o_found = o_cand + up(Mz * 4), o_out = o_found + up(Mz * 4),
                  o_time = o_out + 256, o_coop = o_time + 256, total = o_coop + up(LFD_SELECT_COOP_BYTES);
-    int rc = ensure(ctx, ctx->sel_scratch, total);
+    int rc = ensure(ctx, ctx->sel_scratch, total * (size_t)n_batch);
     if (rc != LFD_OK) return rc;
     unsigned char* base = static_cast<unsigned char*>(ctx->sel_scratch.ptr);
     LfdSelectArgs A;
@@ -593,7 +600,12 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
     A.draws = reinterpret_cast<double*>(base + o_draws);
     A.cand = reinterpret_cast<int*>(base + o_cand);
     A.found = reinterpret_cast<int*>(base + o_found);
-    A.mt = static_cast<unsigned*>(ctx->mt.ptr);
+    A.mt = mt_batch ? mt_batch : static_cast<unsigned*>(ctx->mt.ptr);
+    A.batch_scratch_stride = (long long)total;
+    A.batch_cert_stride = (long long)N;
+    A.batch_out_stride = (long long)capacity;
+    A.batch_mt_stride = mt_batch ? LFD_MT_STATE_STRIDE : 0;
+    A.batch_info = info_batch;
     A.sel_out = reinterpret_cast<long long*>(sel_out);
     A.n_out = reinterpret_cast<int*>(base + o_out);
     A.status = reinterpret_cast<int*>(base + o_out + 4);
@@ -602,7 +614,7 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
     A.sel_offsets_out = sel_offsets_dev;
     *d_info = reinterpret_cast<int*>(base + o_out);
     *d_time = nullptr;
-    const bool timing = !topm && std::getenv("LFD_SELECT_TIMING") != nullptr;
+    const bool timing = !topm && n_batch == 1 && std::getenv("LFD_SELECT_TIMING") != nullptr;
     if (timing) {
         A.timing = reinterpret_cast<unsigned long long*>(base + o_time);
         LFD_HIP(ctx, hipMemsetAsync(base + o_time, 0, 256, ctx->stream));
@@ -615,7 +627,7 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ctx->topm_lds_attr_set = true;
         }
-        hipLaunchKernelGGL(lfd_select_topm_kernel, dim3(1), dim3(LFD_SELECT_BLOCK), lds, ctx->stream, A);
+        hipLaunchKernelGGL(lfd_select_topm_kernel, dim3(1, (unsigned)n_batch), dim3(LFD_SELECT_BLOCK), lds, ctx->stream, A);
     } else {
         // several workgroups (one per CU) when the map is large enough to share out; LFD_SELECT_WORKGROUPS=0 keeps the
         // single-workgroup kernel (both produce the same selection)
@@ -631,10 +643,11 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
         if (n_wg >= 2 && (!timing || timing_mw)) {
             A.coop = base + o_coop;
             A.n_wg = n_wg;
-            LFD_HIP(ctx, hipMemsetAsync(base + o_coop, 0, 64, ctx->stream));       // barrier words and flags
-            hipLaunchKernelGGL(lfd_select_filter_mw_kernel, dim3((unsigned)n_wg + 1u), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A);
+            if (n_batch == 1) LFD_HIP(ctx, hipMemsetAsync(base + o_coop, 0, 64, ctx->stream));       // barrier words and flags
+            else LFD_HIP(ctx, hipMemset2DAsync(base + o_coop, total, 0, 64, (size_t)n_batch, ctx->stream));
+            hipLaunchKernelGGL(lfd_select_filter_mw_kernel, dim3((unsigned)n_wg + 1u, (unsigned)n_batch), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A);
         } else {
-            hipLaunchKernelGGL(lfd_select_filter_kernel, dim3(1), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A);
+            hipLaunchKernelGGL(lfd_select_filter_kernel, dim3(1, (unsigned)n_batch), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A);
         }
     }
     LFD_HIP(ctx, hipGetLastError());
@@ -718,17 +731,33 @@ static int sampled_impl(lfd_context* ctx, const lfd_batch* batch, const lfd_para
         LFD_HIP(ctx, hipMemcpyAsync(sel_pairs, begins.data(), begins.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
         LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));       // the host vector goes out of scope
     }
-    for (int r = 0; r < R; ++r) {
-        if (seeds && !topm) {
-            rc = lfd_rng_seed(ctx, seeds[r]);
-            if (rc != LFD_OK) return rc;
-        }
+    if (!seeds) {            // one reference on the context's MT19937 stream (upstream's single global stream)
         int* d_info = nullptr;
         unsigned char* d_time = nullptr;
-        rc = select_launch(ctx, topm, best + (size_t)r * HW, batch->H, batch->W, M, cap, topm ? 0 : border, topm ? 1 : tiles, topm ? 0.0f : s_override,
-                           reinterpret_cast<int64_t*>(cells + (size_t)r * cap_sel), cap_sel, sel_pairs + 2 * (size_t)r, &d_info, &d_time);
+        rc = select_launch(ctx, topm, best, batch->H, batch->W, M, cap, topm ? 0 : border, topm ? 1 : tiles, topm ? 0.0f : s_override,
+                           reinterpret_cast<int64_t*>(cells), cap_sel, sel_pairs, &d_info, &d_time);
         if (rc != LFD_OK) return rc;
-        LFD_HIP(ctx, hipMemcpyAsync(sel_info + 2 * (size_t)r, d_info, 2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        LFD_HIP(ctx, hipMemcpyAsync(sel_info, d_info, 2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    } else {                 // every reference on its own stream: up to LFD_SELECT_BATCH_MAX selections side by side per launch
+        rc = ensure(ctx, ctx->mt_batch, (size_t)LFD_SELECT_BATCH_MAX * LFD_MT_STATE_STRIDE * sizeof(unsigned));
+        if (rc != LFD_OK) return rc;
+        unsigned* mtb = static_cast<unsigned*>(ctx->mt_batch.ptr);
+        for (int r0 = 0; r0 < R; r0 += LFD_SELECT_BATCH_MAX) {
+            const int nb = std::min(R - r0, (int)LFD_SELECT_BATCH_MAX);
+            if (!topm) {
+                LfdSeedBatch sb;
+                std::memset(&sb, 0, sizeof(sb));
+                for (int i = 0; i < nb; ++i) sb.seed[i] = seeds[r0 + i];
+                hipLaunchKernelGGL(lfd_mt_seed_batch_kernel, dim3((unsigned)nb), dim3(64), 0, ctx->stream, mtb, sb);
+                LFD_HIP(ctx, hipGetLastError());
+            }
+            int* d_info = nullptr;
+            unsigned char* d_time = nullptr;
+            rc = select_launch(ctx, topm, best + (size_t)r0 * HW, batch->H, batch->W, M, cap, topm ? 0 : border, topm ? 1 : tiles, 0.0f,
+                               reinterpret_cast<int64_t*>(cells + (size_t)r0 * cap_sel), cap_sel, sel_pairs + 2 * (size_t)r0, &d_info, &d_time,
+                               nb, mtb, sel_info + 2 * (size_t)r0);
+            if (rc != LFD_OK) return rc;
+        }
     }
     // F2..F10 on the selected cells of all references
     rc = prepare_lookback(ctx, (size_t)R, (size_t)R, false, L);

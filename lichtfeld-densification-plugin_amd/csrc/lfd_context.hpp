@@ -51,7 +51,7 @@ struct lfd_context {
     // indexed-mode scratch
     DeviceBuffer scratch, codes, idx_tab, agg, sel_buf;
     // selection stage: legacy MT19937 stream (625 words) + scratch
-    DeviceBuffer mt, sel_scratch;
+    DeviceBuffer mt, sel_scratch, mt_batch;      // mt_batch: per-reference MT19937 states of lfd_triangulate_sampled_multi
     DeviceBuffer stamps;           // profiling builds: phase stamps of the dense kernel
     // N3 image preparation: coefficient / index tables of the last size pair
     DeviceBuffer img_tab, msk_tab;

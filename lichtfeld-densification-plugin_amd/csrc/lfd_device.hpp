@@ -150,4 +150,14 @@ struct LfdSelectArgs {
     unsigned char* coop;          // multi-workgroup kernel: shared scratch (LFD_SELECT_COOP_BYTES, header zeroed before the launch)
     int n_wg;                     // multi-workgroup kernel: compute workgroups (the grid has one more, which runs the MT19937 stream)
     long long* sel_offsets_out;   // optional device i64 [2]: {begin, begin + n_out} for the indexed kernels that follow in the same stream ([0] = [1] = begin set by the host)
+    // Several references in one launch (blockIdx.y = reference, every pointer above is reference 0's): the kernels move on to
+    // their reference's block first thing (lfd_select_args_of).  All zero / null for a launch of one reference.
+    long long batch_scratch_stride;   // bytes between the scratch blocks (weights ... coop, n_out / status) of consecutive references
+    long long batch_cert_stride;      // elements between their aggregated-certainty maps
+    long long batch_out_stride;       // elements between their sel_out areas
+    long long batch_mt_stride;        // words between their MT19937 states (one stream per reference)
+    int* batch_info;                  // device i32 [2 * n] or null: reference y reports {n_out, status} at [2y], [2y + 1] instead of n_out / status
 };
+#define LFD_SELECT_BATCH_MAX 32       // references per selection launch (17 workgroups each: co-resident with room to spare)
+#define LFD_MT_STATE_STRIDE 640       // words per MT19937 state of a batch (624 key + position, padded)
+struct LfdSeedBatch { unsigned seed[LFD_SELECT_BATCH_MAX]; };

@@ -146,7 +146,34 @@ __device__ int block_excl_scan_i32(int v, int* s_tmp, int tid, int& total) {
 }  // namespace
 
 // =================================================================================================
-extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter_kernel(LfdSelectArgs A) {
+// the arguments of this workgroup's reference (blockIdx.y) in a launch that covers several references
+__device__ __forceinline__ LfdSelectArgs lfd_select_args_of(LfdSelectArgs A) {
+    const long long y = (long long)blockIdx.y;
+    if (A.batch_info) { A.n_out = A.batch_info + 2 * y; A.status = A.n_out + 1; }
+    if (y == 0) return A;
+    const long long sb = A.batch_scratch_stride * y;
+    A.best_cert += A.batch_cert_stride * y;
+    A.weights = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(A.weights) + sb);
+    A.p = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(A.p) + sb);
+    A.cdf = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(A.cdf) + sb);
+    A.first = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(A.first) + sb);
+    A.mark += sb;
+    A.draws = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(A.draws) + sb);
+    A.cand = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(A.cand) + sb);
+    A.found = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(A.found) + sb);
+    if (A.coop) A.coop += sb;
+    if (!A.batch_info) {
+        A.n_out = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(A.n_out) + sb);
+        A.status = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(A.status) + sb);
+    }
+    A.mt += A.batch_mt_stride * y;
+    A.sel_out += A.batch_out_stride * y;
+    if (A.sel_offsets_out) A.sel_offsets_out += 2 * y;
+    return A;
+}
+
+extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter_kernel(LfdSelectArgs A_launch) {
+    const LfdSelectArgs A = lfd_select_args_of(A_launch);
     __shared__ double s_d[kSelBlock / 64];
     __shared__ int s_i[kSelBlock / 64];
     __shared__ double s_chunk[kSelBlock];
@@ -553,7 +580,8 @@ __device__ bool grid_barrier(unsigned* bar, unsigned n_wg_total) {
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter_mw_kernel(LfdSelectArgs A) {
+extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter_mw_kernel(LfdSelectArgs A_launch) {
+    const LfdSelectArgs A = lfd_select_args_of(A_launch);
     __shared__ double s_d[kSelBlock / 64];
     __shared__ int s_i[kSelBlock / 64];
     __shared__ double s_chunk[kSelBlock];
@@ -973,7 +1001,8 @@ __device__ int topm_pick_bin(const unsigned* hist, int n_bins, unsigned need, in
 // value of the M-th largest cell; ties at that value - the norm when many cells sit at the cap - are taken in index
 // order by an ordered count; the winners are then sorted in LDS.  (The first version materialised 64-bit keys and made
 // eight 8-bit passes over them: 19 MB through one CU instead of 4-5 MB.)
-extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_topm_kernel(LfdSelectArgs A) {
+extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_topm_kernel(LfdSelectArgs A_launch) {
+    const LfdSelectArgs A = lfd_select_args_of(A_launch);
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];   // [LFD_SELECT_TOPM_MAX]
     __shared__ unsigned s_hist[2048];
     __shared__ unsigned s_count;
@@ -1101,5 +1130,15 @@ extern "C" __global__ void lfd_mt_seed_kernel(unsigned* mt, unsigned seed) {
         mt[0] = seed;
         for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (unsigned)i;
         mt[624] = 624;      // position: a twist is due before the first output
+    }
+}
+
+// the same for a batch: workgroup b seeds the state of reference b (states LFD_MT_STATE_STRIDE words apart)
+extern "C" __global__ void lfd_mt_seed_batch_kernel(unsigned* mt_base, LfdSeedBatch seeds) {
+    if (threadIdx.x == 0) {
+        unsigned* mt = mt_base + (size_t)blockIdx.x * LFD_MT_STATE_STRIDE;
+        mt[0] = seeds.seed[blockIdx.x];
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (unsigned)i;
+        mt[624] = 624;
     }
 }

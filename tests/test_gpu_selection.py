@@ -299,3 +299,60 @@ def test_sampled_mode_cli_defaults_full_size(dens):
     np.testing.assert_array_equal(out.rgb.cpu().numpy()[ih], res.rgb[io_])
     if out.count == res.count and common.size == res.count:
         np.testing.assert_array_equal(out.cell.cpu().numpy(), res.cell)          # upstream's group order
+
+
+@pytest.mark.parametrize("no_filter", [False, True])
+def test_batched_selection_equals_one_reference_at_a_time(dens, no_filter):
+    """lfd_triangulate_sampled_multi runs the selections of a batch side by side (one launch per 32 references, every reference
+    with its own scratch block, barrier words and MT19937 state): 40 references at 256x256, one of them refusing its input,
+    give bit for bit what 40 seeded single-reference calls give, and leave the context's own stream alone."""
+    import lichtfeld_densification_plugin_amd as lfd
+    from lichtfeld_densification_plugin_amd import synthetic
+    dev = dens.device
+    n_cams = 48
+    cams = synthetic.ring_cameras(n_cams, seed=0)
+    dens.upload_cameras(cams)
+    H = W = 256
+    M = 2500
+    R = 40
+    cfg = lfd.DensePipelineConfig(output_path="", matches_per_ref=M, no_filter=no_filter)
+    params = hb.make_params(cfg)
+    refs, keep = [], []
+    for ref in range(R):
+        nbrs = synthetic.ring_neighbours(n_cams, ref, 3)
+        s = synthetic.synth_reference(cams, ref, nbrs, H, W, H, W, noise_px=0.4, outlier_frac=0.05, channels=2, seed=100 + ref,
+                                      cert_mode="tiefree", device=dev)
+        mask = None
+        if ref == 17 and not no_filter:      # fewer non-zero weights than draws: np.random.choice refuses (status 3), nothing is emitted
+            mask = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+            mask[100, :30] = 1
+        keep.append(s)
+        refs.append(hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=[s.cert[j] for j in range(3)], warp=[s.warp[j] for j in range(3)],
+                                       image=s.image, mask_a=mask))
+    seeds = [1000 + 7 * r for r in range(R)]
+    dens.seed_rng(99)
+    before = dens.rng_state()
+    cap = M + 24 * 24 + 64
+    out = hb.OutputBuffers(cap * R, R, 3, dev, True)
+    dens.launch_sampled_multi(hb.PreparedBatch(refs, W, H), params, M, out, seeds, cap=0.9, border=2, tiles=24)
+    with torch.cuda.stream(dens.stream):
+        got = out.collect(indexed=True, check_selection=False)
+    after = dens.rng_state()
+    assert before[1] == after[1] and np.array_equal(before[0], after[0])
+    info = out.sel_info.cpu().numpy()
+    offs = got.ref_offsets
+    total = 0
+    for r in range(R):
+        if r == 17 and not no_filter:
+            assert int(info[2 * r + 1]) == 3 and offs[r + 1] == offs[r]
+            continue
+        dens.seed_rng(seeds[r])
+        one = dens.triangulate_sampled(hb.PreparedBatch([refs[r]], W, H), params, M, cap=0.9, border=2, tiles=24)
+        lo, hi = int(offs[r]), int(offs[r + 1])
+        assert hi - lo == one.count and int(info[2 * r]) == one.n_selected and int(info[2 * r + 1]) == 0
+        np.testing.assert_array_equal(got.xyz[lo:hi].cpu().numpy(), one.xyz.cpu().numpy())
+        np.testing.assert_array_equal(got.rgb[lo:hi].cpu().numpy(), one.rgb.cpu().numpy())
+        np.testing.assert_array_equal(got.err[lo:hi].cpu().numpy(), one.err.cpu().numpy())
+        np.testing.assert_array_equal(got.cell[lo:hi].cpu().numpy(), one.cell.cpu().numpy())
+        total += one.count
+    assert total > 1000 * (R - 1)
