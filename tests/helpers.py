@@ -66,7 +66,7 @@ def oracle_cam(c):
     return orc.OracleCamera(K=c.K, R=c.R, t=c.t, P=c.P, C=c.C, width=c.width, height=c.height)
 
 
-def flip_report(kept_cells, sref, cams, w_match, h_match, params, axes, sample=None, sampson_rel=1e-12, seed=0):
+def flip_report(kept_cells, sref, cams, w_match, h_match, params, axes, sample=None, sampson_rel=1e-12, seed=0, masks=(None, None)):
     """Cells of one reference that an implementation (``kept_cells`` = the grid cells it kept, dense mode) decides
     differently from the oracle, each classified by the threshold that explains it (``orc.classify_flips``: the band of
     every reject reason is derived from a stated rounding-noise model, see its docstring).
@@ -79,7 +79,7 @@ def flip_report(kept_cells, sref, cams, w_match, h_match, params, axes, sample=N
     warps = [sref.warp[j].cpu().numpy() for j in range(k)]
     ca, cbs = oracle_cam(cams[sref.ref_index]), [oracle_cam(cams[n]) for n in sref.nbr_indices]
     with np.errstate(all="ignore"):
-        best_cert, best_k, agg = orc.prepare_reference(certs, warps, params)
+        best_cert, best_k, agg = orc.prepare_reference(certs, warps, params, masks[0], masks[1])
         if sample is None or sample >= H * W:
             cells = np.arange(H * W, dtype=np.int64)
         else:

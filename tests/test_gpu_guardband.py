@@ -45,6 +45,10 @@ SHAPES = {
     # BASELINE config 5: `precise` = 1280^2 grid over 800-px match images, 8 neighbours, ROI subset of 12 cameras
     "precise_k8_roi": dict(cams=(12, 1297, 840, 960.0), grid=(1280, 1280, 800, 800), k=8, refs=(5,), noise=0.5, outl=0.05,
                            patch=None, reproj=0.8, sample=300000, rate=3e-4),
+    # masks on the reference and on every neighbour + upstream's four-channel warps [xA yA xB yB]: the masked four-cells-at-a-time
+    # front end and the four-channel loads of the dense kernel at full size (core/pipeline.py:405-430)
+    "fast_k3_masks_c4": dict(cams=(185, 1297, 840, 960.0), grid=(512, 512, 512, 512), k=3, refs=(40, 100), noise=0.5, outl=0.05,
+                             patch=None, reproj=0.8, sample=None, rate=3e-4, masks=True, channels=4),
 }
 
 
@@ -59,13 +63,28 @@ def _scene(spec, dev):
     H, W, wm, hm = spec["grid"]
     cams = synthetic.ring_cameras(n, width=w, height=h, focal=f, seed=0, arc=1.2 if n <= 16 else 2.0 * np.pi)
     srefs, refs = [], []
+    rs = np.random.RandomState(11)
+
+    def blob():         # 0 = masked out: a few rectangles, about a fifth of the image
+        m = np.ones((hm, wm), np.uint8)
+        for _ in range(6):
+            y, x = rs.randint(0, hm - hm // 5), rs.randint(0, wm - wm // 5)
+            m[y:y + hm // 6, x:x + wm // 5] = 0
+        return m
     for ref in spec["refs"]:
         nbrs = synthetic.ring_neighbours(n, ref, spec["k"])
         s = synthetic.synth_reference(cams, ref, nbrs, H, W, wm, hm, noise_px=spec["noise"], outlier_frac=spec["outl"],
-                                      channels=2, seed=1000 + ref, cert_mode="smooth", low_parallax_patch=spec["patch"])
+                                      channels=spec.get("channels", 2), seed=1000 + ref, cert_mode="smooth", low_parallax_patch=spec["patch"])
+        r = hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=[s.cert[j].to(dev) for j in range(spec["k"])],
+                               warp=[s.warp[j].contiguous().to(dev) for j in range(spec["k"])], image=s.image.to(dev))
+        s.masks = (None, None)
+        if spec.get("masks"):
+            ma, mbs = blob(), [blob() for _ in range(spec["k"])]
+            s.masks = (ma, mbs)
+            r.mask_a = torch.from_numpy(ma).to(dev)
+            r.mask_b = [torch.from_numpy(m).to(dev) for m in mbs]
         srefs.append(s)
-        refs.append(hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=[s.cert[j].to(dev) for j in range(spec["k"])],
-                                       warp=[s.warp[j].contiguous().to(dev) for j in range(spec["k"])], image=s.image.to(dev)))
+        refs.append(r)
     return cams, srefs, refs
 
 
@@ -81,13 +100,13 @@ def test_every_flip_is_inside_the_derived_band(dev, name):
     batch = hb.PreparedBatch(refs, wm, hm, cameras=cams)          # upstream's F handed to the kernels
     out = dens.triangulate_dense(batch, hb.make_params(cfg))
     cell = out.cell.cpu().numpy().astype(np.int64)
-    axes = (orc.identity_axis_scalar(W), orc.identity_axis_scalar(H))
+    axes = (orc.identity_axis_scalar(W), orc.identity_axis_scalar(H)) if spec.get("channels", 2) == 2 else None
     total = dict(cells=0, flipped=0, out_of_band=0)
     by = {r: 0 for r in orc.FLIP_REASONS}
     xyz, rgb, err = out.xyz.cpu().numpy(), out.rgb.cpu().numpy(), out.err.cpu().numpy()
     for r, s in enumerate(srefs):
         lo, hi = int(out.ref_offsets[r]), int(out.ref_offsets[r + 1])
-        rep = flip_report(cell[lo:hi], s, cams, wm, hm, params, axes, sample=spec["sample"], seed=r)
+        rep = flip_report(cell[lo:hi], s, cams, wm, hm, params, axes, sample=spec["sample"], seed=r, masks=s.masks)
         assert rep["out_of_band"] == 0, f"{name} ref {r}: cells {rep['oob_cells'][:8]} flip outside every band ({rep})"
         for key in total:
             total[key] += rep[key]
