@@ -23,10 +23,10 @@
 #define LFD_DENSE_WAVES_PER_SIMD 7       // register budget of the fused kernel: 512/7 -> <=72 VGPRs (it needs 69-72)
 #endif
 #ifndef LFD_DENSE_ALL_WARPS
-#define LFD_DENSE_ALL_WARPS 0   // 1: dense kernel, k <= 4: the warps of ALL slots ride along with the certainty planes (one memory round trip less, 8 (k-1) B
-                                // per cell more traffic).  Measured (profiles/r2/ablation.txt): the winner's-warp phase falls from 7.5 to 2.3 us per tile but
-                                // the kernel only from 0.317 to 0.310 ms at k = 3 and gets SLOWER at k = 4 (0.356 -> 0.372): with that latency gone the
-                                // vector ALU is the limit.  Off: not worth 1.4 x the HBM traffic.
+#define LFD_DENSE_ALL_WARPS 2   // dense kernel, references with at most this many neighbours (two-channel warps, no masks): the warps of ALL slots ride
+                                // along with the certainty planes - one dependent memory round trip less for 8 (k-1) B per cell more traffic.
+                                // Measured (profiles/r2/ablation.txt): k = 1 0.118 -> 0.116 ms, k = 2 0.307 -> 0.290, k = 3 0.317 -> 0.307 (but 1.44 x
+                                // the algorithmic bytes instead of 1.10 x), k = 4 slower.  On up to two neighbours; 0 = never.
 #endif
 #ifndef LFD_FRONT_PRIO
 #define LFD_FRONT_PRIO 1        // s_setprio of a dense-kernel wave until its geometry loop starts (0 = off): the handful of instructions between the

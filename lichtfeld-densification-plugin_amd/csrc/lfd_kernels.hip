@@ -538,7 +538,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
         // kernel is bound by its chain of memory round trips, not by bandwidth (profiles/r2/phases_*.txt).
         float spec_xb[4] = {0.0f, 0.0f, 0.0f, 0.0f}, spec_yb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         bool have_warps = false;
-        if (!any_mask && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW && ns <= 4 && L.warp_channels == 2) {
+        if (!any_mask && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW && ns <= LFD_DENSE_ALL_WARPS && L.warp_channels == 2) {
             const float th = L.kp.certainty_thresh;
             float4 c[4], wa[4], wb[4];
 #pragma unroll
