@@ -176,6 +176,16 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16):
     return res
 
 
+def device_copy_bandwidth(dev, n_bytes=1 << 30, reps=10):
+    """HBM bytes moved per second by a device-to-device copy of 1 GiB (read + write counted), the practical ceiling beside the
+    8 TB/s of the data sheet."""
+    a = torch.empty(n_bytes, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    ms = _event_ms(lambda: b.copy_(a), reps)
+    del a, b
+    return 2.0 * n_bytes / (ms * 1e-3) / 1e9
+
+
 def _event_ms(fn, reps):
     """Mean HIP-event time of fn() on torch's current stream (the stream the library launches on)."""
     fn()
@@ -512,6 +522,11 @@ def main():
                          "kernel": "lfd_dense_kernel", "kernel_ms": kernel_ms, "kernel_ms_percentiles": kernel_pct,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_cell": bytes_per_cell},
         }
+        # the same time priced against the byte count of a kernel that reads the warps of ALL k neighbours coalesced
+        # (12k + 3 + 28 s per cell) - what lfd_dense_kernel physically does for references with at most LFD_DENSE_ALL_WARPS (2) neighbours
+        line["roofline"]["achieved_all_warps_bytes"] = cells * (12 * args.k + 3 + 28 * s_frac) / (kernel_ms * 1e-3) / 1e9
+        if not args.light:
+            line["roofline"]["device_copy_GBps"] = device_copy_bandwidth(dev)      # what a plain device-to-device copy reaches on this box
         line["roofline"]["valu_busy_frac"] = valu_busy_frac(args)     # the f64 geometry makes the kernel vector-ALU-bound, not HBM-bound
         line["roofline"]["traffic_over_algorithmic"] = (line["roofline"]["traffic"] / algo_bytes) if line["roofline"]["traffic"] else None
         if allgather is not None:
