@@ -75,6 +75,9 @@ int validate_batch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p) {
     if (b->n_refs <= 0) return fail(ctx, LFD_ERR_INVALID, "n_refs must be > 0");
     if (b->k <= 0 || b->k > LFD_MAX_SLOTS) return fail(ctx, LFD_ERR_INVALID, "k must be in [1, LFD_MAX_SLOTS]");
     if (b->H <= 0 || b->W <= 0 || b->w_match <= 1 || b->h_match <= 1) return fail(ctx, LFD_ERR_INVALID, "bad grid / match size");
+    // byte offsets into the match-size image are 32-bit, its rows and columns 24-bit multiplicands (lfd_bilinear_fetch)
+    if (b->w_match >= (1 << 24) || b->h_match >= (1 << 24) || (long long)b->w_match * b->h_match * 3 > 0x7fffffffLL)
+        return fail(ctx, LFD_ERR_INVALID, "match-size image too large");
     if ((long long)b->H * b->W > 0x7fffffffLL) return fail(ctx, LFD_ERR_INVALID, "grid too large");
     if (b->warp_channels != 2 && b->warp_channels != 4) return fail(ctx, LFD_ERR_INVALID, "warp_channels must be 2 or 4");
     if (!b->ref_cam || !b->n_slots || !b->nbr_cam || !b->cert || !b->warp || !b->image)

@@ -207,7 +207,7 @@ __device__ __forceinline__ void lfd_divmod(int cell, int W, float inv_w, int& y,
 // is within one of the quotient and a single correction each way is enough
 __device__ __forceinline__ void lfd_divmod_local(int local, int W, float inv_w, int& dy, int& x) {
     int q = (int)((float)local * inv_w);
-    int r = local - q * W;
+    int r = local - __mul24(q, W);      // q <= 2^22 / W, W < 2^16: the 24-bit multiply is exact (and full rate; v_mul_lo_u32 is quarter rate)
     if (r < 0) { --q; r += W; }
     if (r >= W) { ++q; r -= W; }
     dy = q; x = r;
@@ -419,6 +419,14 @@ __device__ __forceinline__ const T LFD_CONST_AS* lfd_const_as(const T* p) {
 #pragma clang diagnostic ignored "-Wold-style-cast"
     return (const T LFD_CONST_AS*)p;
 #pragma clang diagnostic pop
+}
+
+// 12 * slot as a 24-bit multiply (full rate).  Written as an instruction because the optimiser turns every other spelling of it
+// back into v_mul_lo_u32, which runs at a quarter of the rate - once per cell in the geometry loop.
+__device__ __forceinline__ int lfd_slot_bytes12(int sl) {
+    int o;
+    asm("v_mul_u32_u24 %0, %1, 12" : "=v"(o) : "v"(sl));
+    return o;
 }
 
 struct DenseStage {                // per-tile results, indexed by the cell's slot inside the tile
@@ -672,7 +680,8 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
             // re-read the camera constants from LDS every cell instead of pinning ~60 registers on them
             asm volatile("" ::: "memory");
             const int sl = tid * kCpt + e;
-            const float xan = stage.xyz[3 * sl + 0], yan = stage.xyz[3 * sl + 1], xbn = stage.xyz[3 * sl + 2];
+            float* sxyz = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(stage.xyz) + lfd_slot_bytes12(sl));
+            const float xan = sxyz[0], yan = sxyz[1], xbn = sxyz[2];
             const float ybn = stage.err[sl];
             const int bje = (int)((bj_packed >> (8 * e)) & 0xffu);
             LfdCellResult res;
@@ -683,7 +692,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
             if (cell0 + e < HW) lfd_eval_correspondence(rc, S.pc[bje], xan, yan, xbn, ybn, L.kp, res);
 #endif
             if (res.keep) {
-                stage.xyz[3 * sl + 0] = res.x; stage.xyz[3 * sl + 1] = res.y; stage.xyz[3 * sl + 2] = res.z;
+                sxyz[0] = res.x; sxyz[1] = res.y; sxyz[2] = res.z;
                 stage.err[sl] = res.err;
                 keep_bits |= 1u << e;
             }
@@ -820,24 +829,30 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
 
 #if !defined(LFD_ABLATE_STORES)
         if (wave != 0) {
-            const long long base = (long long)s_tile_excl;
+            // the tile's offset is the same for every lane: kept in scalar registers, so that a record's address is a scalar base
+            // plus a 32-bit per-lane byte offset (no 64-bit vector multiply-adds: those run at a quarter of the rate)
+            const u64 excl = s_tile_excl;
+            const long long base = (long long)(((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(excl >> 32)) << 32) |
+                                               (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)excl));
             long long room = L.capacity - base;          // beyond capacity: counted, not written
             int n = (int)block_total;
             if (room < (long long)n) n = room > 0 ? (int)room : 0;
-            LfdF3* gx = reinterpret_cast<LfdF3*>(L.xyz + 3 * base);
-            LfdF3* gc = reinterpret_cast<LfdF3*>(L.rgb + 3 * base);
-            float* ge = L.err + base;
+            unsigned char* gx = reinterpret_cast<unsigned char*>(L.xyz + 3 * base);
+            unsigned char* gc = reinterpret_cast<unsigned char*>(L.rgb + 3 * base);
+            unsigned char* ge = reinterpret_cast<unsigned char*>(L.err + base);
 #pragma unroll
             for (int u = 0; u < kCopyRecords; ++u) {
                 const int i = ctid + u * kCopyThreads;
                 if (i < n) {
                     const int sl = (int)stage.order[i];
                     LfdF3 p, c;
-                    p.a = stage.xyz[3 * sl + 0]; p.b = stage.xyz[3 * sl + 1]; p.c = stage.xyz[3 * sl + 2];
+                    const float* sxyz = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(stage.xyz) + lfd_slot_bytes12(sl));
+                    p.a = sxyz[0]; p.b = sxyz[1]; p.c = sxyz[2];
                     c.a = rgb[u][0]; c.b = rgb[u][1]; c.c = rgb[u][2];
-                    gx[i] = p;
-                    gc[i] = c;
-                    ge[i] = stage.err[sl];
+                    const unsigned o12 = (unsigned)lfd_slot_bytes12(i), o4 = (unsigned)i * 4u;
+                    *reinterpret_cast<LfdF3*>(gx + o12) = p;
+                    *reinterpret_cast<LfdF3*>(gc + o12) = c;
+                    *reinterpret_cast<float*>(ge + o4) = stage.err[sl];
                     if (L.cell) L.cell[base + i] = tile_cell0 + sl;
                     if (L.slot) L.slot[base + i] = stage.slot[sl];
                 }
