@@ -39,6 +39,18 @@
 #define LFD_EPOCH_BITS 22
 #define LFD_EPOCH_MASK ((1u << LFD_EPOCH_BITS) - 1u)
 #define LFD_VALUE_BITS 40     // survivors-so-far fits 40 bits (1e12 points)
+#ifndef LFD_LOOKBACK_PER_LANE
+#define LFD_LOOKBACK_PER_LANE 1    // tile-state words a lane of the look-back wave reads per round trip (window = 64 x this)
+#endif
+#ifndef LFD_LOOKBACK_LANES
+#define LFD_LOOKBACK_LANES 16      // lanes of the look-back wave that read a tile-state word per round trip (the window).  The words are read past the caches: 16 per round measured 0.306 ms, 32 0.308, 64 0.311, 8 0.316; 128 ... 1024 (several words per lane) 0.32 ... 0.56
+#endif
+#ifndef LFD_LOOKBACK_WATCH_ONE
+#define LFD_LOOKBACK_WATCH_ONE 1     // look-back: one lane watches the nearest predecessor's word until it is published, then the window is read
+#endif
+#ifndef LFD_WATCH_SLEEP
+#define LFD_WATCH_SLEEP 127          // s_sleep argument (x64 cycles, the instruction's maximum: ~4 us) between two looks at the watched word
+#endif
 #ifndef LFD_POLL_SLEEP
 #define LFD_POLL_SLEEP 8       // s_sleep argument (x64 cycles) between two polls of a look-back window
 #endif

@@ -88,33 +88,71 @@ __device__ u64 lookback_exclusive(const LfdLaunch& L, unsigned tile, u64 my_tota
         return 0;
     }
     if (lane == 0) state_store(state + tile, pack_state(kStAggregate, epoch, my_total));
+    // A window of 64 * kPer predecessors per memory round trip: every lane reads kPer consecutive words (nearest first).
+    // The tiles that are themselves waiting here have published their count but no prefix yet; with N of them in flight a
+    // tile walks back through N / window round trips before it meets a prefix, and that walk - not the arithmetic - sets the
+    // life of a tile once N is in the hundreds (1792 resident tiles, about a third of them in this loop): a wide window.
+    constexpr int kPer = LFD_LOOKBACK_PER_LANE;
     u64 excl = 0;
     long long base = (long long)tile - 1;
-    while (true) {
-        const long long j = base - lane;
-        u64 s;
-        if (j >= 0) {
-            s = state_load(state + j);
-            while (__any(state_status(s, epoch) == kStEmpty)) {
-                if (++spins > LFD_SPIN_LIMIT) {          // never hang the GPU: report and bail out
-                    if (lane == 0) atomicExch(L.status, LFD_LAUNCH_TIMEOUT);
-                    return 0;
-                }
-                __builtin_amdgcn_s_sleep(LFD_POLL_SLEEP);
-                if (state_status(s, epoch) == kStEmpty) s = state_load(state + j);
+#if LFD_LOOKBACK_WATCH_ONE
+    // While the predecessors are still computing, ONE lane watches ONE word - the nearest predecessor's.  Tile-state words are
+    // read past the caches (every XCD writes them), and a wave that re-reads its whole window every microsecond, times the
+    // ~500 waves that wait here at any moment, is measurable traffic on the fabric (longer sleeps between the polls alone
+    // were worth 4 %).  Tiles publish roughly in ticket order, so when the nearest one has, the window read below rarely
+    // finds a gap.  The watch sleeps ~4 us between two looks (measured: 0.25 us 0.308 ms, 1 us 0.304, 3 us 0.299, 4 us 0.297,
+    // 8 us 0.300, 16 us 0.318: a tile waits 12 us on average, detecting the end of the wait 2 us late costs less than looking).
+    {
+        u64 w = 0;
+        bool waiting = lane == 0;
+        if (waiting) w = state_load(state + base);
+        while (__any(waiting && state_status(w, epoch) == kStEmpty)) {
+            if (++spins > LFD_SPIN_LIMIT) {
+                if (lane == 0) atomicExch(L.status, LFD_LAUNCH_TIMEOUT);
+                return 0;
             }
-        } else {
-            s = pack_state(kStPrefix, epoch, 0);   // virtual tile -1: prefix 0
+            __builtin_amdgcn_s_sleep(LFD_WATCH_SLEEP);
+            if (waiting && state_status(w, epoch) == kStEmpty) w = state_load(state + base);
         }
-        const u64 is_prefix = __ballot(state_status(s, epoch) == kStPrefix);
-        const u64 val = s & kValueMask;
-        if (is_prefix) {
-            const int first = __ffsll((long long)is_prefix) - 1;   // nearest predecessor with a full prefix
-            excl += wave_sum_u64(lane <= first ? val : 0ull);
+    }
+#endif
+    while (true) {
+        const long long j0 = base - (long long)lane * kPer;
+        u64 s[kPer];
+#pragma unroll
+        for (int p = 0; p < kPer; ++p) {
+            if (lane >= LFD_LOOKBACK_LANES) s[p] = pack_state(kStAggregate, epoch, 0);      // lanes beyond the window: nothing to add
+            else s[p] = (j0 - p >= 0) ? state_load(state + (j0 - p)) : pack_state(kStPrefix, epoch, 0);   // virtual tile -1: prefix 0
+        }
+        for (;;) {
+            bool empty = false;
+#pragma unroll
+            for (int p = 0; p < kPer; ++p) empty = empty || state_status(s[p], epoch) == kStEmpty;
+            if (!__any(empty)) break;
+            if (++spins > LFD_SPIN_LIMIT) {          // never hang the GPU: report and bail out
+                if (lane == 0) atomicExch(L.status, LFD_LAUNCH_TIMEOUT);
+                return 0;
+            }
+            __builtin_amdgcn_s_sleep(LFD_POLL_SLEEP);
+#pragma unroll
+            for (int p = 0; p < kPer; ++p)
+                if (state_status(s[p], epoch) == kStEmpty) s[p] = state_load(state + (j0 - p));
+        }
+        // this lane's words up to and including its nearest prefix
+        u64 sum = 0;
+        bool has = false;
+#pragma unroll
+        for (int p = 0; p < kPer; ++p) {
+            if (!has) { sum += s[p] & kValueMask; has = state_status(s[p], epoch) == kStPrefix; }
+        }
+        const u64 with_prefix = __ballot(has);
+        if (with_prefix) {
+            const int first = __ffsll((long long)with_prefix) - 1;   // the lane that holds the nearest predecessor with a full prefix
+            excl += wave_sum_u64(lane <= first ? sum : 0ull);
             break;
         }
-        excl += wave_sum_u64(val);
-        base -= 64;
+        excl += wave_sum_u64(sum);
+        base -= LFD_LOOKBACK_LANES * kPer;
     }
     if (lane == 0) state_store(state + tile, pack_state(kStPrefix, epoch, excl + my_total));
     return excl;
