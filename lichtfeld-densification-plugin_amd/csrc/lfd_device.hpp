@@ -42,6 +42,12 @@
 #ifndef LFD_LOOKBACK_PER_LANE
 #define LFD_LOOKBACK_PER_LANE 1    // tile-state words a lane of the look-back wave reads per round trip (window = 64 x this)
 #endif
+#ifndef LFD_NT_LOADS
+#define LFD_NT_LOADS 0          // certainty / warp planes with the non-temporal hint: measured slower (0.312 against 0.304)
+#endif
+#ifndef LFD_NT_STORES
+#define LFD_NT_STORES 1         // dense kernel's records (written once, read by nobody on the device) with the non-temporal hint: 0.304 -> 0.300
+#endif
 #ifndef LFD_LOOKBACK_LANES
 #define LFD_LOOKBACK_LANES 16      // lanes of the look-back wave that read a tile-state word per round trip (the window).  The words are read past the caches: 16 per round measured 0.306 ms, 32 0.308, 64 0.311, 8 0.316; 128 ... 1024 (several words per lane) 0.32 ... 0.56
 #endif

@@ -55,11 +55,19 @@ typedef float lfd_f32x2 __attribute__((ext_vector_type(2)));
 template <class T>
 __device__ __forceinline__ const T LFD_GLOBAL_AS* lfd_global(const T* p) { return (const T LFD_GLOBAL_AS*)p; }
 __device__ __forceinline__ float4 load_f32x4(const float* p) {
+#if LFD_NT_LOADS
+    const lfd_f32x4 v = __builtin_nontemporal_load((const lfd_f32x4 LFD_GLOBAL_AS*)p);
+#else
     const lfd_f32x4 v = *(const lfd_f32x4 LFD_GLOBAL_AS*)p;
+#endif
     return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ float2 load_f32x2(const float* p) {
+#if LFD_NT_LOADS
+    const lfd_f32x2 v = __builtin_nontemporal_load((const lfd_f32x2 LFD_GLOBAL_AS*)p);
+#else
     const lfd_f32x2 v = *(const lfd_f32x2 LFD_GLOBAL_AS*)p;
+#endif
     return make_float2(v.x, v.y);
 }
 #pragma clang diagnostic pop
@@ -888,9 +896,18 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
                     p.a = sxyz[0]; p.b = sxyz[1]; p.c = sxyz[2];
                     c.a = rgb[u][0]; c.b = rgb[u][1]; c.c = rgb[u][2];
                     const unsigned o12 = (unsigned)lfd_slot_bytes12(i), o4 = (unsigned)i * 4u;
+#if LFD_NT_STORES
+                    // (component stores: the compiler merges them into one dwordx3 with the nt bit)
+                    float* fx = reinterpret_cast<float*>(gx + o12);
+                    float* fc = reinterpret_cast<float*>(gc + o12);
+                    __builtin_nontemporal_store(p.a, fx); __builtin_nontemporal_store(p.b, fx + 1); __builtin_nontemporal_store(p.c, fx + 2);
+                    __builtin_nontemporal_store(c.a, fc); __builtin_nontemporal_store(c.b, fc + 1); __builtin_nontemporal_store(c.c, fc + 2);
+                    __builtin_nontemporal_store(stage.err[sl], reinterpret_cast<float*>(ge + o4));
+#else
                     *reinterpret_cast<LfdF3*>(gx + o12) = p;
                     *reinterpret_cast<LfdF3*>(gc + o12) = c;
                     *reinterpret_cast<float*>(ge + o4) = stage.err[sl];
+#endif
                     if (L.cell) L.cell[base + i] = tile_cell0 + sl;
                     if (L.slot) L.slot[base + i] = stage.slot[sl];
                 }
