@@ -115,7 +115,7 @@ __device__ u64 lookback_exclusive(const LfdLaunch& L, unsigned tile, u64 my_tota
         bool waiting = lane == 0;
         if (waiting) w = state_load(state + base);
         while (__any(waiting && state_status(w, epoch) == kStEmpty)) {
-            if (++spins > LFD_SPIN_LIMIT) {
+            if (++spins > (LFD_SPIN_LIMIT >> 3)) {       // (~4 us per look: the same few seconds as the window's limit)
                 if (lane == 0) atomicExch(L.status, LFD_LAUNCH_TIMEOUT);
                 return 0;
             }
