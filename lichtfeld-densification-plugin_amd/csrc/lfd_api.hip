@@ -170,6 +170,29 @@ int default_axes(lfd_context* ctx, int W, int H, const float** ax, const float**
     return LFD_OK;
 }
 
+// dense mode's colour tables for the analytic A-grid (lfd_geometry.hpp): built on the host with the per-cell arithmetic itself,
+// once per (grid, match size)
+int colour_tables(lfd_context* ctx, int W, int H, int wm, int hm, const LfdColourCol** cols, const LfdColourRow** rows) {
+    const int key[4] = {W, H, wm, hm};
+    if (!ctx->colour_tab.ptr || std::memcmp(key, ctx->colour_key, sizeof(key)) != 0) {
+        static_assert(sizeof(LfdColourCol) == 16 && sizeof(LfdColourRow) == 16, "colour table entries are 16 bytes");
+        int rc = ensure(ctx, ctx->colour_tab, sizeof(LfdColourCol) * (size_t)W + sizeof(LfdColourRow) * (size_t)H);
+        if (rc != LFD_OK) return rc;
+        std::vector<unsigned char> host(sizeof(LfdColourCol) * (size_t)W + sizeof(LfdColourRow) * (size_t)H);
+        LfdColourCol* hc = reinterpret_cast<LfdColourCol*>(host.data());
+        LfdColourRow* hr = reinterpret_cast<LfdColourRow*>(host.data() + sizeof(LfdColourCol) * (size_t)W);
+        const LfdAxis ax = lfd_make_axis(W), ay = lfd_make_axis(H);
+        for (int x = 0; x < W; ++x) hc[x] = lfd_colour_col(lfd_match_px(lfd_axis_value(ax, x), (float)(wm - 1)), wm);
+        for (int y = 0; y < H; ++y) hr[y] = lfd_colour_row(lfd_match_px(lfd_axis_value(ay, y), (float)(hm - 1)), wm, hm);
+        LFD_HIP(ctx, hipMemcpyAsync(ctx->colour_tab.ptr, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
+        LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(ctx->colour_key, key, sizeof(key));
+    }
+    *cols = static_cast<const LfdColourCol*>(ctx->colour_tab.ptr);
+    *rows = reinterpret_cast<const LfdColourRow*>(static_cast<const unsigned char*>(ctx->colour_tab.ptr) + sizeof(LfdColourCol) * (size_t)W);
+    return LFD_OK;
+}
+
 }  // namespace
 
 void lfd_fill_kernel_params(const lfd_batch* b, const lfd_params* p, LfdKernelParams& kp) {
@@ -333,7 +356,7 @@ void lfd_destroy(lfd_context* ctx) {
     if (ctx->is_host) { delete ctx; return; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->mt, &ctx->mt_batch, &ctx->sel_scratch, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab})
+    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->colour_tab, &ctx->mt, &ctx->mt_batch, &ctx->sel_scratch, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
@@ -456,6 +479,10 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
 #else
     const bool exact_colour = (params->flags & LFD_FLAG_EXACT_COLOUR) != 0;
 #endif
+    if (!exact_colour && L.axis_identity && batch->warp_channels == 2) {      // the f32 blend reads its positions and weights from tables
+        rc = colour_tables(ctx, batch->W, batch->H, batch->w_match, batch->h_match, &L.colour_cols, &L.colour_rows);
+        if (rc != LFD_OK) return rc;
+    }
     if (exact_colour)
         hipLaunchKernelGGL(lfd_dense_exact_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), extra_lds, ctx->stream, L);
     else

@@ -43,6 +43,9 @@ struct lfd_context {
     // default A-grid axes
     DeviceBuffer axes;
     int axes_w = 0, axes_h = 0;
+    // dense mode's colour tables of the analytic A-grid (one entry per grid column / row), for the last grid + match size
+    DeviceBuffer colour_tab;
+    int colour_key[4] = {0, 0, 0, 0};
     // per-pair constants of the current batch (valid while the descriptor tables are unchanged)
     DeviceBuffer consts;
     bool consts_valid = false;

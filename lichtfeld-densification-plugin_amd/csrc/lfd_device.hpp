@@ -116,6 +116,8 @@ struct LfdLaunch {              // kernel argument, passed by value
     unsigned int pad0;
     unsigned int* status;         // 0 = ok, LFD_LAUNCH_TIMEOUT if a look-back spin gave up
     unsigned int* seg_ready;      // == epoch once the workgroup of tile 0 has zeroed seg_counts
+    const LfdColourCol* colour_cols;    // dense mode, analytic A-grid, two-channel warps: [W] / [H] colour tables (lfd_geometry.hpp), else null
+    const LfdColourRow* colour_rows;
     unsigned long long* phase_stamps;   // profiling builds (-DLFD_DENSE_TIMING) with LFD_DENSE_TIMING set in the environment: [n_tiles][16] clock stamps, else null
 };
 

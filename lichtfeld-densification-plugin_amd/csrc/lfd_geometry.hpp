@@ -563,15 +563,11 @@ LFD_HD void lfd_bilinear_rgb(const uint8_t* img, int wi, int hi, float xa_px, fl
 // so the result is within 4 x 255 x 2^-24 of upstream's blend before the division, i.e. within 2.5e-7 of upstream's
 // rgb - the parity tests allow 1/(255*4) = 9.8e-4 and the writers quantise to 1/255.  A clamped column (x1 == x0)
 // reads one texel with both weights upstream; here the weights are folded instead (the sum is the same expression).
-LFD_HD void lfd_blend4_f32(const float* a, const float* b, const float* c, const float* d, int wi, int hi, float xa_px,
-                           float ya_px, float* rgb) {
-    const float x0 = fminf(fmaxf(floorf(xa_px), 0.0f), (float)(wi - 1));
-    const float y0 = fminf(fmaxf(floorf(ya_px), 0.0f), (float)(hi - 1));
-    const float x1 = fminf(x0 + 1.0f, (float)(wi - 1));
-    const float y1 = fminf(y0 + 1.0f, (float)(hi - 1));
-    const float ax = x1 - xa_px, bx = xa_px - x0, ay = y1 - ya_px, by = ya_px - y0;
+// the blend itself, from the four weights' factors (ax = x1 - x, bx = x - x0, ay = y1 - y, by = y - y0; `clamped`: x1 == x0)
+LFD_HD void lfd_blend4_weights_f32(const float* a, const float* b, const float* c, const float* d, float ax, float bx, float ay, float by,
+                                   bool clamped, float* rgb) {
     float wa = ax * ay, wb = bx * ay, wc = ax * by, wd = bx * by;
-    if (x1 == x0) {
+    if (clamped) {
         wa = wa + wb; wb = 0.0f;
         wc = wc + wd; wd = 0.0f;
     }
@@ -579,6 +575,37 @@ LFD_HD void lfd_blend4_f32(const float* a, const float* b, const float* c, const
         const float s = fmaf(d[ch], wd, fmaf(c[ch], wc, fmaf(b[ch], wb, a[ch] * wa)));
         rgb[ch] = s * 0.00392156862745098f;       // RN(1/255): one more ulp, instead of the ~10-instruction IEEE division
     }
+}
+
+LFD_HD void lfd_blend4_f32(const float* a, const float* b, const float* c, const float* d, int wi, int hi, float xa_px,
+                           float ya_px, float* rgb) {
+    const float x0 = fminf(fmaxf(floorf(xa_px), 0.0f), (float)(wi - 1));
+    const float y0 = fminf(fmaxf(floorf(ya_px), 0.0f), (float)(hi - 1));
+    const float x1 = fminf(x0 + 1.0f, (float)(wi - 1));
+    const float y1 = fminf(y0 + 1.0f, (float)(hi - 1));
+    lfd_blend4_weights_f32(a, b, c, d, x1 - xa_px, xa_px - x0, y1 - ya_px, ya_px - y0, x1 == x0, rgb);
+}
+
+// Dense mode with the matcher's own A-grid: the reference position of a cell - and with it the first tap's offset and the
+// weights' factors - depends on the cell's column and row only.  One entry per column and per row, computed once per grid size
+// on the host with the arithmetic above (lfd_api.hip), replaces ~60 vector instructions per survivor by two 16-byte loads.
+struct LfdColourCol { uint32_t off; float ax, bx; uint32_t clamped; };      // off = 3 * x0
+struct LfdColourRow { uint32_t off0, off1; float ay, by; };                 // off = 3 * w_match * y0, 3 * w_match * y1
+LFD_HD LfdColourCol lfd_colour_col(float xa_px, int wi) {
+    const float x0 = fminf(fmaxf(floorf(xa_px), 0.0f), (float)(wi - 1));
+    const float x1 = fminf(x0 + 1.0f, (float)(wi - 1));
+    LfdColourCol c;
+    c.off = 3u * (uint32_t)(int)x0; c.ax = x1 - xa_px; c.bx = xa_px - x0; c.clamped = (x1 == x0) ? 1u : 0u;
+    return c;
+}
+LFD_HD LfdColourRow lfd_colour_row(float ya_px, int wi, int hi) {
+    const float y0 = fminf(fmaxf(floorf(ya_px), 0.0f), (float)(hi - 1));
+    const int iy0 = (int)y0;
+    int iy1 = iy0 + 1; if (iy1 > hi - 1) iy1 = hi - 1; if (iy1 < 0) iy1 = 0;
+    const float y1 = fminf(y0 + 1.0f, (float)(hi - 1));
+    LfdColourRow r;
+    r.off0 = 3u * (uint32_t)wi * (uint32_t)iy0; r.off1 = 3u * (uint32_t)wi * (uint32_t)iy1; r.ay = y1 - ya_px; r.by = ya_px - y0;
+    return r;
 }
 
 // byte-addressed form (CPU twin, indexed kernels): the taps upstream reads, blended by lfd_blend4_f32
@@ -650,6 +677,29 @@ __device__ __forceinline__ void lfd_bilinear_eval(LfdTapRows t, unsigned sh0, un
         const double s = fma(pd, wd, fma(pc, wc, fma(pb, wb, pa * wa)));
         rgb[c] = (float)lfd_div_by_recip(s, 255.0, 1.0 / 255.0);   // == s / 255.0, correctly rounded
     }
+}
+
+// the same from a column entry and a row entry of the colour tables: issue half ...
+__device__ __forceinline__ LfdTapRows lfd_bilinear_fetch_tab(const uint8_t* img, unsigned n_bytes, const LfdColourCol& cc, const LfdColourRow& cr,
+                                                             unsigned& sh0, unsigned& sh1) {
+    const unsigned last = n_bytes - 8u;
+    const unsigned o0 = cr.off0 + cc.off, o1 = cr.off1 + cc.off;
+    const unsigned l0 = o0 < last ? o0 : last, l1 = o1 < last ? o1 : last;
+    sh0 = (o0 - l0) * 8u; sh1 = (o1 - l1) * 8u;
+    LfdTapRows t;
+    t.r0 = lfd_load_u64_unaligned(img + l0);
+    t.r1 = lfd_load_u64_unaligned(img + l1);
+    return t;
+}
+// ... and evaluate half (bit-identical to lfd_bilinear_eval_f32 at the same position)
+__device__ __forceinline__ void lfd_bilinear_eval_tab(LfdTapRows t, unsigned sh0, unsigned sh1, const LfdColourCol& cc, const LfdColourRow& cr, float* rgb) {
+    const unsigned long long r0 = t.r0 >> sh0, r1 = t.r1 >> sh1;
+    const unsigned lo0 = (unsigned)r0, hi0 = (unsigned)(r0 >> 32), lo1 = (unsigned)r1, hi1 = (unsigned)(r1 >> 32);
+    const float a[3] = {(float)(lo0 & 0xffu), (float)((lo0 >> 8) & 0xffu), (float)((lo0 >> 16) & 0xffu)};
+    const float b[3] = {(float)(lo0 >> 24), (float)(hi0 & 0xffu), (float)((hi0 >> 8) & 0xffu)};
+    const float c[3] = {(float)(lo1 & 0xffu), (float)((lo1 >> 8) & 0xffu), (float)((lo1 >> 16) & 0xffu)};
+    const float d[3] = {(float)(lo1 >> 24), (float)(hi1 & 0xffu), (float)((hi1 >> 8) & 0xffu)};
+    lfd_blend4_weights_f32(a, b, c, d, cc.ax, cc.bx, cr.ay, cr.by, cc.clamped != 0u, rgb);
 }
 
 // lfd_blend4_f32 on the two 8-byte windows of lfd_bilinear_fetch: the taps come straight out of the windows with

@@ -50,6 +50,7 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 #define LFD_GLOBAL_AS __attribute__((address_space(1)))
 typedef float lfd_f32x4 __attribute__((ext_vector_type(4)));
 typedef float lfd_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned lfd_u32x4 __attribute__((ext_vector_type(4)));
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wold-style-cast"
 template <class T>
@@ -825,6 +826,38 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
 #if !defined(LFD_ABLATE_STORES)
             const uint8_t* image = S.ref.image;
             const int n_loc = (int)block_total;
+            if (!kExactColour && L.colour_cols) {
+                // analytic A-grid, f32 blend: a cell's reference position, first-tap offset and weight factors come from the
+                // column / row tables (two 16-byte loads instead of ~60 instructions of axis, floor, clamp and offset arithmetic)
+                const unsigned n_bytes = __umul24((unsigned)L.w_match, (unsigned)L.h_match) * 3u;
+#pragma unroll
+                for (int u0 = 0; u0 < kCopyRecords; u0 += LFD_COPY_UNROLL) {
+                    LfdColourCol cc[LFD_COPY_UNROLL];
+                    LfdColourRow cr[LFD_COPY_UNROLL];
+                    LfdTapRows taps[LFD_COPY_UNROLL];
+                    unsigned sh0[LFD_COPY_UNROLL], sh1[LFD_COPY_UNROLL];
+                    if (ctid + u0 * kCopyThreads < n_loc) {       // wave-uniform except in the tile's last partial wave
+#pragma unroll
+                        for (int v = 0; v < LFD_COPY_UNROLL; ++v) {
+                            if (u0 + v >= kCopyRecords) break;
+                            const int i = ctid + (u0 + v) * kCopyThreads;
+                            const int sl = (int)stage.order[i < n_loc ? i : n_loc - 1];
+                            int dy, x;
+                            lfd_divmod_local(tile_x0 + sl, L.W, L.inv_w, dy, x);
+                            const lfd_u32x4 c4 = *reinterpret_cast<const lfd_u32x4 LFD_GLOBAL_AS*>(lfd_global(L.colour_cols) + x);
+                            const lfd_u32x4 r4 = *reinterpret_cast<const lfd_u32x4 LFD_GLOBAL_AS*>(lfd_global(L.colour_rows) + (tile_y0 + dy));
+                            cc[v].off = c4.x; cc[v].ax = __uint_as_float(c4.y); cc[v].bx = __uint_as_float(c4.z); cc[v].clamped = c4.w;
+                            cr[v].off0 = r4.x; cr[v].off1 = r4.y; cr[v].ay = __uint_as_float(r4.z); cr[v].by = __uint_as_float(r4.w);
+                            taps[v] = lfd_bilinear_fetch_tab(image, n_bytes, cc[v], cr[v], sh0[v], sh1[v]);
+                        }
+#pragma unroll
+                        for (int v = 0; v < LFD_COPY_UNROLL; ++v) {
+                            if (u0 + v >= kCopyRecords) break;
+                            lfd_bilinear_eval_tab(taps[v], sh0[v], sh1[v], cc[v], cr[v], rgb[u0 + v]);
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int u0 = 0; u0 < kCopyRecords; u0 += LFD_COPY_UNROLL) {
                 // LFD_COPY_UNROLL records per step: their image rows are in flight before the first colour is evaluated
@@ -866,6 +899,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
 #endif
                     }
                 }
+            }
             }
 #endif
         }

@@ -156,6 +156,25 @@ def test_exact_colour_flag_is_bit_identical_and_default_is_within_tolerance(dev)
     dens.close()
 
 
+def test_colour_tables_equal_the_per_cell_arithmetic(dev):
+    """Dense mode on the matcher's own A-grid reads a cell's reference position, tap offset and weight factors from per-column /
+    per-row tables built on the host (lfd_api.hip: colour_tables); handing the SAME axis values over explicitly switches the
+    tables off.  Both launches return the same bits."""
+    spec = dict(SHAPES["high_k3_patch"], refs=(10,), patch=None)       # 960^2 grid over 640-px images: non-trivial positions
+    H, W, wm, hm = spec["grid"]
+    cams, srefs, refs = _scene(spec, dev)
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    params = hb.make_params(lfd.DensePipelineConfig(output_path=""))
+    tab = dens.triangulate_dense(hb.PreparedBatch(refs, wm, hm), params)
+    axes = (torch.from_numpy(orc.identity_axis_scalar(W)).to(dev), torch.from_numpy(orc.identity_axis_scalar(H)).to(dev))
+    plain = dens.triangulate_dense(hb.PreparedBatch(refs, wm, hm, axes=axes), params)
+    assert tab.count == plain.count and tab.count > 100000
+    assert torch.equal(tab.cell, plain.cell) and torch.equal(tab.xyz, plain.xyz) and torch.equal(tab.err, plain.err)
+    assert torch.equal(tab.rgb, plain.rgb)
+    dens.close()
+
+
 def test_fundamental_read_back_override_is_bit_equal_and_own_f_is_bounded(dev, g1):
     """Row F5: the F the kernels use, read back from the device.  With lfd_batch.fundamental it IS upstream's
     fundamental_from_world2cam result (golden g1, bit for bit); without it the library's closed-form-K^-1 F agrees to
