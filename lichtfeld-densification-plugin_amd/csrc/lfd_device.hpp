@@ -42,6 +42,9 @@
 #ifndef LFD_LOOKBACK_PER_LANE
 #define LFD_LOOKBACK_PER_LANE 1    // tile-state words a lane of the look-back wave reads per round trip (window = 64 x this)
 #endif
+#ifndef LFD_STAGGER_UNITS
+#define LFD_STAGGER_UNITS 48    // dense kernel: start-up stagger per resident-workgroup slot of a CU (x64 cycles; 0 = off)
+#endif
 #ifndef LFD_NT_LOADS
 #define LFD_NT_LOADS 0          // certainty / warp planes with the non-temporal hint: measured slower (0.312 against 0.304)
 #endif

@@ -530,6 +530,16 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
     // ticket is known, together with the ticket atomic, instead of after it.  If the ticket belongs to another reference
     // the block is fetched again the plain way: results never depend on the guess.  (Requesting the certainty planes of
     // tile b the same way does not pay: measured, only 7 % of the workgroups draw exactly ticket b.)
+#if LFD_STAGGER_UNITS > 0
+    // The workgroups that are resident when the launch starts all begin at once and would run through their phases in step -
+    // every tile fetching, then every tile computing (the first generation of tiles lives 48 us, the later ones 33).  The k-th
+    // workgroup a CU receives waits k x ~1.5 us before it draws its ticket (a heuristic on the dispatch order: harmless where it
+    // does not hold).  Measured 0.2966 -> 0.292 ms (profiles/r2/ablation.txt).
+    if (blockIdx.x < 7u * 256u) {
+        const unsigned slot = blockIdx.x >> 8;
+        for (unsigned i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(LFD_STAGGER_UNITS);
+    }
+#endif
     const unsigned tile_guess = blockIdx.x;
     const int r_guess = __builtin_amdgcn_readfirstlane((int)(tile_guess / (unsigned)L.tiles_per_ref));
 #if LFD_FRONT_PRIO > 0
