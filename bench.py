@@ -525,13 +525,13 @@ def main():
         # the same time priced against the byte count of a kernel that reads the warps of ALL k neighbours coalesced
         # (12k + 3 + 28 s per cell) - what lfd_dense_kernel physically does for references with at most LFD_DENSE_ALL_WARPS (2) neighbours
         line["roofline"]["achieved_all_warps_bytes"] = cells * (12 * args.k + 3 + 28 * s_frac) / (kernel_ms * 1e-3) / 1e9
-        if not args.light:
+        if not args.light and world == 1:
             line["roofline"]["device_copy_GBps"] = device_copy_bandwidth(dev)      # what a plain device-to-device copy reaches on this box
         line["roofline"]["valu_busy_frac"] = valu_busy_frac(args)     # the f64 geometry makes the kernel vector-ALU-bound, not HBM-bound
         line["roofline"]["traffic_over_algorithmic"] = (line["roofline"]["traffic"] / algo_bytes) if line["roofline"]["traffic"] else None
         if allgather is not None:
             line["exchange"] = allgather
-        if not args.light:
+        if not args.light and world == 1:     # the side legs (and the CPU baseline) belong to the N = 1 line; at N > 1 the other ranks are waiting
             line["with_d2h"] = d2h_inclusive_rate(dens, batch, params, out, dev)
             line["sampled_mode"] = sampled_mode_rate(args, dens, refs, dims, cfg)
             line["secondary_kernels"] = secondary_kernels(args, dens, batch, refs, dims, cfg, res)
