@@ -235,6 +235,8 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
     L.mask_sx = (float)b->w_match / (float)b->W;
     L.mask_sy = (float)b->h_match / (float)b->H;
     L.inv_w = 1.0f / (float)b->W;
+    L.w_log2 = -1;
+    if ((b->W & (b->W - 1)) == 0) { int l = 0; while ((1 << l) < b->W) ++l; L.w_log2 = l; }
     lfd_fill_kernel_params(b, p, L.kp);
     // per-pair constants: (re)derive when the batch tables, the cameras or the match size changed
     const size_t ref_bytes = ((size_t)b->n_refs * sizeof(LfdRefConst) + 15) & ~size_t(15);

@@ -97,7 +97,8 @@ struct LfdLaunch {              // kernel argument, passed by value
     float inv_w;                // 1.0f / W (cell -> row estimate)
     int32_t axis_identity;      // 1: axis_x/axis_y hold lfd_identity_axis() values, which the kernels may compute (ax, ay) instead of loading
     LfdAxis ax, ay;             // the analytic A-grid axes (valid when axis_identity)
-    int32_t pad1[2];
+    int32_t w_log2;             // log2(W) when W is a power of two (cell -> row / column by shift and mask), else -1
+    int32_t pad1;
     LfdKernelParams kp;
     // outputs
     float* xyz;

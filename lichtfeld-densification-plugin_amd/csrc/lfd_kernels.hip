@@ -252,7 +252,8 @@ __device__ __forceinline__ void lfd_divmod(int cell, int W, float inv_w, int& y,
 
 // the same for a small offset from a known (row, column): local = column0 + offset < 2^22, so the float estimate
 // is within one of the quotient and a single correction each way is enough
-__device__ __forceinline__ void lfd_divmod_local(int local, int W, float inv_w, int& dy, int& x) {
+__device__ __forceinline__ void lfd_divmod_local(int local, int W, float inv_w, int w_log2, int& dy, int& x) {
+    if (w_log2 >= 0) { dy = local >> w_log2; x = local & (W - 1); return; }     // power-of-two rows (uniform branch): two instructions
     int q = (int)((float)local * inv_w);
     int r = local - __mul24(q, W);      // q <= 2^22 / W, W < 2^16: the 24-bit multiply is exact (and full rate; v_mul_lo_u32 is quarter rate)
     if (r < 0) { --q; r += W; }
@@ -660,7 +661,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
             }
         } else if ((L.W & 3) == 0 && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW) {      // masks present
             int dy, x0;
-            lfd_divmod_local(tile_x0 + tid * kCpt, L.W, L.inv_w, dy, x0);
+            lfd_divmod_local(tile_x0 + tid * kCpt, L.W, L.inv_w, L.w_log2, dy, x0);
             float b4[4];
             cells4_best_masked(L, S, cell0, tile_y0 + dy, x0, b4, bj);
         } else {
@@ -681,7 +682,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
             float xa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ya = 0.0f;
             if (L.warp_channels != 4) {
                 int dy, x0;
-                lfd_divmod_local(tile_x0 + tid * kCpt, L.W, L.inv_w, dy, x0);
+                lfd_divmod_local(tile_x0 + tid * kCpt, L.W, L.inv_w, L.w_log2, dy, x0);
                 const int y0 = tile_y0 + dy;
                 if (L.axis_identity) {     // the matcher's linspace, computed instead of loaded
 #pragma unroll
@@ -853,7 +854,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
                             const int i = ctid + (u0 + v) * kCopyThreads;
                             const int sl = (int)stage.order[i < n_loc ? i : n_loc - 1];
                             int dy, x;
-                            lfd_divmod_local(tile_x0 + sl, L.W, L.inv_w, dy, x);
+                            lfd_divmod_local(tile_x0 + sl, L.W, L.inv_w, L.w_log2, dy, x);
                             const lfd_u32x4 c4 = *reinterpret_cast<const lfd_u32x4 LFD_GLOBAL_AS*>(lfd_global(L.colour_cols) + x);
                             const lfd_u32x4 r4 = *reinterpret_cast<const lfd_u32x4 LFD_GLOBAL_AS*>(lfd_global(L.colour_rows) + (tile_y0 + dy));
                             cc[v].off = c4.x; cc[v].ax = __uint_as_float(c4.y); cc[v].bx = __uint_as_float(c4.z); cc[v].clamped = c4.w;
@@ -889,7 +890,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
                                 xan = w2.x; yan = w2.y;
                             } else {
                                 int dy, x;
-                                lfd_divmod_local(tile_x0 + sl, L.W, L.inv_w, dy, x);
+                                lfd_divmod_local(tile_x0 + sl, L.W, L.inv_w, L.w_log2, dy, x);
                                 const int y = tile_y0 + dy;
                                 if (L.axis_identity) { xan = lfd_axis_value(L.ax, x); yan = lfd_axis_value(L.ay, y); }
                                 else { xan = lfd_global(L.axis_x)[x]; yan = lfd_global(L.axis_y)[y]; }
