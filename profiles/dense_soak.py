@@ -1,0 +1,38 @@
+"""Soak of the dense kernel's ordered retirement: many back-to-back launches on the bench workload and on a ragged small one, every launch's
+survivor count, reference offsets and a checksum of the records compared with the first launch's.  python profiles/dense_soak.py [launches]"""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import lichtfeld_densification_plugin_amd as lfd
+from lichtfeld_densification_plugin_amd import synthetic
+from lichtfeld_densification_plugin_amd.core import hip_backend as hb
+
+n_launch = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+dev = torch.device("cuda:0")
+for (n_refs, H, W, k) in ((64, 512, 512, 3), (7, 90, 126, 2), (24, 320, 320, 4)):
+    cams = synthetic.ring_cameras(64, seed=0)
+    refs = []
+    for r in range(n_refs):
+        nb = synthetic.ring_neighbours(64, r, k)
+        s = synthetic.synth_reference(cams, r, nb, H, W, W, H, noise_px=0.5, outlier_frac=0.05, channels=2, seed=r, device=dev)
+        refs.append(hb.ReferenceInputs(ref_cam=r, nbr_cams=nb, cert=[s.cert[j] for j in range(k)], warp=[s.warp[j] for j in range(k)], image=s.image))
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    batch = hb.PreparedBatch(refs, W, H)
+    params = hb.make_params(lfd.DensePipelineConfig(output_path=""))
+    out = hb.OutputBuffers(n_refs * H * W, n_refs, k, dev, with_cell=True)
+    first = None
+    t0 = time.time()
+    for i in range(n_launch):
+        dens.launch_dense(batch, params, out)
+        if i % 50 == 0 or i == n_launch - 1:
+            dens.check_launches()
+            res = out.collect()
+            sig = (res.count, tuple(int(v) for v in res.ref_offsets), float(res.xyz.double().sum().item()), int(res.cell.long().sum().item()))
+            if first is None:
+                first = sig
+            assert sig == first, (i, sig[:1], first[:1])
+    torch.cuda.synchronize()
+    print(f"{n_refs} refs x {k} nbrs x {H}x{W}: {n_launch} launches, {first[0]} survivors each time, {time.time() - t0:.1f} s")
+    dens.close()
