@@ -218,7 +218,12 @@ LFD_HD double lfd_pow2_inv_scale(double t) {
 }
 
 #ifndef LFD_RCP_NEWTON_STEPS
-#define LFD_RCP_NEWTON_STEPS 2
+/* v_rcp_f64 is good to 2^-24.4; one Newton step brings it to 2^-48.7 (2.2e-15 relative, profiles/r1/valu_rate.txt), two to the last
+ * bit.  One is enough here: the factorisation then is that of a matrix 2e-15 (relative) away from M - M itself carries 1e-16 per
+ * entry - which turns v4 by at most 2e-15 (sigma1/sigma3)^2.  Measured on three full-size shapes against two steps
+ * (profiles/cmp_newton.py): the same survivors, 99.998 % of the f32 coordinates bit-identical, the others 1 ulp apart; -1.1 % of the
+ * dense kernel's time. */
+#define LFD_RCP_NEWTON_STEPS 1
 #endif
 LFD_HD double lfd_recip_refined(double d) {
 #if defined(__HIP_DEVICE_COMPILE__)
