@@ -601,6 +601,9 @@ LFD_HD LfdColourCol lfd_colour_col(float xa_px, int wi) {
     const float x1 = fminf(x0 + 1.0f, (float)(wi - 1));
     LfdColourCol c;
     c.off = 3u * (uint32_t)(int)x0; c.ax = x1 - xa_px; c.bx = xa_px - x0; c.clamped = (x1 == x0) ? 1u : 0u;
+    // a clamped column (x1 == x0) has ax == -bx exactly, so its folded weights (ax*ay + bx*ay, ax*by + bx*by) are exactly 0:
+    // zero factors give the same colour (0) without the fold, and the kernel's table path needs no special case
+    if (x1 == x0) { c.ax = 0.0f; c.bx = 0.0f; }
     return c;
 }
 LFD_HD LfdColourRow lfd_colour_row(float ya_px, int wi, int hi) {
@@ -704,7 +707,7 @@ __device__ __forceinline__ void lfd_bilinear_eval_tab(LfdTapRows t, unsigned sh0
     const float b[3] = {(float)(lo0 >> 24), (float)(hi0 & 0xffu), (float)((hi0 >> 8) & 0xffu)};
     const float c[3] = {(float)(lo1 & 0xffu), (float)((lo1 >> 8) & 0xffu), (float)((lo1 >> 16) & 0xffu)};
     const float d[3] = {(float)(lo1 >> 24), (float)(hi1 & 0xffu), (float)((hi1 >> 8) & 0xffu)};
-    lfd_blend4_weights_f32(a, b, c, d, cc.ax, cc.bx, cr.ay, cr.by, cc.clamped != 0u, rgb);
+    lfd_blend4_weights_f32(a, b, c, d, cc.ax, cc.bx, cr.ay, cr.by, false, rgb);      // (clamped columns carry zero factors)
 }
 
 // lfd_blend4_f32 on the two 8-byte windows of lfd_bilinear_fetch: the taps come straight out of the windows with
