@@ -109,9 +109,19 @@ def build_workload(args, rank, world, dev):
                                       outlier_frac=args.outliers, channels=2, seed=1000 + gi, cert_mode="smooth",
                                       device=dev)
         srefs.append(s)
-        refs.append(hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=[s.cert[j] for j in range(args.k)],
-                                       warp=[s.warp[j] for j in range(args.k)], image=s.image))
+        pad = int(os.environ.get("LFD_BENCH_PLANE_PAD", "0"))       # experiment: every plane in its own allocation, `pad` bytes apart
+        if pad > 0:
+            certs, warps = [], []
+            for j in range(args.k):
+                _pads.append(torch.empty(pad, dtype=torch.uint8, device=dev)); certs.append(s.cert[j].clone())
+                _pads.append(torch.empty(pad, dtype=torch.uint8, device=dev)); warps.append(s.warp[j].clone())
+        else:
+            certs, warps = [s.cert[j] for j in range(args.k)], [s.warp[j] for j in range(args.k)]
+        refs.append(hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=certs, warp=warps, image=s.image))
     return cams, refs, srefs, (H, W, w_lr, h_lr), mine
+
+
+_pads = []
 
 
 def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16):
