@@ -48,8 +48,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.m
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--refs", type=int, default=64, help="reference views resident per GPU (per launch)")
     ap.add_argument("--k", type=int, default=3, help="neighbours per reference (GUI default 3)")
     ap.add_argument("--preset", default="fast", choices=sorted(synthetic.ROMA_PRESETS))
