@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--outliers", type=float, default=0.05)
     ap.add_argument("--cpu-sample-refs", type=int, default=24,
                     help="references of the workload timed on the CPU twin (0 = skip the cpu_baseline leg)")
-    ap.add_argument("--spinup-s", type=float, default=0.25, help="untimed spin-up (launch + sync in a loop) before the warm-up steps")
+    ap.add_argument("--spinup-s", type=float, default=0.25, help="untimed spin-up (bursts of 32 back-to-back launches) before the warm-up steps")
     ap.add_argument("--light", action="store_true", help="headline only: skip the secondary legs (profiling passes)")
     ap.add_argument("--parity-refs", type=int, default=2, help="references of the workload checked cell by cell against the oracle (0 = skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -447,8 +447,9 @@ def main():
 
     # untimed spin-up (clocks, first-touch of the output pages), then the W warm-up steps
     t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < args.spinup_s:
-        dens.launch_dense(batch, params, out)
+    while time.perf_counter() - t_spin < args.spinup_s:       # back-to-back like the timed region, so that the power management has settled
+        for _ in range(32):
+            dens.launch_dense(batch, params, out)
         torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         dens.launch_dense(batch, params, out)
@@ -471,6 +472,7 @@ def main():
     kernel_pct = {"p50": float(np.percentile(per_launch, 50)), "p95": float(np.percentile(per_launch, 95)),
                   "min": float(np.min(per_launch)), "max": float(np.max(per_launch))}
     if os.environ.get("LFD_BENCH_DEBUG"):
+        print(f"[rank {rank}] per-launch us: " + " ".join(f"{x * 1e3:.0f}" for x in per_launch), file=sys.stderr)
         print(f"[rank {rank}] per-launch ms: min {min(per_launch):.3f} max {max(per_launch):.3f} mean {kernel_ms:.3f}; "
               f"wall {elapsed * 1e3:.2f} ms for {args.steps} steps", file=sys.stderr)
     dens.check_launches()
