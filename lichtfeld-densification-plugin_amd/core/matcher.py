@@ -75,6 +75,24 @@ def _model_image(im):
     return im
 
 
+class _KeyedDescriptor(torch.nn.Module):
+    """Stands in for RoMaV2's child module ``f`` (the DINOv3 ``Descriptor``, RoMaV2/src/romav2/romav2.py:101,177) while a keyed
+    call runs: ``forward`` answers from the run's FeatureCache under (camera key, input height, input width) - the size is
+    part of the key so that a matcher re-used across settings never serves features of another resolution - and calls the
+    wrapped module on a miss.  ``key`` None: plain call."""
+
+    def __init__(self, inner: torch.nn.Module, cache):
+        super().__init__()
+        self.inner = inner
+        self.cache = cache
+        self.key = None
+
+    def forward(self, img):
+        if self.key is None or self.cache is None:
+            return self.inner(img)
+        return self.cache.get_or_compute(self.key, lambda: self.inner(img), variant=(int(img.shape[-2]), int(img.shape[-1])))
+
+
 class RomaMatcher:
     """Dense matcher with the reference image's features cached across its neighbours."""
 
@@ -109,18 +127,12 @@ class RomaMatcher:
         return self._axes[key]
 
     def set_feature_cache(self, cache) -> None:
-        """A core.scheduler.FeatureCache: backbone features (``model.f`` of the low-resolution image) are then computed once per
-        camera key instead of once per (reference, neighbour) pair.  The vendored model is not modified: its ``f`` is wrapped
-        for the duration of a keyed call."""
+        """A core.scheduler.FeatureCache (or None to switch sharing off): backbone features (``model.f`` of the low-resolution
+        image) are then computed once per camera key instead of once per (reference, neighbour) pair.  The vendored model is
+        not modified: for the duration of a keyed call its child module ``f`` (RoMaV2/src/romav2/romav2.py:101) is replaced by
+        a ``_KeyedDescriptor`` - an nn.Module, which is what ``nn.Module.__setattr__`` accepts for a registered child - and
+        restored afterwards."""
         self._feature_cache = cache
-
-    def _keyed_f(self, key):
-        """``model.f`` memoised under ``key`` (None: plain)."""
-        plain = self._plain_f
-        cache = getattr(self, "_feature_cache", None)
-        if key is None or cache is None:
-            return plain
-        return lambda img: cache.get_or_compute(key, lambda: plain(img))
 
     @torch.inference_mode()
     def match_grids_batch(self, imA, imB_list: Sequence, keys=None) -> List[Tuple[torch.Tensor, torch.Tensor]]:
@@ -131,32 +143,43 @@ class RomaMatcher:
             return []
         torch.set_float32_matmul_precision("highest")
         model = self.model
-        if not hasattr(self, "_plain_f"):
-            self._plain_f = model.f
-        ref_key, nbr_keys = keys if keys is not None else (None, [None] * len(imB_list))
+        cache = getattr(self, "_feature_cache", None)
+        ref_key, nbr_keys = (None, [None] * len(imB_list))
+        if keys is not None and cache is not None:
+            ref_key, nbr_keys = keys[0], list(keys[1])
+            if len(nbr_keys) != len(imB_list):
+                raise ValueError("keys: one neighbour key per neighbour image")
         img_a = model._load_image(_model_image(imA))
         kw = dict(mode="bicubic", align_corners=False, antialias=True)
         a_lr = F.interpolate(img_a, size=(int(model.H_lr), int(model.W_lr)), **kw)
         a_hr = None
         if model.H_hr is not None and model.W_hr is not None:
             a_hr = F.interpolate(img_a, size=(int(model.H_hr), int(model.W_hr)), **kw)
-        feats_a = self._keyed_f(ref_key)(a_lr)     # DINOv3 features of the reference: once per reference (once per RUN with keys)
+        plain_f = model.f
+        keyed = _KeyedDescriptor(plain_f, cache) if cache is not None and keys is not None else None
         out: List[Tuple[torch.Tensor, torch.Tensor]] = []
-        for im_b, key_b in zip(imB_list, nbr_keys):
-            model.f = self._keyed_f(key_b)         # the neighbour's features: looked up instead of recomputed when seen before
-            try:
+        if keyed is not None:
+            model.f = keyed            # the model's own calls of self.f (romav2.py:177) go through the cache while this call lasts
+        try:
+            if keyed is not None:
+                keyed.key = ref_key
+            feats_a = model.f(a_lr)    # DINOv3 features of the reference: once per reference (once per RUN with keys)
+            for im_b, key_b in zip(imB_list, nbr_keys):
+                if keyed is not None:
+                    keyed.key = key_b  # the neighbour's features: looked up instead of recomputed when seen before
                 pred = model.match_from_features(f_list_A=feats_a, img_A_lr=a_lr, imB=_model_image(im_b), img_A_hr=a_hr)
-            finally:
-                model.f = self._plain_f
-            warp_ab = pred["warp_AB"][0]
-            cert = pred["overlap_AB"][0].squeeze(-1).contiguous()
-            H, W = cert.shape
-            if self.two_channel:
-                out.append((warp_ab.contiguous(), cert))
-            else:
-                ax, ay = self.reference_axes(H, W)
-                grid = torch.stack([ax.view(1, W).expand(H, W), ay.view(H, 1).expand(H, W)], dim=-1)
-                out.append((torch.cat([grid, warp_ab], dim=-1).contiguous(), cert))
+                warp_ab = pred["warp_AB"][0]
+                cert = pred["overlap_AB"][0].squeeze(-1).contiguous()
+                H, W = cert.shape
+                if self.two_channel:
+                    out.append((warp_ab.contiguous(), cert))
+                else:
+                    ax, ay = self.reference_axes(H, W)
+                    grid = torch.stack([ax.view(1, W).expand(H, W), ay.view(H, 1).expand(H, W)], dim=-1)
+                    out.append((torch.cat([grid, warp_ab], dim=-1).contiguous(), cert))
+        finally:
+            if keyed is not None:
+                model.f = plain_f
         return out
 
     def match_grids(self, imA, imB):

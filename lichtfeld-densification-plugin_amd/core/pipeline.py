@@ -519,6 +519,7 @@ def run_dense_pipeline(
     stream_writer: Optional[StreamedPlyWriter] = None     # config.stream_output: the output file grows while the run proceeds
     prefetch: Optional[_OrderedPrefetcher] = None
     hot: Optional[_HotPath] = None
+    feat_cache: Optional[FeatureCache] = None
 
     rank_status = 0          # 0 fine, 1 cancelled, 2 failed: agreed on by all ranks before the exchange step (core/distributed.py)
     rank_error: Optional[BaseException] = None
@@ -541,9 +542,10 @@ def run_dense_pipeline(
         hot.dens.seed_rng(int(config.seed))      # upstream: np.random.seed(config.seed) (core/pipeline.py:793)
         # N4: every camera's backbone features once per run, kept exactly until their last use (core/scheduler.py)
         schedule = PairSchedule(refs_local, nn_table, uids, config.nns_per_ref, positions=my_positions)
-        feat_cache = None
-        if bool(getattr(matcher, "supports_feature_keys", False)) and bool(getattr(config, "share_features", True)):
-            feat_cache = FeatureCache(schedule.last_use)
+        if bool(getattr(matcher, "supports_feature_keys", False)):
+            if bool(getattr(config, "share_features", True)):
+                feat_cache = FeatureCache(schedule.last_use)
+            # always (re)set: an injected, warm matcher may still hold the cache of an earlier run - other cameras under the same keys
             matcher.set_feature_cache(feat_cache)
         device_prep = bool(getattr(config, "device_image_prep", False))
         jobs = [(lambda p=p: _pack_reference(p, refs_local[p], camera_records, nn_table, config.nns_per_ref,
@@ -675,6 +677,8 @@ def run_dense_pipeline(
                 progress_callback(10.0 + (float(done - 1) / max(1, total_refs)) * 80.0,
                                   f"Matching {done}/{total_refs} | {done / max(0.001, time.time() - t0):.1f} it/s")
             if packed is None:
+                if feat_cache is not None:
+                    feat_cache.advance(local_i)       # a skipped reference is a schedule position too: its cameras' last uses pass
                 continue
             _raise_if_cancelled(cancel_requested)
             from PIL import Image
@@ -682,8 +686,7 @@ def run_dense_pipeline(
             dev_images = bool(getattr(matcher, "accepts_device_images", False))
             if packed.raw:
                 packed = hot.prepare_on_device(packed, (w_match, h_match), need_host=want_debug or not dev_images)
-            kw_keys = ({"keys": (packed.ref_index, list(packed.nbr_indices))}
-                       if bool(getattr(matcher, "supports_feature_keys", False)) else {})
+            kw_keys = {"keys": (packed.ref_index, list(packed.nbr_indices))} if feat_cache is not None else {}
             if packed.dev is not None and dev_images:
                 results = matcher.match_grids_batch(packed.dev["image"], list(packed.dev["nbr_images"]), **kw_keys)
             else:
@@ -760,6 +763,12 @@ def run_dense_pipeline(
     finally:
         if prefetch is not None:
             prefetch.close()
+        if feat_cache is not None:           # the features of this run's cameras: nothing of them outlives the run
+            feat_cache.clear()
+            try:
+                matcher.set_feature_cache(None)
+            except Exception as exc:
+                log.warn(f"Releasing the feature cache failed: {exc}")
         if own_matcher and matcher is not None:
             try:
                 matcher.close()

@@ -83,14 +83,17 @@ class FeatureCache:
         self.misses = 0
         self.peak = 0
 
-    def get_or_compute(self, key: Hashable, compute):
-        if key in self._store:
+    def get_or_compute(self, key: Hashable, compute, variant: Hashable = ()):
+        """``key`` is what the schedule counts uses of (a camera); ``variant`` distinguishes values of one key that must not be
+        mixed (the matcher passes the backbone's input size) and lives and dies with the key."""
+        slot = (key, variant)
+        if slot in self._store:
             self.hits += 1
-            return self._store[key]
+            return self._store[slot]
         self.misses += 1
         val = compute()
         if self._max <= 0 or len(self._store) < self._max:
-            self._store[key] = val
+            self._store[slot] = val
             self.peak = max(self.peak, len(self._store))
         return val
 
@@ -98,8 +101,11 @@ class FeatureCache:
         """Schedule position ``step`` is done: drop what no later position needs."""
         if not self._last_use:
             return
-        for key in [k for k in self._store if self._last_use.get(k, -1) <= step]:
-            del self._store[key]
+        for slot in [s for s in self._store if self._last_use.get(s[0], -1) <= step]:
+            del self._store[slot]
+
+    def keys(self):
+        return [s[0] for s in self._store]
 
     def clear(self) -> None:
         self._store.clear()

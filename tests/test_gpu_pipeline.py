@@ -350,3 +350,137 @@ def test_grouped_sampled_launches_equal_single_launches(g4, tmp_path):
         np.testing.assert_array_equal(grouped.err, single.err)
         np.testing.assert_array_equal(grouped.points_per_reference, single.points_per_reference)
     assert single.xyz.shape[0] > 1000
+
+
+# ---- N4 through the pipeline: the matcher mirror's feature sharing on an nn.Module model ---------------------------------------
+class _IdDescriptor(torch.nn.Module):
+    """Stand-in for romav2's DINOv3 Descriptor on the device: the "features" of an image are its 8x8 block means, from which the
+    stub model below recovers WHICH camera the image belongs to - features served for the wrong camera change the pair matched."""
+
+    def __init__(self):
+        super().__init__()
+        self.gain = torch.nn.Parameter(torch.ones(1), requires_grad=False)
+        self.calls = 0
+
+    def forward(self, img):
+        self.calls += 1
+        return [torch.nn.functional.adaptive_avg_pool2d(img, 8).reshape(img.shape[0], -1) * self.gain]
+
+
+class _TableRoMa(torch.nn.Module):
+    """RoMaV2's interface as core/matcher.py uses it (an nn.Module, ``f`` a registered child, ``self.f(img_B_lr)`` called from
+    inside the model: RoMaV2/src/romav2/romav2.py:68,101,177); the match itself is looked up in upstream's captured maps by the
+    camera pair the two feature vectors identify."""
+    signatures = None      # (n_cams, 192) block means of the scene's images
+    pair_table = None      # (cam_a, cam_b) -> (warp (H,W,4), cert (H,W))
+    last = None
+
+    class Cfg:
+        def __init__(self, compile=False):
+            pass
+
+    def __init__(self, cfg=None):
+        super().__init__()
+        self.f = _IdDescriptor()
+        self.H_lr = self.W_lr = 64
+        self.H_hr = self.W_hr = None
+        self.bidirectional = False
+        _TableRoMa.last = self
+
+    def apply_setting(self, s):
+        pass
+
+    def _load_image(self, im):
+        dev = self.f.gain.device
+        if isinstance(im, torch.Tensor):
+            return (im.float() / 255.0 if im.dtype == torch.uint8 else im).to(dev)
+        return (torch.from_numpy(np.array(im)).permute(2, 0, 1).unsqueeze(0).float() / 255.0).to(dev)
+
+    def _camera_of(self, feats):
+        sig = _TableRoMa.signatures.to(feats[0].device)
+        return int(torch.cdist(feats[0], sig).argmin().item())
+
+    def match_from_features(self, f_list_A, img_A_lr, imB, img_A_hr=None):
+        img_b = torch.nn.functional.interpolate(self._load_image(imB), size=(self.H_lr, self.W_lr), mode="bicubic", align_corners=False,
+                                                antialias=True)
+        f_b = self.f(img_b)                                      # romav2.py:177
+        warp, cert = _TableRoMa.pair_table[(self._camera_of(f_list_A), self._camera_of(f_b))]
+        dev = img_b.device
+        return {"warp_AB": warp[None, ..., 2:4].to(dev), "overlap_AB": cert[None, ..., None].to(dev)}
+
+
+def _install_table_model(monkeypatch, g4, refs, nn):
+    import sys
+    import types
+    imgs = torch.from_numpy(np.stack([g4["images"][i] for i in range(len(g4["images"]))])).permute(0, 3, 1, 2).float() / 255.0
+    _TableRoMa.signatures = torch.nn.functional.adaptive_avg_pool2d(imgs, 8).reshape(imgs.shape[0], -1)
+    _TableRoMa.pair_table = {(r, int(nn[r][j])): (torch.from_numpy(g4[f"ref{r}_warp"][j]), torch.from_numpy(g4[f"ref{r}_cert"][j]))
+                             for r in refs for j in range(2)}
+    stub = types.ModuleType("romav2")
+    stub.RoMaV2 = _TableRoMa
+    monkeypatch.setitem(sys.modules, "romav2", stub)
+
+
+@pytest.mark.parametrize("device_prep", [False, True])
+def test_feature_sharing_on_an_nn_module_model_gives_the_same_run(g4, tmp_path, monkeypatch, device_prep):
+    """The drop-in's default path (share_features=True) with the real matcher mirror on cuda:0 and an nn.Module model: every
+    camera goes through the backbone once (PairSchedule.n_backbone_forwards_shared) instead of once per reference and once per
+    pair, the model is left untouched, and the PipelineResult is the one of the unshared run and of the table-replaying fake."""
+    from lichtfeld_densification_plugin_amd.core import matcher as mm
+    from lichtfeld_densification_plugin_amd.core.scheduler import PairSchedule
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+    _install_table_model(monkeypatch, g4, refs, nn)
+    sched = PairSchedule(refs, nn, [c.uid for c in cams], 2)
+    kw = dict(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=2, seed=5, viz_interval=0, matches_per_ref=1200,
+              pack_workers=1, device_image_prep=device_prep)
+    runs = {}
+    for share in (True, False):
+        m = mm.RomaMatcher(device="cuda:0", setting="fast")
+        model = _TableRoMa.last
+        child, state_keys = model.f, sorted(model.state_dict())
+        runs[share] = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(share_features=share, **kw), matcher=m)
+        assert model.f is child and sorted(model.state_dict()) == state_keys       # the vendored model is as it was
+        assert getattr(m, "_feature_cache", None) is None                          # nothing of the run's features is kept
+        assert child.calls == (sched.n_backbone_forwards_shared if share else sched.n_backbone_forwards_upstream)
+        m.close()
+    fake = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**kw), matcher=FakeMatcher(64, 64, table, two_channel=True))
+    assert sched.n_backbone_forwards_shared < sched.n_backbone_forwards_upstream and runs[True].xyz.shape[0] > 1000
+    for other in (runs[False], fake):
+        np.testing.assert_array_equal(runs[True].points_per_reference, other.points_per_reference)
+        np.testing.assert_array_equal(runs[True].xyz, other.xyz)
+        np.testing.assert_array_equal(runs[True].rgb, other.rgb)
+        np.testing.assert_array_equal(runs[True].err, other.err)
+    assert runs[True].pairs_matched == sched.n_pairs
+
+
+def test_matcher_fakes_receive_camera_keys_and_the_cache_does_not_outlive_the_run(g4, tmp_path):
+    """A matcher that declares ``supports_feature_keys`` is handed (reference index, [neighbour indices]) with every call while
+    sharing is on, none while it is off - and a cache left over from an earlier run is always replaced (stale entries
+    of another scene under the same camera keys)."""
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+
+    class KeyedFake(FakeMatcher):
+        supports_feature_keys = True
+
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.cache_log, self.keys_seen = [], []
+
+        def set_feature_cache(self, cache):
+            self.cache_log.append(cache)
+
+        def match_grids_batch(self, imA, imB_list, keys=None):
+            self.keys_seen.append(keys)
+            return super().match_grids_batch(imA, imB_list)
+
+    kw = dict(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=2, seed=5, viz_interval=0, matches_per_ref=1200)
+    fm = KeyedFake(64, 64, table)
+    fm.cache_log.append("stale cache of an earlier run")
+    on = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**kw), matcher=fm)
+    assert fm.keys_seen == [(r, [int(n) for n in nn[r][:2]]) for r in refs]
+    assert fm.cache_log[1] is not None and fm.cache_log[-1] is None and len(fm.cache_log[1]) == 0
+    fm2 = KeyedFake(64, 64, table)
+    fm2.cache_log.append("stale cache of an earlier run")
+    off = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(share_features=False, **kw), matcher=fm2)
+    assert fm2.keys_seen == [None] * len(refs) and fm2.cache_log[1:] == [None]
+    np.testing.assert_array_equal(on.xyz, off.xyz)

@@ -45,50 +45,71 @@ def test_feature_cache_computes_each_camera_once_and_evicts_at_last_use():
             val = cache.get_or_compute(cam, lambda cam=cam: computed.append(cam) or ("feat", cam))
             assert val == ("feat", cam)
         cache.advance(step)
-        assert all(s.last_use[c] > step for c in cache._store)                 # nothing dead is kept
+        assert all(s.last_use[c] > step for c in cache.keys())                 # nothing dead is kept
     assert sorted(computed) == sorted(s.uses) and len(computed) == s.n_backbone_forwards_shared
     assert cache.misses == len(computed) and cache.hits == s.n_backbone_forwards_upstream - len(computed)
     assert cache.peak <= s.peak_resident() + 9 and len(cache) == 0
 
 
-class _StubRoMa:
-    """The slice of RoMaV2's interface core/matcher.py touches, with a counter on the backbone."""
+class _StubDescriptor(torch.nn.Module):
+    """Stands for romav2's Descriptor (DINOv3): an nn.Module with a parameter, counting its forward passes."""
+
+    def __init__(self):
+        super().__init__()
+        self.scale = torch.nn.Parameter(torch.ones(1), requires_grad=False)
+        self.calls = 0
+
+    def forward(self, img):
+        self.calls += 1
+        return [img.mean(dim=(2, 3)) * self.scale]
+
+
+class _StubRoMa(torch.nn.Module):
+    """The slice of RoMaV2's interface core/matcher.py touches.  Like the real model (RoMaV2/src/romav2/romav2.py:68,101,177) it
+    is an nn.Module whose backbone ``f`` is a REGISTERED CHILD MODULE and whose own code calls ``self.f(img_B_lr)``: assigning
+    anything but an nn.Module to ``model.f`` raises TypeError, which a plain-class stub would not show."""
 
     class Cfg:
         def __init__(self, compile=False):
             pass
 
-    def __init__(self, cfg):
+    def __init__(self, cfg=None):
+        super().__init__()
+        self.f = _StubDescriptor()
         self.H_lr = self.W_lr = 32
         self.H_hr = self.W_hr = None
         self.bidirectional = False
-        self.backbone_calls = 0
+
+    @property
+    def backbone_calls(self):
+        return self.f.calls
 
     def apply_setting(self, s):
         pass
-
-    def to(self, d):
-        return self
-
-    def eval(self):
-        return self
 
     def _load_image(self, im):
         if isinstance(im, torch.Tensor):
             return im.float() / 255.0 if im.dtype == torch.uint8 else im
         return torch.from_numpy(np.array(im)).permute(2, 0, 1).unsqueeze(0).float() / 255.0
 
-    def f(self, img):
-        self.backbone_calls += 1
-        return [img.mean(dim=(2, 3))]
+    def _forward_from_features(self, f_list_A, img_A_lr, img_B_lr):
+        f_b = self.f(img_B_lr)                       # romav2.py:177
+        shift = (f_list_A[0] - f_b[0]).mean()
+        warp = torch.zeros((1, self.H_lr, self.W_lr, 2), device=img_B_lr.device) + shift
+        return {"warp_AB": warp, "overlap_AB": torch.full((1, self.H_lr, self.W_lr, 1), 0.5, device=img_B_lr.device)}
 
     def match_from_features(self, f_list_A, img_A_lr, imB, img_A_hr=None):
         # RoMaV2._resize_match_image (romav2.py:323-333): the same bicubic antialiased resize the mirror applies to the reference
         img_b = torch.nn.functional.interpolate(self._load_image(imB), size=(self.H_lr, self.W_lr), mode="bicubic", align_corners=False, antialias=True)
-        f_b = self.f(img_b)
-        shift = (f_list_A[0] - f_b[0]).mean()
-        warp = torch.zeros((1, self.H_lr, self.W_lr, 2)) + shift
-        return {"warp_AB": warp, "overlap_AB": torch.full((1, self.H_lr, self.W_lr, 1), 0.5)}
+        return self._forward_from_features(f_list_A, img_A_lr, img_b)
+
+
+def test_the_stub_refuses_what_the_real_model_refuses():
+    """nn.Module.__setattr__ only takes a Module (or None) for a registered child: the round-2 hook (a lambda) dies here."""
+    m = _StubRoMa()
+    with pytest.raises(TypeError):
+        m.f = lambda img: [img]
+    assert "f.scale" in m.state_dict()
 
 
 def test_matcher_mirror_shares_backbone_features_between_references(monkeypatch):
@@ -121,3 +142,43 @@ def test_matcher_mirror_shares_backbone_features_between_references(monkeypatch)
     for a, b in zip(plain, shared):
         for (wa, ca), (wb, cb) in zip(a, b):
             assert torch.equal(wa, wb) and torch.equal(ca, cb)                  # same maps either way
+
+
+def test_keyed_call_leaves_the_model_as_it_found_it(monkeypatch):
+    """The wrapper is installed for the duration of a call only: afterwards (and after an exception inside the model) ``model.f``
+    is the original child again and the state dict has the original keys; features of another input size are never served."""
+    from PIL import Image
+    stub = types.ModuleType("romav2")
+    stub.RoMaV2 = _StubRoMa
+    monkeypatch.setitem(sys.modules, "romav2", stub)
+    from lichtfeld_densification_plugin_amd.core import matcher as mm
+    rs = np.random.RandomState(1)
+    ims = [Image.fromarray(rs.randint(0, 256, (40, 48, 3)).astype(np.uint8)) for _ in range(3)]
+    m = mm.RomaMatcher(device="cpu", setting="turbo")
+    original = m.model.f
+    keys_before = sorted(m.model.state_dict())
+    cache = FeatureCache({0: 5, 1: 5, 2: 5})
+    m.set_feature_cache(cache)
+    m.match_grids_batch(ims[0], [ims[1], ims[2]], keys=(0, [1, 2]))
+    assert m.model.f is original and sorted(m.model.state_dict()) == keys_before and original.calls == 3
+
+    def boom(*a, **k):
+        raise RuntimeError("inside the model")
+    monkeypatch.setattr(m.model, "match_from_features", boom)
+    with pytest.raises(RuntimeError, match="inside the model"):
+        m.match_grids_batch(ims[0], [ims[1]], keys=(0, [1]))
+    assert m.model.f is original
+    monkeypatch.undo()
+    monkeypatch.setitem(sys.modules, "romav2", stub)
+    # the same matcher at another resolution: camera 0's 32x32 features must not answer a 48x48 request
+    m.model.H_lr = m.model.W_lr = 48
+    calls = original.calls
+    m.match_grids_batch(ims[0], [ims[1]], keys=(0, [1]))
+    assert original.calls == calls + 2
+    with pytest.raises(ValueError):
+        m.match_grids_batch(ims[0], [ims[1], ims[2]], keys=(0, [1]))
+    # sharing switched off again: keys are ignored, every call goes to the backbone
+    m.set_feature_cache(None)
+    calls = original.calls
+    m.match_grids_batch(ims[0], [ims[1]], keys=(0, [1]))
+    assert original.calls == calls + 2 and m.model.f is original
