@@ -517,6 +517,17 @@ class HipDensifier:
         if rc != 0:
             raise HipBackendError(f"{what} failed ({rc}): {self._lib.lfd_last_error(self._ctx).decode()}")
 
+    def _same_device(self, batch: "PreparedBatch", out: Optional["OutputBuffers"] = None, *tensors) -> None:
+        """Every pointer handed to the library must live where this context computes: a CPU batch (or one of another GPU) given
+        to a device context would be a memory fault inside a kernel, a device batch given to the CPU twin a host segfault."""
+        if torch.device(batch.device) != self.device:
+            raise ValueError(f"batch lives on {batch.device}, this context computes on {self.device}")
+        if out is not None and out.xyz.device != self.device:
+            raise ValueError(f"output buffers live on {out.xyz.device}, this context computes on {self.device}")
+        for t in tensors:
+            if t is not None and t.device != self.device:
+                raise ValueError(f"tensor on {t.device} handed to a context that computes on {self.device}")
+
     def upload_cameras(self, cams: Sequence[CameraRecord]) -> None:
         K = _f32(np.stack([np.asarray(c.K, np.float32).reshape(9) for c in cams]))
         R = _f32(np.stack([np.asarray(c.R, np.float32).reshape(9) for c in cams]))
@@ -659,10 +670,12 @@ class HipDensifier:
     # -- launches (asynchronous on self.stream) -------------------------------------------------------
     def launch_aggregate(self, batch: PreparedBatch, params: lfd_params, best_cert: torch.Tensor,
                          best_slot: Optional[torch.Tensor]) -> None:
+        self._same_device(batch, None, best_cert, best_slot)
         self._check(self._lib.lfd_aggregate(self._ctx, C.byref(batch.c), C.byref(params), best_cert.data_ptr(),
                                             best_slot.data_ptr() if best_slot is not None else None), "lfd_aggregate")
 
     def launch_dense(self, batch: PreparedBatch, params: lfd_params, out: OutputBuffers) -> None:
+        self._same_device(batch, out)
         self._check(self._lib.lfd_triangulate_dense(self._ctx, C.byref(batch.c), C.byref(params), C.byref(out.c),
                                                     out.ref_offsets.data_ptr(),
                                                     out.seg_counts.data_ptr() if out.with_segments else None),
@@ -672,6 +685,7 @@ class HipDensifier:
                        sel_offsets: Sequence[int], out: OutputBuffers) -> None:
         if sel_idx.dtype != torch.int64 or not sel_idx.is_cuda or not sel_idx.is_contiguous():
             raise ValueError("sel_idx must be a contiguous int64 device tensor")
+        self._same_device(batch, out, sel_idx)
         offs = (C.c_int64 * (batch.n_refs + 1))(*[int(v) for v in sel_offsets])
         self._check(self._lib.lfd_triangulate_indexed(self._ctx, C.byref(batch.c), C.byref(params), sel_idx.data_ptr(),
                                                       offs, C.byref(out.c), out.ref_offsets.data_ptr(),
@@ -682,6 +696,7 @@ class HipDensifier:
                        border: int = 2, tiles: int = 24, s_override: float = 0.0, sel_cells: Optional[torch.Tensor] = None) -> None:
         """One reference view through aggregate -> selection -> indexed triangulation in one asynchronous call
         (lfd_triangulate_sampled): no read-back in between, the selection count stays on the device."""
+        self._same_device(batch, out, sel_cells)
         self._check(self._lib.lfd_triangulate_sampled(self._ctx, C.byref(batch.c), C.byref(params), int(M), C.c_float(cap), int(border),
                                                       int(tiles), C.c_float(s_override), C.byref(out.c), out.ref_offsets.data_ptr(),
                                                       out.seg_counts.data_ptr(), out.seg_order.data_ptr(), out.sel_info.data_ptr(),
@@ -694,6 +709,7 @@ class HipDensifier:
         ``np.random.seed``): lfd_triangulate_sampled_multi.  ``out`` needs capacity n_refs * (M + tiles*tiles + 64)."""
         if len(seeds) != batch.n_refs:
             raise ValueError("one seed per reference")
+        self._same_device(batch, out)
         arr = (C.c_uint32 * batch.n_refs)(*[int(v) & 0xFFFFFFFF for v in seeds])
         self._check(self._lib.lfd_triangulate_sampled_multi(self._ctx, C.byref(batch.c), C.byref(params), int(M), C.c_float(cap), int(border),
                                                             int(tiles), arr, C.byref(out.c), out.ref_offsets.data_ptr(),
@@ -752,12 +768,14 @@ class HostDensifier:
     close = HipDensifier.close
     __del__ = HipDensifier.__del__
     _check = HipDensifier._check
+    _same_device = HipDensifier._same_device
     upload_cameras = HipDensifier.upload_cameras
 
     def check_launches(self) -> None:
         pass
 
     def aggregate(self, batch: PreparedBatch, params: lfd_params):
+        self._same_device(batch)
         best = torch.empty((batch.n_refs, batch.H, batch.W), dtype=torch.float32)
         slot = torch.empty((batch.n_refs, batch.H, batch.W), dtype=torch.uint8)
         self._check(self._lib.lfd_aggregate_host(self._ctx, C.byref(batch.c), C.byref(params), best.data_ptr(), slot.data_ptr()),
@@ -766,6 +784,7 @@ class HostDensifier:
 
     def triangulate_dense(self, batch: PreparedBatch, params: lfd_params, capacity: Optional[int] = None,
                           with_cell: bool = True) -> TriangulationOutput:
+        self._same_device(batch)
         cap = batch.n_refs * batch.H * batch.W if capacity is None else int(capacity)
         out = OutputBuffers(cap, batch.n_refs, batch.k, self.device, with_cell)
         self._check(self._lib.lfd_triangulate_dense_host(self._ctx, C.byref(batch.c), C.byref(params), C.byref(out.c),
@@ -777,6 +796,7 @@ class HostDensifier:
                             sel_offsets: Sequence[int], with_cell: bool = True) -> TriangulationOutput:
         if sel_idx.dtype != torch.int64 or sel_idx.is_cuda or not sel_idx.is_contiguous():
             raise ValueError("sel_idx must be a contiguous int64 CPU tensor")
+        self._same_device(batch)
         out = OutputBuffers(int(sel_offsets[-1]), batch.n_refs, batch.k, self.device, with_cell)
         offs = (C.c_int64 * (batch.n_refs + 1))(*[int(v) for v in sel_offsets])
         self._check(self._lib.lfd_triangulate_indexed_host(self._ctx, C.byref(batch.c), C.byref(params), sel_idx.data_ptr(), offs,

@@ -87,6 +87,13 @@ class _KeyedDescriptor(torch.nn.Module):
         self.cache = cache
         self.key = None
 
+    def __getattr__(self, name):
+        # anything the model reads from its backbone besides calling it (parameters, buffers, config) is the wrapped module's
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__("inner"), name)
+
     def forward(self, img):
         if self.key is None or self.cache is None:
             return self.inner(img)

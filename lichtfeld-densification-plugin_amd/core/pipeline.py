@@ -287,7 +287,13 @@ class _HotPath:
         self.config = config
         self.sample_cap = float(sample_cap)
         self.w_match, self.h_match = int(w_match), int(h_match)
-        self.dens = densifier if densifier is not None else hb.HipDensifier(dev)
+        self.on_host = dev.type == "cpu"          # config.backend == "host": the CPU twin, chosen by the caller
+        if densifier is not None:
+            self.dens = densifier
+        else:
+            self.dens = hb.HostDensifier(int(getattr(config, "host_threads", 0))) if self.on_host else hb.HipDensifier(dev)
+        if self.dens.device.type != dev.type:
+            raise ValueError(f"backend runs on {dev} but the densifier handed in lives on {self.dens.device}")
         self._own = densifier is None
         self.dens.upload_cameras(cams)
         self.cams = list(cams) if bool(getattr(config, "upstream_fundamental", True)) else None
@@ -350,7 +356,7 @@ class _HotPath:
         stage and no debug preview to feed (``need_best``), the three steps are ONE asynchronous call
         (lfd_triangulate_sampled): the selection count never visits the host."""
         batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes, cameras=self.cams)
-        on_device = self.config.selection_backend == "device"
+        on_device = self.config.selection_backend == "device" and not self.on_host
         fusable = on_device and (not self.config.no_filter or self.config.matches_per_ref <= self.dens.TOP_M_MAX)
         if fusable and not need_best:
             if device_seed is not None and not self.config.no_filter:
@@ -396,6 +402,8 @@ class _HotPath:
         call consumes no random numbers and falls back to the host stage, which would then see the stream AFTER i+1's draws) -
         or every reference has its own stream anyway."""
         cfg = self.config
+        if self.on_host:
+            return False
         fusable = cfg.selection_backend == "device" and (not cfg.no_filter or cfg.matches_per_ref <= self.dens.TOP_M_MAX)
         exact_ok = cfg.no_filter or per_ref_rng or float(cfg.certainty_thresh) >= 2.0 ** -29 * H * W * max(self.sample_cap, 1e-6)
         return fusable and not need_best and exact_ok
@@ -429,6 +437,9 @@ class _HotPath:
 
     def pack_ply_bytes(self, xyz: torch.Tensor, rgb: torch.Tensor) -> bytes:
         """The survivors' 15-byte PLY records, quantised and packed on the device (only file payload crosses PCIe)."""
+        if self.on_host:
+            from .writers import ply_records
+            return ply_records(xyz.numpy(), to_uint8_rgb(rgb.numpy())).tobytes()
         return self.dens.pack_ply(xyz, rgb).cpu().numpy().tobytes()
 
     def dense(self, refs: List[hb.ReferenceInputs], axes) -> hb.TriangulationOutput:
@@ -480,10 +491,13 @@ def run_dense_pipeline(
     matcher=None,
     densifier: Optional[hb.HipDensifier] = None,
     device: Optional[torch.device] = None,
+    backend: Optional[str] = None,
 ) -> PipelineResult:
     """See module docstring.  ``matcher`` / ``densifier`` / ``device`` are injection points for
     tests and for callers that keep a warm model; by default a RomaMatcher is created (and released)
-    per run exactly like upstream."""
+    per run exactly like upstream.  ``backend`` ("device" | "host", default ``config.backend``): "host" runs the per-reference
+    path on the CPU twin of the C-ABI (HostDensifier + core/sampling.py) - upstream's CPU-only configuration, chosen by the
+    caller; a "device" run without a GPU raises HipBackendError, it never turns into a host run."""
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
@@ -498,9 +512,18 @@ def run_dense_pipeline(
         ensure_dir(config.output_path)
         intermediate_base = os.path.splitext(config.output_path)[0] + "_intermediate"
 
-    if not torch.cuda.is_available():
-        raise hb.HipBackendError("no GPU visible: the dense-initialisation hot path has no CPU fallback")
-    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    backend = str(backend if backend is not None else getattr(config, "backend", "device"))
+    if backend not in ("device", "host"):
+        raise ValueError("backend must be 'device' or 'host'")
+    if backend == "host":
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise hb.HipBackendError("no GPU visible: the dense-initialisation hot path has no CPU fallback "
+                                     "(backend=\"host\" selects the CPU twin explicitly)")
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if dev.type != "cuda":
+            raise hb.HipBackendError(f"backend=\"device\" needs a cuda (HIP) device, got {dev}")
 
     per_ref_rng = bool(config.per_reference_rng) or world > 1
     stream_rng = np.random.RandomState(int(config.seed))     # upstream: np.random.seed(config.seed), global stream
@@ -539,7 +562,8 @@ def run_dense_pipeline(
 
         w_match, h_match = int(matcher.w_resized), int(matcher.h_resized)
         hot = _HotPath(camera_records, config, float(matcher.sample_thresh), w_match, h_match, dev, densifier)
-        hot.dens.seed_rng(int(config.seed))      # upstream: np.random.seed(config.seed) (core/pipeline.py:793)
+        if not hot.on_host:
+            hot.dens.seed_rng(int(config.seed))      # upstream: np.random.seed(config.seed) (core/pipeline.py:793); the host backend draws from stream_rng
         # N4: every camera's backbone features once per run, kept exactly until their last use (core/scheduler.py)
         schedule = PairSchedule(refs_local, nn_table, uids, config.nns_per_ref, positions=my_positions)
         if bool(getattr(matcher, "supports_feature_keys", False)):
@@ -547,7 +571,7 @@ def run_dense_pipeline(
                 feat_cache = FeatureCache(schedule.last_use)
             # always (re)set: an injected, warm matcher may still hold the cache of an earlier run - other cameras under the same keys
             matcher.set_feature_cache(feat_cache)
-        device_prep = bool(getattr(config, "device_image_prep", False))
+        device_prep = bool(getattr(config, "device_image_prep", False)) and backend == "device"
         jobs = [(lambda p=p: _pack_reference(p, refs_local[p], camera_records, nn_table, config.nns_per_ref,
                                              (w_match, h_match), cancel_requested, raw=device_prep)) for p in my_positions]
         prefetch = _OrderedPrefetcher(jobs, workers=int(getattr(config, "pack_workers", 4)),

@@ -65,6 +65,15 @@ class DensePipelineConfig:
     # compute every camera's backbone (DINOv3) features once per run and share them between the references that list the camera
     # (core/scheduler.py); upstream recomputes a neighbour's features for every reference
     share_features: bool = True
+    # where the per-reference hot path runs.  "device": the HIP kernels (needs a GPU; raises HipBackendError without one - there is
+    # no fallback).  "host": the CPU twin of the C-ABI (lfd_create_host: the host build of the kernels' per-cell source on the host
+    # cores) with the host sampling stage - upstream's CPU-only configuration (densify.py:148-212 run without a GPU, BASELINE
+    # config 1); chosen by the caller, never automatically.
+    backend: str = "device"
+    # how the survivors of a sharded run (torch.distributed, world > 1) reach the writer: "all_gather" leaves the whole cloud on
+    # every rank (what BASELINE's north star names), "gather_to_root" sends every rank's records straight to their place in rank
+    # 0's buffer (the other ranks return their own shard only)
+    exchange: str = "all_gather"
 
     def __post_init__(self) -> None:
         if self.triangulation_mode not in TRIANGULATION_MODES:
@@ -74,6 +83,10 @@ class DensePipelineConfig:
             raise ValueError("refs_per_launch must be >= 1")
         if self.selection_backend not in ("device", "host"):
             raise ValueError("selection_backend must be 'device' or 'host'")
+        if self.backend not in ("device", "host"):
+            raise ValueError("backend must be 'device' or 'host'")
+        if self.exchange not in ("all_gather", "gather_to_root"):
+            raise ValueError("exchange must be 'all_gather' or 'gather_to_root'")
 
 
 @dataclasses.dataclass

@@ -355,7 +355,7 @@ int lfd_create(int device_index, void* hip_stream, lfd_context** out) {
 
 void lfd_destroy(lfd_context* ctx) {
     if (!ctx) return;
-    if (ctx->is_host) { delete ctx; return; }
+    if (ctx->is_host) { lfd_host_pool_destroy(ctx->host_pool); delete ctx; return; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->colour_tab, &ctx->mt, &ctx->mt_batch, &ctx->sel_scratch, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab})

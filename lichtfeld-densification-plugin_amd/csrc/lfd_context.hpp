@@ -15,10 +15,15 @@ struct DeviceBuffer {
     size_t bytes = 0;
 };
 
+struct LfdHostPool;                              // lfd_host.hip: the host context's parked worker threads
+void lfd_host_pool_destroy(LfdHostPool* p);
+
 struct lfd_context {
     // a context made by lfd_create_host() never touches HIP: it serves the *_host entry points only
     bool is_host = false;
     int host_threads = 1;
+    LfdHostPool* host_pool = nullptr;            // created with the context, joined by lfd_destroy
+    std::vector<unsigned char> host_stage;       // survivors of the chunks in flight (lfd_triangulate_dense_host), kept across calls
     std::vector<LfdCam> host_cams;
     int device = 0;
     hipStream_t stream = nullptr;

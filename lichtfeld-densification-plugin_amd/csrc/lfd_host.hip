@@ -9,7 +9,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -35,16 +38,76 @@ struct HostLaunch {
     bool exact_colour;
 };
 
+}  // namespace
+
+// The host context's worker threads: started once by lfd_create_host, parked on a condition variable between calls, joined by
+// lfd_destroy.  A call hands them a chunk count and a function; chunks are claimed with one atomic counter (the calling thread
+// works too), so the cost per call is one wake-up instead of n_threads thread creations.
+struct LfdHostPool {
+    explicit LfdHostPool(int n_threads) {
+        const int extra = std::max(0, n_threads - 1);         // the caller is a worker as well
+        workers.reserve((size_t)extra);
+        for (int t = 0; t < extra; ++t) workers.emplace_back([this]() { loop(); });
+    }
+    ~LfdHostPool() {
+        { std::lock_guard<std::mutex> g(m); stop = true; ++generation; }
+        wake.notify_all();
+        for (auto& th : workers) th.join();
+    }
+    void run(int n_chunks, int max_threads, const std::function<void(int)>& fn) {
+        if (n_chunks <= 0) return;
+        const int helpers = std::min({(int)workers.size(), std::max(0, max_threads - 1), n_chunks - 1});
+        if (helpers == 0) { for (int c = 0; c < n_chunks; ++c) fn(c); return; }
+        {
+            std::lock_guard<std::mutex> g(m);
+            job = &fn; total = n_chunks; next.store(0); wanted = helpers; joined = 0; finished = 0; ++generation;
+        }
+        wake.notify_all();
+        for (int c = next.fetch_add(1); c < n_chunks; c = next.fetch_add(1)) fn(c);
+        std::unique_lock<std::mutex> g(m);
+        wanted = joined;                                      // no late joiner may start on this job any more
+        done.wait(g, [this]() { return finished == joined; });
+        job = nullptr;
+    }
+
+private:
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* fn = nullptr;
+            int n = 0;
+            {
+                std::unique_lock<std::mutex> g(m);
+                wake.wait(g, [&]() { return generation != seen; });
+                seen = generation;
+                if (stop) return;
+                if (job == nullptr || joined >= wanted) continue;
+                ++joined; fn = job; n = total;
+            }
+            for (int c = next.fetch_add(1); c < n; c = next.fetch_add(1)) (*fn)(c);
+            { std::lock_guard<std::mutex> g(m); ++finished; }
+            done.notify_one();
+        }
+    }
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable wake, done;
+    const std::function<void(int)>* job = nullptr;
+    std::atomic<int> next{0};
+    int total = 0, wanted = 0, joined = 0, finished = 0;
+    unsigned long long generation = 0;
+    bool stop = false;
+};
+
+void lfd_host_pool_destroy(LfdHostPool* p) { delete p; }      // lfd_destroy (lfd_api.hip)
+
+namespace {
+
 template <class Fn>
-void parallel_chunks(int n_chunks, int n_threads, Fn fn) {
-    n_threads = std::max(1, std::min(n_threads, n_chunks));
-    if (n_threads == 1) { for (int c = 0; c < n_chunks; ++c) fn(c); return; }
-    std::atomic<int> next(0);
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)n_threads);
-    for (int t = 0; t < n_threads; ++t)
-        pool.emplace_back([&]() { for (int c = next.fetch_add(1); c < n_chunks; c = next.fetch_add(1)) fn(c); });
-    for (auto& th : pool) th.join();
+void parallel_chunks(lfd_context* ctx, int n_chunks, Fn fn) {
+    const std::function<void(int)> f(fn);
+    if (ctx->host_pool) ctx->host_pool->run(n_chunks, ctx->host_threads, f);
+    else for (int c = 0; c < n_chunks; ++c) f(c);
 }
 
 int validate_host(lfd_context* ctx, const lfd_batch* b, const lfd_params* p) {
@@ -182,6 +245,7 @@ int lfd_create_host(int32_t n_threads, lfd_context** out) {
     ctx->is_host = true;
     const unsigned hw = std::thread::hardware_concurrency();
     ctx->host_threads = n_threads > 0 ? n_threads : (hw ? (int)hw : 1);
+    if (ctx->host_threads > 1) ctx->host_pool = new LfdHostPool(ctx->host_threads);
     *out = ctx;
     return LFD_OK;
 }
@@ -195,7 +259,7 @@ int lfd_aggregate_host(lfd_context* ctx, const lfd_batch* b, const lfd_params* p
     HostLaunch L;
     prepare_host(b, p, L);
     const int chunks_per_ref = (L.HW + kChunk - 1) / kChunk;
-    parallel_chunks(b->n_refs * chunks_per_ref, ctx->host_threads, [&](int c) {
+    parallel_chunks(ctx, b->n_refs * chunks_per_ref, [&](int c) {
         const int r = c / chunks_per_ref, c0 = (c - r * chunks_per_ref) * kChunk, c1 = std::min(c0 + kChunk, L.HW);
         for (int cell = c0; cell < c1; ++cell) {
             float best; int bj;
@@ -216,31 +280,51 @@ int lfd_triangulate_dense_host(lfd_context* ctx, const lfd_batch* b, const lfd_p
     HostLaunch L;
     prepare_host(b, p, L);
     const int chunks_per_ref = (L.HW + kChunk - 1) / kChunk;
-    const int n_chunks = b->n_refs * chunks_per_ref;
     std::vector<HostRef> refs((size_t)b->n_refs);
     for (int r = 0; r < b->n_refs; ++r) make_ref(ctx, L, r, refs[(size_t)r]);
-    std::vector<std::vector<HostPoint>> kept((size_t)n_chunks);
-    parallel_chunks(n_chunks, ctx->host_threads, [&](int c) {
-        const int r = c / chunks_per_ref, c0 = (c - r * chunks_per_ref) * kChunk, c1 = std::min(c0 + kChunk, L.HW);
-        std::vector<HostPoint>& v = kept[(size_t)c];
-        v.reserve((size_t)(c1 - c0));
-        HostPoint pt; int bj;
-        for (int cell = c0; cell < c1; ++cell)
-            if (host_eval_cell(L, refs[(size_t)r], r, cell, pt, bj)) v.push_back(pt);
-    });
-    // ordered compaction: references in batch order, cells in raster order (the device's look-back scan)
-    std::vector<long long> start((size_t)n_chunks + 1, 0);
-    for (int c = 0; c < n_chunks; ++c) start[(size_t)c + 1] = start[(size_t)c] + (long long)kept[(size_t)c].size();
-    for (int r = 0; r <= b->n_refs; ++r) ref_offsets[r] = start[(size_t)std::min(r * chunks_per_ref, n_chunks)];
+    // Every chunk parks its survivors at its own fixed place of a staging area that belongs to the context (chunk c at
+    // c * kChunk: no allocation, no growth, nothing shared between threads); a prefix over the chunk counts then gives every
+    // chunk its place in the output - references in batch order, cells in raster order, the device's look-back scan - and a
+    // second parallel sweep moves the records there.  References are taken in groups so that the staging area stays bounded.
+    const int refs_per_group = std::max(1, (int)(((size_t)256 << 20) / (sizeof(HostPoint) * (size_t)chunks_per_ref * kChunk)));
+    const int group_chunks = std::min(b->n_refs, refs_per_group) * chunks_per_ref;
+    if (ctx->host_stage.size() < (size_t)group_chunks * kChunk * sizeof(HostPoint)) ctx->host_stage.resize((size_t)group_chunks * kChunk * sizeof(HostPoint));
+    HostPoint* stage = reinterpret_cast<HostPoint*>(ctx->host_stage.data());
+    std::vector<int> kept((size_t)group_chunks);
+    std::vector<int> per_slot(seg_counts ? (size_t)group_chunks * LFD_MAX_SLOTS : 0);
+    std::vector<long long> start((size_t)group_chunks + 1);
     if (seg_counts) std::memset(seg_counts, 0, sizeof(int32_t) * (size_t)b->n_refs * b->k);
-    parallel_chunks(n_chunks, ctx->host_threads, [&](int c) {
-        long long pos = start[(size_t)c];
-        for (const HostPoint& pt : kept[(size_t)c]) store_point(out, pos++, pt);
-    });
-    if (seg_counts)
-        for (int c = 0; c < n_chunks; ++c)
-            for (const HostPoint& pt : kept[(size_t)c]) seg_counts[(size_t)(c / chunks_per_ref) * b->k + pt.slot] += 1;
-    if (start[(size_t)n_chunks] > out->capacity) return lfd_fail(ctx, LFD_ERR_CAPACITY, "output capacity too small (counts are valid)");
+    long long total = 0;
+    for (int r0 = 0; r0 < b->n_refs; r0 += refs_per_group) {
+        const int nr = std::min(refs_per_group, b->n_refs - r0), nc = nr * chunks_per_ref;
+        parallel_chunks(ctx, nc, [&](int c) {
+            const int r = r0 + c / chunks_per_ref, c0 = (c % chunks_per_ref) * kChunk, c1 = std::min(c0 + kChunk, L.HW);
+            HostPoint* v = stage + (size_t)c * kChunk;
+            int n = 0, bj;
+            for (int cell = c0; cell < c1; ++cell)
+                if (host_eval_cell(L, refs[(size_t)r], r, cell, v[n], bj)) ++n;
+            kept[(size_t)c] = n;
+            if (seg_counts) {
+                int* cnt = per_slot.data() + (size_t)c * LFD_MAX_SLOTS;
+                for (int j = 0; j < LFD_MAX_SLOTS; ++j) cnt[j] = 0;
+                for (int i = 0; i < n; ++i) cnt[v[i].slot] += 1;
+            }
+        });
+        start[0] = total;
+        for (int c = 0; c < nc; ++c) start[(size_t)c + 1] = start[(size_t)c] + kept[(size_t)c];
+        for (int r = 0; r < nr; ++r) ref_offsets[r0 + r] = start[(size_t)r * chunks_per_ref];
+        total = start[(size_t)nc];
+        parallel_chunks(ctx, nc, [&](int c) {
+            long long pos = start[(size_t)c];
+            const HostPoint* v = stage + (size_t)c * kChunk;
+            for (int i = 0; i < kept[(size_t)c]; ++i) store_point(out, pos++, v[i]);
+        });
+        if (seg_counts)
+            for (int c = 0; c < nc; ++c)
+                for (int j = 0; j < b->k; ++j) seg_counts[(size_t)(r0 + c / chunks_per_ref) * b->k + j] += per_slot[(size_t)c * LFD_MAX_SLOTS + j];
+    }
+    ref_offsets[b->n_refs] = total;
+    if (total > out->capacity) return lfd_fail(ctx, LFD_ERR_CAPACITY, "output capacity too small (counts are valid)");
     return LFD_OK;
 }
 
@@ -266,7 +350,7 @@ int lfd_triangulate_indexed_host(lfd_context* ctx, const lfd_batch* b, const lfd
         std::vector<HostPoint> pts((size_t)n_sel);
         std::vector<int8_t> code((size_t)n_sel, (int8_t)-1);          // -1 dropped index, else slot | 0x40 when kept
         const int n_chunks = (int)((n_sel + kChunk - 1) / kChunk);
-        parallel_chunks(n_chunks, ctx->host_threads, [&](int c) {
+        parallel_chunks(ctx, n_chunks, [&](int c) {
             const long long i0 = (long long)c * kChunk, i1 = std::min<long long>(i0 + kChunk, n_sel);
             for (long long i = i0; i < i1; ++i) {
                 const long long cl = sel_idx[s0 + i];
