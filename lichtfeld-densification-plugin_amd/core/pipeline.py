@@ -43,7 +43,7 @@ from .matcher import RomaMatcher, has_cached_romav2_weights, romav2_cached_weigh
 from .sampling import select_samples_with_coverage
 from .scheduler import FeatureCache, PairSchedule
 from .types import CameraRecord, DensePipelineConfig
-from .writers import CumulativePlyBody, StreamedPlyWriter, ensure_dir, write_ply
+from .writers import CumulativePlyBody, StreamedPlyWriter, ensure_dir, ply_records, write_ply
 
 _DEBUG_PREVIEW_INTERVAL = 3      # upstream core/pipeline.py:34
 _PREVIEW_MAX_MATCHES = 10000     # upstream core/pipeline.py:50
@@ -435,10 +435,15 @@ class _HotPath:
             self.dens.check_launches()
         return res if res.count else None
 
+    def pack_ply_tensor(self, xyz: torch.Tensor, rgb: torch.Tensor) -> torch.Tensor:
+        """The same records as a uint8 tensor that stays where the points are (what a sharded run sends to the writer rank)."""
+        if self.on_host:
+            return torch.from_numpy(ply_records(xyz.numpy(), to_uint8_rgb(rgb.numpy())).view(np.uint8).reshape(-1).copy())
+        return self.dens.pack_ply(xyz, rgb)
+
     def pack_ply_bytes(self, xyz: torch.Tensor, rgb: torch.Tensor) -> bytes:
         """The survivors' 15-byte PLY records, quantised and packed on the device (only file payload crosses PCIe)."""
         if self.on_host:
-            from .writers import ply_records
             return ply_records(xyz.numpy(), to_uint8_rgb(rgb.numpy())).tobytes()
         return self.dens.pack_ply(xyz, rgb).cpu().numpy().tobytes()
 
@@ -543,6 +548,7 @@ def run_dense_pipeline(
     prefetch: Optional[_OrderedPrefetcher] = None
     hot: Optional[_HotPath] = None
     feat_cache: Optional[FeatureCache] = None
+    shard_stream: Optional[lfd_dist.ShardedPlyStream] = None
 
     rank_status = 0          # 0 fine, 1 cancelled, 2 failed: agreed on by all ranks before the exchange step (core/distributed.py)
     rank_error: Optional[BaseException] = None
@@ -581,9 +587,14 @@ def run_dense_pipeline(
         inflight: List[Tuple[int, _PackedReference, object]] = []                       # sampled mode: launched, not yet read back
         if on_sequential_viz and viz_interval > 0 and intermediate_base:
             cum_body = CumulativePlyBody()
-        if (bool(getattr(config, "stream_output", False)) and world == 1 and str(config.output_path).lower().endswith(".ply")
+        if (bool(getattr(config, "stream_output", False)) and str(config.output_path).lower().endswith(".ply")
                 and int(config.max_points) <= 0 and float(config.voxel_size) <= 0.0):
-            stream_writer = StreamedPlyWriter(config.output_path)
+            if rank == 0:
+                stream_writer = StreamedPlyWriter(config.output_path)
+            if world > 1:
+                # sharded run (BASELINE config 5): every rank packs its finished references' records on the device, rank 0 appends
+                # them to the file in global reference order as they arrive (core/distributed.py)
+                shard_stream = lfd_dist.ShardedPlyStream(dist, len(refs_local), stream_writer, dev)
 
         def emit(local_i: int, packed: _PackedReference, xyz, rgb, err, dbg, dev_pts=None) -> None:
             nonlocal refs_with_points
@@ -593,11 +604,15 @@ def run_dense_pipeline(
             err_parts.append(err)
             counts_local[local_i] = int(xyz.shape[0]) if xyz is not None else int(dev_pts[0].shape[0])
             refs_with_points += 1
-            if cum_body is not None or stream_writer is not None:
+            if shard_stream is not None:
+                # sharded streamed output: the records stay where they were packed until they travel to rank 0
+                shard_stream.push(local_i, hot.pack_ply_tensor(dev_pts[0], dev_pts[1]) if dev_pts is not None
+                                  else torch.from_numpy(ply_records(xyz, to_uint8_rgb(rgb)).view(np.uint8).reshape(-1).copy()))
+            if cum_body is not None or (stream_writer is not None and shard_stream is None):
                 # this reference's PLY records, packed once (on the device when the points are there): the previews and the
                 # streamed output are made of these bytes, nothing is re-concatenated or re-quantised later
                 body = hot.pack_ply_bytes(dev_pts[0], dev_pts[1]) if dev_pts is not None else None
-                for sink in (cum_body, stream_writer):
+                for sink in (cum_body, stream_writer if shard_stream is None else None):
                     if sink is None:
                         continue
                     if body is not None:
@@ -798,6 +813,11 @@ def run_dense_pipeline(
                 matcher.close()
             except Exception as exc:
                 log.warn(f"Matcher cleanup failed: {exc}")
+        if shard_stream is not None:
+            try:
+                shard_stream.finish()         # rank 0 receives what is left (a rank that stopped early sends empty references)
+            except Exception as exc:
+                log.warn(f"Finishing the sharded output stream failed: {exc}")
         if stream_writer is not None:
             try:
                 stream_writer.close()         # patches the vertex count into the header
@@ -835,22 +855,29 @@ def run_dense_pipeline(
         xyz, rgb, err = (t.cpu().numpy() for t in device_points)
     else:
         xyz, rgb, err = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0,), np.float32)
-    if world > 1:       # the one exchange step: ordered all-gather of the survivors over RCCL, from where they already are (HBM)
+    n_points_global = int(xyz.shape[0])
+    if world > 1:       # the one exchange step: the survivors travel over RCCL from where they already are (HBM), ordered by reference
         if dev_parts:
             lx, lc, le = (torch.cat([p[i] for p in dev_parts], 0) for i in range(3))
         else:
             lx, lc, le = (torch.zeros((0, 3), device=dev), torch.zeros((0, 3), device=dev), torch.zeros((0,), device=dev))
-        gx, gc_, ge, counts = lfd_dist.all_gather_by_reference(lx, lc, le, counts_local, len(refs_local), dist)
+        if str(getattr(config, "exchange", "all_gather")) == "gather_to_root":
+            # only rank 0 consumes the cloud (it writes the file): every record travels once, straight to its place on rank 0;
+            # the other ranks return their own shard
+            gx, gc_, ge, counts = lfd_dist.gather_to_root_by_reference(lx, lc, le, counts_local, len(refs_local), dist)
+        else:
+            gx, gc_, ge, counts = lfd_dist.all_gather_by_reference(lx, lc, le, counts_local, len(refs_local), dist)
         xyz, rgb, err = gx.cpu().numpy(), gc_.cpu().numpy(), ge.cpu().numpy()
         device_points = (gx, gc_, ge)
+        n_points_global = int(counts.sum())
         t = torch.tensor([refs_with_points, pair_counter], dtype=torch.int64,
                          device=lfd_dist._collective_device(gx, dist))
         dist.all_reduce(t)
         refs_with_points, pair_counter = int(t[0].item()), int(t[1].item())
 
-    if xyz.shape[0] == 0:
+    if n_points_global == 0:
         raise RuntimeError("No points triangulated. Try adjusting parameters.")
     return PipelineResult(xyz=xyz, rgb=rgb, err=err, elapsed_seconds=time.time() - t0,
                           pairs_processed=refs_with_points, pairs_matched=pair_counter, points_per_reference=counts,
                           device_points=device_points,
-                          streamed_path=config.output_path if stream_writer is not None else None)
+                          streamed_path=config.output_path if (stream_writer is not None or shard_stream is not None) else None)

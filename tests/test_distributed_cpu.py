@@ -27,7 +27,7 @@ def _make_points(n_refs, seed=0):
     return counts, pts
 
 
-def _worker(rank, world, port, n_refs, q):
+def _worker(rank, world, port, n_refs, q, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,18 +39,34 @@ def _worker(rank, world, port, n_refs, q):
         gx, gc, ge, gcounts = lfd_dist.all_gather_by_reference(t[:, 0:3], t[:, 3:6], t[:, 6], [counts[g] for g in mine],
                                                                 n_refs, dist)
         ax, ac, ae, rc = lfd_dist.all_gather_points(t[:, 0:3], t[:, 3:6], t[:, 6], dist)
-        q.put((rank, gx.numpy(), gc.numpy(), ge.numpy(), gcounts, ax.numpy(), rc))
+        # the same exchange as a gather to rank 0: the root holds the ordered cloud, the other rank keeps its own shard
+        rx, rcol, re, rcounts = lfd_dist.gather_to_root_by_reference(t[:, 0:3], t[:, 3:6], t[:, 6], [counts[g] for g in mine], n_refs, dist)
+        root = np.concatenate([rx.numpy(), rcol.numpy(), re.numpy()[:, None]], 1)
+        # streamed PLY: 15-byte records per reference (here: the first 15 bytes of every 28-byte record), rank 0 writes the file
+        path = os.path.join(tmp, "stream.ply")
+        from lichtfeld_densification_plugin_amd.core.writers import StreamedPlyWriter
+        writer = StreamedPlyWriter(path) if rank == 0 else None
+        stream = lfd_dist.ShardedPlyStream(dist, n_refs, writer, torch.device("cpu"))
+        for i, g in enumerate(mine):
+            if counts[g]:                         # references without points are never pushed (the pipeline's emit() is not called)
+                stream.push(i, torch.from_numpy(np.ascontiguousarray(pts[g].view(np.uint8).reshape(-1, 28)[:, :15]).reshape(-1)))
+        stream.finish()
+        if writer is not None:
+            writer.close()
+        dist.barrier()
+        q.put((rank, gx.numpy(), gc.numpy(), ge.numpy(), gcounts, ax.numpy(), rc, root, rcounts))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("n_refs", [7, 2, 1])
-def test_ordered_all_gather_world2(n_refs):
+def test_ordered_all_gather_world2(n_refs, tmp_path):
     world = 2
+    tmp = str(tmp_path)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_refs, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_refs, q, tmp)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
@@ -59,7 +75,11 @@ def test_ordered_all_gather_world2(n_refs):
         assert p.exitcode == 0
     counts, pts = _make_points(n_refs)
     full = np.concatenate(pts, 0)
-    for rank, gx, gc, ge, gcounts, ax, rc in results:
+    for rank, gx, gc, ge, gcounts, ax, rc, root, rcounts in results:
+        np.testing.assert_array_equal(rcounts, counts)
+        mine = lfd_dist.shard_references(n_refs, rank, world)
+        own = np.concatenate([pts[g] for g in mine], 0) if mine else np.zeros((0, 7), np.float32)
+        np.testing.assert_array_equal(root, full if rank == 0 else own)     # gather_to_root: the ordered cloud on rank 0 only
         np.testing.assert_array_equal(gcounts, counts)
         np.testing.assert_array_equal(gx, full[:, 0:3])      # == the single-process sequence
         np.testing.assert_array_equal(gc, full[:, 3:6])
@@ -72,3 +92,28 @@ def test_shard_references_partition():
         owned = [lfd_dist.shard_references(n, r, w) for r in range(w)]
         assert sorted(sum(owned, [])) == list(range(n))
         assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1
+
+
+def test_streamed_file_of_two_ranks_is_the_single_writer_file(tmp_path):
+    """ShardedPlyStream (exercised by the workers above): the file rank 0 wrote while both ranks pushed their references equals
+    what one process appending the references in order writes."""
+    from lichtfeld_densification_plugin_amd.core.writers import StreamedPlyWriter
+    n_refs, world = 7, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_refs, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for _ in range(world):
+        q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    counts, pts = _make_points(n_refs)
+    ref = os.path.join(str(tmp_path), "single.ply")
+    with StreamedPlyWriter(ref) as w:
+        for g in range(n_refs):
+            if counts[g]:
+                w.append_packed(np.ascontiguousarray(pts[g].view(np.uint8).reshape(-1, 28)[:, :15]).tobytes())
+    assert open(os.path.join(str(tmp_path), "stream.ply"), "rb").read() == open(ref, "rb").read()

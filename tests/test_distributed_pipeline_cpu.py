@@ -1,0 +1,99 @@
+"""The whole driver loop sharded over two ranks WITHOUT a GPU: run_dense_pipeline(backend="host") (the CPU twin) under gloo,
+references dealt round-robin, both exchange modes and the streamed writer of a sharded run (BASELINE config 5's "streamed writer"),
+against the single-process run and upstream's write_ply of its result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import lichtfeld_densification_plugin_amd as lfd
+from lichtfeld_densification_plugin_amd.core import pipeline as pl
+from helpers import oracle_cams
+
+
+class _Replay:
+    sample_thresh = 0.9
+
+    def __init__(self, table):
+        self.w_resized = self.h_resized = 64
+        self.table, self.calls = table, 0
+
+    def match_grids_batch(self, imA, imB_list):
+        res = self.table[self.calls]
+        self.calls += 1
+        return res
+
+    def close(self):
+        pass
+
+
+def _scene(g4, tmp):
+    from PIL import Image
+    cams = []
+    for i, c in enumerate(oracle_cams(g4)):
+        path = os.path.join(tmp, f"im{i:02d}.png")
+        if not os.path.exists(path):
+            Image.fromarray(g4["images"][i]).save(path)
+        cams.append(lfd.CameraRecord(uid=int(g4["cam_uid"][i]), image_path=path, width=c.width, height=c.height, K=c.K, R=c.R, t=c.t, P=c.P, C=c.C))
+    refs = [int(r) for r in g4["refs_local"]]
+    table = [[(torch.from_numpy(g4[f"ref{r}_warp"][j]), torch.from_numpy(g4[f"ref{r}_cert"][j])) for j in range(2)] for r in refs]
+    return cams, refs, g4["nn_table"], table
+
+
+def _rank(rank, world, port, tmp, cfg_kw, q):
+    import torch.distributed as dist
+    from conftest import load_golden
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cams, refs, nn, table = _scene(load_golden("g4_pipeline.npz"), tmp)
+        mine = [table[i] for i in range(len(refs)) if i % world == rank]
+        res = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**cfg_kw), matcher=_Replay(mine))
+        q.put((rank, res.xyz, res.rgb, res.err, res.points_per_reference, res.pairs_processed, res.pairs_matched, res.streamed_path))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,exchange", [("sampled", "all_gather"), ("sampled", "gather_to_root"), ("dense", "gather_to_root")])
+def test_two_host_ranks_equal_one_and_stream_the_same_file(g4, tmp_path, mode, exchange):
+    import torch.multiprocessing as mp
+    from lichtfeld_densification_plugin_amd.core import writers
+    from lichtfeld_densification_plugin_amd.core.image_io import to_uint8_rgb
+    tmp = str(tmp_path)
+    cams, refs, nn, table = _scene(g4, tmp)
+    kw = dict(nns_per_ref=2, seed=5, viz_interval=0, matches_per_ref=1200, triangulation_mode=mode, per_reference_rng=True, backend="host",
+              pack_workers=1)
+    single = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(output_path=os.path.join(tmp, "single.ply"), **kw), matcher=_Replay(table))
+    writers.write_ply(os.path.join(tmp, "single.ply"), single.xyz, to_uint8_rgb(single.rgb))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    out = os.path.join(tmp, "sharded.ply")
+    cfg_kw = dict(output_path=out, exchange=exchange, stream_output=True, **kw)
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, tmp, cfg_kw, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    world = 2
+    for rank, xyz, rgb, err, counts, n_refs, n_pairs, streamed in results:
+        np.testing.assert_array_equal(counts, single.points_per_reference)
+        assert n_refs == single.pairs_processed and n_pairs == single.pairs_matched and streamed == out
+        if exchange == "all_gather" or rank == 0:
+            np.testing.assert_array_equal(xyz, single.xyz)
+            np.testing.assert_array_equal(rgb, single.rgb)
+            np.testing.assert_array_equal(err, single.err)
+        else:                                   # gather_to_root: the other rank returns its own shard
+            offs = np.concatenate([[0], np.cumsum(single.points_per_reference)])
+            own = np.concatenate([single.xyz[offs[g]:offs[g + 1]] for g in range(rank, len(refs), world)])
+            np.testing.assert_array_equal(xyz, own)
+    # the streamed file of the sharded run: the single run's cloud through upstream's writer, byte for byte behind the header
+    head, body = open(out, "rb").read().split(b"end_header\n", 1)
+    ref_head, ref_body = open(os.path.join(tmp, "single.ply"), "rb").read().split(b"end_header\n", 1)
+    assert body == ref_body
+    assert [l for l in head.decode().split("\n") if l and not l.startswith("comment")] == [l for l in ref_head.decode().split("\n") if l]
