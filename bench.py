@@ -44,15 +44,33 @@ from lichtfeld_densification_plugin_amd.core import hip_backend as hb  # noqa: E
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
 
+# the synthetic stand-ins of BASELINE.json's configurations (garden: 185 cameras on a ring, 1297x840 images)
+WORKLOADS = {
+    "config2": dict(refs=64, k=3, preset="fast", n_cams=185, arc=None,
+                    what="config[1]: garden @fast, GUI default thresholds, 64 reference views x 3 neighbours resident"),
+    "config4": dict(refs=56, k=8, preset="fast", n_cams=185, arc=None,
+                    what="config[3]: garden, all cameras, ref-fraction 0.3 -> 56 reference views x 8 neighbours = 448 pairs, sharded"),
+    "config5": dict(refs=12, k=8, preset="precise", n_cams=12, arc=0.6,
+                    what="config[4]: `precise` 1280x1280 grid, ROI of 12 selected cameras (neighbours clamped to 11 -> 8), sharded"),
+}
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--refs", type=int, default=64, help="reference views resident per GPU (per launch)")
-    ap.add_argument("--k", type=int, default=3, help="neighbours per reference (GUI default 3)")
-    ap.add_argument("--preset", default="fast", choices=sorted(synthetic.ROMA_PRESETS))
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS),
+                    help="BASELINE.json configuration the synthetic workload follows (sets the defaults of --refs / --k / --preset)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --refs reference views PER GPU (the work grows with N); strong: --refs in TOTAL, dealt round-robin over the ranks "
+                         "(one scene, e.g. --workload config4 = 56 references x 8 neighbours)")
+    ap.add_argument("--refs", type=int, default=None, help="reference views resident per GPU (weak) / in total (strong)")
+    ap.add_argument("--k", type=int, default=None, help="neighbours per reference (GUI default 3)")
+    ap.add_argument("--preset", default=None, choices=sorted(synthetic.ROMA_PRESETS))
+    ap.add_argument("--cached-batch", action="store_true",
+                    help="re-launch ONE prepared batch (descriptor upload and per-pair constants skipped after the first launch) instead of "
+                         "alternating two distinct batches - profiling passes that want the dense kernel alone")
     ap.add_argument("--noise-px", type=float, default=0.5)
     ap.add_argument("--outliers", type=float, default=0.05)
     ap.add_argument("--cpu-sample-refs", type=int, default=24,
@@ -62,7 +80,12 @@ def parse_args():
     ap.add_argument("--parity-refs", type=int, default=2, help="references of the workload checked cell by cell against the oracle (0 = skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc run of this same command (profiles/)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    w = WORKLOADS[args.workload]
+    args.refs = w["refs"] if args.refs is None else args.refs
+    args.k = w["k"] if args.k is None else args.k
+    args.preset = w["preset"] if args.preset is None else args.preset
+    return args
 
 
 def _committed_pmc(args):
@@ -79,12 +102,15 @@ def _committed_pmc(args):
 
 
 def traffic_bytes(args):
-    """HBM bytes per launch of the fused kernel: --traffic-bytes, else the committed PMC measurement
-    (profiles/traffic.json) when it was taken on this same workload, else null."""
+    """(HBM bytes per launch of the fused kernel, where the number comes from): --traffic-bytes, else the committed PMC measurement
+    (profiles/traffic.json) when it was taken on this same workload, else (null, null).  PMC counters cannot be read from inside
+    this process: the figure is never measured by the run that prints it, and the line says so (`traffic_source`)."""
     if args.traffic_bytes is not None:
-        return args.traffic_bytes
+        return args.traffic_bytes, "--traffic-bytes (rocprofv3 --pmc run of this command by the caller)"
     t = _committed_pmc(args)
-    return float(t["traffic_bytes"]) if t else None
+    if t:
+        return float(t["traffic_bytes"]), "profiles/traffic.json: " + str(t.get("source", "committed rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE)"))
+    return None, None
 
 
 def valu_busy_frac(args):
@@ -94,17 +120,21 @@ def valu_busy_frac(args):
 
 
 def build_workload(args, rank, world, dev):
-    """Global reference list dealt round-robin; this rank generates and keeps only its share."""
+    """Global reference list dealt round-robin; this rank generates and keeps only its share.  weak scaling: --refs references per
+    rank; strong scaling: --refs in total (BASELINE's metric is ONE scene at 1/2/4/8 GPUs)."""
     h_lr, w_lr, H, W = synthetic.ROMA_PRESETS[args.preset]
-    n_cams = 185
-    cams = synthetic.ring_cameras(n_cams, seed=0)
-    total_refs = args.refs * world
-    ref_ids = [(i * 3) % n_cams for i in range(total_refs)]          # spread over the ring
+    wl = WORKLOADS[args.workload]
+    n_cams = wl["n_cams"]
+    cams = synthetic.ring_cameras(n_cams, seed=0, **({"arc": wl["arc"]} if wl["arc"] else {}))
+    total_refs = args.refs * world if args.scaling == "weak" else args.refs
+    step = 3 if n_cams >= 3 * total_refs or n_cams % 3 else 1
+    ref_ids = [(i * step) % n_cams for i in range(total_refs)]          # spread over the ring
     mine = [i for i in range(total_refs) if i % world == rank]
+    k = min(args.k, n_cams - 1)
     refs, srefs = [], []
     for gi in mine:
         ref = ref_ids[gi]
-        nbrs = synthetic.ring_neighbours(n_cams, ref, args.k)
+        nbrs = synthetic.ring_neighbours(n_cams, ref, k) if not wl["arc"] else sorted(range(n_cams), key=lambda c: (abs(c - ref), c))[1:k + 1]
         s = synthetic.synth_reference(cams, ref, nbrs, H, W, w_lr, h_lr, noise_px=args.noise_px,
                                       outlier_frac=args.outliers, channels=2, seed=1000 + gi, cert_mode="smooth",
                                       device=dev)
@@ -112,13 +142,14 @@ def build_workload(args, rank, world, dev):
         pad = int(os.environ.get("LFD_BENCH_PLANE_PAD", "0"))       # experiment: every plane in its own allocation, `pad` bytes apart
         if pad > 0:
             certs, warps = [], []
-            for j in range(args.k):
+            for j in range(k):
                 _pads.append(torch.empty(pad, dtype=torch.uint8, device=dev)); certs.append(s.cert[j].clone())
                 _pads.append(torch.empty(pad, dtype=torch.uint8, device=dev)); warps.append(s.warp[j].clone())
         else:
-            certs, warps = [s.cert[j] for j in range(args.k)], [s.warp[j] for j in range(args.k)]
+            certs, warps = [s.cert[j] for j in range(k)], [s.warp[j] for j in range(k)]
         refs.append(hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=certs, warp=warps, image=s.image))
-    return cams, refs, srefs, (H, W, w_lr, h_lr), mine
+    args.k = k
+    return cams, refs, srefs, (H, W, w_lr, h_lr), mine, total_refs
 
 
 _pads = []
@@ -285,24 +316,40 @@ def cpu_baseline(args, cams, srefs, dims, cfg):
     params = hb.make_params(cfg)
     out = {}
     n_hw = os.cpu_count() or 1
-    for label, threads in (("all", 0), ("one", 1)):
+
+    def timed_dense(twin, b, refs_used, min_s=2.0, max_passes=64):
+        """Whole passes over the sample until at least ``min_s`` seconds have been measured (the pool's threads are parked between
+        calls; the first, untimed pass faults the output pages in)."""
+        twin.triangulate_dense(b, params)
+        n, pts, t0 = 0, 0, time.perf_counter()
+        while True:
+            pts += twin.triangulate_dense(b, params).count
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= min_s or n >= max_passes:
+                break
+        return dict(points_per_s=pts / dt, cells_per_s=n * refs_used * H * W / dt, pairs_per_s=n * refs_used * args.k / dt,
+                    seconds=dt, passes=n, references=refs_used, threads=twin.n_threads)
+
+    ladder = sorted({t for t in (1, 16, 64, n_hw) if t <= n_hw})
+    scaling = []
+    for threads in ladder:
         twin = hb.HostDensifier(threads)
         twin.upload_cameras(cams)
-        refs_used = len(host_refs) if threads != 1 else max(1, len(host_refs) // 4)
+        refs_used = len(host_refs) if threads >= 16 else max(1, len(host_refs) // 6)
         b = batch if refs_used == len(host_refs) else hb.PreparedBatch(host_refs[:refs_used], wm, hm, cameras=cams)
-        twin.triangulate_dense(b, params)                       # warm (page faults of the output buffers)
-        t0 = time.perf_counter()
-        res = twin.triangulate_dense(b, params)
-        dt = time.perf_counter() - t0
-        out[label] = dict(points_per_s=res.count / dt, cells_per_s=refs_used * H * W / dt, pairs_per_s=refs_used * args.k / dt,
-                          seconds=dt, references=refs_used, threads=twin.n_threads)
-        if threads == 0:     # upstream's own mode on the twin, reference after reference
-            rng = np.random.RandomState(cfg.seed)
+        r = timed_dense(twin, b, refs_used)
+        scaling.append(r)
+        if threads == 1:
+            out["one"] = r
+        if threads == n_hw:
+            out["all"] = r
+            rng = np.random.RandomState(cfg.seed)     # upstream's own mode on the twin, reference after reference
             t0 = time.perf_counter()
             pts = 0
             n_s = min(8, len(host_refs))
-            for r in host_refs[:n_s]:
-                b1 = hb.PreparedBatch([r], wm, hm, cameras=cams)
+            for rf in host_refs[:n_s]:
+                b1 = hb.PreparedBatch([rf], wm, hm, cameras=cams)
                 best, _ = twin.aggregate(b1, params)
                 sel = select_samples_with_coverage(best[0], cfg.matches_per_ref, cap=0.9, border=2, tiles=24, rng=rng)
                 pts += twin.triangulate_indexed(b1, params, torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int64)), [0, int(sel.size)]).count
@@ -334,11 +381,14 @@ def cpu_baseline(args, cams, srefs, dims, cfg):
         ctx.restore_original_limits()
     a = out["all"]
     return {"value": a["points_per_s"], "unit": "points/s", "cores": a["threads"], "kind": "port",
-            "sample": f"{a['references']} reference views x {args.k} neighbours x {H}x{W} cells of this workload, dense mode "
-                      f"({a['seconds']:.2f} s on {a['threads']} threads of {n_hw} host CPUs; CPU twin of the C-ABI = host build of the kernels' source)",
+            "sample": f"{a['passes']} passes over {a['references']} reference views x {args.k} neighbours x {H}x{W} cells of this workload, dense mode "
+                      f"({a['seconds']:.2f} s on {a['threads']} threads of {n_hw} host CPUs; CPU twin of the C-ABI = host build of the kernels' source, "
+                      f"persistent thread pool)",
+            "scaling": [{"threads": r["threads"], "points_per_s": r["points_per_s"], "seconds": r["seconds"], "passes": r["passes"],
+                         "references": r["references"]} for r in scaling],
             "pairs_per_s": a["pairs_per_s"], "cells_per_s": a["cells_per_s"],
             "one_thread": {"value": out["one"]["points_per_s"], "cores": 1, "pairs_per_s": out["one"]["pairs_per_s"],
-                           "sample": f"{out['one']['references']} references, {out['one']['seconds']:.2f} s"},
+                           "sample": f"{out['one']['passes']} passes over {out['one']['references']} references, {out['one']['seconds']:.2f} s"},
             "sampled_mode": out["sampled"],
             "oracle_numpy": {"value": opts / dto, "cores": 1, "pairs_per_s": n_o * args.k / dto,
                              "sample": f"{n_o} references dense, {dto:.1f} s, BLAS threads limited to 1 (upstream's arithmetic: batched LAPACK f32 SVD)"},
@@ -430,13 +480,20 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    cams, refs, srefs, dims, mine = build_workload(args, rank, world, dev)
+    cams, refs, srefs, dims, mine, total_refs = build_workload(args, rank, world, dev)
     H, W, wm, hm = dims
     cfg = lfd.DensePipelineConfig(output_path="", roma_setting=args.preset, nns_per_ref=args.k)   # GUI defaults
     params = hb.make_params(cfg)
     dens = hb.HipDensifier(dev)
     dens.upload_cameras(cams)
+    if not refs:
+        raise SystemExit(f"rank {rank} owns no reference view: --refs {args.refs} ({args.scaling}) over {world} ranks")
+    # Two DISTINCT batches alternate in the timed loop (the same planes, the references in another order: other descriptor
+    # tables, other per-pair constants), as in a real run where every launch sees a new batch: the descriptor upload and
+    # lfd_pair_setup_kernel are then inside the timed region.  They are issued by lfd_prepare_batch, so that the HIP events
+    # around the launch that follows bracket the dense kernel alone.
     batch = hb.PreparedBatch(refs, wm, hm, cameras=cams)      # the pipeline's default: upstream's own F handed to the kernels
+    batches = [batch] if (args.cached_batch or len(refs) < 2) else [batch, hb.PreparedBatch(refs[1:] + refs[:1], wm, hm, cameras=cams)]
     out = hb.OutputBuffers(len(refs) * H * W, len(refs), args.k, dev, with_cell=False, with_segments=False)   # upstream emits xyz, rgb, err only
 
     def barrier():
@@ -445,30 +502,42 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    def step(i, evs=None):
+        b = batches[i % len(batches)]
+        if evs is not None:
+            evs[0].record()
+        dens.prepare(b, params)         # tables + per-pair constants of THIS batch (a no-op when it is the batch of the last launch)
+        if evs is not None:
+            evs[1].record()             # same stream the kernel is launched on (torch's current stream)
+        dens.launch_dense(b, params, out)
+        if evs is not None:
+            evs[2].record()
+
     # untimed spin-up (clocks, first-touch of the output pages), then the W warm-up steps
     t_spin = time.perf_counter()
+    n_spin = 0
     while time.perf_counter() - t_spin < args.spinup_s:       # back-to-back like the timed region, so that the power management has settled
         for _ in range(32):
-            dens.launch_dense(batch, params, out)
+            step(n_spin); n_spin += 1
         torch.cuda.synchronize(dev)
-    for _ in range(args.warmup):
-        dens.launch_dense(batch, params, out)
+    for i in range(args.warmup):
+        step(i)
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     host_t = []
-    for a, b in ev:
-        a.record()                      # same stream the kernel is launched on (torch's current stream)
-        dens.launch_dense(batch, params, out)
-        b.record()
+    for i, e3 in enumerate(ev):
+        step(i, e3)
         host_t.append(time.perf_counter() - t0)
     t_enq = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
     if os.environ.get("LFD_BENCH_DEBUG"):
         print(f"[rank {rank}] enqueue done at {t_enq * 1e3:.2f} ms, first 5 host stamps {[round(x * 1e3, 2) for x in host_t[:5]]}", file=sys.stderr)
-    per_launch = [a.elapsed_time(b) for a, b in ev]
+    per_launch = [e1.elapsed_time(e2) for _e0, e1, e2 in ev]
+    per_prepare = [e0.elapsed_time(e1) for e0, e1, _e2 in ev]
     kernel_ms = float(np.mean(per_launch))
+    fresh_batch_ms = float(np.mean(per_prepare))
     kernel_pct = {"p50": float(np.percentile(per_launch, 50)), "p95": float(np.percentile(per_launch, 95)),
                   "min": float(np.min(per_launch)), "max": float(np.max(per_launch))}
     if os.environ.get("LFD_BENCH_DEBUG"):
@@ -478,9 +547,11 @@ def main():
     dens.check_launches()
     res = out.collect()
     n_pts = res.count
+    last_batch = batches[(args.steps - 1) % len(batches)] if args.steps > 0 else batch
+    rot = 1 if (last_batch is not batch) else 0           # the last launch's references are `refs` rotated by this much
 
     cdev = dev if backend != "gloo" else torch.device("cpu")
-    stats = torch.tensor([elapsed, float(n_pts), kernel_ms], dtype=torch.float64, device=cdev)
+    stats = torch.tensor([elapsed, float(n_pts), kernel_ms, fresh_batch_ms], dtype=torch.float64, device=cdev)
     allgather = None
     if dist is not None:
         tmax = stats.clone()
@@ -489,20 +560,32 @@ def main():
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0].item())
         total_pts = float(tsum[1].item())
-        # the one exchange step of the path: ordered all-gather of the survivors from HBM (outside the timed region, timed on its own)
+        # the one exchange step of the path, from HBM, outside the timed region and timed on its own - in both forms: the ordered
+        # all-gather the north star names, and the gather to the writer rank (core/distributed.py)
         from lichtfeld_densification_plugin_amd.core import distributed as lfd_dist
         offs = res.ref_offsets
-        counts_local = [int(offs[i + 1] - offs[i]) for i in range(len(refs))]
-        gathered = lfd_dist.all_gather_by_reference(res.xyz, res.rgb, res.err, counts_local, args.refs * world, dist)   # warm
-        barrier()
-        t_ag = time.perf_counter()
-        gathered = lfd_dist.all_gather_by_reference(res.xyz, res.rgb, res.err, counts_local, args.refs * world, dist)
-        barrier()
-        ag = torch.tensor([time.perf_counter() - t_ag], dtype=torch.float64, device=cdev)
-        dist.all_reduce(ag, op=dist.ReduceOp.MAX)
-        assert gathered[0].shape[0] == int(total_pts), (gathered[0].shape, total_pts)
-        assert int(gathered[3].sum()) == int(total_pts) and gathered[3].shape[0] == args.refs * world
-        allgather = {"allgather_ms": float(ag[0].item()) * 1e3, "bytes_gathered": int(total_pts) * 28, "backend": backend,
+        cl = [int(offs[i + 1] - offs[i]) for i in range(len(refs))]
+        if rot:                         # back to this rank's own reference order (the exchange orders by global reference position)
+            order = list(range(len(refs) - rot, len(refs))) + list(range(0, len(refs) - rot))
+            pieces = [(int(offs[i]), int(offs[i + 1])) for i in order]
+            lx = torch.cat([res.xyz[a:b] for a, b in pieces]); lc = torch.cat([res.rgb[a:b] for a, b in pieces]); le = torch.cat([res.err[a:b] for a, b in pieces])
+            counts_local = [cl[i] for i in order]
+        else:
+            lx, lc, le, counts_local = res.xyz, res.rgb, res.err, cl
+        timings = {}
+        for name, fn in (("allgather_ms", lfd_dist.all_gather_by_reference), ("gather_to_root_ms", lfd_dist.gather_to_root_by_reference)):
+            gathered = fn(lx, lc, le, counts_local, total_refs, dist)     # warm
+            barrier()
+            t_ag = time.perf_counter()
+            gathered = fn(lx, lc, le, counts_local, total_refs, dist)
+            barrier()
+            ag = torch.tensor([time.perf_counter() - t_ag], dtype=torch.float64, device=cdev)
+            dist.all_reduce(ag, op=dist.ReduceOp.MAX)
+            timings[name] = float(ag[0].item()) * 1e3
+            if name == "allgather_ms" or rank == 0:
+                assert gathered[0].shape[0] == int(total_pts), (gathered[0].shape, total_pts)
+            assert int(gathered[3].sum()) == int(total_pts) and gathered[3].shape[0] == total_refs
+        allgather = {**timings, "bytes_gathered": int(total_pts) * 28, "backend": backend,
                      "points": int(total_pts), "order": "global reference position (1-GPU sequence)"}
     else:
         total_pts = float(n_pts)
@@ -514,32 +597,44 @@ def main():
         algo_bytes = cells * bytes_per_cell
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         value = total_pts * args.steps / elapsed
+        traffic, traffic_source = traffic_bytes(args)
+        rccl = world if backend == "nccl" else (1 if dist is None else 0)
         line = {
             "metric": "triangulated points/sec + pairs/sec, MipNeRF360 garden @fast, 1/2/4/8 GPU",     # BASELINE.json's metric; value = points/s, pairs_per_s beside it
-            "value": value, "unit": "points/s", "n_gpus": world, "rccl_ranks": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "points/s", "n_gpus": world, "rccl_ranks": rccl, "collective_backend": backend, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32 (+f64 Sampson/DLT solve)", "data": "synthetic",
-            "config": {"workload": f"garden-like ring of 185 cameras 1297x840, `{args.preset}` grid {H}x{W}, "
-                                   f"{args.refs} reference views x {args.k} neighbours resident per GPU, "
+            "config": {"workload": f"{WORKLOADS[args.workload]['what']}: ring of {WORKLOADS[args.workload]['n_cams']} cameras 1297x840, `{args.preset}` grid {H}x{W}, "
+                                   f"{args.refs} reference views x {args.k} neighbours {'resident per GPU' if args.scaling == 'weak' else 'in total, dealt over the ranks'}, "
                                    f"default thresholds (certainty 0.2 / sampson 5.0 / reproj 0.8 / parallax 0.5 deg), "
                                    f"noise {args.noise_px} px, {args.outliers:.0%} outliers",
-                       "kernel": "fused dense filter+triangulate kernel (lfd_dense_kernel)", "mode": "dense", "refs_per_gpu": args.refs, "neighbours": args.k, "grid": [H, W],
-                       "sharding": f"references round-robin over {world} rank(s)"},
-            "pairs_per_s": args.refs * world * args.k * args.steps / elapsed,
-            "cells_per_s": cells * world * args.steps / elapsed,
+                       "kernel": "fused dense filter+triangulate kernel (lfd_dense_kernel)", "mode": "dense", "refs_per_gpu": len(refs), "refs_total": total_refs,
+                       "neighbours": args.k, "grid": [H, W], "sharding": f"references round-robin over {world} rank(s)",
+                       "batches_in_rotation": len(batches)},
+            "pairs_per_s": total_refs * args.k * args.steps / elapsed,
+            "cells_per_s": total_refs * H * W * args.steps / elapsed,
             "survivor_fraction": s_frac,
+            # one step = lfd_prepare_batch (descriptor upload + per-pair constants of a batch the context has not just seen) + the dense kernel
+            "compute_ms": elapsed / args.steps * 1e3, "kernel_ms": kernel_ms, "fresh_batch_ms": fresh_batch_ms,
+            "end_to_end": None,
+            "end_to_end_note": "points/s including the RoMa-v2 forward (SURVEY 8d iii) is unmeasured: neither the RoMa-v2 weights nor torchvision are on the box",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic_bytes(args),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "lfd_dense_kernel", "kernel_ms": kernel_ms, "kernel_ms_percentiles": kernel_pct,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_cell": bytes_per_cell},
         }
+        if allgather is not None:
+            # the exchange follows the timed region once per job: the whole-job rate with it = points / (one step + the exchange)
+            step_s = elapsed / args.steps
+            line["value_incl_exchange"] = total_pts / (step_s + allgather["allgather_ms"] * 1e-3)
+            line["value_incl_gather_to_root"] = total_pts / (step_s + allgather["gather_to_root_ms"] * 1e-3)
         # the same time priced against the byte count of a kernel that reads the warps of ALL k neighbours coalesced
         # (12k + 3 + 28 s per cell) - what lfd_dense_kernel physically does for references with at most LFD_DENSE_ALL_WARPS (2) neighbours
         line["roofline"]["achieved_all_warps_bytes"] = cells * (12 * args.k + 3 + 28 * s_frac) / (kernel_ms * 1e-3) / 1e9
         if not args.light and world == 1:
             line["roofline"]["device_copy_GBps"] = device_copy_bandwidth(dev)      # what a plain device-to-device copy reaches on this box
-        line["roofline"]["valu_busy_frac"] = valu_busy_frac(args)     # the f64 geometry makes the kernel vector-ALU-bound, not HBM-bound
+        line["roofline"]["valu_busy_frac"] = valu_busy_frac(args)     # the f64 geometry makes the kernel vector-ALU-bound, not HBM-bound (same source as `traffic`)
         line["roofline"]["traffic_over_algorithmic"] = (line["roofline"]["traffic"] / algo_bytes) if line["roofline"]["traffic"] else None
         if allgather is not None:
             line["exchange"] = allgather

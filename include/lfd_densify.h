@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LFD_ABI_VERSION 2
+#define LFD_ABI_VERSION 3
 #define LFD_MAX_SLOTS 16 /* neighbours per reference handled by one launch */
 
 enum lfd_status {
@@ -105,6 +105,10 @@ int lfd_abi_version(void);
 int lfd_create(int device_index, void* hip_stream, lfd_context** out);
 void lfd_destroy(lfd_context* ctx);
 int lfd_set_stream(lfd_context* ctx, void* hip_stream);
+/* The profiling / A-B switches of the environment (LFD_DENSE_EXTRA_LDS, LFD_INDEXED_SPLIT, LFD_SELECT_WORKGROUPS, LFD_SELECT_TIMING,
+ * LFD_DENSE_TIMING) are read when a context is created, never on a launch path; a test or profiling script that changes them for a
+ * live context calls this to have them read again. */
+int lfd_reload_env(lfd_context* ctx);
 const char* lfd_last_error(const lfd_context* ctx); /* ctx may be NULL: last creation error */
 
 /* Camera table, all host f32 row-major as upstream's CameraRecord holds them
@@ -113,6 +117,13 @@ int lfd_upload_cameras(lfd_context* ctx, int32_t n, const float* K, const float*
                        const float* P, const float* C, const int32_t* wh);
 
 /* ---- the hot path ------------------------------------------------------------------------------ */
+/* Optional: the batch-dependent preparation of a launch on its own - validation, upload of the descriptor tables (skipped when the
+ * device already holds the same tables) and the per-(reference, neighbour) constants (F5: fundamental matrices, projection blocks,
+ * core/geometry.py:53-55,122-130) - stream-ordered, asynchronous.  Every compute entry point below does the same itself when the
+ * batch differs from the last one it saw; calling this first only moves that work (a driver can issue it for reference i+1 while
+ * reference i computes, and a benchmark can time the kernels apart from it). */
+int lfd_prepare_batch(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params);
+
 /* P1+F1: certainty floor, masks, per-cell arg-max over the neighbours (first maximum wins).
  * best_cert: device f32 [n_refs*H*W]; best_slot: device u8 [n_refs*H*W] or NULL. */
 int lfd_aggregate(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params,

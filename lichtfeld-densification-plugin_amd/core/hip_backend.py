@@ -18,7 +18,7 @@ import torch
 from .types import CameraRecord, DensePipelineConfig
 
 LFD_MAX_SLOTS = 16
-LFD_ABI_VERSION = 2
+LFD_ABI_VERSION = 3
 LFD_FLAG_EXACT_COLOUR = 1     # lfd_params.flags: dense mode blends colours with upstream's f64 arithmetic (bit-identical rgb)
 _LIB_NAME = "liblfd_densify.so"
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -80,10 +80,12 @@ def load_library() -> C.CDLL:
     lib.lfd_destroy.argtypes = [ctxp]
     lib.lfd_destroy.restype = None
     lib.lfd_set_stream.argtypes = [ctxp, C.c_void_p]
+    lib.lfd_reload_env.argtypes = [ctxp]
     lib.lfd_last_error.argtypes = [ctxp]
     lib.lfd_last_error.restype = C.c_char_p
     fptr = C.POINTER(C.c_float)
     lib.lfd_upload_cameras.argtypes = [ctxp, C.c_int32, fptr, fptr, fptr, fptr, fptr, C.POINTER(C.c_int32)]
+    lib.lfd_prepare_batch.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params)]
     lib.lfd_aggregate.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p, C.c_void_p]
     lib.lfd_triangulate_dense.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.POINTER(lfd_points),
                                           C.c_void_p, C.c_void_p]
@@ -128,7 +130,7 @@ def load_library() -> C.CDLL:
     lib.lfd_host_null_vector.restype = C.c_int
     lib.lfd_host_eval_correspondence.argtypes = [fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                                  C.c_int32, C.POINTER(lfd_params), fptr]
-    for name in ("lfd_create", "lfd_set_stream", "lfd_upload_cameras", "lfd_aggregate", "lfd_triangulate_dense",
+    for name in ("lfd_create", "lfd_set_stream", "lfd_reload_env", "lfd_upload_cameras", "lfd_prepare_batch", "lfd_aggregate", "lfd_triangulate_dense",
                  "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_triangulate_sampled_multi", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
                  "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_identity_axis",
                  "lfd_host_fundamental", "lfd_get_pair_fundamental", "lfd_create_host", "lfd_aggregate_host",
@@ -546,6 +548,10 @@ class HipDensifier:
                     "lfd_get_pair_fundamental")
         return out.reshape(n_refs, k, 3, 3)
 
+    def reload_env(self) -> None:
+        """Re-read the profiling switches of the environment (they are read at creation only, lfd_reload_env)."""
+        self._check(self._lib.lfd_reload_env(self._ctx), "lfd_reload_env")
+
     def check_launches(self) -> None:
         """Synchronise and raise if a kernel reported a look-back timeout."""
         st = C.c_int32(0)
@@ -668,6 +674,12 @@ class HipDensifier:
         return out[:int(n.value)]
 
     # -- launches (asynchronous on self.stream) -------------------------------------------------------
+    def prepare(self, batch: PreparedBatch, params: lfd_params) -> None:
+        """Upload the batch's descriptor tables and derive its per-pair constants now (lfd_prepare_batch); the launch that follows
+        for the same batch then finds them in place."""
+        self._same_device(batch)
+        self._check(self._lib.lfd_prepare_batch(self._ctx, C.byref(batch.c), C.byref(params)), "lfd_prepare_batch")
+
     def launch_aggregate(self, batch: PreparedBatch, params: lfd_params, best_cert: torch.Tensor,
                          best_slot: Optional[torch.Tensor]) -> None:
         self._same_device(batch, None, best_cert, best_slot)

@@ -16,7 +16,7 @@
 extern "C" __global__ void lfd_aggregate_kernel(LfdLaunch L, float* best_cert, uint8_t* best_slot);
 extern "C" __global__ void lfd_dense_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_dense_exact_kernel(LfdLaunch L);
-extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* ref_out, LfdPairConst* pair_out);
+extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* ref_out, LfdPairConst* pair_out, double* row1_out);
 extern "C" __global__ void lfd_select_filter_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_pack_ply_kernel(const float* xyz, const float* rgb, long long n, unsigned char* out);
 extern "C" __global__ void lfd_pack_points3d_kernel(const float* xyz, const float* rgb, const float* err, long long n,
@@ -240,22 +240,29 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
     lfd_fill_kernel_params(b, p, L.kp);
     // per-pair constants: (re)derive when the batch tables, the cameras or the match size changed
     const size_t ref_bytes = ((size_t)b->n_refs * sizeof(LfdRefConst) + 15) & ~size_t(15);
-    const size_t need = ref_bytes + (size_t)b->n_refs * b->k * sizeof(LfdPairConst);
+    const size_t pair_bytes = ((size_t)b->n_refs * b->k * sizeof(LfdPairConst) + 15) & ~size_t(15);
+    // two-channel warps take the A-grid from the axes: the reference view's v row of the DLT matrix then depends on the grid row only
+    // and is multiplied out once per (reference, row) beside the per-pair constants
+    const bool row1 = b->warp_channels == 2;
+    const size_t need = ref_bytes + pair_bytes + (row1 ? (size_t)b->n_refs * b->H * 10 * sizeof(double) : 0);
     if (ctx->consts.bytes < need) ctx->consts_valid = false;
     rc = ensure(ctx, ctx->consts, need);
     if (rc != LFD_OK) return rc;
     LfdRefConst* d_rc = static_cast<LfdRefConst*>(ctx->consts.ptr);
     LfdPairConst* d_pc = reinterpret_cast<LfdPairConst*>(static_cast<unsigned char*>(ctx->consts.ptr) + ref_bytes);
+    double* d_row1 = row1 ? reinterpret_cast<double*>(static_cast<unsigned char*>(ctx->consts.ptr) + ref_bytes + pair_bytes) : nullptr;
     L.ref_const = d_rc;
     L.pair_const = d_pc;
-    if (!ctx->consts_valid || ctx->consts_wm != b->w_match || ctx->consts_hm != b->h_match) {
-        const int n = b->n_refs * b->k + b->n_refs;
-        hipLaunchKernelGGL(lfd_pair_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, L, d_rc, d_pc);
+    L.row1_tab = d_row1;
+    const int key[6] = {b->w_match, b->h_match, b->H, b->W, b->warp_channels, 0};
+    if (!ctx->consts_valid || std::memcmp(key, ctx->consts_key, sizeof(key)) != 0 || ctx->consts_axis_y != L.axis_y) {
+        const int n = b->n_refs * b->k + b->n_refs + (row1 ? b->n_refs * b->H : 0);
+        hipLaunchKernelGGL(lfd_pair_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, L, d_rc, d_pc, d_row1);
         LFD_HIP(ctx, hipGetLastError());
         ctx->consts_valid = true;
         ctx->consts_refs = b->n_refs; ctx->consts_k = b->k;
-        ctx->consts_wm = b->w_match;
-        ctx->consts_hm = b->h_match;
+        std::memcpy(ctx->consts_key, key, sizeof(key));
+        ctx->consts_axis_y = L.axis_y;
     }
     return LFD_OK;
 }
@@ -302,6 +309,15 @@ int prepare_lookback(lfd_context* ctx, size_t n_tiles, size_t n_tickets, bool la
     return LFD_OK;
 }
 
+void read_env_switches(lfd_context* ctx) {
+    ctx->env = LfdEnvSwitches();
+    if (const char* e = std::getenv("LFD_DENSE_EXTRA_LDS")) ctx->env.dense_extra_lds = (size_t)std::atol(e);
+    if (const char* e = std::getenv("LFD_DENSE_TIMING")) ctx->env.dense_timing_path = e;
+    if (const char* e = std::getenv("LFD_INDEXED_SPLIT")) ctx->env.indexed_split = std::atoi(e) != 0;
+    if (const char* e = std::getenv("LFD_SELECT_TIMING")) ctx->env.select_timing = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("LFD_SELECT_WORKGROUPS")) ctx->env.select_workgroups = std::atoi(e);
+}
+
 int check_points(lfd_context* ctx, const lfd_points* out, const long long* ref_offsets) {
     if (!out || !out->xyz || !out->rgb || !out->err) return fail(ctx, LFD_ERR_INVALID, "null output buffers");
     if (out->capacity < 0) return fail(ctx, LFD_ERR_INVALID, "negative capacity");
@@ -340,6 +356,7 @@ int lfd_create(int device_index, void* hip_stream, lfd_context** out) {
     lfd_context* ctx = new lfd_context();
     ctx->device = device_index;
     ctx->stream = static_cast<hipStream_t>(hip_stream);
+    read_env_switches(ctx);      // profiling / A-B switches: read ONCE here, never on a launch path
     e = hipSetDevice(device_index);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device_index);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pinned_free, hipEventDisableTiming);
@@ -364,6 +381,12 @@ void lfd_destroy(lfd_context* ctx) {
     if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
     if (ctx->pinned_free) (void)hipEventDestroy(ctx->pinned_free);
     delete ctx;
+}
+
+int lfd_reload_env(lfd_context* ctx) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    read_env_switches(ctx);
+    return LFD_OK;
 }
 
 int lfd_set_stream(lfd_context* ctx, void* hip_stream) {
@@ -435,6 +458,11 @@ int lfd_upload_cameras(lfd_context* ctx, int32_t n, const float* K, const float*
     return LFD_OK;
 }
 
+int lfd_prepare_batch(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params) {
+    LfdLaunch L;
+    return prepare_launch(ctx, batch, params, nullptr, 0, L, nullptr);
+}
+
 int lfd_aggregate(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, float* best_cert, uint8_t* best_slot) {
     LfdLaunch L;
     int rc = prepare_launch(ctx, batch, params, nullptr, 0, L, nullptr);
@@ -466,9 +494,9 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
     L.ref_offsets = reinterpret_cast<long long*>(ref_offsets);
     L.seg_counts = seg_counts;                // zeroed inside the kernel (tile 0), no memset launch
     size_t extra_lds = 0;                     // profiling switch: dynamic LDS lowers the number of resident workgroups
-    if (const char* e = std::getenv("LFD_DENSE_EXTRA_LDS")) extra_lds = (size_t)std::atol(e);
+    extra_lds = ctx->env.dense_extra_lds;
 #if defined(LFD_DENSE_TIMING)            // profiling builds: per-tile phase stamps, dumped to the file named by LFD_DENSE_TIMING
-    const char* stamp_path = std::getenv("LFD_DENSE_TIMING");
+    const char* stamp_path = ctx->env.dense_timing_path.empty() ? nullptr : ctx->env.dense_timing_path.c_str();
     if (stamp_path) {
         rc = ensure(ctx, ctx->stamps, n_tiles * 2 * 12 * sizeof(unsigned long long));
         if (rc != LFD_OK) return rc;
@@ -531,7 +559,7 @@ int lfd_triangulate_indexed(lfd_context* ctx, const lfd_batch* batch, const lfd_
     // pass A (the per-cell arithmetic) runs on the whole chip, one thread per selected cell; the per-reference workgroups
     // of lfd_indexed_kernel then only order and scatter.  LFD_INDEXED_SPLIT=0 keeps everything in the one kernel.
     bool split = true;
-    if (const char* e = std::getenv("LFD_INDEXED_SPLIT")) split = std::atoi(e) != 0;
+    split = ctx->env.indexed_split;
     long long max_sel = 0;
     for (int r = 0; r < batch->n_refs; ++r) max_sel = std::max<long long>(max_sel, sel_offsets[r + 1] - sel_offsets[r]);
     unsigned* tab = nullptr;
@@ -646,7 +674,7 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
     A.sel_offsets_out = sel_offsets_dev;
     *d_info = reinterpret_cast<int*>(base + o_out);
     *d_time = nullptr;
-    const bool timing = !topm && n_batch == 1 && std::getenv("LFD_SELECT_TIMING") != nullptr;
+    const bool timing = !topm && n_batch == 1 && ctx->env.select_timing != 0;
     if (timing) {
         A.timing = reinterpret_cast<unsigned long long*>(base + o_time);
         LFD_HIP(ctx, hipMemsetAsync(base + o_time, 0, 256, ctx->stream));
@@ -664,14 +692,14 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
         // several workgroups (one per CU) when the map is large enough to share out; LFD_SELECT_WORKGROUPS=0 keeps the
         // single-workgroup kernel (both produce the same selection)
         int n_wg = LFD_SELECT_DEFAULT_WG;
-        if (const char* e = std::getenv("LFD_SELECT_WORKGROUPS")) n_wg = std::atoi(e);
+        if (ctx->env.select_workgroups >= 0) n_wg = ctx->env.select_workgroups;
         n_wg = std::min(std::min(n_wg, (int)LFD_SELECT_MAX_WG), (int)(N / 8192));
         {
             const int tile = std::max(1, W / tiles);
             const long long nbins = (long long)((W - 1) / tile + 1) * ((H - 1) / tile + 1);
             if (nbins > LFD_SELECT_MAX_BINS) return fail(ctx, LFD_ERR_INVALID, "selection: too many coverage bins");
         }
-        const bool timing_mw = timing && std::atoi(std::getenv("LFD_SELECT_TIMING")) == 2;     // 2: stamps of workgroup 0 of the multi-workgroup kernel
+        const bool timing_mw = timing && ctx->env.select_timing == 2;     // 2: stamps of workgroup 0 of the multi-workgroup kernel
         if (n_wg >= 2 && (!timing || timing_mw)) {
             A.coop = base + o_coop;
             A.n_wg = n_wg;

@@ -18,7 +18,16 @@ struct DeviceBuffer {
 struct LfdHostPool;                              // lfd_host.hip: the host context's parked worker threads
 void lfd_host_pool_destroy(LfdHostPool* p);
 
+struct LfdEnvSwitches {          // profiling / A-B switches of the environment, read once by lfd_create
+    size_t dense_extra_lds = 0;           // LFD_DENSE_EXTRA_LDS: dynamic LDS per dense workgroup (lowers the resident workgroups per CU)
+    std::string dense_timing_path;        // LFD_DENSE_TIMING (profiling builds): file the per-tile phase stamps are dumped to
+    bool indexed_split = true;            // LFD_INDEXED_SPLIT=0: indexed mode in one kernel
+    int select_timing = 0;                // LFD_SELECT_TIMING: 1 phase stamps of the selection kernel, 2 of the multi-workgroup one
+    int select_workgroups = -1;           // LFD_SELECT_WORKGROUPS: compute workgroups of the selection (-1: default)
+};
+
 struct lfd_context {
+    LfdEnvSwitches env;
     // a context made by lfd_create_host() never touches HIP: it serves the *_host entry points only
     bool is_host = false;
     int host_threads = 1;
@@ -54,7 +63,8 @@ struct lfd_context {
     // per-pair constants of the current batch (valid while the descriptor tables are unchanged)
     DeviceBuffer consts;
     bool consts_valid = false;
-    int consts_wm = 0, consts_hm = 0;
+    int consts_key[6] = {0, 0, 0, 0, 0, 0};      // match size, grid, warp channels the constants were derived for
+    const float* consts_axis_y = nullptr;        // ... and the y axis the row table was built from
     int consts_refs = 0, consts_k = 0;
     // indexed-mode scratch
     DeviceBuffer scratch, codes, idx_tab, agg, sel_buf;

@@ -17,6 +17,7 @@ for ref in range(0, 24, 3):
 batches = [hb.PreparedBatch([r], 512, 512) for r in refs]
 for g in sys.argv[1:] or ["4", "16"]:
     os.environ["LFD_SELECT_WORKGROUPS"] = g
+    dens.reload_env()
     lat = []
     for it in range(400):
         torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -19,6 +19,7 @@ for it in range(n):
     res = {}
     for g in (0, int(rs.choice([2, 3, 8, 16, 31, 64]))):
         os.environ["LFD_SELECT_WORKGROUPS"] = str(g)
+        dens.reload_env()
         dens.seed_rng(it)
         a = dens.select_samples(t, M).cpu().numpy()
         b = dens.select_samples(t, M).cpu().numpy()

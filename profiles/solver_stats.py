@@ -114,3 +114,62 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def predicted_rule(A, E=1e-8, maxit=8):
+    """Loop solves (after the free one) under the one-test rule: two solves, then ONE test that predicts the error of the iterate
+    in hand from the last two direction changes (d2 = |x3 - x2| ~ err(x2), q_est = d2 / d1) and, from the same two numbers, how
+    many more solves bring it under E."""
+    A = A.astype(np.float64)
+    _, sv, Vt = np.linalg.svd(A)
+    mu = sv ** 2
+    c = Vt[:, :, 3]
+    ratio = mu[:, 3:4] / np.maximum(mu, 1e-300)
+
+    def chart(k):
+        x = np.einsum("ni,nij->nj", c * ratio ** k, Vt)
+        return x[:, :3] / x[:, 3:4]
+    x1, x2, x3 = chart(1), chart(2), chart(3)
+    d1 = np.abs(x2 - x1).max(1) / np.maximum(np.abs(x2).max(1), 1e-300)
+    d2 = np.abs(x3 - x2).max(1) / np.maximum(np.abs(x3).max(1), 1e-300)
+    q_est = np.minimum(d2 / np.maximum(d1, 1e-300), 0.5)
+    err3 = d2 * q_est / (1 - q_est)
+    n_more = np.zeros(A.shape[0], int)
+    e = err3.copy()
+    for _ in range(maxit):
+        need = e > E
+        n_more += need
+        e = np.where(need, e * q_est, e)
+    true_err = np.abs(chart(20) - x3).max(1) / np.maximum(np.abs(x3).max(1), 1e-300)
+    return 2 + n_more, err3, true_err
+
+
+def main2():
+    H = W = wm = hm = 512
+    cams = synthetic.ring_cameras(185, seed=0)
+    gi = 0
+    ref = 0
+    nbrs = synthetic.ring_neighbours(185, ref, 3)
+    s = synthetic.synth_reference(cams, ref, nbrs, H, W, wm, hm, noise_px=0.5, outlier_frac=0.05, channels=2, seed=1000 + gi, cert_mode="smooth")
+    cert = np.maximum(s.cert.numpy(), np.float32(0.2))
+    bj = cert.argmax(0)
+    Aw = np.empty((H, W, 4, 4), np.float32)
+    se = np.empty((H, W))
+    for j in range(3):
+        A, sj = build_rows(cams, s, j, H, W, wm, hm)
+        m = bj == j
+        Aw[m] = A[m]; se[m] = sj[m]
+    passed = (se < 5.0).reshape(-1)
+    idx = np.nonzero(passed)[0]
+    for E in (1e-8, 3e-8, 1e-7, 1e-6):
+        n, err3, true3 = predicted_rule(Aw.reshape(-1, 4, 4)[idx], E)
+        it = np.zeros(H * W, int); it[idx] = n
+        wave = it.reshape(-1, 4, 64, 4).max(axis=2)
+        act = wave > 0
+        ok = true3 <= np.maximum(err3 * 3, 1e-13)
+        print(f"E={E:g}: loop solves per cell {n.mean():.2f}, per wave step {wave[act].mean():.2f} hist {np.bincount(wave[act].reshape(-1))}; "
+              f"prediction >= true error/3 on {ok.mean():.5f} of the cells")
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "predict":
+    main2()

@@ -94,4 +94,4 @@ def flip_report(kept_cells, sref, cams, w_match, h_match, params, axes, sample=N
     reason, _ = orc.classify_flips(flipped, best_k, agg, ca, cbs, w_match, h_match, params, axes=axes, sampson_rel=sampson_rel)
     by = {name: int((reason == i).sum()) for i, name in enumerate(orc.FLIP_REASONS)}
     return dict(cells=int(cells.size), flipped=int(flipped.size), out_of_band=int((reason < 0).sum()), by_reason=by,
-                oob_cells=flipped[reason < 0].tolist(), oracle=res, compared=cells)
+                oob_cells=flipped[reason < 0].tolist(), oracle=res, compared=cells, best_k=best_k, agg=agg, cam_a=ca, cams_b=cbs)

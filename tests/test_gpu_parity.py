@@ -314,7 +314,7 @@ def test_dense_full_size_properties(dev):
                                   s.image.numpy(), ca, cbs, 512, 512, params, axes=axes_np)
     lo, hi = offs[r], offs[r + 1]
     sym = np.setxor1d(cell[lo:hi], d["cell"])
-    assert sym.size <= 1e-3 * H * W, f"{sym.size} cells differ (guard band expected to be ~1e-4)"
+    assert sym.size <= 3e-4 * H * W, f"{sym.size} cells differ (measured: 1.5e-4 of the cells, every one inside its band - tests/test_gpu_guardband.py)"
     common = np.intersect1d(cell[lo:hi], d["cell"])
     ph = np.searchsorted(cell[lo:hi], common) + lo
     po = np.searchsorted(d["cell"], common)
@@ -420,6 +420,7 @@ def test_indexed_split_kernels_equal_the_single_kernel(dev, monkeypatch):
     got = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("LFD_INDEXED_SPLIT", mode)
+        dens.reload_env()                     # the switches are read at creation, not per launch
         out = dens.triangulate_indexed(batch, params, sel_t, offs)
         got[mode] = [out.xyz.cpu().numpy().copy(), out.rgb.cpu().numpy().copy(), out.err.cpu().numpy().copy(), out.cell.cpu().numpy().copy(),
                      out.slot.cpu().numpy().copy(), out.ref_offsets.copy(), out.seg_counts.copy(), out.seg_order.copy()]

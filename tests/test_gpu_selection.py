@@ -147,6 +147,7 @@ def test_multi_workgroup_kernel_equals_single_workgroup_kernel(dens, monkeypatch
     out = {}
     for mode, val in (("single", "0"), ("multi", str(n_wg))):
         monkeypatch.setenv("LFD_SELECT_WORKGROUPS", val)
+        dens.reload_env()
         dens.seed_rng(seed)
         sel = dens.select_samples(t, M)
         sel2 = dens.select_samples(t, M)                              # a second reference continues the stream
@@ -157,6 +158,7 @@ def test_multi_workgroup_kernel_equals_single_workgroup_kernel(dens, monkeypatch
     np.testing.assert_array_equal(out["single"][3], out["multi"][3])
     # refused input (fewer non-zero weights than draws): ValueError like upstream, stream untouched
     monkeypatch.setenv("LFD_SELECT_WORKGROUPS", str(n_wg))
+    dens.reload_env()
     sparse = np.zeros((h, w), np.float32)
     sparse[h // 2, : min(w, 50)] = 0.5
     dens.seed_rng(seed)
@@ -165,6 +167,8 @@ def test_multi_workgroup_kernel_equals_single_workgroup_kernel(dens, monkeypatch
         dens.select_samples(torch.from_numpy(sparse).to(dens.device), M)
     after = dens.rng_state()
     assert before[1] == after[1] and np.array_equal(before[0], after[0])
+    monkeypatch.delenv("LFD_SELECT_WORKGROUPS")
+    dens.reload_env()                                                  # the shared context goes back to its defaults
 
 
 @pytest.mark.parametrize("no_filter", [False, True])
