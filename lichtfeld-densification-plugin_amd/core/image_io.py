@@ -6,10 +6,55 @@ pixels: RGB via PIL, resized to the matcher resolution with ``Image.BILINEAR``; 
 from __future__ import annotations
 
 import os
-from functools import lru_cache
+import threading
+from collections import OrderedDict
+from functools import lru_cache, wraps
 from typing import Tuple
 
 import numpy as np
+
+# Budget of the two caches of DECODED (full-resolution) files below.  Upstream only ever caches match-size arrays (~0.8 MB each); a
+# decoded 12-24 MP photograph is 36-72 MB, so these caches are bounded by BYTES, not by entries: at the default a camera's decode
+# survives until the neighbouring references that list it again have been packed (a few dozen images), never tens of GB.
+DECODE_CACHE_BYTES = int(os.environ.get("LFD_DECODE_CACHE_MB", "1024")) << 20
+
+
+def _byte_bounded_cache(budget_of):
+    """``lru_cache`` for functions of hashable arguments returning NumPy arrays, evicting least-recently-used entries while the
+    arrays held exceed ``budget_of()`` bytes (an array larger than the whole budget is returned uncached).  Thread-safe: the pack
+    threads of the pipeline call the decoders concurrently."""
+    def deco(fn):
+        store: "OrderedDict[tuple, np.ndarray]" = OrderedDict()
+        lock = threading.Lock()
+        state = {"bytes": 0, "hits": 0, "misses": 0}
+
+        @wraps(fn)
+        def wrapper(*args):
+            with lock:
+                if args in store:
+                    store.move_to_end(args)
+                    state["hits"] += 1
+                    return store[args]
+                state["misses"] += 1
+            val = fn(*args)                       # decode outside the lock
+            with lock:
+                if args not in store and val.nbytes <= budget_of():
+                    store[args] = val
+                    state["bytes"] += val.nbytes
+                    while state["bytes"] > budget_of() and len(store) > 1:
+                        _, old = store.popitem(last=False)
+                        state["bytes"] -= old.nbytes
+            return val
+
+        def cache_clear():
+            with lock:
+                store.clear()
+                state.update(bytes=0, hits=0, misses=0)
+
+        wrapper.cache_clear = cache_clear
+        wrapper.cache_info = lambda: dict(state, entries=len(store), budget=budget_of())
+        return wrapper
+    return deco
 
 
 def image_dir(scene_root: str, preferred: str) -> str:
@@ -64,7 +109,7 @@ def load_mask01(path: str, size: Tuple[int, int], invert: bool = False, threshol
     return out
 
 
-@lru_cache(maxsize=512)
+@_byte_bounded_cache(lambda: DECODE_CACHE_BYTES)
 def decode_rgb_u8(path: str) -> np.ndarray:
     """(h, w, 3) u8 array of ``path`` as decoded (no resize): input of the device image preparation (lfd_prepare_image)."""
     from PIL import Image
@@ -73,7 +118,7 @@ def decode_rgb_u8(path: str) -> np.ndarray:
     return arr
 
 
-@lru_cache(maxsize=512)
+@_byte_bounded_cache(lambda: DECODE_CACHE_BYTES)
 def decode_mask_l(path: str) -> np.ndarray:
     """(h, w) u8 "L" conversion of a mask file as decoded (no resize, no threshold): input of lfd_prepare_mask."""
     from PIL import Image

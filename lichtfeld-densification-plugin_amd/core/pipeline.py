@@ -683,17 +683,15 @@ def run_dense_pipeline(
                         continue
                     if one is not None:
                         dev_parts.append((one.xyz.clone(), one.rgb.clone(), one.err.clone()))
-                        h1 = one.host_arrays()
-                        emit(li, pk, h1[0], h1[1], h1[2], None, dev_parts[-1])
+                        emit(li, pk, None, None, None, None, dev_parts[-1])
                 return
             if res is None:
                 return
-            hx, hc, he = res.xyz.cpu().numpy(), res.rgb.cpu().numpy(), res.err.cpu().numpy()
             for bi, (li, pk, _ref, _axes, _seed) in enumerate(items):
                 lo, hi = int(res.ref_offsets[bi]), int(res.ref_offsets[bi + 1])
                 if hi > lo:
                     dev_parts.append((res.xyz[lo:hi].clone(), res.rgb[lo:hi].clone(), res.err[lo:hi].clone()))
-                    emit(li, pk, hx[lo:hi], hc[lo:hi], he[lo:hi], None, dev_parts[-1])
+                    emit(li, pk, None, None, None, None, dev_parts[-1])
 
         def finish_one() -> None:
             """Collect the oldest launched reference (sampled mode) and emit it: references are emitted in launch order."""
@@ -705,9 +703,10 @@ def run_dense_pipeline(
                 return
             if res is None:
                 return
+            # the survivors stay where they are: the trimmed device copy is what the previews, the streamed output, the exchange and
+            # the device-side writers consume; the host arrays of the result are ONE copy at the end of the run
             dev_parts.append((res.xyz.clone(), res.rgb.clone(), res.err.clone()))
-            hx, hc, he = res.host_arrays()
-            emit(li, pk, hx, hc, he, None, dev_parts[-1])
+            emit(li, pk, None, None, None, None, dev_parts[-1])
 
         for local_i, packed in enumerate(prefetch):
             _raise_if_cancelled(cancel_requested)
@@ -787,8 +786,7 @@ def run_dense_pipeline(
                 dbg = {"matches": hot.debug_matches(ref, out.cell, out.slot, axes, best),
                        "pair_index": {j: first_pair + j for j in range(len(certs))}}
             dev_parts.append((out.xyz.clone(), out.rgb.clone(), out.err.clone()))
-            hx, hc, he = out.host_arrays()
-            emit(local_i, packed, hx, hc, he, dbg, dev_parts[-1])
+            emit(local_i, packed, None, None, None, dbg, dev_parts[-1])
         flush_group()
         while inflight:
             finish_one()
@@ -851,7 +849,7 @@ def run_dense_pipeline(
                          torch.cat([p[2] for p in dev_parts], 0))
     if xyz_parts and all(x is not None for x in xyz_parts):
         xyz, rgb, err = np.concatenate(xyz_parts, 0), np.concatenate(rgb_parts, 0), np.concatenate(err_parts, 0)
-    elif xyz_parts and device_points is not None:      # dense mode: the survivors cross PCIe once, here
+    elif xyz_parts and device_points is not None:      # the survivors cross PCIe once, here
         xyz, rgb, err = (t.cpu().numpy() for t in device_points)
     else:
         xyz, rgb, err = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0,), np.float32)

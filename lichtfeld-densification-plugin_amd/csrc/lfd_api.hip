@@ -16,7 +16,7 @@
 extern "C" __global__ void lfd_aggregate_kernel(LfdLaunch L, float* best_cert, uint8_t* best_slot);
 extern "C" __global__ void lfd_dense_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_dense_exact_kernel(LfdLaunch L);
-extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* ref_out, LfdPairConst* pair_out, double* row1_out);
+extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* ref_out, LfdPairConst* pair_out);
 extern "C" __global__ void lfd_select_filter_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_pack_ply_kernel(const float* xyz, const float* rgb, long long n, unsigned char* out);
 extern "C" __global__ void lfd_pack_points3d_kernel(const float* xyz, const float* rgb, const float* err, long long n,
@@ -240,29 +240,22 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
     lfd_fill_kernel_params(b, p, L.kp);
     // per-pair constants: (re)derive when the batch tables, the cameras or the match size changed
     const size_t ref_bytes = ((size_t)b->n_refs * sizeof(LfdRefConst) + 15) & ~size_t(15);
-    const size_t pair_bytes = ((size_t)b->n_refs * b->k * sizeof(LfdPairConst) + 15) & ~size_t(15);
-    // two-channel warps take the A-grid from the axes: the reference view's v row of the DLT matrix then depends on the grid row only
-    // and is multiplied out once per (reference, row) beside the per-pair constants
-    const bool row1 = b->warp_channels == 2;
-    const size_t need = ref_bytes + pair_bytes + (row1 ? (size_t)b->n_refs * b->H * 10 * sizeof(double) : 0);
+    const size_t need = ref_bytes + (size_t)b->n_refs * b->k * sizeof(LfdPairConst);
     if (ctx->consts.bytes < need) ctx->consts_valid = false;
     rc = ensure(ctx, ctx->consts, need);
     if (rc != LFD_OK) return rc;
     LfdRefConst* d_rc = static_cast<LfdRefConst*>(ctx->consts.ptr);
     LfdPairConst* d_pc = reinterpret_cast<LfdPairConst*>(static_cast<unsigned char*>(ctx->consts.ptr) + ref_bytes);
-    double* d_row1 = row1 ? reinterpret_cast<double*>(static_cast<unsigned char*>(ctx->consts.ptr) + ref_bytes + pair_bytes) : nullptr;
     L.ref_const = d_rc;
     L.pair_const = d_pc;
-    L.row1_tab = d_row1;
-    const int key[6] = {b->w_match, b->h_match, b->H, b->W, b->warp_channels, 0};
-    if (!ctx->consts_valid || std::memcmp(key, ctx->consts_key, sizeof(key)) != 0 || ctx->consts_axis_y != L.axis_y) {
-        const int n = b->n_refs * b->k + b->n_refs + (row1 ? b->n_refs * b->H : 0);
-        hipLaunchKernelGGL(lfd_pair_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, L, d_rc, d_pc, d_row1);
+    if (!ctx->consts_valid || ctx->consts_wm != b->w_match || ctx->consts_hm != b->h_match) {
+        const int n = b->n_refs * b->k + b->n_refs;
+        hipLaunchKernelGGL(lfd_pair_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, L, d_rc, d_pc);
         LFD_HIP(ctx, hipGetLastError());
         ctx->consts_valid = true;
         ctx->consts_refs = b->n_refs; ctx->consts_k = b->k;
-        std::memcpy(ctx->consts_key, key, sizeof(key));
-        ctx->consts_axis_y = L.axis_y;
+        ctx->consts_wm = b->w_match;
+        ctx->consts_hm = b->h_match;
     }
     return LFD_OK;
 }

@@ -63,8 +63,7 @@ struct lfd_context {
     // per-pair constants of the current batch (valid while the descriptor tables are unchanged)
     DeviceBuffer consts;
     bool consts_valid = false;
-    int consts_key[6] = {0, 0, 0, 0, 0, 0};      // match size, grid, warp channels the constants were derived for
-    const float* consts_axis_y = nullptr;        // ... and the y axis the row table was built from
+    int consts_wm = 0, consts_hm = 0;
     int consts_refs = 0, consts_k = 0;
     // indexed-mode scratch
     DeviceBuffer scratch, codes, idx_tab, agg, sel_buf;

@@ -33,9 +33,6 @@
                                 // front end's memory requests then go ahead of older waves' f64 streams instead of waiting for a free slot
                                 // (profiles/r2/ablation.txt: 0.331 -> 0.318 ms)
 #endif
-#ifndef LFD_ROW1_TABLE
-#define LFD_ROW1_TABLE 1        // dense kernel: the reference view's v row of A^T A from a per-(reference, grid row) table staged in LDS (0 = computed per cell)
-#endif
 #define LFD_INDEXED_BLOCK 1024  // one workgroup (16 waves) per reference in the indexed kernel
 #define LFD_INDEXED_EVAL_BLOCK 256   // cells per workgroup of the indexed-mode evaluation kernel
 
@@ -123,7 +120,6 @@ struct LfdLaunch {              // kernel argument, passed by value
     unsigned int pad0;
     unsigned int* status;         // 0 = ok, LFD_LAUNCH_TIMEOUT if a look-back spin gave up
     unsigned int* seg_ready;      // == epoch once the workgroup of tile 0 has zeroed seg_counts
-    const double* row1_tab;             // [n_refs][H][10]: lfd_row1_products of every grid row (two-channel warps: the A-grid comes from the axes), else null
     const LfdColourCol* colour_cols;    // dense mode, analytic A-grid, two-channel warps: [W] / [H] colour tables (lfd_geometry.hpp), else null
     const LfdColourRow* colour_rows;
     unsigned long long* phase_stamps;   // profiling builds (-DLFD_DENSE_TIMING) with LFD_DENSE_TIMING set in the environment: [n_tiles][16] clock stamps, else null

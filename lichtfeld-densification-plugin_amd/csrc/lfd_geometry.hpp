@@ -205,18 +205,6 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
 #ifndef LFD_NULLVEC_MAXIT
 #define LFD_NULLVEC_MAXIT 8       /* solves per pass */
 #endif
-#ifndef LFD_SOLVER_PREDICT
-/* 1: the unshifted pass makes two solves after the free one and then ONE test that predicts the error of the iterate in hand from
- * the last two direction changes (the iteration is linear: err(x3) = d2 * q, q = d2 / d1), and - when that is not yet below
- * LFD_NULLVEC_ERR - how many more solves bring it there; those run without further tests.  0: a test after every solve from the second
- * on (direction change of the last solve below LFD_NULLVEC_TOL), as in rounds 1-2. */
-#define LFD_SOLVER_PREDICT 1
-#endif
-#ifndef LFD_NULLVEC_ERR
-/* predicted error (relative to the largest coordinate of X = x_i / x_3) at which the iteration stops: 1e-8 is a sixth of an f32 ulp of the
- * coordinates the vector is rounded to */
-#define LFD_NULLVEC_ERR 1e-8
-#endif
 #ifndef LFD_NULLVEC_PASSES
 #define LFD_NULLVEC_PASSES 4      /* first pass unshifted, the others shifted by the Rayleigh quotient */
 #endif
@@ -255,25 +243,18 @@ LFD_HD double lfd_recip_refined(double d) {
 // nor M = A^T A stays live across the solves (30 registers on the device); the shifted passes, which are the only
 // ones that need M a second time, are rare (sigma4/sigma3 close to 1) and simply rebuild it.
 template <class RowFn>
-LFD_HD int lfd_null_vector_rows(RowFn rows, double* c, const double* row1 = nullptr) {
+LFD_HD int lfd_null_vector_rows(RowFn rows, double* c) {
     double m00, m01, m02, m03, m11, m12, m13, m22, m23, m33;
 #define LFD_BUILD_M()                                                                                                   \
     {                                                                                                                   \
         float Af[16];                                                                                                   \
         rows(Af);                                                                                                       \
-        /* M = A^T A, upper triangle (products of f32 values are exact in f64).  Row 1 - the reference view's v row, which  \
-         * depends on the cell's grid ROW only - goes first: its ten products are exact, so a caller that holds them          \
-         * (`row1`: one table entry per grid row, lfd_row1_products) hands them over instead and the sums are the same bits */ \
-        if (row1) {                                                                                                     \
-            m00 = row1[0]; m01 = row1[1]; m02 = row1[2]; m03 = row1[3]; m11 = row1[4]; m12 = row1[5]; m13 = row1[6];    \
-            m22 = row1[7]; m23 = row1[8]; m33 = row1[9];                                                                \
-        } else {                                                                                                        \
-            const double a0 = (double)Af[4], a1 = (double)Af[5], a2 = (double)Af[6], a3 = (double)Af[7];                \
+        {   /* M = A^T A, upper triangle (products of f32 values are exact in f64) */                                   \
+            const double a0 = (double)Af[0], a1 = (double)Af[1], a2 = (double)Af[2], a3 = (double)Af[3];                \
             m00 = a0 * a0; m01 = a0 * a1; m02 = a0 * a2; m03 = a0 * a3;                                                 \
             m11 = a1 * a1; m12 = a1 * a2; m13 = a1 * a3; m22 = a2 * a2; m23 = a2 * a3; m33 = a3 * a3;                   \
         }                                                                                                               \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                 \
-            if (r == 1) continue;                                                                                       \
+        _Pragma("unroll") for (int r = 1; r < 4; ++r) {                                                                 \
             const double a0 = (double)Af[4 * r + 0], a1 = (double)Af[4 * r + 1], a2 = (double)Af[4 * r + 2],            \
                          a3 = (double)Af[4 * r + 3];                                                                    \
             m00 = fma(a0, a0, m00); m01 = fma(a0, a1, m01); m02 = fma(a0, a2, m02); m03 = fma(a0, a3, m03);             \
@@ -314,50 +295,17 @@ LFD_HD int lfd_null_vector_rows(RowFn rows, double* c, const double* row1 = null
             it = 1;
         }
         bool settled = false;
-#define LFD_SOLVE_STEP()    /* x <- d3 * (M - sh I)^-1 x : forward (L), diagonal, backward (L^T) */                         \
-        {                                                                                                               \
-            const double y1 = fma(-l10, x0, x1);                                                                        \
-            const double y2 = fma(-l21, y1, fma(-l20, x0, x2));                                                         \
-            const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, x0, x3)));                                          \
-            const double z0 = x0 * s0, z1 = y1 * s1, z2 = y2 * s2;                                                      \
-            x3 = y3;                                                                                                    \
-            x2 = fma(-l32, x3, z2);                                                                                     \
-            x1 = fma(-l21, x2, fma(-l31, x3, z1));                                                                      \
-            x0 = fma(-l10, x1, fma(-l20, x2, fma(-l30, x3, z0)));                                                       \
-        }
-#if LFD_SOLVER_PREDICT
-        if (pass == 0) {
-            // The iteration is linear: once the components along v1, v2 have died (one solve), the error of iterate k is
-            // err_k = err_1 q^(k-1) along v3, and the change between two iterates IS the error of the older one.  Two solves after
-            // the free one give the changes d1 = |X2 - X1| and d2 = |X3 - X2| (X = x_i / x_3, cross-multiplied: no division), hence
-            // q = d2 / d1 and the error of the iterate in hand, err_3 = d2 q / (1 - q) <= 2 d2^2 / d1.  That ONE test replaces the
-            // test after every solve; iterates that are not there yet run the further solves they need - each divides the error
-            // by 1 / q - without looking again.  Everything relative to the largest coordinate of X.
-            const double p0 = x0, p1 = x1, p2 = x2;                       // X1 (x3 == 1 after the free solve)
-            LFD_SOLVE_STEP();
-            const double d1 = fmax(fmax(fabs(fma(-x3, p0, x0)), fabs(fma(-x3, p1, x1))), fabs(fma(-x3, p2, x2)));      // |X2 - X1| |x3|
-            const double q0 = x0, q1 = x1, q2 = x2, q3 = x3;
-            LFD_SOLVE_STEP();
-            it = 3;
-            const double d2 = fmax(fmax(fabs(fma(x0, q3, -(x3 * q0))), fabs(fma(x1, q3, -(x3 * q1)))), fabs(fma(x2, q3, -(x3 * q2))));   // |X3 - X2| |x3 q3|
-            const double xm = fmax(fmax(fabs(x0), fabs(x1)), fabs(x2));   // |X3|inf |x3|
-            const double den = d1 * fabs(x3);                             // q = d2 / den
-            double lhs = d2 * d2;                                         // err_3 <= E  <=>  2 d2^2 <= E den |q3| xm
-            double rhs = (0.5 * LFD_NULLVEC_ERR) * (den * (fabs(q3) * xm));
-            if (d2 <= 0.5 * den) {                                        // converging at q <= 1/2 (false for NaN): the prediction holds
-                while (!(lhs <= rhs) && it < 3 + LFD_NULLVEC_MAXIT) {     // a lane leaves when ITS prediction is met
-                    LFD_SOLVE_STEP();
-                    ++it;
-                    lhs *= d2; rhs *= den;
-                }
-                settled = lhs <= rhs;
-            }
-        }
-        if (!settled)
-#endif
         for (int k = 1;; ++k) {
             const double o0 = x0, o1 = x1, o2 = x2, o3 = x3;
-            LFD_SOLVE_STEP();
+            // x <- d3 * (M - sh I)^-1 x : forward (L), diagonal, backward (L^T)
+            const double y1 = fma(-l10, x0, x1);
+            const double y2 = fma(-l21, y1, fma(-l20, x0, x2));
+            const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, x0, x3)));
+            const double z0 = x0 * s0, z1 = y1 * s1, z2 = y2 * s2;
+            x3 = y3;
+            x2 = fma(-l32, x3, z2);
+            x1 = fma(-l21, x2, fma(-l31, x3, z1));
+            x0 = fma(-l10, x1, fma(-l20, x2, fma(-l30, x3, z0)));
             ++it;
             if (k >= 2) {
                 // direction change of the last solve, measured on the inhomogeneous coordinates x_i / x_3 (cross-multiplied):
@@ -396,7 +344,6 @@ LFD_HD int lfd_null_vector_rows(RowFn rows, double* c, const double* row1 = null
     c[0] = x0; c[1] = x1; c[2] = x2; c[3] = x3;
     return it;
 #undef LFD_BUILD_M
-#undef LFD_SOLVE_STEP
 }
 
 struct LfdCopyRows {
@@ -413,18 +360,6 @@ LFD_HD int lfd_null_vector(const float* Af, double* c) {
 LFD_HD double lfd_div_by_recip(double a, double b, double r) {
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
-}
-
-// ---- the reference view's v row of the DLT matrix, multiplied out -------------------------------------------------------
-// Row 1 of A is va * P[2][c] - P[1][c] (f32, multiply then subtract, core/geometry.py:72-75) with va the reference pixel's v:
-// on the matcher's own A-grid it depends on the grid ROW of the cell only.  Its ten products a_i a_j (upper triangle; exact in
-// f64) are what M = A^T A starts from, so one entry per (reference, grid row) - built once per batch by lfd_pair_setup_kernel -
-// replaces 4 f32 multiplies, 4 subtractions, 4 conversions and 10 f64 multiplies per cell of the dense kernel.
-LFD_HD void lfd_row1_products(const float* Pi, float va, double* m10) {
-    const double a0 = (double)(va * Pi[8] - Pi[1]), a1 = (double)(va * Pi[9] - Pi[3]), a2 = (double)(va * Pi[10] - Pi[5]),
-                 a3 = (double)(va * Pi[11] - Pi[7]);
-    m10[0] = a0 * a0; m10[1] = a0 * a1; m10[2] = a0 * a2; m10[3] = a0 * a3;
-    m10[4] = a1 * a1; m10[5] = a1 * a2; m10[6] = a1 * a3; m10[7] = a2 * a2; m10[8] = a2 * a3; m10[9] = a3 * a3;
 }
 
 // ---- one correspondence -------------------------------------------------------------------------
@@ -479,9 +414,8 @@ LFD_HD float lfd_reproj_sq(const float* P, float X0, float X1, float X2, float X
 
 LFD_HD bool lfd_finite(float x) { return fabsf(x) <= 3.402823466e+38f; }   // false for NaN/Inf
 
-// `row1`: the ten products of the reference view's v row for this cell's grid row (lfd_row1_products of the same va), or null.
 LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& pc, float xan, float yan,
-                                    float xbn, float ybn, const LfdKernelParams& kp, LfdCellResult& o, const double* row1 = nullptr) {
+                                    float xbn, float ybn, const LfdKernelParams& kp, LfdCellResult& o) {
     const float xa = lfd_match_px(xan, kp.wm1), ya = lfd_match_px(yan, kp.hm1);
     const float xb = lfd_match_px(xbn, kp.wm1), yb = lfd_match_px(ybn, kp.hm1);
     const float ua = xa * rc.sx, va = ya * rc.sy;
@@ -546,7 +480,7 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
 #else
     {
         const Rows rows{rc, pc, ua, va, ub, vb};
-        lfd_null_vector_rows(rows, c, row1);
+        lfd_null_vector_rows(rows, c);
     }
 #endif
     // upstream: Xh = unit null vector, w = (|Xh[3]| < 1e-12 ? 1e-12 : Xh[3]), X = Xh / w

@@ -373,20 +373,9 @@ __device__ __forceinline__ void cell_coords(const LfdLaunch& L, const BlockShare
 // F5: per-(reference, neighbour) constants, once per batch (skipped when the batch is unchanged)
 // =================================================================================================
 extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* __restrict__ ref_out,
-                                                 LfdPairConst* __restrict__ pair_out, double* __restrict__ row1_out) {
+                                                 LfdPairConst* __restrict__ pair_out) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int n_pairs = L.n_refs * L.k;
-    if (row1_out && i >= n_pairs + L.n_refs) {       // one entry per (reference, grid row): the v row of the reference view, multiplied out
-        const int e = i - (n_pairs + L.n_refs);
-        if (e < L.n_refs * L.H) {
-            const int r = e / L.H, y = e - r * L.H;
-            LfdRefConst rc;
-            lfd_make_ref_const(L.cams[L.refs[r].cam], L.w_match, L.h_match, rc);
-            const float va = lfd_match_px(L.axis_y[y], L.kp.hm1) * rc.sy;       // exactly lfd_eval_correspondence's va of a cell in row y
-            lfd_row1_products(rc.P, va, row1_out + (size_t)e * 10);
-        }
-        return;
-    }
     if (i < n_pairs) {
         const int r = i / L.k, j = i - r * L.k;
         if (j < L.refs[r].n_slots) {
@@ -517,9 +506,6 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
     __shared__ unsigned s_wave_cnt[kBlock / 64];
     __shared__ unsigned s_slot_cnt[LFD_MAX_SLOTS];
     __shared__ u64 s_tile_excl;
-#if LFD_ROW1_TABLE
-    __shared__ __attribute__((aligned(16))) double s_row1[kBlock / 64][2][10];     // lfd_row1_products of the (at most two) grid rows each WAVE's 256 cells touch
-#endif
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -609,24 +595,6 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
             tile_y0 = __builtin_amdgcn_readfirstlane(ty); tile_x0 = __builtin_amdgcn_readfirstlane(tx);
         }
 
-#if LFD_ROW1_TABLE
-        // The reference view's v row of A^T A, multiplied out per (reference, grid row) by lfd_pair_setup_kernel: every wave parks the
-        // entries of the two rows its 256 cells can touch (W >= 256) in its OWN corner of LDS - written and read by the same wave,
-        // whose LDS operations execute in order, so no workgroup barrier is involved - and the geometry loop reads them back.
-        const bool use_row1 = L.row1_tab != nullptr && L.W >= 256;
-        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-        int wave_dy = 0;
-        if (use_row1) {
-            int wx;
-            lfd_divmod_local(tile_x0 + wave_u * 64 * kCpt, L.W, L.inv_w, L.w_log2, wave_dy, wx);
-            wave_dy = __builtin_amdgcn_readfirstlane(wave_dy);
-            const int y0 = tile_y0 + wave_dy;
-            const int n_rows = min(2, L.H - y0);
-            if (lane < n_rows * 20)
-                reinterpret_cast<unsigned*>(&s_row1[wave_u][0][0])[lane] =
-                    lfd_global(reinterpret_cast<const unsigned*>(L.row1_tab + ((size_t)r * L.H + y0) * 10))[lane];
-        }
-#endif
         // ---- stage 1: certainty floor + arg-max over the neighbour slots (coalesced 16-B loads) -----
         int bj[kCpt];
 #if LFD_DENSE_ALL_WARPS
@@ -779,17 +747,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
 #if defined(LFD_ABLATE_EVAL)
             if (cell0 + e < HW) { res.keep = xbn > -0.9f; res.x = xan; res.y = yan; res.z = xbn; res.err = ybn; res.xa_px = 1.0f; res.ya_px = 1.0f; }
 #else
-#if LFD_ROW1_TABLE
-            const double* row1 = nullptr;
-            if (use_row1) {
-                int dy, xx;
-                lfd_divmod_local(tile_x0 + sl, L.W, L.inv_w, L.w_log2, dy, xx);
-                row1 = &s_row1[wave_u][dy - wave_dy][0];
-            }
-            if (cell0 + e < HW) lfd_eval_correspondence(rc, S.pc[bje], xan, yan, xbn, ybn, L.kp, res, row1);
-#else
             if (cell0 + e < HW) lfd_eval_correspondence(rc, S.pc[bje], xan, yan, xbn, ybn, L.kp, res);
-#endif
 #endif
             if (res.keep) {
                 sxyz[0] = res.x; sxyz[1] = res.y; sxyz[2] = res.z;

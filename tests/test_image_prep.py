@@ -1,6 +1,8 @@
 """N3 image preparation: Pillow's BILINEAR / NEAREST resampling restated (oracle/image_oracle.py) and run on the device
 (csrc/lfd_image.hip), against golden g7 = what upstream's own functions (core/image_utils.py load_rgb_resized /
 load_mask_resized_np / apply_mask_to_rgb) return for synthetic images."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -77,3 +79,30 @@ def test_device_image_prep_is_byte_exact(g7):
         m = rs.randint(0, 256, (h, w)).astype(np.uint8)
         np.testing.assert_array_equal(dens.prepare_mask(torch.from_numpy(m).to(dev), (wo, ho)).cpu().numpy(), io.mask01_resized(m, (wo, ho)))
     dens.close()
+
+
+def test_decode_cache_is_bounded_by_bytes(tmp_path, monkeypatch):
+    """The caches of DECODED full-resolution files (device_image_prep) hold at most DECODE_CACHE_BYTES of arrays, least recently used
+    first out - not 512 entries of whatever size (a 24 MP photograph is 72 MB)."""
+    from PIL import Image
+    from lichtfeld_densification_plugin_amd.core import image_io
+    image_io.decode_rgb_u8.cache_clear()
+    paths = []
+    rs = np.random.RandomState(0)
+    for i in range(6):
+        p = os.path.join(str(tmp_path), f"d{i}.png")
+        Image.fromarray(rs.randint(0, 256, (100, 120, 3)).astype(np.uint8)).save(p)
+        paths.append(p)
+    one = 100 * 120 * 3
+    monkeypatch.setattr(image_io, "DECODE_CACHE_BYTES", int(3.5 * one))
+    arrs = [image_io.decode_rgb_u8(p) for p in paths]
+    info = image_io.decode_rgb_u8.cache_info()
+    assert info["entries"] == 3 and info["bytes"] == 3 * one and info["misses"] == 6
+    assert image_io.decode_rgb_u8(paths[5]) is arrs[5] and image_io.decode_rgb_u8.cache_info()["hits"] == 1      # most recent: still there
+    again = image_io.decode_rgb_u8(paths[0])                                                                       # evicted: decoded again
+    assert again is not arrs[0] and np.array_equal(again, arrs[0]) and not again.flags.writeable
+    monkeypatch.setattr(image_io, "DECODE_CACHE_BYTES", one // 2)                                                  # larger than the budget: not cached
+    image_io.decode_rgb_u8.cache_clear()
+    image_io.decode_rgb_u8(paths[1])
+    assert image_io.decode_rgb_u8.cache_info()["entries"] == 0
+    image_io.decode_rgb_u8.cache_clear()
