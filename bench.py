@@ -488,12 +488,16 @@ def main():
     dens.upload_cameras(cams)
     if not refs:
         raise SystemExit(f"rank {rank} owns no reference view: --refs {args.refs} ({args.scaling}) over {world} ranks")
-    # Two DISTINCT batches alternate in the timed loop (the same planes, the references in another order: other descriptor
-    # tables, other per-pair constants), as in a real run where every launch sees a new batch: the descriptor upload and
-    # lfd_pair_setup_kernel are then inside the timed region.  They are issued by lfd_prepare_batch, so that the HIP events
-    # around the launch that follows bracket the dense kernel alone.
+    # DISTINCT batches rotate in the timed loop (the same planes, the references in another order: other descriptor tables,
+    # other per-pair constants), as in a real run where every launch sees a new batch: the descriptor upload and
+    # lfd_pair_setup_kernel are then inside the timed region.  They are issued by lfd_prepare_batch - which stages them on the
+    # context's preparation stream, beside the kernels of the batch before - so that the HIP events around the launch that
+    # follows bracket the dense kernel alone.
     batch = hb.PreparedBatch(refs, wm, hm, cameras=cams)      # the pipeline's default: upstream's own F handed to the kernels
-    batches = [batch] if (args.cached_batch or len(refs) < 2) else [batch, hb.PreparedBatch(refs[1:] + refs[:1], wm, hm, cameras=cams)]
+    # (three: the context keeps the tables of the last TWO batches on the device, so that the next one can be staged while the current
+    # one computes; with fewer than three distinct batches in rotation nothing would ever be uploaded again)
+    n_rot = 1 if (args.cached_batch or len(refs) < 3) else 3
+    batches = [batch] + [hb.PreparedBatch(refs[j:] + refs[:j], wm, hm, cameras=cams) for j in range(1, n_rot)]
     out = hb.OutputBuffers(len(refs) * H * W, len(refs), args.k, dev, with_cell=False, with_segments=False)   # upstream emits xyz, rgb, err only
 
     def barrier():
@@ -547,8 +551,7 @@ def main():
     dens.check_launches()
     res = out.collect()
     n_pts = res.count
-    last_batch = batches[(args.steps - 1) % len(batches)] if args.steps > 0 else batch
-    rot = 1 if (last_batch is not batch) else 0           # the last launch's references are `refs` rotated by this much
+    rot = (args.steps - 1) % len(batches) if args.steps > 0 else 0      # the last launch's references are `refs` rotated by this much
 
     cdev = dev if backend != "gloo" else torch.device("cpu")
     stats = torch.tensor([elapsed, float(n_pts), kernel_ms, fresh_batch_ms], dtype=torch.float64, device=cdev)

@@ -56,6 +56,7 @@ int ensure(lfd_context* ctx, DeviceBuffer& b, size_t bytes, bool zero = false) {
     if (b.bytes >= bytes && b.ptr) return LFD_OK;
     if (b.ptr) {
         LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->prep_stream) LFD_HIP(ctx, hipStreamSynchronize(ctx->prep_stream));
         LFD_HIP(ctx, hipFree(b.ptr));
         b.ptr = nullptr; b.bytes = 0;
     }
@@ -98,8 +99,18 @@ int validate_batch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p) {
     return LFD_OK;
 }
 
-// Build refs|slots|extra into one blob, upload only when it differs from what the device holds.
-int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, size_t n_extra,
+int slot_events(lfd_context* ctx, LfdBatchSlot& sl) {
+    if (!sl.pinned_free) LFD_HIP(ctx, hipEventCreateWithFlags(&sl.pinned_free, hipEventDisableTiming));
+    if (!sl.ready) LFD_HIP(ctx, hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+    if (!sl.idle) LFD_HIP(ctx, hipEventCreateWithFlags(&sl.idle, hipEventDisableTiming));
+    return LFD_OK;
+}
+
+// Build refs|slots|extra into one blob and find it a slot: a slot that already holds these tables is reused as it is; otherwise the
+// blob is uploaded - by a launch into the slot of the last launch, on the launch stream (stream order protects the kernels still
+// reading it); by lfd_prepare_batch (`ahead`) into the OTHER slot, on the preparation stream, behind the event that marks the end
+// of that slot's last user - so that it runs beside the kernels of the batch before it.
+int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, size_t n_extra, bool ahead, int* slot_out, hipStream_t* stream_out,
                   const LfdRefDesc** d_refs, const LfdSlotDesc** d_slots, const long long** d_extra, const float** d_fund) {
     const size_t nr = (size_t)b->n_refs, ns = nr * (size_t)b->k;
     const size_t off_slots = (nr * sizeof(LfdRefDesc) + 15) & ~size_t(15);
@@ -129,28 +140,63 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
     }
     if (n_extra) std::memcpy(blob.data() + off_extra, extra, n_extra * sizeof(long long));
     if (b->fundamental) std::memcpy(blob.data() + off_fund, b->fundamental, ns * 9 * sizeof(float));
-    int rc = ensure(ctx, ctx->desc, total);
-    if (rc != LFD_OK) return rc;
-    if (blob != ctx->desc_cache) {
-        if (ctx->pinned_bytes < total) {
-            if (ctx->pinned_in_flight) { LFD_HIP(ctx, hipEventSynchronize(ctx->pinned_free)); ctx->pinned_in_flight = false; }
-            if (ctx->pinned) LFD_HIP(ctx, hipHostFree(ctx->pinned));
-            ctx->pinned = nullptr;
-            ctx->pinned_bytes = std::max<size_t>(total * 2, 1 << 16);
-            LFD_HIP(ctx, hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
-        }
-        if (ctx->pinned_in_flight) { LFD_HIP(ctx, hipEventSynchronize(ctx->pinned_free)); ctx->pinned_in_flight = false; }
-        std::memcpy(ctx->pinned, blob.data(), total);
-        LFD_HIP(ctx, hipMemcpyAsync(ctx->desc.ptr, ctx->pinned, total, hipMemcpyHostToDevice, ctx->stream));
-        LFD_HIP(ctx, hipEventRecord(ctx->pinned_free, ctx->stream));
-        ctx->pinned_in_flight = true;
-        ctx->desc_cache.swap(blob);
-        ctx->consts_valid = false;
+
+    int si = -1;
+    for (int c = 0; c < 2; ++c) {
+        const int i = c == 0 ? ctx->cur : 1 - ctx->cur;
+        if (ctx->slot[i].desc.ptr && ctx->slot[i].cache == blob) { si = i; break; }
     }
-    *d_refs = reinterpret_cast<const LfdRefDesc*>(ctx->desc.ptr);
-    *d_slots = reinterpret_cast<const LfdSlotDesc*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_slots);
-    if (d_extra) *d_extra = reinterpret_cast<const long long*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_extra);
-    *d_fund = b->fundamental ? reinterpret_cast<const float*>(static_cast<unsigned char*>(ctx->desc.ptr) + off_fund) : nullptr;
+    hipStream_t st = ctx->stream;
+    if (si >= 0) {                                   // the tables are (or are about to be) in place
+        LfdBatchSlot& sl = ctx->slot[si];
+        if (!ahead && sl.ready_pending) {            // staged ahead on the preparation stream: the launch stream waits for that, once
+            LFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.ready, 0));
+            sl.ready_pending = false;
+        }
+        if (ahead && sl.ready_pending) st = ctx->prep_stream;      // (a second lfd_prepare_batch of the same batch: stay behind the first)
+    } else {
+        if (ahead) {
+            if (!ctx->prep_stream) LFD_HIP(ctx, hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
+            si = ctx->last_used < 0 ? ctx->cur : 1 - ctx->cur;
+            st = ctx->prep_stream;
+        } else {
+            si = ctx->cur;
+        }
+        LfdBatchSlot& sl = ctx->slot[si];
+        int rc = slot_events(ctx, sl);
+        if (rc != LFD_OK) return rc;
+        if (ahead) {
+            // the kernels of this slot's last user must be through (the event sits where the launch after it began), and so must
+            // whatever a launch issued for the slot in the launch stream since (si == cur only before the first launch)
+            if (sl.used) LFD_HIP(ctx, hipStreamWaitEvent(st, sl.idle, 0));
+        } else if (sl.ready_pending) {               // an unused staging of another batch is still on its way into this slot
+            LFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.ready, 0));
+            sl.ready_pending = false;
+        }
+        rc = ensure(ctx, sl.desc, total);
+        if (rc != LFD_OK) return rc;
+        if (sl.pinned_bytes < total) {
+            if (sl.pinned_in_flight) { LFD_HIP(ctx, hipEventSynchronize(sl.pinned_free)); sl.pinned_in_flight = false; }
+            if (sl.pinned) LFD_HIP(ctx, hipHostFree(sl.pinned));
+            sl.pinned = nullptr;
+            sl.pinned_bytes = std::max<size_t>(total * 2, 1 << 16);
+            LFD_HIP(ctx, hipHostMalloc(&sl.pinned, sl.pinned_bytes, hipHostMallocDefault));
+        }
+        if (sl.pinned_in_flight) { LFD_HIP(ctx, hipEventSynchronize(sl.pinned_free)); sl.pinned_in_flight = false; }
+        std::memcpy(sl.pinned, blob.data(), total);
+        LFD_HIP(ctx, hipMemcpyAsync(sl.desc.ptr, sl.pinned, total, hipMemcpyHostToDevice, st));
+        LFD_HIP(ctx, hipEventRecord(sl.pinned_free, st));
+        sl.pinned_in_flight = true;
+        sl.cache.swap(blob);
+        sl.consts_valid = false;
+    }
+    LfdBatchSlot& sl = ctx->slot[si];
+    *slot_out = si;
+    *stream_out = st;
+    *d_refs = reinterpret_cast<const LfdRefDesc*>(sl.desc.ptr);
+    *d_slots = reinterpret_cast<const LfdSlotDesc*>(static_cast<unsigned char*>(sl.desc.ptr) + off_slots);
+    if (d_extra) *d_extra = reinterpret_cast<const long long*>(static_cast<unsigned char*>(sl.desc.ptr) + off_extra);
+    *d_fund = b->fundamental ? reinterpret_cast<const float*>(static_cast<unsigned char*>(sl.desc.ptr) + off_fund) : nullptr;
     return LFD_OK;
 }
 
@@ -211,13 +257,24 @@ void lfd_fill_kernel_params(const lfd_batch* b, const lfd_params* p, LfdKernelPa
 namespace {
 
 int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, const long long* extra, size_t n_extra,
-                   LfdLaunch& L, const long long** d_extra) {
+                   LfdLaunch& L, const long long** d_extra, bool ahead = false) {
     int rc = validate_batch(ctx, b, p);
     if (rc != LFD_OK) return rc;
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     std::memset(&L, 0, sizeof(L));
-    rc = upload_tables(ctx, b, extra, n_extra, &L.refs, &L.slots, d_extra, &L.fund_override);
+    if (!ahead && ctx->last_used >= 0) {
+        // the kernels of the previous launch end here in the launch stream: from this point on its slot may be refilled ahead
+        LfdBatchSlot& prev = ctx->slot[ctx->last_used];
+        rc = slot_events(ctx, prev);
+        if (rc != LFD_OK) return rc;
+        LFD_HIP(ctx, hipEventRecord(prev.idle, ctx->stream));
+        prev.used = true;
+    }
+    int si = 0;
+    hipStream_t st = ctx->stream;
+    rc = upload_tables(ctx, b, extra, n_extra, ahead, &si, &st, &L.refs, &L.slots, d_extra, &L.fund_override);
     if (rc != LFD_OK) return rc;
+    LfdBatchSlot& sl = ctx->slot[si];
     L.cams = static_cast<const LfdCam*>(ctx->cams.ptr);
     if (b->axis_x) { L.axis_x = b->axis_x; L.axis_y = b->axis_y; }
     else {
@@ -241,22 +298,27 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
     // per-pair constants: (re)derive when the batch tables, the cameras or the match size changed
     const size_t ref_bytes = ((size_t)b->n_refs * sizeof(LfdRefConst) + 15) & ~size_t(15);
     const size_t need = ref_bytes + (size_t)b->n_refs * b->k * sizeof(LfdPairConst);
-    if (ctx->consts.bytes < need) ctx->consts_valid = false;
-    rc = ensure(ctx, ctx->consts, need);
+    if (sl.consts.bytes < need) sl.consts_valid = false;
+    rc = ensure(ctx, sl.consts, need);
     if (rc != LFD_OK) return rc;
-    LfdRefConst* d_rc = static_cast<LfdRefConst*>(ctx->consts.ptr);
-    LfdPairConst* d_pc = reinterpret_cast<LfdPairConst*>(static_cast<unsigned char*>(ctx->consts.ptr) + ref_bytes);
+    LfdRefConst* d_rc = static_cast<LfdRefConst*>(sl.consts.ptr);
+    LfdPairConst* d_pc = reinterpret_cast<LfdPairConst*>(static_cast<unsigned char*>(sl.consts.ptr) + ref_bytes);
     L.ref_const = d_rc;
     L.pair_const = d_pc;
-    if (!ctx->consts_valid || ctx->consts_wm != b->w_match || ctx->consts_hm != b->h_match) {
+    if (!sl.consts_valid || sl.wm != b->w_match || sl.hm != b->h_match) {
         const int n = b->n_refs * b->k + b->n_refs;
-        hipLaunchKernelGGL(lfd_pair_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, L, d_rc, d_pc);
+        hipLaunchKernelGGL(lfd_pair_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, L, d_rc, d_pc);
         LFD_HIP(ctx, hipGetLastError());
-        ctx->consts_valid = true;
-        ctx->consts_refs = b->n_refs; ctx->consts_k = b->k;
-        ctx->consts_wm = b->w_match;
-        ctx->consts_hm = b->h_match;
+        sl.consts_valid = true;
+        sl.refs = b->n_refs; sl.k = b->k;
+        sl.wm = b->w_match;
+        sl.hm = b->h_match;
+        if (st != ctx->stream) {                 // issued ahead: the launch that uses the slot waits for this
+            LFD_HIP(ctx, hipEventRecord(sl.ready, st));
+            sl.ready_pending = true;
+        }
     }
+    if (!ahead) { ctx->cur = si; ctx->last_used = si; }
     return LFD_OK;
 }
 
@@ -352,7 +414,6 @@ int lfd_create(int device_index, void* hip_stream, lfd_context** out) {
     read_env_switches(ctx);      // profiling / A-B switches: read ONCE here, never on a launch path
     e = hipSetDevice(device_index);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device_index);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pinned_free, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned_words), 16 * sizeof(int), hipHostMallocDefault);
     if (e != hipSuccess) {
         std::string m = std::string("context init: ") + hipGetErrorString(e);
@@ -368,11 +429,16 @@ void lfd_destroy(lfd_context* ctx) {
     if (ctx->is_host) { lfd_host_pool_destroy(ctx->host_pool); delete ctx; return; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuffer* b : {&ctx->cams, &ctx->desc, &ctx->ws, &ctx->axes, &ctx->consts, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->colour_tab, &ctx->mt, &ctx->mt_batch, &ctx->sel_scratch, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab})
+    if (ctx->prep_stream) { (void)hipStreamSynchronize(ctx->prep_stream); (void)hipStreamDestroy(ctx->prep_stream); }
+    for (LfdBatchSlot& sl : ctx->slot) {
+        if (sl.desc.ptr) (void)hipFree(sl.desc.ptr);
+        if (sl.consts.ptr) (void)hipFree(sl.consts.ptr);
+        if (sl.pinned) (void)hipHostFree(sl.pinned);
+        for (hipEvent_t ev : {sl.pinned_free, sl.ready, sl.idle}) if (ev) (void)hipEventDestroy(ev);
+    }
+    for (DeviceBuffer* b : {&ctx->cams, &ctx->ws, &ctx->axes, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->colour_tab, &ctx->mt, &ctx->mt_batch, &ctx->sel_scratch, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab})
         if (b->ptr) (void)hipFree(b->ptr);
-    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
-    if (ctx->pinned_free) (void)hipEventDestroy(ctx->pinned_free);
     delete ctx;
 }
 
@@ -387,6 +453,9 @@ int lfd_set_stream(lfd_context* ctx, void* hip_stream) {
     if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->prep_stream) LFD_HIP(ctx, hipStreamSynchronize(ctx->prep_stream));
+    for (LfdBatchSlot& sl : ctx->slot) { sl.ready_pending = false; sl.used = false; }      // everything issued so far has completed
+    ctx->last_used = -1;
     ctx->stream = static_cast<hipStream_t>(hip_stream);
     return LFD_OK;
 }
@@ -411,12 +480,13 @@ int lfd_launch_status(lfd_context* ctx, int32_t* status_out) {
 int lfd_get_pair_fundamental(lfd_context* ctx, int32_t n_pairs, double* F_out_host) {
     if (!ctx || !F_out_host || n_pairs <= 0) return fail(ctx, LFD_ERR_INVALID, "bad arguments");
     if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
-    if (!ctx->consts_valid || !ctx->consts.ptr) return fail(ctx, LFD_ERR_STATE, "no batch has been prepared on this context yet");
-    if (n_pairs != ctx->consts_refs * ctx->consts_k) return fail(ctx, LFD_ERR_INVALID, "n_pairs must be n_refs * k of the last batch");
+    const LfdBatchSlot& sl = ctx->slot[ctx->cur];        // the batch of the last launch
+    if (ctx->last_used < 0 || !sl.consts_valid || !sl.consts.ptr) return fail(ctx, LFD_ERR_STATE, "no batch has been launched on this context yet");
+    if (n_pairs != sl.refs * sl.k) return fail(ctx, LFD_ERR_INVALID, "n_pairs must be n_refs * k of the last batch");
     LFD_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t ref_bytes = ((size_t)ctx->consts_refs * sizeof(LfdRefConst) + 15) & ~size_t(15);
+    const size_t ref_bytes = ((size_t)sl.refs * sizeof(LfdRefConst) + 15) & ~size_t(15);
     std::vector<LfdPairConst> host((size_t)n_pairs);
-    LFD_HIP(ctx, hipMemcpyAsync(host.data(), static_cast<unsigned char*>(ctx->consts.ptr) + ref_bytes, host.size() * sizeof(LfdPairConst),
+    LFD_HIP(ctx, hipMemcpyAsync(host.data(), static_cast<unsigned char*>(sl.consts.ptr) + ref_bytes, host.size() * sizeof(LfdPairConst),
                                 hipMemcpyDeviceToHost, ctx->stream));
     LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n_pairs; ++i)
@@ -446,14 +516,15 @@ int lfd_upload_cameras(lfd_context* ctx, int32_t n, const float* K, const float*
     if (rc != LFD_OK) return rc;
     LFD_HIP(ctx, hipMemcpyAsync(ctx->cams.ptr, cams.data(), cams.size() * sizeof(LfdCam), hipMemcpyHostToDevice, ctx->stream));
     LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->prep_stream) LFD_HIP(ctx, hipStreamSynchronize(ctx->prep_stream));
     ctx->n_cams = n;
-    ctx->consts_valid = false;
+    for (LfdBatchSlot& sl : ctx->slot) sl.consts_valid = false;      // every constant block derives from the camera table
     return LFD_OK;
 }
 
 int lfd_prepare_batch(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params) {
     LfdLaunch L;
-    return prepare_launch(ctx, batch, params, nullptr, 0, L, nullptr);
+    return prepare_launch(ctx, batch, params, nullptr, 0, L, nullptr, /*ahead=*/true);
 }
 
 int lfd_aggregate(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, float* best_cert, uint8_t* best_slot) {

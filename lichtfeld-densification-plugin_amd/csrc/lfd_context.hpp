@@ -18,6 +18,24 @@ struct DeviceBuffer {
 struct LfdHostPool;                              // lfd_host.hip: the host context's parked worker threads
 void lfd_host_pool_destroy(LfdHostPool* p);
 
+// One of the two places a batch's tables live on the device: descriptor tables (refs | slots | selection offsets | fundamental matrices)
+// and the per-pair constants derived from them.  Two slots let lfd_prepare_batch stage batch i+1 - on the context's own preparation
+// stream - while the kernels of batch i still read theirs.
+struct LfdBatchSlot {
+    DeviceBuffer desc, consts;
+    std::vector<unsigned char> cache;      // what `desc` currently holds (or will hold once the stream has caught up)
+    bool consts_valid = false;
+    int wm = 0, hm = 0, refs = 0, k = 0;   // what the constants were derived for
+    void* pinned = nullptr;                // host staging of the table upload
+    size_t pinned_bytes = 0;
+    hipEvent_t pinned_free = nullptr;      // behind the upload that last read `pinned`
+    bool pinned_in_flight = false;
+    hipEvent_t ready = nullptr;            // behind upload + setup issued on the preparation stream
+    bool ready_pending = false;            // ... which the launch stream has not been told to wait for yet
+    hipEvent_t idle = nullptr;             // on the launch stream, where the launch AFTER this slot's last user begins
+    bool used = false;
+};
+
 struct LfdEnvSwitches {          // profiling / A-B switches of the environment, read once by lfd_create
     size_t dense_extra_lds = 0;           // LFD_DENSE_EXTRA_LDS: dynamic LDS per dense workgroup (lowers the resident workgroups per CU)
     std::string dense_timing_path;        // LFD_DENSE_TIMING (profiling builds): file the per-tile phase stamps are dumped to
@@ -40,14 +58,12 @@ struct lfd_context {
     // camera table
     DeviceBuffer cams;
     int32_t n_cams = 0;
-    // descriptor tables: refs | slots | sel_offsets, staged through pinned memory
-    DeviceBuffer desc;
-    void* pinned = nullptr;
-    size_t pinned_bytes = 0;
-    hipEvent_t pinned_free = nullptr;
-    bool pinned_in_flight = false;
+    // descriptor tables + per-pair constants of the batches in flight (see LfdBatchSlot)
+    LfdBatchSlot slot[2];
+    int cur = 0;                   // slot of the last launch
+    int last_used = -1;            // ... -1 before the first one
+    hipStream_t prep_stream = nullptr;   // lfd_prepare_batch's uploads and setup kernels (created on first use)
     int* pinned_words = nullptr;   // 16 pinned ints: landing place of the small synchronous read-backs (status, selection count)
-    std::vector<unsigned char> desc_cache;   // what the device table currently holds
     // look-back workspace: [0] u64 ticket counter, [1..] tile states
     DeviceBuffer ws;
     unsigned long long tickets_issued = 0;   // host mirror of the device ticket counter (indexed kernel)
@@ -60,11 +76,6 @@ struct lfd_context {
     // dense mode's colour tables of the analytic A-grid (one entry per grid column / row), for the last grid + match size
     DeviceBuffer colour_tab;
     int colour_key[4] = {0, 0, 0, 0};
-    // per-pair constants of the current batch (valid while the descriptor tables are unchanged)
-    DeviceBuffer consts;
-    bool consts_valid = false;
-    int consts_wm = 0, consts_hm = 0;
-    int consts_refs = 0, consts_k = 0;
     // indexed-mode scratch
     DeviceBuffer scratch, codes, idx_tab, agg, sel_buf;
     // selection stage: legacy MT19937 stream (625 words) + scratch

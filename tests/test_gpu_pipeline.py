@@ -227,7 +227,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert d["rccl_ranks"] == 0 and d["collective_backend"] == "gloo"          # two ranks on one GPU exchange through host buffers, and the line says so
     assert d["exchange"]["points"] > 0 and d["exchange"]["allgather_ms"] > 0 and d["exchange"]["bytes_gathered"] == 28 * d["exchange"]["points"]
     assert d["exchange"]["gather_to_root_ms"] > 0 and 0 < d["value_incl_exchange"] < d["value"] and d["value_incl_gather_to_root"] > 0
-    assert d["compute_ms"] >= d["kernel_ms"] > 0 and d["fresh_batch_ms"] >= 0 and d["config"]["batches_in_rotation"] == 2
+    assert d["compute_ms"] >= d["kernel_ms"] > 0 and d["fresh_batch_ms"] >= 0 and d["config"]["batches_in_rotation"] == 3
     assert d["end_to_end"] is None and "unmeasured" in d["end_to_end_note"] and "traffic_source" in d["roofline"]
     # strong scaling: ONE scene (config 4's 56 references x 8 neighbours, here 6 x 8 at `turbo`) dealt over the ranks
     cmd_s = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "config4", "--refs", "6",

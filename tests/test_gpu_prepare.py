@@ -1,0 +1,65 @@
+"""lfd_prepare_batch: the tables and per-pair constants of batch i+1 are staged on the context's preparation stream, into the slot the
+batch before last used, while the kernels of batch i run.  Back-to-back launches over rotating batches must return exactly what a fresh
+context returns for each batch alone (a race between the staging and a running kernel would show as wrong constants)."""
+import numpy as np
+import pytest
+import torch
+
+import lichtfeld_densification_plugin_amd as lfd
+from lichtfeld_densification_plugin_amd import synthetic
+from lichtfeld_densification_plugin_amd.core import hip_backend as hb
+
+pytestmark = pytest.mark.gpu
+
+
+def _refs(dev, cams, ids, k, H, W):
+    out = []
+    for gi, ref in enumerate(ids):
+        nbrs = synthetic.ring_neighbours(len(cams), ref, k)
+        s = synthetic.synth_reference(cams, ref, nbrs, H, W, W, H, noise_px=0.5, outlier_frac=0.05, channels=2, seed=300 + gi, cert_mode="smooth", device=dev)
+        out.append(hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=[s.cert[j] for j in range(k)], warp=[s.warp[j] for j in range(k)], image=s.image))
+    return out
+
+
+@pytest.mark.parametrize("with_prepare", [True, False])
+def test_staged_batches_equal_fresh_contexts(with_prepare):
+    dev = torch.device("cuda:0")
+    H = W = 256
+    cams = synthetic.ring_cameras(60, seed=0)
+    groups = [_refs(dev, cams, ids, 3, H, W) for ids in ([0, 7, 14, 21], [3, 33, 43], [50, 5, 11, 17, 23], [9, 29])]
+    params = hb.make_params(lfd.DensePipelineConfig(output_path=""))
+    expected = []
+    for g in groups:                                   # every batch alone, on a context of its own
+        d = hb.HipDensifier(dev)
+        d.upload_cameras(cams)
+        o = d.triangulate_dense(hb.PreparedBatch(g, W, H, cameras=cams), params)
+        expected.append((o.count, o.xyz.clone(), o.rgb.clone(), o.err.clone(), o.ref_offsets.copy()))
+        d.close()
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    batches = [hb.PreparedBatch(g, W, H, cameras=cams) for g in groups]
+    outs = [hb.OutputBuffers(len(g) * H * W, len(g), 3, dev) for g in groups]
+    order = [0, 1, 2, 3, 0, 2, 1, 3, 3, 0, 1, 2] * 4
+    rounds = []
+    if with_prepare:
+        dens.prepare(batches[order[0]], params)
+    for i, b in enumerate(order):                      # everything enqueued back to back, nothing read until the end of a round of four
+        dens.launch_dense(batches[b], params, outs[b])
+        if with_prepare and i + 1 < len(order):
+            dens.prepare(batches[order[i + 1]], params)      # staged while the launch above runs
+        if i % 4 == 3:
+            dens.check_launches()
+            for bb in set(order[i - 3:i + 1]):
+                r = outs[bb].collect()
+                rounds.append((bb, r.count, r.xyz.clone(), r.rgb.clone(), r.err.clone(), r.ref_offsets.copy()))
+    assert len(rounds) >= 30
+    for bb, n, xyz, rgb, err, offs in rounds:
+        e = expected[bb]
+        assert n == e[0] and np.array_equal(offs, e[4])
+        assert torch.equal(xyz, e[1]) and torch.equal(rgb, e[2]) and torch.equal(err, e[3])
+    # the read-back of the constants refers to the batch of the LAST launch, whatever was staged after it
+    dens.prepare(batches[0], params)
+    F = dens.pair_fundamentals(len(groups[order[-1]]), 3)
+    a, b0 = groups[order[-1]][0].ref_cam, groups[order[-1]][0].nbr_cams[0]
+    np.testing.assert_array_equal(F[0, 0].astype(np.float32), hb.fundamental_from_world2cam(cams[a].K, cams[a].R, cams[a].t, cams[b0].K, cams[b0].R, cams[b0].t))
+    dens.close()
