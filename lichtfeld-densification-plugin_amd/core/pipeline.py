@@ -40,7 +40,7 @@ from .debug_viz import MatchDebugState, MatchPreview
 from .hostlog import log
 from .image_io import black_out, decode_mask_l, decode_rgb_u8, load_mask01, load_rgb_u8, to_uint8_rgb
 from .matcher import RomaMatcher, has_cached_romav2_weights, romav2_cached_weights_paths
-from .sampling import select_samples_with_coverage
+from .sampling import select_samples_with_coverage, upstream_weight_sum
 from .scheduler import FeatureCache, PairSchedule
 from .types import CameraRecord, DensePipelineConfig
 from .writers import CumulativePlyBody, StreamedPlyWriter, ensure_dir, ply_records, write_ply
@@ -358,7 +358,9 @@ class _HotPath:
         batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes, cameras=self.cams)
         on_device = self.config.selection_backend == "device" and not self.on_host
         fusable = on_device and (not self.config.no_filter or self.config.matches_per_ref <= self.dens.TOP_M_MAX)
-        if fusable and not need_best:
+        # upstream's own normaliser (torch's f32 sum of the weights, on this host) for the single-stream, filtered selection
+        torch_sum = on_device and not self.config.no_filter and device_seed is None and bool(getattr(self.config, "upstream_normaliser", True))
+        if fusable and not need_best and not torch_sum:
             if device_seed is not None and not self.config.no_filter:
                 self.dens.seed_rng(device_seed)
             try:
@@ -374,7 +376,10 @@ class _HotPath:
             if device_seed is not None:
                 self.dens.seed_rng(device_seed)
             try:
-                sel_t = self.dens.select_samples(best[0], self.config.matches_per_ref, cap=self.sample_cap, border=2, tiles=24)
+                s_up = upstream_weight_sum(best[0], cap=self.sample_cap, border=2) if torch_sum else 0.0
+                # (a sum <= 0 is upstream's "nothing to sample" case, which the device stage reports itself from its exact sum)
+                sel_t = self.dens.select_samples(best[0], self.config.matches_per_ref, cap=self.sample_cap, border=2, tiles=24,
+                                                 s_override=s_up if s_up > 0.0 else 0.0)
             except hb.SelectionInexact:
                 # upstream handles such maps normally (core/sampling.py:27-32): run its host stage on the stream the device
                 # holds (the refused call consumed nothing) and hand the advanced stream back
@@ -404,6 +409,8 @@ class _HotPath:
         cfg = self.config
         if self.on_host:
             return False
+        if cfg.selection_backend == "device" and not cfg.no_filter and not per_ref_rng and bool(getattr(cfg, "upstream_normaliser", True)):
+            return False         # the normaliser comes from the host: one reference at a time
         fusable = cfg.selection_backend == "device" and (not cfg.no_filter or cfg.matches_per_ref <= self.dens.TOP_M_MAX)
         exact_ok = cfg.no_filter or per_ref_rng or float(cfg.certainty_thresh) >= 2.0 ** -29 * H * W * max(self.sample_cap, 1e-6)
         return fusable and not need_best and exact_ok

@@ -16,6 +16,18 @@ import numpy as np
 import torch
 
 
+def upstream_weight_sum(cert_map, cap: float = 0.9, border: int = 2) -> float:
+    """Upstream's normaliser of the sampling weights (core/sampling.py:23-31 there): the torch CPU f32 ``sum`` of the capped,
+    border-masked certainty map - the same library call on the same values, so the same rounding as upstream on this machine."""
+    cert = torch.as_tensor(cert_map).detach().to("cpu", torch.float32)
+    cert = torch.clamp(cert, max=cap)
+    H, W = cert.shape
+    ys = torch.arange(H).view(H, 1)
+    xs = torch.arange(W).view(1, W)
+    inside = (xs >= border) & (xs <= W - 1 - border) & (ys >= border) & (ys <= H - 1 - border)
+    return float((cert * inside.to(torch.float32)).reshape(-1).sum())
+
+
 def select_samples_with_coverage(cert_map, M: int, cap: float = 0.9, border: int = 2, tiles: int = 24,
                                  no_filter: bool = False, rng: Optional[np.random.RandomState] = None) -> np.ndarray:
     """Flat indices (int64) of the cells to triangulate.

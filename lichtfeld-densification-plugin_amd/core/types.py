@@ -50,6 +50,15 @@ class DensePipelineConfig:
     # whole per-reference path stays on the GPU) or "host" (core/sampling.py: the library calls
     # upstream makes, including torch's own f32 sum as the normaliser).
     selection_backend: str = "device"
+    # selection_backend="device", one RNG stream (upstream's mode): normalise the sampling weights with upstream's OWN normaliser - torch's
+    # CPU f32 `sum` of the weight map, computed on this host exactly as core/sampling.py:27-31 computes it - instead of the device's
+    # correctly rounded exact sum.  torch's sum rounds differently from the exact one on most maps (by 1-2 ulp, depending on the
+    # host's thread count and vector ISA), which moves a cumulative-sum boundary under a draw on up to a quarter of the maps; with
+    # this on, the cells drawn are the ones upstream draws ON THE SAME MACHINE, bit for bit, at the price of one 1 MB read-back and a
+    # host reduction per reference (~0.2 ms; the fused asynchronous call and the launch-ahead are then not used).  Off: everything
+    # stays on the device (0.2 ms per reference, pipelined).  Sharded / per-reference-stream runs always use the exact sum: they do not
+    # reproduce upstream's single stream anyway.
+    upstream_normaliser: bool = True
     # dense mode only: blend colours with upstream's f64 arithmetic (bit-identical rgb) instead of f32 (within 2.5e-7)
     exact_colour: bool = False
     # hand upstream's own fundamental matrices (np.linalg.inv products, computed on the host exactly as upstream computes

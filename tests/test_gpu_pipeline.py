@@ -283,7 +283,7 @@ def test_launch_ahead_equals_the_synchronous_loop(g4, tmp_path, per_ref, monkeyp
     the counts come back behind an event): same points, same order, same per-reference counts as the one-at-a-time loop."""
     cams, refs, nn, table = _scene(g4, str(tmp_path))
     kw = dict(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=2, seed=5, viz_interval=0, matches_per_ref=1200,
-              per_reference_rng=per_ref)
+              per_reference_rng=per_ref, upstream_normaliser=False)       # (upstream's normaliser needs the host between two references)
     ahead = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**kw), matcher=FakeMatcher(64, 64, table))
     calls = {"n": 0}
     orig = pl._HotPath.launch_sampled
@@ -496,3 +496,43 @@ def test_matcher_fakes_receive_camera_keys_and_the_cache_does_not_outlive_the_ru
     off = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(share_features=False, **kw), matcher=fm2)
     assert fm2.keys_seen == [None] * len(refs) and fm2.cache_log[1:] == [None]
     np.testing.assert_array_equal(on.xyz, off.xyz)
+
+
+def test_device_selection_with_upstreams_normaliser_is_the_host_stage_on_this_machine(tmp_path):
+    """selection_backend="device" (the default) with upstream_normaliser (the default): the sampling weights are normalised with
+    torch's own CPU f32 sum - upstream's library call, on this machine - and the draws run on the device.  Cells drawn, their order,
+    the RNG stream across references and every output are those of selection_backend="host" (core/sampling.py = upstream's calls),
+    at full size (512x512, M = 10000), where the exact sum and torch's differ on most maps."""
+    from PIL import Image
+    from lichtfeld_densification_plugin_amd import synthetic
+    from lichtfeld_densification_plugin_amd.core.sampling import upstream_weight_sum
+    H = W = 512
+    cams = synthetic.ring_cameras(40, seed=0)
+    refs = [2, 11, 23, 31]
+    nn = np.array([synthetic.ring_neighbours(40, r, 3) for r in range(40)])
+    table, differ = [], 0
+    for gi, r in enumerate(refs):
+        s = synthetic.synth_reference(cams, r, list(nn[r]), H, W, W, H, noise_px=0.5, outlier_frac=0.05, channels=4, seed=70 + gi, cert_mode="smooth")
+        cams[r].image_path = os.path.join(str(tmp_path), f"v{r}.png")
+        Image.fromarray(s.image.numpy()).save(cams[r].image_path)
+        table.append([(s.warp[j], s.cert[j]) for j in range(3)])
+        best = torch.clamp(s.cert, min=0.2).max(dim=0).values
+        w = torch.clamp(best, max=0.9)[2:-2, 2:-2].double().sum().item()
+        differ += int(np.float32(w) != np.float32(upstream_weight_sum(best)))
+    for c in cams:
+        if not c.image_path or not os.path.exists(c.image_path):
+            c.image_path = cams[refs[0]].image_path                         # neighbours' images are only loaded, never sampled
+    kw = dict(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=3, seed=9, viz_interval=0, pack_workers=1)
+
+    def run(**extra):
+        return pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**kw, **extra), matcher=FakeMatcher(W, H, table))
+    dev_up, host = run(selection_backend="device"), run(selection_backend="host")
+    np.testing.assert_array_equal(dev_up.points_per_reference, host.points_per_reference)
+    np.testing.assert_array_equal(dev_up.xyz, host.xyz)
+    np.testing.assert_array_equal(dev_up.rgb, host.rgb)
+    np.testing.assert_array_equal(dev_up.err, host.err)
+    assert dev_up.xyz.shape[0] > 4 * 6000
+    exact = run(selection_backend="device", upstream_normaliser=False)      # everything on the device: the exact sum
+    assert abs(int(exact.xyz.shape[0]) - int(host.xyz.shape[0])) < 200
+    print(f"[normaliser] torch's f32 sum differs from the exact sum on {differ} of {len(refs)} maps; "
+          f"points: upstream's normaliser {dev_up.xyz.shape[0]}, exact sum {exact.xyz.shape[0]}")
