@@ -97,7 +97,27 @@ class _KeyedDescriptor(torch.nn.Module):
     def forward(self, img):
         if self.key is None or self.cache is None:
             return self.inner(img)
-        return self.cache.get_or_compute(self.key, lambda: self.inner(img), variant=(int(img.shape[-2]), int(img.shape[-1])))
+        variant = (int(img.shape[-2]), int(img.shape[-1]))
+        if not isinstance(self.key, (list, tuple)):
+            return self.cache.get_or_compute(self.key, lambda: self.inner(img), variant=variant)
+        # a batch of images, one key each (several pairs per forward): the cameras seen before come from the cache, the others go
+        # through the backbone together - ONE pass - and are kept sample by sample
+        keys = list(self.key)
+        if len(keys) != int(img.shape[0]):
+            raise ValueError("one camera key per image of the batch")
+        vals = [self.cache.lookup(k, variant) if k is not None else None for k in keys]
+        miss = [i for i, v in enumerate(vals) if v is None]
+        if miss:
+            out = self.inner(img[miss] if len(miss) < len(keys) else img)
+            self._returns_tensor = isinstance(out, torch.Tensor)
+            levels = [out] if self._returns_tensor else list(out)
+            for j, i in enumerate(miss):
+                mine = [t[j:j + 1] for t in levels]
+                kept = mine[0] if self._returns_tensor else mine          # the same form the one-image path keeps
+                vals[i] = self.cache.store(keys[i], kept, variant) if keys[i] is not None else kept
+        per_image = [[v] if isinstance(v, torch.Tensor) else list(v) for v in vals]
+        stacked = [torch.cat([v[lv] for v in per_image], 0) for lv in range(len(per_image[0]))]
+        return stacked[0] if isinstance(vals[0], torch.Tensor) else stacked
 
 
 class RomaMatcher:
@@ -106,7 +126,11 @@ class RomaMatcher:
     accepts_device_images = True      # match_grids_batch takes (h, w, 3) u8 device tensors as well as PIL images
     supports_feature_keys = True      # match_grids_batch(..., keys=(ref_key, [nbr_keys])) shares backbone features between references
 
-    def __init__(self, device: str = "cuda", mode: str = "outdoor", setting: str = "fast", two_channel: bool = True):
+    def __init__(self, device: str = "cuda", mode: str = "outdoor", setting: str = "fast", two_channel: bool = True,
+                 pairs_per_forward: int = 1):
+        """``pairs_per_forward`` > 1: the neighbours of a reference go through the model that many at a time (one batched forward,
+        RoMaV2/tests/test_bidirectional.py runs B = 8) instead of one pair per forward as upstream's loop does (core/matcher.py:175-188
+        there).  Batched GEMMs may round differently from single ones: the default stays 1, upstream's behaviour."""
         del mode
         RoMaV2 = _import_romav2()
         self.device = torch.device(device)
@@ -122,6 +146,7 @@ class RomaMatcher:
         self.sample_thresh = 0.9
         self.w_resized, self.h_resized = int(self.model.W_lr), int(self.model.H_lr)
         self.two_channel = bool(two_channel)
+        self.pairs_per_forward = max(1, int(pairs_per_forward))
         self._axes: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
         log.info(f"RoMaV2 initialized (setting={setting}, H_lr={self.model.H_lr}, W_lr={self.model.W_lr}, device={device})")
 
@@ -171,19 +196,36 @@ class RomaMatcher:
             if keyed is not None:
                 keyed.key = ref_key
             feats_a = model.f(a_lr)    # DINOv3 features of the reference: once per reference (once per RUN with keys)
-            for im_b, key_b in zip(imB_list, nbr_keys):
-                if keyed is not None:
-                    keyed.key = key_b  # the neighbour's features: looked up instead of recomputed when seen before
-                pred = model.match_from_features(f_list_A=feats_a, img_A_lr=a_lr, imB=_model_image(im_b), img_A_hr=a_hr)
-                warp_ab = pred["warp_AB"][0]
-                cert = pred["overlap_AB"][0].squeeze(-1).contiguous()
-                H, W = cert.shape
-                if self.two_channel:
-                    out.append((warp_ab.contiguous(), cert))
+            P = self.pairs_per_forward
+            for c0 in range(0, len(imB_list), P):
+                chunk, chunk_keys = list(imB_list[c0:c0 + P]), list(nbr_keys[c0:c0 + P])
+                if len(chunk) == 1:
+                    if keyed is not None:
+                        keyed.key = chunk_keys[0]  # the neighbour's features: looked up instead of recomputed when seen before
+                    pred = model.match_from_features(f_list_A=feats_a, img_A_lr=a_lr, imB=_model_image(chunk[0]), img_A_hr=a_hr)
                 else:
-                    ax, ay = self.reference_axes(H, W)
-                    grid = torch.stack([ax.view(1, W).expand(H, W), ay.view(H, 1).expand(H, W)], dim=-1)
-                    out.append((torch.cat([grid, warp_ab], dim=-1).contiguous(), cert))
+                    # several pairs in ONE forward: the neighbours stacked along the batch axis, the reference's features and images
+                    # broadcast to them (RoMaV2.match_from_features' own steps - _load_image, _resize_match_image, _match_core -
+                    # on a batch, romav2.py:404-428)
+                    n = len(chunk)
+                    img_b = torch.cat([model._load_image(_model_image(b)) for b in chunk], dim=0)
+                    b_lr, b_hr = model._resize_match_image(img_b)
+                    if keyed is not None:
+                        keyed.key = chunk_keys
+                    fa = [t.expand(n, *t.shape[1:]) if t.shape[0] == 1 else t for t in feats_a]
+                    pred = model._match_core(f_list_A=fa, img_A_lr=a_lr.expand(n, -1, -1, -1), img_B_lr=b_lr,
+                                             img_A_hr=a_hr.expand(n, -1, -1, -1) if (a_hr is not None and b_hr is not None) else None,
+                                             img_B_hr=b_hr)
+                for i in range(len(chunk)):
+                    warp_ab = pred["warp_AB"][i]
+                    cert = pred["overlap_AB"][i].squeeze(-1).contiguous()
+                    H, W = cert.shape
+                    if self.two_channel:
+                        out.append((warp_ab.contiguous(), cert))
+                    else:
+                        ax, ay = self.reference_axes(H, W)
+                        grid = torch.stack([ax.view(1, W).expand(H, W), ay.view(H, 1).expand(H, W)], dim=-1)
+                        out.append((torch.cat([grid, warp_ab], dim=-1).contiguous(), cert))
         finally:
             if keyed is not None:
                 model.f = plain_f

@@ -568,7 +568,8 @@ def run_dense_pipeline(
         if not cached:
             log.info("RoMaV2 weights not found in cache; expected cache paths: " + ", ".join(romav2_cached_weights_paths()))
         if own_matcher:
-            matcher = RomaMatcher(device=str(dev), mode="outdoor", setting=config.roma_setting)
+            matcher = RomaMatcher(device=str(dev), mode="outdoor", setting=config.roma_setting,
+                                  pairs_per_forward=int(getattr(config, "pairs_per_forward", 1)))
             if not cached and progress_callback is not None:
                 progress_callback(10.0, "RoMa v2 model installation complete. Starting matching...")
         _raise_if_cancelled(cancel_requested)

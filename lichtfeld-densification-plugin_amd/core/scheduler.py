@@ -97,6 +97,23 @@ class FeatureCache:
             self.peak = max(self.peak, len(self._store))
         return val
 
+    def lookup(self, key: Hashable, variant: Hashable = ()):
+        """The value held for (key, variant) or None; counted as a hit / a miss like get_or_compute."""
+        slot = (key, variant)
+        if slot in self._store:
+            self.hits += 1
+            return self._store[slot]
+        self.misses += 1
+        return None
+
+    def store(self, key: Hashable, val, variant: Hashable = ()):
+        """Keep ``val`` for (key, variant) (what get_or_compute does after computing); returns ``val``."""
+        slot = (key, variant)
+        if slot not in self._store and (self._max <= 0 or len(self._store) < self._max):
+            self._store[slot] = val
+            self.peak = max(self.peak, len(self._store))
+        return val
+
     def advance(self, step: int) -> None:
         """Schedule position ``step`` is done: drop what no later position needs."""
         if not self._last_use:

@@ -74,6 +74,9 @@ class DensePipelineConfig:
     # compute every camera's backbone (DINOv3) features once per run and share them between the references that list the camera
     # (core/scheduler.py); upstream recomputes a neighbour's features for every reference
     share_features: bool = True
+    # neighbours of a reference matched per RoMa-v2 forward (one batched pass through the model instead of one pass per pair, which is
+    # what upstream's loop does, core/matcher.py:175-188).  1 = upstream's behaviour; batched GEMMs may round differently from single ones
+    pairs_per_forward: int = 1
     # where the per-reference hot path runs.  "device": the HIP kernels (needs a GPU; raises HipBackendError without one - there is
     # no fallback).  "host": the CPU twin of the C-ABI (lfd_create_host: the host build of the kernels' per-cell source on the host
     # cores) with the host sampling stage - upstream's CPU-only configuration (densify.py:148-212 run without a GPU, BASELINE

@@ -182,3 +182,62 @@ def test_keyed_call_leaves_the_model_as_it_found_it(monkeypatch):
     calls = original.calls
     m.match_grids_batch(ims[0], [ims[1]], keys=(0, [1]))
     assert original.calls == calls + 2 and m.model.f is original
+
+
+class _BatchStubRoMa(_StubRoMa):
+    """... with RoMaV2's batched entry points (romav2.py:323-372: _resize_match_image and _match_core work on a batch)."""
+
+    def _resize_match_image(self, img):
+        return torch.nn.functional.interpolate(img, size=(self.H_lr, self.W_lr), mode="bicubic", align_corners=False, antialias=True), None
+
+    def _match_core(self, f_list_A, img_A_lr, img_B_lr, img_A_hr=None, img_B_hr=None):
+        f_b = self.f(img_B_lr)                                           # one backbone pass for the whole batch
+        n = img_B_lr.shape[0]
+        shift = (f_list_A[0] - f_b[0]).mean(dim=1).view(n, 1, 1, 1)      # per pair, the arithmetic of _forward_from_features
+        warp = torch.zeros((n, self.H_lr, self.W_lr, 2)) + shift
+        return {"warp_AB": warp, "overlap_AB": torch.full((n, self.H_lr, self.W_lr, 1), 0.5)}
+
+    def _forward_from_features(self, f_list_A, img_A_lr, img_B_lr):
+        return self._match_core(f_list_A, img_A_lr, img_B_lr)
+
+
+@pytest.mark.parametrize("share", [False, True])
+def test_several_pairs_per_forward_equal_one_pair_per_forward(monkeypatch, share):
+    """N4, second half: ``pairs_per_forward`` = P stacks P neighbours of a reference into one model forward (upstream's loop runs one
+    pair per forward, core/matcher.py:175-188; RoMaV2's own tests run batches of 8).  On a model whose arithmetic is per sample the maps
+    are the same bits; the backbone is CALLED fewer times, and with shared features it still sees every camera exactly once."""
+    from PIL import Image
+    stub = types.ModuleType("romav2")
+    stub.RoMaV2 = _BatchStubRoMa
+    monkeypatch.setitem(sys.modules, "romav2", stub)
+    from lichtfeld_densification_plugin_amd.core import matcher as mm
+    rs = np.random.RandomState(3)
+    images = {i: Image.fromarray(rs.randint(0, 256, (40, 48, 3)).astype(np.uint8)) for i in range(8)}
+    work = [(0, [1, 2, 3, 4, 5]), (1, [0, 2, 6]), (2, [1, 3, 7, 5])]
+    nn = {r: n for r, n in work}
+    nn.update({i: [] for i in range(8) if i not in nn})
+    sched = PairSchedule([w[0] for w in work], nn, list(range(8)), 5)
+
+    def run(P):
+        m = mm.RomaMatcher(device="cpu", setting="turbo", pairs_per_forward=P)
+        images_seen = []
+        inner_forward = m.model.f.forward
+        m.model.f.forward = lambda img: (images_seen.append(int(img.shape[0])), inner_forward(img))[1]
+        cache = FeatureCache(sched.last_use)
+        if share:
+            m.set_feature_cache(cache)
+        outs = []
+        for step, (r, nbrs) in enumerate(work):
+            outs.append(m.match_grids_batch(images[r], [images[n] for n in nbrs], **({"keys": (r, nbrs)} if share else {})))
+            cache.advance(step)
+        return outs, images_seen
+
+    single, seen1 = run(1)
+    for P in (2, 3, 8):
+        batched, seenP = run(P)
+        assert sum(seenP) == sum(seen1) == (sched.n_backbone_forwards_shared if share else sched.n_backbone_forwards_upstream)
+        assert len(seenP) < len(seen1) and max(seenP) <= P            # fewer, larger passes
+        for a, b in zip(single, batched):
+            assert len(a) == len(b)
+            for (wa, ca), (wb, cb) in zip(a, b):
+                assert torch.equal(wa, wb) and torch.equal(ca, cb)
