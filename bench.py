@@ -491,8 +491,8 @@ def main():
     params = hb.make_params(cfg)
     dens = hb.HipDensifier(dev)
     dens.upload_cameras(cams)
-    if not refs:
-        raise SystemExit(f"rank {rank} owns no reference view: --refs {args.refs} ({args.scaling}) over {world} ranks")
+    if total_refs < world:        # (the same verdict on every rank, before any collective: nobody is left waiting in a barrier)
+        raise SystemExit(f"--refs {args.refs} ({args.scaling} scaling) leaves a rank without a reference view: {total_refs} references over {world} ranks")
     # DISTINCT batches rotate in the timed loop (the same planes, the references in another order: other descriptor tables,
     # other per-pair constants), as in a real run where every launch sees a new batch: the descriptor upload and
     # lfd_pair_setup_kernel are then inside the timed region.  They are issued by lfd_prepare_batch - which stages them on the

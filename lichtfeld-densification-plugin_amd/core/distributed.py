@@ -229,7 +229,8 @@ class ShardedPlyStream:
         if n > 0:
             payload = torch.empty(n, dtype=torch.uint8, device=self.dev)
             self.dist.recv(payload, src, group=self.group)
-            self.writer.append_packed(payload.cpu().numpy().tobytes())
+            if self.writer is not None:           # (no writer: the file could not be opened - the records are received and dropped)
+                self.writer.append_packed(payload.cpu().numpy().tobytes())
 
     def _advance_to(self, global_pos: int) -> None:
         """Write every reference of the other ranks that precedes ``global_pos`` (own references before it had no points)."""
@@ -246,8 +247,8 @@ class ShardedPlyStream:
         if self.rank == self.root:
             g = self.root + int(local_index) * self.world
             self._advance_to(g)
-            raw = body if isinstance(body, (bytes, bytearray)) else body.cpu().numpy().tobytes()
-            self.writer.append_packed(raw)
+            if self.writer is not None:
+                self.writer.append_packed(body if isinstance(body, (bytes, bytearray)) else body.cpu().numpy().tobytes())
             self._next_global = g + 1
             return
         if isinstance(body, (bytes, bytearray)):

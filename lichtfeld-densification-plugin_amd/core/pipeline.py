@@ -597,12 +597,15 @@ def run_dense_pipeline(
             cum_body = CumulativePlyBody()
         if (bool(getattr(config, "stream_output", False)) and str(config.output_path).lower().endswith(".ply")
                 and int(config.max_points) <= 0 and float(config.voxel_size) <= 0.0):
-            if rank == 0:
-                stream_writer = StreamedPlyWriter(config.output_path)
             if world > 1:
                 # sharded run (BASELINE config 5): every rank packs its finished references' records on the device, rank 0 appends
-                # them to the file in global reference order as they arrive (core/distributed.py)
-                shard_stream = lfd_dist.ShardedPlyStream(dist, len(refs_local), stream_writer, dev)
+                # them to the file in global reference order as they arrive (core/distributed.py).  Created on every rank BEFORE rank
+                # 0 opens the file: if that fails, rank 0 still receives (and drops) what the others send, nobody is left blocked
+                shard_stream = lfd_dist.ShardedPlyStream(dist, len(refs_local), None, dev)
+            if rank == 0:
+                stream_writer = StreamedPlyWriter(config.output_path)
+                if shard_stream is not None:
+                    shard_stream.writer = stream_writer
 
         def emit(local_i: int, packed: _PackedReference, xyz, rgb, err, dbg, dev_pts=None) -> None:
             nonlocal refs_with_points
