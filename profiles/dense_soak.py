@@ -1,5 +1,7 @@
-"""Soak of the dense kernel's ordered retirement: many back-to-back launches on the bench workload and on a ragged small one, every launch's
-survivor count, reference offsets and a checksum of the records compared with the first launch's.  python profiles/dense_soak.py [launches]"""
+"""Soak of the dense kernel's ordered retirement and of the staged batch preparation: many back-to-back launches on the bench workload and
+on a ragged small one - three distinct batches in rotation (the references in another order), each staged by lfd_prepare_batch on the
+preparation stream while the launch before it runs - every sampled launch's survivor count, reference offsets and checksums of the records
+compared with the first launch of the same batch.  python profiles/dense_soak.py [launches]"""
 import os, sys, time
 import numpy as np
 import torch
@@ -19,20 +21,22 @@ for (n_refs, H, W, k) in ((64, 512, 512, 3), (7, 90, 126, 2), (24, 320, 320, 4))
         refs.append(hb.ReferenceInputs(ref_cam=r, nbr_cams=nb, cert=[s.cert[j] for j in range(k)], warp=[s.warp[j] for j in range(k)], image=s.image))
     dens = hb.HipDensifier(dev)
     dens.upload_cameras(cams)
-    batch = hb.PreparedBatch(refs, W, H)
+    batches = [hb.PreparedBatch(refs[j:] + refs[:j], W, H) for j in range(3)]
     params = hb.make_params(lfd.DensePipelineConfig(output_path=""))
     out = hb.OutputBuffers(n_refs * H * W, n_refs, k, dev, with_cell=True)
-    first = None
+    first = {}
     t0 = time.time()
+    dens.prepare(batches[0], params)
     for i in range(n_launch):
-        dens.launch_dense(batch, params, out)
-        if i % 50 == 0 or i == n_launch - 1:
+        dens.launch_dense(batches[i % 3], params, out)
+        sample = i % 50 in (0, 1, 2) or i == n_launch - 1
+        if not sample and i + 1 < n_launch:
+            dens.prepare(batches[(i + 1) % 3], params)          # staged beside the launch above
+        if sample:
             dens.check_launches()
             res = out.collect()
             sig = (res.count, tuple(int(v) for v in res.ref_offsets), float(res.xyz.double().sum().item()), int(res.cell.long().sum().item()))
-            if first is None:
-                first = sig
-            assert sig == first, (i, sig[:1], first[:1])
+            assert first.setdefault(i % 3, sig) == sig, (i, sig[:1], first[i % 3][:1])
     torch.cuda.synchronize()
-    print(f"{n_refs} refs x {k} nbrs x {H}x{W}: {n_launch} launches, {first[0]} survivors each time, {time.time() - t0:.1f} s")
+    print(f"{n_refs} refs x {k} nbrs x {H}x{W}: {n_launch} launches over 3 rotating batches, {first[0][0]} survivors each time, {time.time() - t0:.1f} s")
     dens.close()

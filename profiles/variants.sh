@@ -11,7 +11,9 @@ if [ "$1" = "build" ]; then
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
     [ "$flags" = "$spec" ] && flags=""
-    ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fno-fast-math -Wno-unused-function -mllvm -amdgpu-sched-strategy=max-ilp $flags \
+    sched="-mllvm -amdgpu-sched-strategy=max-ilp"
+    case "$flags" in *amdgpu-sched-strategy*) sched="";; esac      # a variant may bring its own scheduler strategy
+    ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fno-fast-math -Wno-unused-function $sched $flags \
         -pthread $SRC/lfd_api.hip $SRC/lfd_kernels.hip $SRC/lfd_select.hip $SRC/lfd_writer.hip $SRC/lfd_host.hip $SRC/lfd_image.hip -o $VD/$name.so || echo "BUILD FAILED $name" ) &
     while [ $(jobs -r | wc -l) -ge 6 ]; do sleep 0.5; done
   done
