@@ -165,10 +165,12 @@ LFD_HD void lfd_make_ref_const(const LfdCam& c, int w_match, int h_match, LfdRef
     o.pad = 0.0f;
 }
 
+// `F_given`: the caller's fundamental matrix (f32, row-major; upstream's fundamental_from_world2cam result) or null - then it is derived here
 LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index, int w_match, int h_match,
-                                LfdPairConst& o) {
+                                LfdPairConst& o, const float* F_given = nullptr) {
     float F[9];
-    lfd_fundamental(a.K, a.R, a.t, b.K, b.R, b.t, F);
+    if (F_given) { for (int i = 0; i < 9; ++i) F[i] = F_given[i]; }
+    else lfd_fundamental(a.K, a.R, a.t, b.K, b.R, b.t, F);
     for (int i = 0; i < 9; ++i) o.F[i] = (double)F[i];
     lfd_interleave_p(b.P, o.P);
     for (int i = 0; i < 3; ++i) o.C[i] = b.C[i];

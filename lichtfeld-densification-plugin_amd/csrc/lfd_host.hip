@@ -159,9 +159,8 @@ void make_ref(const lfd_context* ctx, const HostLaunch& L, int r, HostRef& R) {
     lfd_make_ref_const(ca, b->w_match, b->h_match, R.rc);
     for (int j = 0; j < b->n_slots[r]; ++j) {
         const size_t s = (size_t)r * b->k + j;
-        lfd_make_pair_const(ca, ctx->host_cams[(size_t)b->nbr_cam[s]], b->nbr_cam[s], b->w_match, b->h_match, R.pc[j]);
-        if (b->fundamental)
-            for (int e = 0; e < 9; ++e) R.pc[j].F[e] = (double)b->fundamental[s * 9 + e];
+        lfd_make_pair_const(ca, ctx->host_cams[(size_t)b->nbr_cam[s]], b->nbr_cam[s], b->w_match, b->h_match, R.pc[j],
+                            b->fundamental ? b->fundamental + s * 9 : nullptr);
     }
 }
 

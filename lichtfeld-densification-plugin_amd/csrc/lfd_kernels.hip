@@ -379,9 +379,9 @@ extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* __res
     if (i < n_pairs) {
         const int r = i / L.k, j = i - r * L.k;
         if (j < L.refs[r].n_slots) {
-            lfd_make_pair_const(L.cams[L.refs[r].cam], L.cams[L.slots[i].cam], L.slots[i].cam, L.w_match, L.h_match, pair_out[i]);
-            if (L.fund_override)       // the caller's F (upstream's fundamental_from_world2cam result) replaces the one derived here
-                for (int e = 0; e < 9; ++e) pair_out[i].F[e] = (double)L.fund_override[(size_t)i * 9 + e];
+            // (with the caller's F - upstream's fundamental_from_world2cam result - nothing is derived here: half of this kernel's work)
+            lfd_make_pair_const(L.cams[L.refs[r].cam], L.cams[L.slots[i].cam], L.slots[i].cam, L.w_match, L.h_match, pair_out[i],
+                                L.fund_override ? L.fund_override + (size_t)i * 9 : nullptr);
         }
     } else if (i < n_pairs + L.n_refs) {
         const int r = i - n_pairs;
