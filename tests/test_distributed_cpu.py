@@ -59,9 +59,9 @@ def _worker(rank, world, port, n_refs, q, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_refs", [7, 2, 1])
-def test_ordered_all_gather_world2(n_refs, tmp_path):
-    world = 2
+@pytest.mark.parametrize("n_refs,world", [(7, 2), (2, 2), (1, 2), (10, 3), (5, 4), (2, 3)])
+def test_ordered_all_gather_world2(n_refs, world, tmp_path):
+    """(world 3 and 4: uneven shards, a rank without any reference when n_refs < world ... )"""
     tmp = str(tmp_path)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
