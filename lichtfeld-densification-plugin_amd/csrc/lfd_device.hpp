@@ -20,7 +20,8 @@
 #endif
 #define LFD_DENSE_CPT 4         // consecutive grid cells per thread (one 16-byte certainty load per slot)
 #ifndef LFD_DENSE_WAVES_PER_SIMD
-#define LFD_DENSE_WAVES_PER_SIMD 7       // register budget of the fused kernel: 512/7 -> <=72 VGPRs (it needs 69-72)
+#define LFD_DENSE_WAVES_PER_SIMD 8       // register budget of the fused kernel: 512/8 = 64 VGPRs.  Round 3: the geometry loop fits (63-64, no scratch) since
+                                         // nothing constant is kept in vector registers across it any more, and the tile's LDS block is 20.4 KB: eight workgroups per CU (7: 0.2819, 8: see profiles/r3/ablation.txt)
 #endif
 #ifndef LFD_DENSE_ALL_WARPS
 #define LFD_DENSE_ALL_WARPS 2   // dense kernel, references with at most this many neighbours (two-channel warps, no masks): the warps of ALL slots ride

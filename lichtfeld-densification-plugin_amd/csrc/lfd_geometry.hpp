@@ -213,10 +213,13 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
 
 LFD_HD double lfd_pow2_inv_scale(double t) {
     // 2^-e with t = m * 2^e, m in [0.5, 1): exact rescaling.  t <= 0, Inf or NaN give 1.0.
-    if (!(t > 0.0) || !(t < 1.7976931348623157e308)) return 1.0;
     int e;
     (void)frexp(t, &e);
-    return ldexp(1.0, -e);
+    int es = ((t > 0.0) && (t < 1.7976931348623157e308)) ? -e : 0;     // the EXPONENT is selected, not the result: no 1.0 literal to keep in a register
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(es));            // (... and the optimiser must not turn it back into a select of the two results)
+#endif
+    return ldexp(1.0, es);
 }
 
 #ifndef LFD_RCP_NEWTON_STEPS
@@ -227,6 +230,23 @@ LFD_HD double lfd_pow2_inv_scale(double t) {
  * dense kernel's time. */
 #define LFD_RCP_NEWTON_STEPS 1
 #endif
+// Square root of the RARE paths (the Rayleigh shift of a second solver pass, the w -> 0 guard): on the device the 1-instruction
+// v_rsq_f64 with two coupled Newton steps (~1e-15) instead of the compiler's IEEE expansion, whose range-scaling constants would
+// otherwise sit in vector registers across the whole geometry loop; neither value is compared with anything.
+LFD_HD double lfd_sqrt_rare(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = __builtin_amdgcn_rsq(x);
+    double s = x * r, h = 0.5 * r;
+    double d = fma(-h, s, 0.5);
+    s = fma(s, d, s); h = fma(h, d, h);
+    d = fma(-s, s, x);
+    s = fma(d, h, s);
+    return (x > 0.0) ? s : 0.0;
+#else
+    return sqrt(x);
+#endif
+}
+
 LFD_HD double lfd_recip_refined(double d) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double r = __builtin_amdgcn_rcp(d);       // v_rcp_f64 is an approximation (profiles/microbench/valu_rate.hip measures it); Newton steps bring it to ~1 ulp
@@ -340,7 +360,7 @@ LFD_HD int lfd_null_vector_rows(RowFn rows, double* c) {
             // stays positive definite and the iteration cannot lock on to v3 (rate ~eps instead of q)
             const double e0 = fma(-rho, x0, t0), e1 = fma(-rho, x1, t1), e2 = fma(-rho, x2, t2), e3 = fma(-rho, x3, t3);
             const double rr = fma(e3, e3, fma(e2, e2, fma(e1, e1, e0 * e0)));
-            sh = rho - sqrt(rr * rden);
+            sh = rho - lfd_sqrt_rare(rr * rden);
         }
     }
     c[0] = x0; c[1] = x1; c[2] = x2; c[3] = x3;
@@ -407,7 +427,10 @@ LFD_HD float lfd_reproj_sq(const float* P, float X0, float X1, float X2, float X
     const float px = lfd_proj_row(P, 0, X0, X1, X2, X3);
     const float py = lfd_proj_row(P, 1, X0, X1, X2, X3);
     pz = lfd_proj_row(P, 2, X0, X1, X2, X3);
-    const float z = (pz < 1e-12f) ? 1e-12f : pz;          // np.maximum(z, 1e-12): NaN stays NaN
+    // np.maximum(z, 1e-12).  (fmaxf returns the bound for a NaN depth where NumPy returns NaN: a NaN depth comes with NaN numerators - X
+    // itself is NaN - so the quotients and the error are NaN either way; the maximum takes its bound as an instruction literal, the
+    // compare-and-select form kept it in a vector register across the whole geometry loop.)
+    const float z = fmaxf(pz, 1e-12f);
     const float rz = lfd_rcp_f32(z);                       // one reciprocal, two Markstein-corrected quotients
     const float du = lfd_div_by_recip_f32(px, z, rz) - u;
     const float dv = lfd_div_by_recip_f32(py, z, rz) - v;
@@ -436,7 +459,7 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
         const double ft0 = fma(F[3], y2, fma(F[0], x2, F[6]));
         const double ft1 = fma(F[4], y2, fma(F[1], x2, F[7]));
         const double num = fma(x2, fx0, fma(y2, fx1, fx2));
-        const double den = fma(ft1, ft1, fma(ft0, ft0, fma(fx1, fx1, fma(fx0, fx0, 1e-12))));
+        const double den = fma(ft1, ft1, fma(ft0, ft0, fma(fx1, fx1, fx0 * fx0))) + 1e-12;      // (the constant last: an operand of the add, not a register to preload)
         // se = num^2/den < thresh  <=>  num^2 < thresh*den  (den > 0); differs from the division only
         // within one f64 ulp of the threshold, and NaN still rejects
         if (!((num * num) < kp.sampson_thresh * den)) return;
@@ -492,7 +515,7 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
     const double n2 = fma(c[0], c[0], fma(c[1], c[1], fma(c[2], c[2], c33)));
     float X0, X1, X2, X3;
     if (c33 < 1e-24 * n2) {
-        const double inv = 1.0 / (sqrt(n2) * 1e-12);
+        const double inv = lfd_recip_refined(lfd_sqrt_rare(n2) * 1e-12);
         X0 = (float)(c[0] * inv); X1 = (float)(c[1] * inv); X2 = (float)(c[2] * inv); X3 = (float)(c[3] * inv);
     } else {
         // r = 1/c3 to ~1 ulp of f64 (Newton-refined v_rcp_f64 on the device); the quotients are rounded to f32

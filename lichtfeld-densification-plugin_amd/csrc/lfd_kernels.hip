@@ -480,8 +480,7 @@ __device__ __forceinline__ int lfd_slot_bytes12(int sl) {
 struct DenseStage {                // per-tile results, indexed by the cell's slot inside the tile
     float xyz[3 * kTile];
     float err[kTile];
-    unsigned short order[kTile];   // order[i] = tile slot of the i-th survivor (raster order)
-    unsigned char slot[kTile];
+    unsigned char slot[kTile];     // (the order map - order[i] = tile slot of the i-th survivor, raster order - lives in BlockShared::pc, see below)
 };
 
 struct __attribute__((packed, aligned(4))) LfdF3 { float a, b, c; };
@@ -500,12 +499,27 @@ constexpr int kCopyRecords = (kTile + kCopyThreads - 1) / kCopyThreads;
 
 template <bool kExactColour>
 __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
-    __shared__ BlockShared S;
-    __shared__ DenseStage stage;
-    __shared__ unsigned s_ticket;
-    __shared__ unsigned s_wave_cnt[kBlock / 64];
-    __shared__ unsigned s_slot_cnt[LFD_MAX_SLOTS];
-    __shared__ u64 s_tile_excl;
+    // one LDS block, the per-pair constants first: S.pc[slot] is then addressed as slot * sizeof(LfdPairConst) + an instruction offset,
+    // with no base to keep in a vector register across the geometry loop
+    struct DenseShared {
+        BlockShared S;
+        DenseStage stage;
+        u64 tile_excl;
+        unsigned ticket;
+        unsigned wave_cnt[kBlock / 64];
+        unsigned slot_cnt[LFD_MAX_SLOTS];
+    };
+    __shared__ DenseShared sh;
+    BlockShared& S = sh.S;
+    DenseStage& stage = sh.stage;
+    // The order map (2 KB) lives where the per-pair constants were: those are last read in the geometry loop, the map is written behind
+    // the barrier that follows it.  With it the block is 20.4 KB: eight workgroups fit the 160 KB of a CU (22.4 KB: seven).
+    static_assert(sizeof(sh.S.pc) >= kTile * sizeof(unsigned short), "the order map does not fit the per-pair constant block");
+    unsigned short* const stage_order = reinterpret_cast<unsigned short*>(sh.S.pc);
+    unsigned& s_ticket = sh.ticket;
+    unsigned (&s_wave_cnt)[kBlock / 64] = sh.wave_cnt;
+    unsigned (&s_slot_cnt)[LFD_MAX_SLOTS] = sh.slot_cnt;
+    u64& s_tile_excl = sh.tile_excl;
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -536,7 +550,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
     // every tile fetching, then every tile computing (the first generation of tiles lives 48 us, the later ones 33).  The k-th
     // workgroup a CU receives waits k x ~1.5 us before it draws its ticket (a heuristic on the dispatch order: harmless where it
     // does not hold).  Measured 0.2966 -> 0.292 ms (profiles/r2/ablation.txt).
-    if (blockIdx.x < 7u * 256u) {
+    if (blockIdx.x < (unsigned)LFD_DENSE_WAVES_PER_SIMD * 256u) {      // (one resident workgroup per wave slot of a SIMD, 256 CUs)
         const unsigned slot = blockIdx.x >> 8;
         for (unsigned i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(LFD_STAGGER_UNITS);
     }
@@ -734,9 +748,10 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
         // ---- stage 3: per-correspondence geometry + colour; survivors overwrite their slot -------------
         unsigned keep_bits = 0;
 #pragma unroll 1
-        for (int e = 0; e < kCpt; ++e) {
+        for (int ev = 0; ev < kCpt; ++ev) {
             // re-read the camera constants from LDS every cell instead of pinning ~60 registers on them
             asm volatile("" ::: "memory");
+            const int e = __builtin_amdgcn_readfirstlane(ev);      // the cell counter is the same for every lane: a scalar register
             const int sl = tid * kCpt + e;
             float* sxyz = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(stage.xyz) + lfd_slot_bytes12(sl));
             const float xan = sxyz[0], yan = sxyz[1], xbn = sxyz[2];
@@ -794,9 +809,9 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
             unsigned lpos = wave_off + (incl - my_cnt);
 #pragma unroll
             for (int e = 0; e < kCpt; ++e)
-                if ((keep_bits >> e) & 1u) stage.order[lpos++] = (unsigned short)(tid * kCpt + e);
+                if ((keep_bits >> e) & 1u) stage_order[lpos++] = (unsigned short)(tid * kCpt + e);
         }
-        __syncthreads();                          // stage.order complete
+        __syncthreads();                          // the order map is complete
         LFD_STAMP(7);
         if (L.seg_counts && tid < ns && s_slot_cnt[tid]) {
             // the workgroup of tile 0 zeroed the array and raised seg_ready when the launch began (no memset launch)
@@ -852,7 +867,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
                         for (int v = 0; v < LFD_COPY_UNROLL; ++v) {
                             if (u0 + v >= kCopyRecords) break;
                             const int i = ctid + (u0 + v) * kCopyThreads;
-                            const int sl = (int)stage.order[i < n_loc ? i : n_loc - 1];
+                            const int sl = (int)stage_order[i < n_loc ? i : n_loc - 1];
                             int dy, x;
                             lfd_divmod_local(tile_x0 + sl, L.W, L.inv_w, L.w_log2, dy, x);
                             const lfd_u32x4 c4 = *reinterpret_cast<const lfd_u32x4 LFD_GLOBAL_AS*>(lfd_global(L.colour_cols) + x);
@@ -880,7 +895,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
                     for (int v = 0; v < LFD_COPY_UNROLL; ++v) {
                         if (u0 + v >= kCopyRecords) break;
                         const int i = ctid + (u0 + v) * kCopyThreads;
-                        const int sl = (int)stage.order[i < n_loc ? i : n_loc - 1];
+                        const int sl = (int)stage_order[i < n_loc ? i : n_loc - 1];
                         {   // reference position in match pixels, from the A-grid coordinates of the cell (not staged: LDS is
                             // one of the two things that limit the number of resident workgroups)
                             const int cell = tile_cell0 + sl;
@@ -935,7 +950,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
             for (int u = 0; u < kCopyRecords; ++u) {
                 const int i = ctid + u * kCopyThreads;
                 if (i < n) {
-                    const int sl = (int)stage.order[i];
+                    const int sl = (int)stage_order[i];
                     LfdF3 p, c;
                     const float* sxyz = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(stage.xyz) + lfd_slot_bytes12(sl));
                     p.a = sxyz[0]; p.b = sxyz[1]; p.c = sxyz[2];
