@@ -492,7 +492,9 @@ constexpr int kCopyRecords = (kTile + kCopyThreads - 1) / kCopyThreads;
 // phase stamps of the dense kernel (profiling builds only): lane 0 of waves 0 and 1 record the shader clock at the phase
 // boundaries of their tile; profiles/dense_phases.py turns them into a per-phase latency table
 #if defined(LFD_DENSE_TIMING)
-#define LFD_STAMP(i) do { if (L.phase_stamps && lane == 0 && wave < 2) stamps[(i)] = __builtin_readcyclecounter(); } while (0)
+// (written straight to memory, keyed by the workgroup index - tickets and workgroup indices run in step to within a few tiles: twelve
+// stamps kept in registers would cost the timing build the eighth wave per SIMD)
+#define LFD_STAMP(i) do { if (L.phase_stamps && lane == 0 && wave < 2) L.phase_stamps[((size_t)blockIdx.x * 2 + wave) * 12 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define LFD_STAMP(i) do { } while (0)
 #endif
@@ -524,7 +526,6 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 #if defined(LFD_DENSE_TIMING)
-    unsigned long long stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     LFD_STAMP(0);
     // Tickets: a workgroup learns its tile from an atomic counter, so every tile a look-back can wait for is
@@ -596,7 +597,10 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
         }
         LFD_STAMP(2);
 #if defined(LFD_DENSE_TIMING)
-        stamps[0] = (stamps[0] & ~3ull) | (r == r_guess ? 1ull : 0ull) | (tile == tile_guess ? 2ull : 0ull);     // did the guess hold?
+        if (L.phase_stamps && lane == 0 && wave < 2) {      // did the guess hold?  (low bits of stamp 0)
+            unsigned long long* s0 = L.phase_stamps + ((size_t)blockIdx.x * 2 + wave) * 12;
+            *s0 = (*s0 & ~3ull) | (r == r_guess ? 1ull : 0ull) | (tile == tile_guess ? 2ull : 0ull);
+        }
 #endif
         const int ns = S.ref.n_slots;
         const bool any_mask = S.ref.any_mask != 0;
@@ -978,8 +982,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
         LFD_STAMP(10);
         if (L.phase_stamps && lane == 0 && wave < 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores retired: the wave could end here
-            stamps[11] = __builtin_readcyclecounter();
-            for (int i = 0; i < 12; ++i) L.phase_stamps[((size_t)tile * 2 + wave) * 12 + i] = stamps[i];
+            L.phase_stamps[((size_t)blockIdx.x * 2 + wave) * 12 + 11] = __builtin_readcyclecounter();
         }
 #endif
     }
