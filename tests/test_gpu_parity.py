@@ -167,12 +167,14 @@ def _oracle_cam(c):
     return orc.OracleCamera(K=c.K, R=c.R, t=c.t, P=c.P, C=c.C, width=c.width, height=c.height)
 
 
-@pytest.mark.parametrize("H,W,wm,hm,channels,no_filter", [(64, 64, 64, 64, 2, False), (48, 80, 80, 48, 4, False),
-                                                          (96, 96, 64, 64, 2, False), (64, 64, 64, 64, 2, True),
-                                                          (50, 50, 50, 50, 4, False)])
-def test_dense_matches_oracle(dev, H, W, wm, hm, channels, no_filter):
+@pytest.mark.parametrize("H,W,wm,hm,channels,no_filter,slots", [(64, 64, 64, 64, 2, False, [3, 1, 2]), (48, 80, 80, 48, 4, False, [3, 1, 2]),
+                                                                (96, 96, 64, 64, 2, False, [3, 1, 2]), (64, 64, 64, 64, 2, True, [3, 1, 2]),
+                                                                (50, 50, 50, 50, 4, False, [3, 1, 2]),
+                                                                # the most neighbours a launch takes (LFD_MAX_SLOTS = 16), beside ragged counts
+                                                                (64, 64, 64, 64, 2, False, [16, 9, 1]), (40, 72, 72, 40, 4, False, [16, 5, 16])])
+def test_dense_matches_oracle(dev, H, W, wm, hm, channels, no_filter, slots):
     """Fused kernel over every cell of several references with differing neighbour counts."""
-    cams, refs, srefs = _synthetic_batch(dev, 3, [3, 1, 2], H, W, wm, hm, seed=5, channels=channels)
+    cams, refs, srefs = _synthetic_batch(dev, 3, slots, H, W, wm, hm, seed=5, channels=channels)
     cfg = lfd.DensePipelineConfig(output_path="", no_filter=no_filter)
     params = orc.OracleParams(no_filter=no_filter)
     dens = hb.HipDensifier(dev)

@@ -139,3 +139,36 @@ def test_twin_and_device_contexts_do_not_stand_in_for_each_other():
     if not torch.cuda.is_available():
         with pytest.raises(hb.HipBackendError, match="no GPU|no CPU fallback"):
             hb.HipDensifier()
+
+
+def test_sixteen_neighbours_and_one_more():
+    """LFD_MAX_SLOTS = 16 neighbour slots per reference is the most a launch takes: the twin on a reference with all 16 (beside ragged
+    ones) against the oracle, cell by cell through the derived bands; a 17th is refused where the batch is built."""
+    H, W = 40, 56
+    cams = synthetic.ring_cameras(60, seed=3)
+    refs, srefs = [], []
+    for i, k in enumerate((16, 5, 16)):
+        ref = (7 * i + 3) % 60
+        nbrs = synthetic.ring_neighbours(60, ref, k)
+        s = synthetic.synth_reference(cams, ref, nbrs, H, W, W, H, noise_px=0.4, outlier_frac=0.05, channels=2, seed=11 + i, cert_mode="smooth")
+        srefs.append(s)
+        refs.append(hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=[s.cert[j] for j in range(k)], warp=[s.warp[j].contiguous() for j in range(k)],
+                                       image=s.image))
+    twin = hb.HostDensifier(2)
+    twin.upload_cameras(cams)
+    batch = hb.PreparedBatch(refs, W, H, cameras=cams)
+    assert batch.k == 16
+    out = twin.triangulate_dense(batch, hb.make_params(lfd.DensePipelineConfig(output_path="")))
+    cell, slot = out.cell.numpy().astype(np.int64), out.slot.numpy().astype(np.int64)
+    axes = (orc.identity_axis_scalar(W), orc.identity_axis_scalar(H))
+    for r, s in enumerate(srefs):
+        lo, hi = int(out.ref_offsets[r]), int(out.ref_offsets[r + 1])
+        rep = flip_report(cell[lo:hi], s, cams, W, H, orc.OracleParams(), axes)
+        assert rep["out_of_band"] == 0 and rep["flipped"] <= 3, rep
+        np.testing.assert_array_equal(slot[lo:hi], rep["best_k"].reshape(-1)[cell[lo:hi]])       # the winner among up to 16 slots
+        assert slot[lo:hi].max() >= min(8, len(s.nbr_indices) - 1) and hi - lo > 0.5 * H * W
+    twin.close()
+    nbrs = synthetic.ring_neighbours(60, 0, 17)
+    s = srefs[0]
+    with pytest.raises(ValueError, match="neighbour slots"):
+        hb.PreparedBatch([hb.ReferenceInputs(ref_cam=0, nbr_cams=nbrs, cert=[s.cert[0]] * 17, warp=[s.warp[0].contiguous()] * 17, image=s.image)], W, H)
