@@ -19,7 +19,7 @@ capability is driven exactly as before.  Sharding (multi-GPU) deals whole refere
 from __future__ import annotations
 
 import dataclasses
-from typing import Dict, Hashable, List, Optional, Sequence, Tuple
+from typing import Dict, Hashable, List, Optional, Sequence
 
 
 @dataclasses.dataclass
