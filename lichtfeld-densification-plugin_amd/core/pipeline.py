@@ -24,6 +24,7 @@ round-robin to the ranks and the survivors are all-gathered in reference order a
 """
 from __future__ import annotations
 
+import collections
 import dataclasses
 import gc
 import os
@@ -44,6 +45,9 @@ from .sampling import select_samples_with_coverage, upstream_weight_sum
 from .scheduler import FeatureCache, PairSchedule
 from .types import CameraRecord, DensePipelineConfig
 from .writers import CumulativePlyBody, StreamedPlyWriter, ensure_dir, ply_records, write_ply
+
+# device_image_prep: bytes of prepared match-size images / masks kept on the device per run (LFD_PREPARED_CACHE_MB; 0 = keep none)
+PREPARED_CACHE_BYTES = int(os.environ.get("LFD_PREPARED_CACHE_MB", "4096")) << 20
 
 _DEBUG_PREVIEW_INTERVAL = 3      # upstream core/pipeline.py:34
 _PREVIEW_MAX_MATCHES = 10000     # upstream core/pipeline.py:50
@@ -295,11 +299,15 @@ class _HotPath:
         if self.dens.device.type != dev.type:
             raise ValueError(f"backend runs on {dev} but the densifier handed in lives on {self.dens.device}")
         self._own = densifier is None
+        self._prepared: "collections.OrderedDict" = collections.OrderedDict()      # device_image_prep: camera -> (image, mask) at match size
+        self._prepared_bytes = 0
         self.dens.upload_cameras(cams)
         self.cams = list(cams) if bool(getattr(config, "upstream_fundamental", True)) else None
         self.params = hb.make_params(config, sample_cap)
 
     def close(self) -> None:
+        self._prepared.clear()
+        self._prepared_bytes = 0
         if self._own:
             self.dens.close()
 
@@ -312,12 +320,29 @@ class _HotPath:
         def up(a):
             return torch.from_numpy(np.array(a, dtype=np.uint8, copy=True)).to(dev)      # the decode cache hands out read-only arrays
 
-        def one(img, mask_l):
+        def one(cam_index, img, mask_l):
+            # A camera is prepared the same way whether it is the reference or a neighbour, and it appears in ~k + 1 packages of a
+            # run: the prepared match-size tensors (0.8 MB + 0.26 MB at 512^2) stay on the device, least recently used first out
+            # beyond PREPARED_CACHE_BYTES - upstream keeps its resized images the same way (core/image_utils.py lru caches) - so a
+            # decoded full-resolution image (36-72 MB at 12-24 MP) is uploaded and resized once per run, not once per appearance.
+            key = (int(cam_index), int(size_wh[0]), int(size_wh[1]), mask_l is not None)
+            hit = self._prepared.get(key)
+            if hit is not None:
+                self._prepared.move_to_end(key)
+                return hit
             m01 = self.dens.prepare_mask(up(mask_l), size_wh) if mask_l is not None else None
-            return self.dens.prepare_image(up(img), size_wh, m01), m01
+            entry = (self.dens.prepare_image(up(img), size_wh, m01), m01)
+            nbytes = entry[0].numel() + (m01.numel() if m01 is not None else 0)
+            if nbytes <= PREPARED_CACHE_BYTES:
+                self._prepared[key] = entry
+                self._prepared_bytes += nbytes
+                while self._prepared_bytes > PREPARED_CACHE_BYTES:
+                    _k, old = self._prepared.popitem(last=False)
+                    self._prepared_bytes -= old[0].numel() + (old[1].numel() if old[1] is not None else 0)
+            return entry
 
-        img_a, mask_a = one(packed.image, packed.mask_a)
-        nbrs = [one(im, mk) for im, mk in zip(packed.nbr_images, packed.nbr_masks)]
+        img_a, mask_a = one(packed.ref_index, packed.image, packed.mask_a)
+        nbrs = [one(ci, im, mk) for ci, im, mk in zip(packed.nbr_indices, packed.nbr_images, packed.nbr_masks)]
         out = dataclasses.replace(packed, raw=False, dev={"image": img_a, "mask_a": mask_a, "nbr_images": [n[0] for n in nbrs],
                                                           "nbr_masks": [n[1] for n in nbrs]})
         if need_host:

@@ -9,6 +9,7 @@ import torch
 
 import lichtfeld_densification_plugin_amd as lfd
 from lichtfeld_densification_plugin_amd.core import pipeline as pl
+from lichtfeld_densification_plugin_amd.core import hip_backend as hb
 from lichtfeld_densification_plugin_amd.core.debug_viz import MatchDebugState
 from helpers import oracle_cams
 
@@ -345,6 +346,53 @@ def test_device_image_prep_gives_the_host_prepared_run(g4, tmp_path, device_matc
     np.testing.assert_array_equal(devr.points_per_reference, host.points_per_reference)
     if device_matcher:
         assert seen and all(a and b for a, b in seen)
+
+
+def test_prepared_images_stay_on_the_device_once_per_camera(g4, tmp_path, monkeypatch):
+    """device_image_prep prepares a camera ONCE per run: it appears as a reference and as a neighbour of others (here 3 cameras in
+    3 x (1 + 2) places), the match-size tensors stay on the device (bounded by PREPARED_CACHE_BYTES, least recently used first
+    out); with the cache switched off every appearance is prepared again - and the run is the same."""
+    from PIL import Image
+    ocams = oracle_cams(g4)
+    rs = np.random.RandomState(4)
+    cams = []
+    for i, c in enumerate(ocams):
+        ip, mp = os.path.join(str(tmp_path), f"p{i:02d}.png"), os.path.join(str(tmp_path), f"p{i:02d}_mask.png")
+        Image.fromarray(rs.randint(0, 256, (90, 121, 3)).astype(np.uint8)).save(ip)
+        m = np.full((90, 121), 255, np.uint8)
+        m[5 + i:30 + i, 10:60] = 0
+        Image.fromarray(m, mode="L").save(mp)
+        cam = lfd.CameraRecord(uid=int(g4["cam_uid"][i]), image_path=ip, width=c.width, height=c.height, K=c.K, R=c.R, t=c.t, P=c.P, C=c.C)
+        cam.mask_path = mp
+        cams.append(cam)
+    refs = [int(r) for r in g4["refs_local"]]
+    table = [[(torch.from_numpy(g4[f"ref{r}_warp"][j]), torch.from_numpy(g4[f"ref{r}_cert"][j])) for j in range(2)] for r in refs]
+    calls = {"image": 0, "mask": 0}
+    real_image, real_mask = hb.HipDensifier.prepare_image, hb.HipDensifier.prepare_mask
+
+    def count_image(self, *a, **k):
+        calls["image"] += 1
+        return real_image(self, *a, **k)
+
+    def count_mask(self, *a, **k):
+        calls["mask"] += 1
+        return real_mask(self, *a, **k)
+
+    monkeypatch.setattr(hb.HipDensifier, "prepare_image", count_image)
+    monkeypatch.setattr(hb.HipDensifier, "prepare_mask", count_mask)
+    kw = dict(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=2, seed=5, viz_interval=0, matches_per_ref=1200, device_image_prep=True)
+    cached = pl.run_dense_pipeline(cams, refs, g4["nn_table"], lfd.DensePipelineConfig(**kw), matcher=FakeMatcher(64, 64, table))
+    n_places = len(refs) * 3
+    used = {int(r) for r in refs} | {int(n) for r in refs for n in list(g4["nn_table"][r])[:2]}
+    assert calls == {"image": len(used), "mask": len(used)} and len(used) < n_places
+    calls.update(image=0, mask=0)
+    monkeypatch.setattr(pl, "PREPARED_CACHE_BYTES", 0)
+    plain = pl.run_dense_pipeline(cams, refs, g4["nn_table"], lfd.DensePipelineConfig(**kw), matcher=FakeMatcher(64, 64, table))
+    assert calls == {"image": n_places, "mask": n_places}
+    assert cached.xyz.shape[0] > 300
+    np.testing.assert_array_equal(cached.xyz, plain.xyz)
+    np.testing.assert_array_equal(cached.rgb, plain.rgb)
+    np.testing.assert_array_equal(cached.points_per_reference, plain.points_per_reference)
 
 
 def test_grouped_sampled_launches_equal_single_launches(g4, tmp_path):
