@@ -21,6 +21,8 @@ if [ "$1" = "build" ]; then
   ls -la $VD
 else
   shift
+  # (round 3: `run --light --steps 400` - the bench's own sustained loop without the heavy side legs - repeats to +-0.3 %; the default
+  # of 60 steps after a full pass carries the launch-time transient and reads ~10 % higher, comparable only within one log)
   for so in $VD/*.so; do
     name=$(basename $so .so)
     LFD_DENSIFY_LIB=$so python $REPO/bench.py --cpu-sample-refs 0 --steps 60 "$@" 2>&1 | python -c "
