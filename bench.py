@@ -531,21 +531,36 @@ def main():
         torch.cuda.synchronize(dev)
     for i in range(args.warmup):
         step(i)
+    dens.time_dense_kernels(args.steps)       # (creates the timed launches' event pairs: before the barrier, not inside the timed region)
     barrier()
-    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
+    # The timed region: EXACTLY K steps, nothing else in the stream.  Every launch carries a start and a stop event of its own
+    # (lfd_kernel_timing: hipExtLaunchKernelGGL, recorded on the launch stream where the kernel begins and ends - what a kernel
+    # trace reports): the dense kernel's duration is measured live, inside the timed region, without a packet that is not the step's.
     t0 = time.perf_counter()
     host_t = []
-    for i, e3 in enumerate(ev):
-        step(i, e3)
+    for i in range(args.steps):
+        step(i)
         host_t.append(time.perf_counter() - t0)
     t_enq = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
     if os.environ.get("LFD_BENCH_DEBUG"):
         print(f"[rank {rank}] enqueue done at {t_enq * 1e3:.2f} ms, first 5 host stamps {[round(x * 1e3, 2) for x in host_t[:5]]}", file=sys.stderr)
-    per_launch = [e1.elapsed_time(e2) for _e0, e1, e2 in ev]
-    per_prepare = [e0.elapsed_time(e1) for e0, e1, _e2 in ev]
+    per_launch = [float(x) for x in dens.dense_kernel_times_ms()]
+    dens.time_dense_kernels(0)
+    if len(per_launch) != args.steps:
+        raise SystemExit(f"{len(per_launch)} kernel timings for {args.steps} steps")
     kernel_ms = float(np.mean(per_launch))
+    # A second pass of the same K steps, outside the value: events recorded AROUND the two calls of a step - what is left of the batch
+    # preparation in the launch stream (`fresh_batch_ms`) and the launch as a caller's events see it (`kernel_ms_bracketed`: the
+    # kernel plus the dispatch gap in front of it).  Three more packets per step, which is why this is not the timed region.
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
+    for i, e3 in enumerate(ev):
+        step(i, e3)
+    barrier()
+    per_bracket = [e1.elapsed_time(e2) for _e0, e1, e2 in ev]
+    per_prepare = [e0.elapsed_time(e1) for e0, e1, _e2 in ev]
+    kernel_ms_bracketed = float(np.mean(per_bracket))
     fresh_batch_ms = float(np.mean(per_prepare))
     kernel_pct = {"p50": float(np.percentile(per_launch, 50)), "p95": float(np.percentile(per_launch, 95)),
                   "min": float(np.min(per_launch)), "max": float(np.max(per_launch))}
@@ -630,6 +645,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "lfd_dense_kernel", "kernel_ms": kernel_ms, "kernel_ms_percentiles": kernel_pct,
+                         "kernel_ms_source": "HIP start/stop events of each timed launch (hipExtLaunchKernelGGL) on the launch stream, mean over the timed region",
+                         "kernel_ms_bracketed": kernel_ms_bracketed,      # events recorded around the call instead: they include the dispatch gap before the kernel
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_cell": bytes_per_cell},
         }
         if allgather is not None:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LFD_ABI_VERSION 3
+#define LFD_ABI_VERSION 4
 #define LFD_MAX_SLOTS 16 /* neighbours per reference handled by one launch */
 
 enum lfd_status {
@@ -109,6 +109,13 @@ int lfd_set_stream(lfd_context* ctx, void* hip_stream);
  * LFD_DENSE_TIMING) are read when a context is created, never on a launch path; a test or profiling script that changes them for a
  * live context calls this to have them read again. */
 int lfd_reload_env(lfd_context* ctx);
+/* Measurement: the device-side duration of the dense kernel's launches.  lfd_kernel_timing(ctx, n) makes the next n launches of
+ * lfd_triangulate_dense carry a start and a stop event of their own (recorded by the command processor where the kernel begins and
+ * ends: the figure a kernel trace reports, without the dispatch gaps that events recorded around the call include); n = 0 switches it
+ * off.  lfd_kernel_timing_read waits for the last timed launch and writes the durations in launch order (milliseconds; at most
+ * `capacity`, *n_out = how many), then starts a new series.  Asynchronous launches stay asynchronous. */
+int lfd_kernel_timing(lfd_context* ctx, int32_t n_launches);
+int lfd_kernel_timing_read(lfd_context* ctx, float* ms, int32_t capacity, int32_t* n_out);
 const char* lfd_last_error(const lfd_context* ctx); /* ctx may be NULL: last creation error */
 
 /* Camera table, all host f32 row-major as upstream's CameraRecord holds them

@@ -18,7 +18,7 @@ import torch
 from .types import CameraRecord, DensePipelineConfig
 
 LFD_MAX_SLOTS = 16
-LFD_ABI_VERSION = 3
+LFD_ABI_VERSION = 4
 LFD_FLAG_EXACT_COLOUR = 1     # lfd_params.flags: dense mode blends colours with upstream's f64 arithmetic (bit-identical rgb)
 _LIB_NAME = "liblfd_densify.so"
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -81,6 +81,8 @@ def load_library() -> C.CDLL:
     lib.lfd_destroy.restype = None
     lib.lfd_set_stream.argtypes = [ctxp, C.c_void_p]
     lib.lfd_reload_env.argtypes = [ctxp]
+    lib.lfd_kernel_timing.argtypes = [ctxp, C.c_int32]
+    lib.lfd_kernel_timing_read.argtypes = [ctxp, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]
     lib.lfd_last_error.argtypes = [ctxp]
     lib.lfd_last_error.restype = C.c_char_p
     fptr = C.POINTER(C.c_float)
@@ -130,7 +132,7 @@ def load_library() -> C.CDLL:
     lib.lfd_host_null_vector.restype = C.c_int
     lib.lfd_host_eval_correspondence.argtypes = [fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                                  C.c_int32, C.POINTER(lfd_params), fptr]
-    for name in ("lfd_create", "lfd_set_stream", "lfd_reload_env", "lfd_upload_cameras", "lfd_prepare_batch", "lfd_aggregate", "lfd_triangulate_dense",
+    for name in ("lfd_create", "lfd_set_stream", "lfd_reload_env", "lfd_kernel_timing", "lfd_kernel_timing_read", "lfd_upload_cameras", "lfd_prepare_batch", "lfd_aggregate", "lfd_triangulate_dense",
                  "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_triangulate_sampled_multi", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
                  "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_identity_axis",
                  "lfd_host_fundamental", "lfd_get_pair_fundamental", "lfd_create_host", "lfd_aggregate_host",
@@ -551,6 +553,19 @@ class HipDensifier:
     def reload_env(self) -> None:
         """Re-read the profiling switches of the environment (they are read at creation only, lfd_reload_env)."""
         self._check(self._lib.lfd_reload_env(self._ctx), "lfd_reload_env")
+
+    def time_dense_kernels(self, n_launches: int) -> None:
+        """The next ``n_launches`` dense launches carry start / stop events of their own (lfd_kernel_timing): the kernel's device-side
+        duration, as a kernel trace reports it.  0 switches the timing off."""
+        self._check(self._lib.lfd_kernel_timing(self._ctx, int(n_launches)), "lfd_kernel_timing")
+
+    def dense_kernel_times_ms(self) -> np.ndarray:
+        """Durations (ms, launch order) of the dense launches timed since ``time_dense_kernels`` / the last read; waits for the last one."""
+        cap = 1 << 20
+        n = C.c_int32(0)
+        buf = np.zeros(cap, np.float32)
+        self._check(self._lib.lfd_kernel_timing_read(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n)), "lfd_kernel_timing_read")
+        return buf[:n.value].astype(np.float64)
 
     def check_launches(self) -> None:
         """Synchronise and raise if a kernel reported a look-back timeout."""

@@ -1,6 +1,7 @@
 // Host side of the C-ABI declared in include/lfd_densify.h: context, tables, launches.
 // No compute happens on the host here except the tiny helpers the header lists as host-side.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -436,10 +437,46 @@ void lfd_destroy(lfd_context* ctx) {
         if (sl.pinned) (void)hipHostFree(sl.pinned);
         for (hipEvent_t ev : {sl.pinned_free, sl.ready, sl.idle}) if (ev) (void)hipEventDestroy(ev);
     }
+    for (hipEvent_t ev : ctx->kt_start) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->kt_stop) (void)hipEventDestroy(ev);
     for (DeviceBuffer* b : {&ctx->cams, &ctx->ws, &ctx->axes, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->colour_tab, &ctx->mt, &ctx->mt_batch, &ctx->sel_scratch, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
     delete ctx;
+}
+
+int lfd_kernel_timing(lfd_context* ctx, int32_t n_launches) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
+    if (n_launches < 0 || n_launches > (1 << 20)) return fail(ctx, LFD_ERR_INVALID, "lfd_kernel_timing: n_launches must be in [0, 2^20]");
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));           // no launch is still using the events that go
+    while (ctx->kt_start.size() > (size_t)n_launches) {
+        (void)hipEventDestroy(ctx->kt_start.back()); (void)hipEventDestroy(ctx->kt_stop.back());
+        ctx->kt_start.pop_back(); ctx->kt_stop.pop_back();
+    }
+    while (ctx->kt_start.size() < (size_t)n_launches) {
+        hipEvent_t a = nullptr, b = nullptr;
+        LFD_HIP(ctx, hipEventCreate(&a));
+        hipError_t e = hipEventCreate(&b);
+        if (e != hipSuccess) { (void)hipEventDestroy(a); return fail(ctx, LFD_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+        ctx->kt_start.push_back(a); ctx->kt_stop.push_back(b);
+    }
+    ctx->kt_used = 0;
+    return LFD_OK;
+}
+
+int lfd_kernel_timing_read(lfd_context* ctx, float* ms, int32_t capacity, int32_t* n_out) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
+    if (!n_out || capacity < 0 || (capacity > 0 && !ms)) return fail(ctx, LFD_ERR_INVALID, "lfd_kernel_timing_read: bad arguments");
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = std::min(ctx->kt_used, (size_t)capacity);
+    if (ctx->kt_used) LFD_HIP(ctx, hipEventSynchronize(ctx->kt_stop[ctx->kt_used - 1]));
+    for (size_t i = 0; i < n; ++i) LFD_HIP(ctx, hipEventElapsedTime(ms + i, ctx->kt_start[i], ctx->kt_stop[i]));
+    *n_out = (int32_t)n;
+    ctx->kt_used = 0;
+    return LFD_OK;
 }
 
 int lfd_reload_env(lfd_context* ctx) {
@@ -577,7 +614,14 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
         rc = colour_tables(ctx, batch->W, batch->H, batch->w_match, batch->h_match, &L.colour_cols, &L.colour_rows);
         if (rc != LFD_OK) return rc;
     }
-    if (exact_colour)
+    hipEvent_t t_start = nullptr, t_stop = nullptr;          // lfd_kernel_timing: this launch's own events
+    if (ctx->kt_used < ctx->kt_start.size()) { t_start = ctx->kt_start[ctx->kt_used]; t_stop = ctx->kt_stop[ctx->kt_used]; ++ctx->kt_used; }
+    if (t_start) {
+        if (exact_colour)
+            hipExtLaunchKernelGGL(lfd_dense_exact_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), (unsigned)extra_lds, ctx->stream, t_start, t_stop, 0, L);
+        else
+            hipExtLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), (unsigned)extra_lds, ctx->stream, t_start, t_stop, 0, L);
+    } else if (exact_colour)
         hipLaunchKernelGGL(lfd_dense_exact_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), extra_lds, ctx->stream, L);
     else
         hipLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), extra_lds, ctx->stream, L);

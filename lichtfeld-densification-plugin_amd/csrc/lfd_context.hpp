@@ -86,6 +86,9 @@ struct lfd_context {
     int img_key[4] = {0, 0, 0, 0}, img_ks[2] = {0, 0};
     int msk_key[4] = {0, 0, 0, 0}, msk_inv = 0;
     float msk_thr = -1.0f;
+    // lfd_kernel_timing: start / stop events handed to the dense kernel's launches (hipExtLaunchKernelGGL), a ring of `kt_start.size()`
+    std::vector<hipEvent_t> kt_start, kt_stop;
+    size_t kt_used = 0;            // launches timed since the last read
     bool mt_seeded = false;
     bool topm_lds_attr_set = false;   // hipFuncSetAttribute is per device: remembered per context, not per process
 };

@@ -63,3 +63,44 @@ def test_staged_batches_equal_fresh_contexts(with_prepare):
     a, b0 = groups[order[-1]][0].ref_cam, groups[order[-1]][0].nbr_cams[0]
     np.testing.assert_array_equal(F[0, 0].astype(np.float32), hb.fundamental_from_world2cam(cams[a].K, cams[a].R, cams[a].t, cams[b0].K, cams[b0].R, cams[b0].t))
     dens.close()
+
+
+def test_kernel_timing_reports_each_timed_launch_and_changes_nothing():
+    """lfd_kernel_timing: the next n dense launches carry a start and a stop event of their own (the kernel's device-side duration);
+    the durations come back in launch order, launches beyond n are not timed, results are those of untimed launches, and the
+    figure is not larger than what events recorded around the call see."""
+    dev = torch.device("cuda:0")
+    H = W = 256
+    cams = synthetic.ring_cameras(60, seed=0)
+    refs = _refs(dev, cams, [0, 7, 14, 21, 28, 35], 3, H, W)
+    params = hb.make_params(lfd.DensePipelineConfig(output_path=""))
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    batch = hb.PreparedBatch(refs, W, H, cameras=cams)
+    out = hb.OutputBuffers(len(refs) * H * W, len(refs), 3, dev)
+    dens.launch_dense(batch, params, out)
+    plain = out.collect()
+    want = (plain.count, plain.xyz.clone(), plain.rgb.clone(), plain.err.clone())
+    assert dens.dense_kernel_times_ms().size == 0                 # nothing was asked for
+    dens.time_dense_kernels(4)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(6)]
+    for a, b in ev:                                               # six launches back to back, four of them timed
+        a.record()
+        dens.launch_dense(batch, params, out)
+        b.record()
+    t = dens.dense_kernel_times_ms()
+    assert t.shape == (4,) and np.all(t > 0.0)
+    bracket = np.array([a.elapsed_time(b) for a, b in ev[:4]])
+    assert np.all(t <= bracket * 1.02 + 0.002), (t, bracket)     # the kernel alone never takes longer than the call's bracket
+    assert t.mean() > 0.3 * bracket.mean()
+    got = out.collect()
+    assert got.count == want[0] and torch.equal(got.xyz, want[1]) and torch.equal(got.rgb, want[2]) and torch.equal(got.err, want[3])
+    assert dens.dense_kernel_times_ms().size == 0                 # read once
+    dens.launch_dense(batch, params, out)                         # a new series starts at the first event pair
+    dens.launch_dense(batch, params, out)
+    assert dens.dense_kernel_times_ms().shape == (2,)
+    dens.time_dense_kernels(0)
+    dens.launch_dense(batch, params, out)
+    assert dens.dense_kernel_times_ms().size == 0
+    dens.check_launches()
+    dens.close()
