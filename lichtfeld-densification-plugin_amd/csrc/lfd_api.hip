@@ -169,7 +169,7 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
         if (ahead) {
             // the kernels of this slot's last user must be through (the event sits where the launch after it began), and so must
             // whatever a launch issued for the slot in the launch stream since (si == cur only before the first launch)
-            if (sl.used) LFD_HIP(ctx, hipStreamWaitEvent(st, sl.idle, 0));
+            if (sl.used) LFD_HIP(ctx, hipStreamWaitEvent(st, sl.idle_attached ? sl.idle_ext : sl.idle, 0));
         } else if (sl.ready_pending) {               // an unused staging of another batch is still on its way into this slot
             LFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.ready, 0));
             sl.ready_pending = false;
@@ -268,7 +268,7 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
         LfdBatchSlot& prev = ctx->slot[ctx->last_used];
         rc = slot_events(ctx, prev);
         if (rc != LFD_OK) return rc;
-        LFD_HIP(ctx, hipEventRecord(prev.idle, ctx->stream));
+        if (!prev.idle_attached) LFD_HIP(ctx, hipEventRecord(prev.idle, ctx->stream));     // (a dense launch carried its own marker)
         prev.used = true;
     }
     int si = 0;
@@ -319,7 +319,10 @@ int prepare_launch(lfd_context* ctx, const lfd_batch* b, const lfd_params* p, co
             sl.ready_pending = true;
         }
     }
-    if (!ahead) { ctx->cur = si; ctx->last_used = si; }
+    if (!ahead) {
+        ctx->cur = si; ctx->last_used = si;
+        sl.idle_attached = false;          // this launch becomes the slot's last user: its end is marked by the launch itself or by the next one
+    }
     return LFD_OK;
 }
 
@@ -451,6 +454,8 @@ int lfd_kernel_timing(lfd_context* ctx, int32_t n_launches) {
     if (n_launches < 0 || n_launches > (1 << 20)) return fail(ctx, LFD_ERR_INVALID, "lfd_kernel_timing: n_launches must be in [0, 2^20]");
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));           // no launch is still using the events that go
+    if (ctx->prep_stream) LFD_HIP(ctx, hipStreamSynchronize(ctx->prep_stream));
+    for (LfdBatchSlot& sl : ctx->slot) { sl.idle_attached = false; sl.idle_ext = nullptr; sl.used = false; }      // (nor is a slot waiting on one)
     while (ctx->kt_start.size() > (size_t)n_launches) {
         (void)hipEventDestroy(ctx->kt_start.back()); (void)hipEventDestroy(ctx->kt_stop.back());
         ctx->kt_start.pop_back(); ctx->kt_stop.pop_back();
@@ -491,7 +496,7 @@ int lfd_set_stream(lfd_context* ctx, void* hip_stream) {
     LFD_HIP(ctx, hipSetDevice(ctx->device));
     LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->prep_stream) LFD_HIP(ctx, hipStreamSynchronize(ctx->prep_stream));
-    for (LfdBatchSlot& sl : ctx->slot) { sl.ready_pending = false; sl.used = false; }      // everything issued so far has completed
+    for (LfdBatchSlot& sl : ctx->slot) { sl.ready_pending = false; sl.used = false; sl.idle_attached = false; }      // everything issued so far has completed
     ctx->last_used = -1;
     ctx->stream = static_cast<hipStream_t>(hip_stream);
     return LFD_OK;
@@ -614,17 +619,20 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
         rc = colour_tables(ctx, batch->W, batch->H, batch->w_match, batch->h_match, &L.colour_cols, &L.colour_rows);
         if (rc != LFD_OK) return rc;
     }
-    hipEvent_t t_start = nullptr, t_stop = nullptr;          // lfd_kernel_timing: this launch's own events
+    // The launch carries its own stop event (hipExtLaunchKernelGGL): it marks the end of this batch slot's last user - what the staging
+    // of a later batch into the slot waits for - without a marker packet of its own in the stream; with lfd_kernel_timing switched on
+    // the pair of events is the next of its ring and doubles as that marker.
+    LfdBatchSlot& used_slot = ctx->slot[ctx->cur];
+    rc = slot_events(ctx, used_slot);
+    if (rc != LFD_OK) return rc;
+    hipEvent_t t_start = nullptr, t_stop = used_slot.idle;
     if (ctx->kt_used < ctx->kt_start.size()) { t_start = ctx->kt_start[ctx->kt_used]; t_stop = ctx->kt_stop[ctx->kt_used]; ++ctx->kt_used; }
-    if (t_start) {
-        if (exact_colour)
-            hipExtLaunchKernelGGL(lfd_dense_exact_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), (unsigned)extra_lds, ctx->stream, t_start, t_stop, 0, L);
-        else
-            hipExtLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), (unsigned)extra_lds, ctx->stream, t_start, t_stop, 0, L);
-    } else if (exact_colour)
-        hipLaunchKernelGGL(lfd_dense_exact_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), extra_lds, ctx->stream, L);
+    if (exact_colour)
+        hipExtLaunchKernelGGL(lfd_dense_exact_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), (unsigned)extra_lds, ctx->stream, t_start, t_stop, 0, L);
     else
-        hipLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), extra_lds, ctx->stream, L);
+        hipExtLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), (unsigned)extra_lds, ctx->stream, t_start, t_stop, 0, L);
+    used_slot.idle_ext = t_stop;
+    used_slot.idle_attached = true;
     LFD_HIP(ctx, hipGetLastError());
 #if defined(LFD_DENSE_TIMING)
     if (stamp_path) {

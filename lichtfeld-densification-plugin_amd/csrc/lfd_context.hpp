@@ -32,7 +32,9 @@ struct LfdBatchSlot {
     bool pinned_in_flight = false;
     hipEvent_t ready = nullptr;            // behind upload + setup issued on the preparation stream
     bool ready_pending = false;            // ... which the launch stream has not been told to wait for yet
-    hipEvent_t idle = nullptr;             // on the launch stream, where the launch AFTER this slot's last user begins
+    hipEvent_t idle = nullptr;             // on the launch stream, where the launch AFTER this slot's last user begins ...
+    hipEvent_t idle_ext = nullptr;         // ... or, when that user was a dense launch, the stop event the kernel itself carried (no packet of
+    bool idle_attached = false;            //     its own in the stream): `idle`, or an event of lfd_kernel_timing's ring (not owned)
     bool used = false;
 };
 
