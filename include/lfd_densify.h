@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LFD_ABI_VERSION 4
+#define LFD_ABI_VERSION 5
 #define LFD_MAX_SLOTS 16 /* neighbours per reference handled by one launch */
 
 enum lfd_status {
@@ -142,6 +142,34 @@ int lfd_aggregate(lfd_context* ctx, const lfd_batch* batch, const lfd_params* pa
  * last = total); seg_counts: device i32 [n_refs*k] survivors per (reference, slot) or NULL. */
 int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params,
                           const lfd_points* out, int64_t* ref_offsets, int32_t* seg_counts);
+
+/* The same kernel with UNORDERED RETIREMENT (opt-in; the default entry point above stays ordered).  The ordered kernel makes a tile wait
+ * for the survivor counts of every tile before it (a decoupled look-back: a fifth of a tile's life on the benchmark shape); here a tile
+ * claims room with ONE atomic on its reference's cursor and records where it went:
+ *   - reference r owns the region [r*H*W, (r+1)*H*W) of out (out->capacity >= n_refs*H*W, else LFD_ERR_CAPACITY); its survivors fill
+ *     [r*H*W, r*H*W + ref_counts[r]) tile after tile in the order the tiles RETIRED, raster order inside a tile;
+ *   - table[r * lfd_dense_tiles_per_ref(H, W) + t] = {offset inside the reference's region, survivors} of the reference's t-th tile
+ *     (tile t covers grid cells [1024 t, 1024 t + 1024));
+ *   - ref_counts: device i64 [n_refs] survivors per reference (it is the cursor array: zeroed by the launch itself).
+ * Raster order is tile order, so the consumers below restore upstream's sequence from the table: lfd_order_segments writes the ordered
+ * structure-of-arrays result (bit-identical to lfd_triangulate_dense's), lfd_pack_ply_segments / lfd_pack_points3d_segments write the
+ * file payload in raster order straight from the unordered buffers.  The reference interface both forms replace is the per-group
+ * concatenation of core/pipeline.py:753-780,917-919. */
+typedef struct lfd_tile_segment { int32_t offset; int32_t count; } lfd_tile_segment;
+#define LFD_FLAG_TILE_SEGMENTS 2 /* informational: set in lfd_params.flags by callers that take the unordered route (the entry point decides) */
+int lfd_dense_tiles_per_ref(int32_t H, int32_t W); /* host helper: rows of the tile table per reference */
+int lfd_triangulate_dense_segments(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, const lfd_points* out,
+                                   int64_t* ref_counts, int32_t* seg_counts, lfd_tile_segment* table);
+/* src: the unordered buffers of lfd_triangulate_dense_segments (capacity ignored); dst: ordered result, at most dst->capacity records
+ * (cell / slot copied when both sides give them); ref_offsets: device i64 [n_refs + 1] or NULL.  Asynchronous on the context's stream. */
+int lfd_order_segments(lfd_context* ctx, int32_t n_refs, int32_t H, int32_t W, const lfd_tile_segment* table, const lfd_points* src,
+                       const lfd_points* dst, int64_t* ref_offsets);
+/* lfd_pack_ply / lfd_pack_points3d through the table: out receives min(total, capacity) records in raster order (ids count from
+ * id_base + 1 in that order); ref_offsets as above (the caller reads the total there). */
+int lfd_pack_ply_segments(lfd_context* ctx, int32_t n_refs, int32_t H, int32_t W, const lfd_tile_segment* table, const float* xyz,
+                          const float* rgb, int64_t capacity, uint8_t* out, int64_t* ref_offsets);
+int lfd_pack_points3d_segments(lfd_context* ctx, int32_t n_refs, int32_t H, int32_t W, const lfd_tile_segment* table, const float* xyz,
+                               const float* rgb, const float* err, int64_t capacity, uint64_t id_base, uint8_t* out, int64_t* ref_offsets);
 
 /* Upstream-equivalent mode: only the selected cells (sel_idx: device i64, concatenated per
  * reference; sel_offsets: host i64 [n_refs+1]) are triangulated, and survivors are emitted in

@@ -12,6 +12,11 @@ rgb f32x3, err f32), in one of two forms:
     point to point (grouped send / receive), straight to their reference-ordered place in rank 0's pre-sized buffer - no
     padding to the largest rank, no concatenation, no second index gather, and 1/world of the all-gather's traffic.
 
+``OverlappedExchange`` is the same exchange in ROUNDS that run beside the compute: every ``refs_per_round`` local references the
+finished references' records are handed to an asynchronous collective (all-gather, or gather to the writer rank) while the next batch
+computes; the result is the same ordered sequence.  When the consumer is the PLY writer the 15-byte device-packed records travel
+instead of the 28-byte rows.
+
 ``ShardedPlyStream`` is the streamed writer of a sharded run (BASELINE config 5): every rank packs the PLY records of its
 finished references on the device and rank 0 appends them to the output file in global reference order as they arrive.
 
@@ -49,10 +54,14 @@ def _collective_device(t: torch.Tensor, dist, group=None) -> torch.device:
 
 
 def _backend_name(dist, group=None) -> str:
-    try:
-        return str(dist.get_backend(group)).lower()
-    except Exception:
-        return "nccl"
+    """Backend of the (initialised) process group.  An error of ``get_backend`` - a group that was never initialised, a rank that is not
+    a member - propagates: answering "nccl" for it would send host tensors down the device branch instead of failing."""
+    return str(dist.get_backend(group)).lower()
+
+
+def _global_rank(dist, group, r: int) -> int:
+    """Point-to-point calls take GLOBAL ranks as peers even when ``group=`` is given; ``r`` is a rank inside ``group``."""
+    return int(r) if group is None else int(dist.get_global_rank(group, int(r)))
 
 
 def _all_gather_rows(mine: torch.Tensor, world: int, dist, group=None) -> torch.Tensor:
@@ -176,11 +185,11 @@ def gather_to_root_by_reference(xyz: torch.Tensor, rgb: torch.Tensor, err: torch
             if r == root:
                 dst.copy_(local[int(within[r, i]):int(within[r, i]) + n])
             else:
-                ops.append(dist.P2POp(dist.irecv, dst, r, group))
+                ops.append(dist.P2POp(dist.irecv, dst, _global_rank(dist, group, r), group))
     else:
         for i, n in enumerate(int(c) for c in ref_counts):
             if n:
-                ops.append(dist.P2POp(dist.isend, local[int(within[rank, i]):int(within[rank, i]) + n], root, group))
+                ops.append(dist.P2POp(dist.isend, local[int(within[rank, i]):int(within[rank, i]) + n], _global_rank(dist, group, root), group))
     if ops:
         for work in dist.batch_isend_irecv(ops):
             work.wait()
@@ -195,9 +204,17 @@ class ShardedPlyStream:
     (lfd_pack_ply) of each of its references that produced points, in local order, and ``finish()`` at the end.  Rank 0 owns the
     ``StreamedPlyWriter``: whenever it pushes one of its own references it first receives - point to point, a count then the
     records - every reference of the other ranks that precedes it in the global order, so the file grows in the 1-GPU sequence
-    while the run proceeds.  The other ranks never wait: their sends are asynchronous and kept alive until ``finish``.
+    while the run proceeds.  The other ranks do not wait on the HOST: their sends are asynchronous and kept alive until ``finish``.
+    On the DEVICE they are coupled to rank 0 under RCCL: a point-to-point send is a rendezvous kernel on the communicator's stream that
+    spins until rank 0 posts the matching receive - which it does when it reaches its own reference at that global position - so one
+    header and one payload send per reference queue up there, and anything that synchronises the whole device on a non-root rank
+    (a ``hipFree`` behind a reallocation, ``torch.cuda.empty_cache``) waits until rank 0 has caught up.  (Under gloo the sends are
+    buffered by the transport.)
     A reference without points (skipped, failed, nothing survived) travels as a count of 0, which keeps the ranks in step; a rank
-    that stops early still calls ``finish`` (the pipeline does so in its error path), which sends 0 for what is left."""
+    that stops early still calls ``finish`` (the pipeline does so in its error path), which sends 0 for what is left.
+    A writer that fails on rank 0 (disk full, I/O error) does not stop the protocol: the first error is kept, the writer is dropped,
+    the remaining payloads are received and discarded, and ``finish`` raises the kept error once everything has been drained - the other
+    ranks' sends complete and the run's status agreement reports the failure."""
 
     def __init__(self, dist, n_refs_global: int, writer, device, group=None, root: int = 0):
         self.dist, self.group, self.root = dist, group, int(root)
@@ -210,27 +227,39 @@ class ShardedPlyStream:
         self._pending = []             # non-root: (work, tensor) of sends in flight
         self._n_local = len(shard_references(self.n_refs, self.rank, self.world))
         self.finished = False
+        self.writer_error: Optional[BaseException] = None      # root: first failure of the writer (re-raised by finish() after the drain)
+        self._root_global = _global_rank(dist, group, self.root)
 
     # -- non-root ---------------------------------------------------------------------------------------------------------
     def _send(self, body: Optional[torch.Tensor]) -> None:
         n = 0 if body is None else int(body.numel())
         head = torch.tensor([n], dtype=torch.int64, device=self.dev)
-        self._pending.append((self.dist.isend(head, self.root, group=self.group), head))
+        self._pending.append((self.dist.isend(head, self._root_global, group=self.group), head))
         if n:
             payload = body.to(self.dev).contiguous()
-            self._pending.append((self.dist.isend(payload, self.root, group=self.group), payload))
+            self._pending.append((self.dist.isend(payload, self._root_global, group=self.group), payload))
         self._pending = [(w, t) for w, t in self._pending if not w.is_completed()]
 
     # -- root ---------------------------------------------------------------------------------------------------------------
+    def _write(self, data: bytes) -> None:
+        """Append to the file; the FIRST failure is kept and the writer dropped - receiving goes on, so that the protocol completes."""
+        if self.writer is None:                   # (no writer: the file could not be opened, or an earlier append failed - the records are dropped)
+            return
+        try:
+            self.writer.append_packed(data)
+        except BaseException as exc:              # noqa: BLE001 - re-raised by finish()
+            self.writer_error = exc
+            self.writer = None
+
     def _recv_into_file(self, src: int) -> None:
+        peer = _global_rank(self.dist, self.group, src)
         head = torch.zeros(1, dtype=torch.int64, device=self.dev)
-        self.dist.recv(head, src, group=self.group)
+        self.dist.recv(head, peer, group=self.group)
         n = int(head.item())
         if n > 0:
             payload = torch.empty(n, dtype=torch.uint8, device=self.dev)
-            self.dist.recv(payload, src, group=self.group)
-            if self.writer is not None:           # (no writer: the file could not be opened - the records are received and dropped)
-                self.writer.append_packed(payload.cpu().numpy().tobytes())
+            self.dist.recv(payload, peer, group=self.group)
+            self._write(payload.cpu().numpy().tobytes())
 
     def _advance_to(self, global_pos: int) -> None:
         """Write every reference of the other ranks that precedes ``global_pos`` (own references before it had no points)."""
@@ -247,8 +276,7 @@ class ShardedPlyStream:
         if self.rank == self.root:
             g = self.root + int(local_index) * self.world
             self._advance_to(g)
-            if self.writer is not None:
-                self.writer.append_packed(body if isinstance(body, (bytes, bytearray)) else body.cpu().numpy().tobytes())
+            self._write(body if isinstance(body, (bytes, bytearray)) else body.cpu().numpy().tobytes())
             self._next_global = g + 1
             return
         if isinstance(body, (bytes, bytearray)):
@@ -265,7 +293,9 @@ class ShardedPlyStream:
             return
         self.finished = True
         if self.rank == self.root:
-            self._advance_to(self.n_refs)
+            self._advance_to(self.n_refs)         # drains every peer even when the writer has failed
+            if self.writer_error is not None:
+                raise self.writer_error
             return
         while self._next_local < self._n_local:
             self._send(None)
@@ -273,3 +303,173 @@ class ShardedPlyStream:
         for w, _t in self._pending:
             w.wait()
         self._pending = []
+
+
+RECORD_F32 = "f32"     # 28-byte rows: xyz f32 x 3, rgb f32 x 3, err f32 (what PipelineResult holds)
+RECORD_PLY = "ply"     # 15-byte PLY vertex records packed on the device (lfd_pack_ply): xyz f32 LE x 3, rgb u8 x 3 - for runs whose consumer is the writer
+
+
+class OverlappedExchange:
+    """The exchange of a sharded run in ROUNDS that overlap the compute (no upstream counterpart: upstream has no multi-GPU code).
+
+    Local references are taken in rounds of ``refs_per_round`` (round c = local references [c*B, (c+1)*B), global positions
+    ``rank + i*world``).  ``push(local_index, records)`` hands over one finished reference; when a push (or ``finish``) moves past the end of
+    a round, the round is CLOSED: its per-reference counts go into a small asynchronous all-gather, and the round BEFORE it - whose counts
+    have long arrived - sends its records, padded to that round's largest rank, as one asynchronous collective (``all_gather``: every rank
+    receives every rank's records; ``gather_to_root``: only rank ``root`` does).  Nothing on the host waits for a collective until ``finish``,
+    and the collectives run on the communicator's own stream beside the kernels of the next batch (under gloo - CPU tests, ranks sharing a
+    GPU - the records cross to host tensors first).  Every rank runs the same number of rounds (ranks that own fewer references close empty
+    ones in ``finish``), so the collectives stay matched whatever a rank skipped.
+
+    ``record``: RECORD_F32 - ``records`` is an (n, 7) float32 tensor; RECORD_PLY - an (n * 15,) uint8 tensor of device-packed PLY records.
+    ``finish()`` returns ``(records, counts)``: the records of ALL references in global reference order - the 1-rank sequence - as one tensor
+    of the same kind ((N, 7) float32 / (N * 15,) uint8; on every rank for ``all_gather``, on ``root`` for ``gather_to_root``, where the other
+    ranks get their own shard back) and the (n_refs_global,) survivor counts."""
+
+    def __init__(self, dist, n_refs_global: int, refs_per_round: int, device, form: str = "all_gather", record: str = RECORD_F32,
+                 group=None, root: int = 0):
+        if form not in ("all_gather", "gather_to_root"):
+            raise ValueError("form must be 'all_gather' or 'gather_to_root'")
+        if record not in (RECORD_F32, RECORD_PLY):
+            raise ValueError("record must be 'f32' or 'ply'")
+        self.dist, self.group, self.root = dist, group, int(root)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.n_refs = int(n_refs_global)
+        self.B = max(1, int(refs_per_round))
+        self.form, self.record = form, record
+        self.cols, self.dtype = (7, torch.float32) if record == RECORD_F32 else (15, torch.uint8)
+        self.home = torch.device(device)
+        self.dev = torch.device("cpu") if "gloo" in _backend_name(dist, group) else self.home
+        self.n_local = len(shard_references(self.n_refs, self.rank, self.world))
+        n_local_max = (self.n_refs + self.world - 1) // self.world
+        self.n_rounds = (n_local_max + self.B - 1) // self.B
+        self._open: dict = {}              # local index -> records of the round being filled
+        self._cur = 0                      # round being filled
+        self._rounds: list = []            # closed rounds: dict(counts_out, counts_work, payload, n_local, work, gathered, table)
+        self._last_local = -1
+        self.finished = False
+        self.bytes_sent = 0                # this rank's padded payload bytes handed to collectives (bench)
+
+    # ---------------------------------------------------------------------------------------------------------------------------------
+    def push(self, local_index: int, records: Optional[torch.Tensor]) -> None:
+        """Records of this rank's ``local_index``-th reference (None / empty: no survivors); local indices must increase."""
+        if self.finished:
+            raise RuntimeError("push after finish")
+        li = int(local_index)
+        if li <= self._last_local or li >= self.n_local:
+            raise ValueError(f"local reference {li} out of order or out of range (last {self._last_local}, owned {self.n_local})")
+        self._last_local = li
+        while self._cur < li // self.B:
+            self._close_round()
+        if records is not None and records.numel():
+            rec = records.reshape(-1, self.cols)
+            if rec.dtype != self.dtype:
+                raise ValueError(f"records must be {self.dtype} with {self.cols} columns per point")
+            self._open[li] = rec
+
+    def _close_round(self) -> None:
+        c = self._cur
+        counts = torch.zeros(self.B, dtype=torch.int64)
+        parts = []
+        for j in range(self.B):
+            rec = self._open.pop(c * self.B + j, None)
+            if rec is not None:
+                counts[j] = rec.shape[0]
+                parts.append(rec)
+        payload = (torch.cat(parts, 0) if len(parts) > 1 else parts[0]) if parts else torch.empty((0, self.cols), dtype=self.dtype, device=self.home)
+        cnt_in = counts.to(self.dev)
+        cnt_out = torch.empty(self.world * self.B, dtype=torch.int64, device=self.dev)
+        work = self.dist.all_gather_into_tensor(cnt_out, cnt_in, group=self.group, async_op=True)
+        self._rounds.append(dict(counts_in=cnt_in, counts_out=cnt_out, counts_work=work, payload=payload, n_local=int(counts.sum()),
+                                 local_counts=counts, work=None, gathered=None, table=None, padded=None))
+        self._cur += 1
+        if c >= 1:
+            self._send_round(c - 1)           # its counts were gathered a whole round ago
+
+    def _send_round(self, c: int) -> None:
+        st = self._rounds[c]
+        st["counts_work"].wait()
+        # the gathered counts as a host table: a few dozen integers (under RCCL their copy is ordered behind the collective by wait())
+        table = st["counts_out"].cpu().view(self.world, self.B).numpy().copy()
+        st["table"] = table
+        rows = int(table.sum(axis=1).max())
+        if rows == 0:
+            return
+        padded = torch.zeros((rows, self.cols), dtype=self.dtype, device=self.dev)
+        if st["n_local"]:
+            padded[:st["n_local"]] = st["payload"].to(self.dev)
+        st["padded"] = padded
+        self.bytes_sent += padded.numel() * padded.element_size()
+        if self.form == "all_gather":
+            out = torch.empty((self.world, rows, self.cols), dtype=self.dtype, device=self.dev)
+            st["gathered"] = out
+            st["work"] = self.dist.all_gather_into_tensor(out.view(-1), padded.view(-1), group=self.group, async_op=True)
+        else:
+            if self.rank == self.root:
+                out = torch.empty((self.world, rows, self.cols), dtype=self.dtype, device=self.dev)
+                st["gathered"] = out
+                st["work"] = self.dist.gather(padded, [out[r] for r in range(self.world)], dst=_global_rank(self.dist, self.group, self.root),
+                                              group=self.group, async_op=True)
+            else:
+                st["work"] = self.dist.gather(padded, None, dst=_global_rank(self.dist, self.group, self.root), group=self.group, async_op=True)
+
+    def finish(self):
+        """Close what is left (every rank runs ``n_rounds`` rounds), wait for the collectives, return the ordered records and counts."""
+        if self.finished:
+            raise RuntimeError("finish called twice")
+        self.finished = True
+        while self._cur < self.n_rounds:
+            self._close_round()
+        if self.n_rounds:
+            self._send_round(self.n_rounds - 1)
+        for st in self._rounds:
+            if st["work"] is not None:
+                st["work"].wait()
+        global_counts = np.zeros(self.n_refs, np.int64)
+        for c, st in enumerate(self._rounds):
+            for r in range(self.world):
+                for j in range(self.B):
+                    g = r + (c * self.B + j) * self.world
+                    if g < self.n_refs:
+                        global_counts[g] = st["table"][r, j]
+        have_all = self.form == "all_gather" or self.rank == self.root
+        if not have_all:            # gather_to_root, another rank: its own shard, untouched
+            own = [st["payload"] for st in self._rounds if st["n_local"]]
+            mine = torch.cat(own, 0) if own else torch.empty((0, self.cols), dtype=self.dtype, device=self.home)
+            return self._shape(mine.to(self.home)), global_counts
+        offsets = np.concatenate([[0], np.cumsum(global_counts)])
+        out = torch.empty((int(offsets[-1]), self.cols), dtype=self.dtype, device=self.dev)
+        for c, st in enumerate(self._rounds):
+            if st["gathered"] is None:
+                continue
+            within = np.concatenate([np.zeros((self.world, 1), np.int64), np.cumsum(st["table"], axis=1)], axis=1)
+            for r in range(self.world):
+                for j in range(self.B):
+                    g = r + (c * self.B + j) * self.world
+                    n = int(st["table"][r, j])
+                    if g < self.n_refs and n:
+                        out[int(offsets[g]):int(offsets[g]) + n] = st["gathered"][r, int(within[r, j]):int(within[r, j]) + n]
+        return self._shape(out.to(self.home)), global_counts
+
+    def _shape(self, t: torch.Tensor) -> torch.Tensor:
+        return t if self.record == RECORD_F32 else t.reshape(-1)
+
+
+def rows_from_points(xyz: torch.Tensor, rgb: torch.Tensor, err: torch.Tensor) -> torch.Tensor:
+    """(n, 7) float32 rows [x y z r g b err] of one reference, as RECORD_F32 travels."""
+    n = int(xyz.shape[0])
+    rows = torch.empty((n, 7), dtype=torch.float32, device=xyz.device)
+    if n:
+        rows[:, 0:3] = xyz
+        rows[:, 3:6] = rgb
+        rows[:, 6] = err
+    return rows
+
+
+def points_from_ply_records(records: torch.Tensor):
+    """(xyz f32 (n,3), rgb f32 (n,3) = u8 / 255) out of 15-byte PLY records: positions exactly as computed, colours as the writer
+    quantised them (re-quantising them gives the same bytes: |k/255 * 255 - k| < 1e-4)."""
+    rec = records.reshape(-1, 15)
+    xyz = rec[:, :12].contiguous().view(torch.float32).reshape(-1, 3)
+    rgb = rec[:, 12:15].to(torch.float32) / 255.0
+    return xyz, rgb

@@ -18,8 +18,9 @@ import torch
 from .types import CameraRecord, DensePipelineConfig
 
 LFD_MAX_SLOTS = 16
-LFD_ABI_VERSION = 4
+LFD_ABI_VERSION = 5
 LFD_FLAG_EXACT_COLOUR = 1     # lfd_params.flags: dense mode blends colours with upstream's f64 arithmetic (bit-identical rgb)
+LFD_FLAG_TILE_SEGMENTS = 2    # informational: the caller takes the unordered-retirement route (lfd_triangulate_dense_segments)
 _LIB_NAME = "liblfd_densify.so"
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -91,6 +92,13 @@ def load_library() -> C.CDLL:
     lib.lfd_aggregate.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p, C.c_void_p]
     lib.lfd_triangulate_dense.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.POINTER(lfd_points),
                                           C.c_void_p, C.c_void_p]
+    lib.lfd_dense_tiles_per_ref.argtypes = [C.c_int32, C.c_int32]
+    lib.lfd_triangulate_dense_segments.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.POINTER(lfd_points),
+                                                   C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.lfd_order_segments.argtypes = [ctxp, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(lfd_points), C.POINTER(lfd_points), C.c_void_p]
+    lib.lfd_pack_ply_segments.argtypes = [ctxp, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.lfd_pack_points3d_segments.argtypes = [ctxp, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                               C.c_uint64, C.c_void_p, C.c_void_p]
     lib.lfd_triangulate_indexed.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p,
                                             C.POINTER(C.c_int64), C.POINTER(lfd_points), C.c_void_p, C.c_void_p,
                                             C.c_void_p]
@@ -133,6 +141,7 @@ def load_library() -> C.CDLL:
     lib.lfd_host_eval_correspondence.argtypes = [fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                                  C.c_int32, C.POINTER(lfd_params), fptr]
     for name in ("lfd_create", "lfd_set_stream", "lfd_reload_env", "lfd_kernel_timing", "lfd_kernel_timing_read", "lfd_upload_cameras", "lfd_prepare_batch", "lfd_aggregate", "lfd_triangulate_dense",
+                 "lfd_dense_tiles_per_ref", "lfd_triangulate_dense_segments", "lfd_order_segments", "lfd_pack_ply_segments", "lfd_pack_points3d_segments",
                  "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_triangulate_sampled_multi", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
                  "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_identity_axis",
                  "lfd_host_fundamental", "lfd_get_pair_fundamental", "lfd_create_host", "lfd_aggregate_host",
@@ -293,6 +302,20 @@ class TriangulationOutput:
     @property
     def count(self) -> int:
         return int(self.ref_offsets[-1])
+
+
+@dataclasses.dataclass
+class SegmentedOutput:
+    """What lfd_triangulate_dense_segments leaves on the device: reference r's survivors in rows [r*H*W, r*H*W + ref_counts[r]) of the
+    buffers, tile after tile in the order the tiles retired; ``table[r * tiles_per_ref + t] = (offset, count)`` of every tile.  The ordered
+    result / the file payload come out of ``HipDensifier.order_segments`` / ``pack_ply_segments`` / ``pack_points3d_segments``."""
+    buffers: "OutputBuffers"
+    table: torch.Tensor          # (n_refs * tiles_per_ref, 2) i32
+    ref_counts: torch.Tensor     # (n_refs,) i64, device
+    n_refs: int
+    H: int
+    W: int
+    k: int
 
 
 class PreparedBatch:
@@ -707,6 +730,54 @@ class HipDensifier:
                                                     out.ref_offsets.data_ptr(),
                                                     out.seg_counts.data_ptr() if out.with_segments else None),
                     "lfd_triangulate_dense")
+
+    # -- unordered retirement (opt-in): tiles claim room with one atomic, the consumers restore raster order from the tile table ------------
+    def launch_dense_segments(self, batch: PreparedBatch, params: lfd_params, out: OutputBuffers, table: torch.Tensor,
+                              ref_counts: torch.Tensor) -> None:
+        self._same_device(batch, out, table, ref_counts)
+        if table.dtype != torch.int32 or ref_counts.dtype != torch.int64 or not table.is_contiguous():
+            raise ValueError("table must be a contiguous int32 (n_tiles, 2) tensor, ref_counts int64 (n_refs,)")
+        self._check(self._lib.lfd_triangulate_dense_segments(self._ctx, C.byref(batch.c), C.byref(params), C.byref(out.c), ref_counts.data_ptr(),
+                                                             out.seg_counts.data_ptr() if out.with_segments else None, table.data_ptr()),
+                    "lfd_triangulate_dense_segments")
+
+    def triangulate_dense_segments(self, batch: PreparedBatch, params: lfd_params, with_cell: bool = True) -> SegmentedOutput:
+        out = OutputBuffers(batch.n_refs * batch.H * batch.W, batch.n_refs, batch.k, self.device, with_cell)
+        tpr = int(self._lib.lfd_dense_tiles_per_ref(batch.H, batch.W))
+        table = torch.zeros((batch.n_refs * tpr, 2), dtype=torch.int32, device=self.device)
+        counts = torch.zeros((batch.n_refs,), dtype=torch.int64, device=self.device)
+        self.launch_dense_segments(batch, params, out, table, counts)
+        self.check_launches()
+        return SegmentedOutput(out, table, counts, batch.n_refs, batch.H, batch.W, batch.k)
+
+    def order_segments(self, seg: SegmentedOutput, into: Optional[OutputBuffers] = None) -> TriangulationOutput:
+        """The ordered structure-of-arrays result of a segmented launch: what lfd_triangulate_dense would have returned, bit for bit."""
+        src = seg.buffers
+        dst = into if into is not None else OutputBuffers(src.capacity, seg.n_refs, seg.k, self.device, with_cell=src.cell is not None)
+        self._check(self._lib.lfd_order_segments(self._ctx, seg.n_refs, seg.H, seg.W, seg.table.data_ptr(), C.byref(src.c), C.byref(dst.c),
+                                                 dst.ref_offsets.data_ptr()), "lfd_order_segments")
+        dst.seg_counts.copy_(src.seg_counts)
+        return dst.collect()
+
+    def pack_ply_segments(self, seg: SegmentedOutput):
+        """(PLY body in raster order as a u8 device tensor, ref_offsets (n_refs + 1,) host i64) straight from the unordered buffers."""
+        cap = seg.buffers.capacity
+        out = torch.empty((max(cap * 15, 4),), dtype=torch.uint8, device=self.device)
+        offs = torch.zeros((seg.n_refs + 1,), dtype=torch.int64, device=self.device)
+        self._check(self._lib.lfd_pack_ply_segments(self._ctx, seg.n_refs, seg.H, seg.W, seg.table.data_ptr(), seg.buffers.xyz.data_ptr(),
+                                                    seg.buffers.rgb.data_ptr(), cap, out.data_ptr(), offs.data_ptr()), "lfd_pack_ply_segments")
+        h = offs.cpu().numpy()
+        return out[:int(h[-1]) * 15], h
+
+    def pack_points3d_segments(self, seg: SegmentedOutput, id_base: int = 0):
+        cap = seg.buffers.capacity
+        out = torch.empty((max(cap * 43, 4),), dtype=torch.uint8, device=self.device)
+        offs = torch.zeros((seg.n_refs + 1,), dtype=torch.int64, device=self.device)
+        self._check(self._lib.lfd_pack_points3d_segments(self._ctx, seg.n_refs, seg.H, seg.W, seg.table.data_ptr(), seg.buffers.xyz.data_ptr(),
+                                                         seg.buffers.rgb.data_ptr(), seg.buffers.err.data_ptr(), cap, int(id_base), out.data_ptr(),
+                                                         offs.data_ptr()), "lfd_pack_points3d_segments")
+        h = offs.cpu().numpy()
+        return out[:int(h[-1]) * 43], h
 
     def launch_indexed(self, batch: PreparedBatch, params: lfd_params, sel_idx: torch.Tensor,
                        sel_offsets: Sequence[int], out: OutputBuffers) -> None:

@@ -207,9 +207,11 @@ class RomaMatcher:
                     # several pairs in ONE forward: the neighbours stacked along the batch axis, the reference's features and images
                     # broadcast to them (RoMaV2.match_from_features' own steps - _load_image, _resize_match_image, _match_core -
                     # on a batch, romav2.py:404-428)
+                    # (every neighbour is resized on its own first - they may come in different sizes - then stacked)
                     n = len(chunk)
-                    img_b = torch.cat([model._load_image(_model_image(b)) for b in chunk], dim=0)
-                    b_lr, b_hr = model._resize_match_image(img_b)
+                    sized = [model._resize_match_image(model._load_image(_model_image(b))) for b in chunk]
+                    b_lr = torch.cat([s_[0] for s_ in sized], dim=0)
+                    b_hr = torch.cat([s_[1] for s_ in sized], dim=0) if sized[0][1] is not None else None
                     if keyed is not None:
                         keyed.key = chunk_keys
                     fa = [t.expand(n, *t.shape[1:]) if t.shape[0] == 1 else t for t in feats_a]

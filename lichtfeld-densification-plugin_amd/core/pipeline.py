@@ -481,6 +481,9 @@ class _HotPath:
 
     def dense(self, refs: List[hb.ReferenceInputs], axes) -> hb.TriangulationOutput:
         batch = hb.PreparedBatch(refs, self.w_match, self.h_match, axes=axes, cameras=self.cams)
+        if bool(getattr(self.config, "dense_tile_segments", False)) and not self.on_host:
+            # unordered retirement (no look-back), raster order restored from the tile table: the same result, bit for bit
+            return self.dens.order_segments(self.dens.triangulate_dense_segments(batch, self.params))
         return self.dens.triangulate_dense(batch, self.params)
 
     def debug_matches(self, ref: hb.ReferenceInputs, out_cell: torch.Tensor, out_slot: torch.Tensor, axes,
@@ -584,6 +587,26 @@ def run_dense_pipeline(
 
     rank_status = 0          # 0 fine, 1 cancelled, 2 failed: agreed on by all ranks before the exchange step (core/distributed.py)
     rank_error: Optional[BaseException] = None
+    # What a sharded run exchanges while it proceeds is decided from the configuration and the world ALONE and set up here, before
+    # anything can fail: every rank then reaches the matching finish() in `finally` whatever went wrong on it (a matcher that cannot be
+    # built, no memory for the context, a cancellation) - it sends empty references / closes empty rounds - and nobody is left blocked
+    # in a receive or a collective ahead of the status agreement.
+    stream_wanted = (bool(getattr(config, "stream_output", False)) and str(config.output_path).lower().endswith(".ply")
+                     and int(config.max_points) <= 0 and float(config.voxel_size) <= 0.0)
+    xchg: Optional[lfd_dist.OverlappedExchange] = None
+    xchg_result = None
+    if world > 1:
+        if stream_wanted:
+            # sharded streamed output (BASELINE config 5): every rank packs its finished references' records on the device, rank 0 appends
+            # them to the file in global reference order as they arrive.  Rank 0 opens the file inside the try: if that fails it still
+            # receives (and drops) what the others send.
+            shard_stream = lfd_dist.ShardedPlyStream(dist, len(refs_local), None, dev)
+        if bool(getattr(config, "exchange_overlap", True)):
+            rec = str(getattr(config, "exchange_records", "f32"))
+            if rec == "auto":
+                rec = "ply" if (str(config.output_path).lower().endswith(".ply") and float(config.voxel_size) <= 0.0) else "f32"
+            per_round = int(getattr(config, "exchange_round", 0)) or max(int(config.refs_per_launch), 4)
+            xchg = lfd_dist.OverlappedExchange(dist, len(refs_local), per_round, dev, form=str(getattr(config, "exchange", "all_gather")), record=rec)
     try:
         cached = has_cached_romav2_weights() if own_matcher else True
         msg = "Initializing RoMa v2 model..." if cached else "Installing model weights..."
@@ -620,13 +643,7 @@ def run_dense_pipeline(
         inflight: List[Tuple[int, _PackedReference, object]] = []                       # sampled mode: launched, not yet read back
         if on_sequential_viz and viz_interval > 0 and intermediate_base:
             cum_body = CumulativePlyBody()
-        if (bool(getattr(config, "stream_output", False)) and str(config.output_path).lower().endswith(".ply")
-                and int(config.max_points) <= 0 and float(config.voxel_size) <= 0.0):
-            if world > 1:
-                # sharded run (BASELINE config 5): every rank packs its finished references' records on the device, rank 0 appends
-                # them to the file in global reference order as they arrive (core/distributed.py).  Created on every rank BEFORE rank
-                # 0 opens the file: if that fails, rank 0 still receives (and drops) what the others send, nobody is left blocked
-                shard_stream = lfd_dist.ShardedPlyStream(dist, len(refs_local), None, dev)
+        if stream_wanted:
             if rank == 0:
                 stream_writer = StreamedPlyWriter(config.output_path)
                 if shard_stream is not None:
@@ -640,10 +657,22 @@ def run_dense_pipeline(
             err_parts.append(err)
             counts_local[local_i] = int(xyz.shape[0]) if xyz is not None else int(dev_pts[0].shape[0])
             refs_with_points += 1
+            packed_t = None
+            if shard_stream is not None or (xchg is not None and xchg.record == lfd_dist.RECORD_PLY):
+                packed_t = (hot.pack_ply_tensor(dev_pts[0], dev_pts[1]) if dev_pts is not None
+                            else torch.from_numpy(ply_records(xyz, to_uint8_rgb(rgb)).view(np.uint8).reshape(-1).copy()))
             if shard_stream is not None:
                 # sharded streamed output: the records stay where they were packed until they travel to rank 0
-                shard_stream.push(local_i, hot.pack_ply_tensor(dev_pts[0], dev_pts[1]) if dev_pts is not None
-                                  else torch.from_numpy(ply_records(xyz, to_uint8_rgb(rgb)).view(np.uint8).reshape(-1).copy()))
+                shard_stream.push(local_i, packed_t)
+            if xchg is not None:
+                # the overlapped exchange: this reference's records join the round being filled; a round that is complete leaves in an
+                # asynchronous collective while the next batch computes
+                if xchg.record == lfd_dist.RECORD_PLY:
+                    xchg.push(local_i, packed_t)
+                elif dev_pts is not None:
+                    xchg.push(local_i, lfd_dist.rows_from_points(dev_pts[0], dev_pts[1], dev_pts[2]))
+                else:
+                    xchg.push(local_i, lfd_dist.rows_from_points(torch.from_numpy(xyz), torch.from_numpy(rgb), torch.from_numpy(err)).to(dev))
             if cum_body is not None or (stream_writer is not None and shard_stream is None):
                 # this reference's PLY records, packed once (on the device when the points are there): the previews and the
                 # streamed output are made of these bytes, nothing is re-concatenated or re-quantised later
@@ -850,8 +879,17 @@ def run_dense_pipeline(
         if shard_stream is not None:
             try:
                 shard_stream.finish()         # rank 0 receives what is left (a rank that stopped early sends empty references)
+            except Exception as exc:          # (incl. a writer failure kept until the peers were drained: the run has failed on this rank)
+                log.error(f"The sharded output stream failed: {exc}")
+                if rank_status == 0:
+                    rank_status, rank_error = 2, exc
+        if xchg is not None:
+            try:
+                xchg_result = xchg.finish()   # closes the rounds that are left (empty ones on a rank that stopped early) and waits for the collectives
             except Exception as exc:
-                log.warn(f"Finishing the sharded output stream failed: {exc}")
+                log.error(f"The overlapped exchange failed: {exc}")
+                if rank_status == 0:
+                    rank_status, rank_error = 2, exc
         if stream_writer is not None:
             try:
                 stream_writer.close()         # patches the vertex count into the header
@@ -890,7 +928,21 @@ def run_dense_pipeline(
     else:
         xyz, rgb, err = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0,), np.float32)
     n_points_global = int(xyz.shape[0])
-    if world > 1:       # the one exchange step: the survivors travel over RCCL from where they already are (HBM), ordered by reference
+    if world > 1 and xchg_result is not None:
+        # the rounds travelled beside the compute; what is left is to name the parts of the ordered records
+        recs, counts = xchg_result
+        if xchg.record == lfd_dist.RECORD_PLY:
+            gx, gc_ = lfd_dist.points_from_ply_records(recs)
+            ge = torch.zeros((int(gx.shape[0]),), dtype=torch.float32, device=gx.device)
+        else:
+            gx, gc_, ge = recs[:, 0:3].contiguous(), recs[:, 3:6].contiguous(), recs[:, 6].contiguous()
+        xyz, rgb, err = gx.cpu().numpy(), gc_.cpu().numpy(), ge.cpu().numpy()
+        device_points = (gx, gc_, ge)
+        n_points_global = int(counts.sum())
+        t = torch.tensor([refs_with_points, pair_counter], dtype=torch.int64, device=lfd_dist._collective_device(gx, dist))
+        dist.all_reduce(t)
+        refs_with_points, pair_counter = int(t[0].item()), int(t[1].item())
+    elif world > 1:       # the one exchange step: the survivors travel over RCCL from where they already are (HBM), ordered by reference
         if dev_parts:
             lx, lc, le = (torch.cat([p[i] for p in dev_parts], 0) for i in range(3))
         else:

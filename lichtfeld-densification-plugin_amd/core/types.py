@@ -86,6 +86,19 @@ class DensePipelineConfig:
     # every rank (what BASELINE's north star names), "gather_to_root" sends every rank's records straight to their place in rank
     # 0's buffer (the other ranks return their own shard only)
     exchange: str = "all_gather"
+    # sharded runs: the exchange happens in ROUNDS beside the compute (core/distributed.py::OverlappedExchange) - every
+    # ``exchange_round`` local references (0: ``refs_per_launch``, at least 4) the finished references' records go into an asynchronous
+    # collective while the next batch computes - instead of ONE exchange after the last reference.  The result is the same sequence.
+    exchange_overlap: bool = True
+    exchange_round: int = 0
+    # what travels: "f32" the 28-byte rows the result holds (xyz, rgb, err as f32); "ply" the 15-byte PLY vertex records packed on the
+    # device (positions exact, colours as the writer quantises them, no reprojection error: ``PipelineResult.rgb`` is then u8 / 255 and
+    # ``err`` zero - the written file is the same bytes); "auto": "ply" when the output is a .ply and no voxel filter has to see f32
+    # colours, else "f32".  Only used by the overlapped exchange of a sharded run.
+    exchange_records: str = "f32"
+    # dense mode: the kernel with UNORDERED retirement (lfd_triangulate_dense_segments: no look-back, ~6 % less kernel time); raster order is
+    # restored from the tile table by lfd_order_segments (bit-identical result).  Opt-in.
+    dense_tile_segments: bool = False
 
     def __post_init__(self) -> None:
         if self.triangulation_mode not in TRIANGULATION_MODES:
@@ -99,6 +112,10 @@ class DensePipelineConfig:
             raise ValueError("backend must be 'device' or 'host'")
         if self.exchange not in ("all_gather", "gather_to_root"):
             raise ValueError("exchange must be 'all_gather' or 'gather_to_root'")
+        if self.exchange_records not in ("f32", "ply", "auto"):
+            raise ValueError("exchange_records must be 'f32', 'ply' or 'auto'")
+        if int(self.exchange_round) < 0:
+            raise ValueError("exchange_round must be >= 0")
 
 
 @dataclasses.dataclass

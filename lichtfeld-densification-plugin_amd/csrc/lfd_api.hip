@@ -17,6 +17,17 @@
 extern "C" __global__ void lfd_aggregate_kernel(LfdLaunch L, float* best_cert, uint8_t* best_slot);
 extern "C" __global__ void lfd_dense_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_dense_exact_kernel(LfdLaunch L);
+extern "C" __global__ void lfd_dense_segments_kernel(LfdLaunch L);
+extern "C" __global__ void lfd_dense_segments_exact_kernel(LfdLaunch L);
+extern "C" __global__ void lfd_segment_scan_kernel(const LfdTileSeg* table, int n_tiles, int tiles_per_ref, int n_refs, long long* tile_dst, long long* ref_offsets);
+extern "C" __global__ void lfd_order_segments_kernel(const long long* tile_dst, const LfdTileSeg* table, long long hw, int tiles_per_ref, int n_tiles,
+                                                     const float* sxyz, const float* srgb, const float* serr, const int* scell, const unsigned char* sslot,
+                                                     float* dxyz, float* drgb, float* derr, int* dcell, unsigned char* dslot, long long capacity);
+extern "C" __global__ void lfd_pack_ply_segments_kernel(const long long* tile_dst, const LfdTileSeg* table, long long hw, int tiles_per_ref, int n_tiles,
+                                                        const float* xyz, const float* rgb, long long capacity, unsigned char* out);
+extern "C" __global__ void lfd_pack_points3d_segments_kernel(const long long* tile_dst, const LfdTileSeg* table, long long hw, int tiles_per_ref, int n_tiles,
+                                                             const float* xyz, const float* rgb, const float* err, long long capacity,
+                                                             unsigned long long id_base, unsigned char* out);
 extern "C" __global__ void lfd_pair_setup_kernel(LfdLaunch L, LfdRefConst* ref_out, LfdPairConst* pair_out);
 extern "C" __global__ void lfd_select_filter_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_pack_ply_kernel(const float* xyz, const float* rgb, long long n, unsigned char* out);
@@ -442,7 +453,7 @@ void lfd_destroy(lfd_context* ctx) {
     }
     for (hipEvent_t ev : ctx->kt_start) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->kt_stop) (void)hipEventDestroy(ev);
-    for (DeviceBuffer* b : {&ctx->cams, &ctx->ws, &ctx->axes, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->colour_tab, &ctx->mt, &ctx->mt_batch, &ctx->sel_scratch, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab})
+    for (DeviceBuffer* b : {&ctx->cams, &ctx->ws, &ctx->axes, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->colour_tab, &ctx->mt, &ctx->mt_batch, &ctx->sel_scratch, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab, &ctx->seg_scan})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
     delete ctx;
@@ -583,13 +594,17 @@ int lfd_aggregate(lfd_context* ctx, const lfd_batch* batch, const lfd_params* pa
     return LFD_OK;
 }
 
-int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, const lfd_points* out,
-                          int64_t* ref_offsets, int32_t* seg_counts) {
+// the dense launch in its two forms: ordered (ref_offsets; ref_counts / table null) and unordered retirement (ref_counts + table)
+static int dense_launch(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, const lfd_points* out,
+                        int64_t* ref_offsets, int32_t* seg_counts, int64_t* ref_counts, lfd_tile_segment* table) {
+    const bool unordered = table != nullptr;
     LfdLaunch L;
     int rc = prepare_launch(ctx, batch, params, nullptr, 0, L, nullptr);
     if (rc != LFD_OK) return rc;
-    rc = check_points(ctx, out, reinterpret_cast<long long*>(ref_offsets));
+    rc = check_points(ctx, out, reinterpret_cast<long long*>(unordered ? ref_counts : ref_offsets));
     if (rc != LFD_OK) return rc;
+    if (unordered && out->capacity < (int64_t)batch->n_refs * batch->H * batch->W)
+        return fail(ctx, LFD_ERR_CAPACITY, "lfd_triangulate_dense_segments: capacity must be n_refs * H * W (every reference owns a region of H * W records)");
     const size_t n_tiles = (size_t)batch->n_refs * (size_t)L.tiles_per_ref;
     if (n_tiles > 0x7fffffffu) return fail(ctx, LFD_ERR_INVALID, "too many tiles in one launch");
     const size_t grid = n_tiles;              // one workgroup per tile, numbered by ticket
@@ -599,6 +614,9 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
     L.capacity = out->capacity;
     L.ref_offsets = reinterpret_cast<long long*>(ref_offsets);
     L.seg_counts = seg_counts;                // zeroed inside the kernel (tile 0), no memset launch
+    static_assert(sizeof(lfd_tile_segment) == sizeof(LfdTileSeg), "lfd_tile_segment is the kernels' LfdTileSeg");
+    L.ref_cursor = reinterpret_cast<unsigned long long*>(ref_counts);      // (zeroed the same way)
+    L.tile_table = reinterpret_cast<LfdTileSeg*>(table);
     size_t extra_lds = 0;                     // profiling switch: dynamic LDS lowers the number of resident workgroups
     extra_lds = ctx->env.dense_extra_lds;
 #if defined(LFD_DENSE_TIMING)            // profiling builds: per-tile phase stamps, dumped to the file named by LFD_DENSE_TIMING
@@ -627,13 +645,12 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
     if (rc != LFD_OK) return rc;
     hipEvent_t t_start = nullptr, t_stop = used_slot.idle;
     if (ctx->kt_used < ctx->kt_start.size()) { t_start = ctx->kt_start[ctx->kt_used]; t_stop = ctx->kt_stop[ctx->kt_used]; ++ctx->kt_used; }
-    if (exact_colour)
-        hipExtLaunchKernelGGL(lfd_dense_exact_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), (unsigned)extra_lds, ctx->stream, t_start, t_stop, 0, L);
-    else
-        hipExtLaunchKernelGGL(lfd_dense_kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), (unsigned)extra_lds, ctx->stream, t_start, t_stop, 0, L);
-    used_slot.idle_ext = t_stop;
-    used_slot.idle_attached = true;
+    auto kernel = unordered ? (exact_colour ? lfd_dense_segments_exact_kernel : lfd_dense_segments_kernel)
+                            : (exact_colour ? lfd_dense_exact_kernel : lfd_dense_kernel);
+    hipExtLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), (unsigned)extra_lds, ctx->stream, t_start, t_stop, 0, L);
     LFD_HIP(ctx, hipGetLastError());
+    used_slot.idle_ext = t_stop;          // (only behind a launch that went out: a later staging into the slot waits for THIS event)
+    used_slot.idle_attached = true;
 #if defined(LFD_DENSE_TIMING)
     if (stamp_path) {
         std::vector<unsigned long long> host(n_tiles * 2 * 12);
@@ -642,6 +659,88 @@ int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_pa
         if (FILE* f = std::fopen(stamp_path, "wb")) { std::fwrite(host.data(), sizeof(unsigned long long), host.size(), f); std::fclose(f); }
     }
 #endif
+    return LFD_OK;
+}
+
+int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, const lfd_points* out,
+                          int64_t* ref_offsets, int32_t* seg_counts) {
+    return dense_launch(ctx, batch, params, out, ref_offsets, seg_counts, nullptr, nullptr);
+}
+
+int lfd_dense_tiles_per_ref(int32_t H, int32_t W) {
+    if (H <= 0 || W <= 0) return 0;
+    const long long tile = LFD_DENSE_BLOCK * LFD_DENSE_CPT;
+    return (int)(((long long)H * W + tile - 1) / tile);
+}
+
+int lfd_triangulate_dense_segments(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, const lfd_points* out,
+                                   int64_t* ref_counts, int32_t* seg_counts, lfd_tile_segment* table) {
+    if (ctx && !table) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_dense_segments: the tile table is required");
+    return dense_launch(ctx, batch, params, out, nullptr, seg_counts, ref_counts, table);
+}
+
+// exclusive prefix of the table in tile order into the context's scratch (tile_dst[n_tiles + 1]); the launches that follow read it
+static int segment_scan(lfd_context* ctx, int32_t n_refs, int32_t H, int32_t W, const lfd_tile_segment* table, int64_t* ref_offsets,
+                        const long long** tile_dst, int* tpr_out, int* n_tiles_out) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
+    if (n_refs <= 0 || H <= 0 || W <= 0 || !table) return fail(ctx, LFD_ERR_INVALID, "bad segment arguments");
+    const int tpr = lfd_dense_tiles_per_ref(H, W);
+    const long long n_tiles = (long long)n_refs * tpr;
+    if (n_tiles > 0x7fffffffLL) return fail(ctx, LFD_ERR_INVALID, "too many tiles");
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, ctx->seg_scan, ((size_t)n_tiles + 1) * sizeof(long long) + ((size_t)n_tiles + 2) * sizeof(int));      // prefix + chunk index
+    if (rc != LFD_OK) return rc;
+    long long* dst = static_cast<long long*>(ctx->seg_scan.ptr);
+    hipLaunchKernelGGL(lfd_segment_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const LfdTileSeg*>(table), (int)n_tiles, tpr,
+                       (int)n_refs, dst, reinterpret_cast<long long*>(ref_offsets));
+    LFD_HIP(ctx, hipGetLastError());
+    *tile_dst = dst; *tpr_out = tpr; *n_tiles_out = (int)n_tiles;
+    return LFD_OK;
+}
+
+int lfd_order_segments(lfd_context* ctx, int32_t n_refs, int32_t H, int32_t W, const lfd_tile_segment* table, const lfd_points* src,
+                       const lfd_points* dst, int64_t* ref_offsets) {
+    const long long* tile_dst = nullptr; int tpr = 0, n_tiles = 0;
+    int rc = segment_scan(ctx, n_refs, H, W, table, ref_offsets, &tile_dst, &tpr, &n_tiles);
+    if (rc != LFD_OK) return rc;
+    if (!src || !dst || !src->xyz || !src->rgb || !src->err || !dst->xyz || !dst->rgb || !dst->err) return fail(ctx, LFD_ERR_INVALID, "null point buffers");
+    if (dst->capacity <= 0) return LFD_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((dst->capacity + 1023) / 1024, 8192);
+    hipLaunchKernelGGL(lfd_order_segments_kernel, dim3(grid), dim3(256), 0, ctx->stream, tile_dst, reinterpret_cast<const LfdTileSeg*>(table),
+                       (long long)H * W, tpr, n_tiles, src->xyz, src->rgb, src->err, src->cell, src->slot, dst->xyz, dst->rgb, dst->err, dst->cell,
+                       dst->slot, (long long)dst->capacity);
+    LFD_HIP(ctx, hipGetLastError());
+    return LFD_OK;
+}
+
+int lfd_pack_ply_segments(lfd_context* ctx, int32_t n_refs, int32_t H, int32_t W, const lfd_tile_segment* table, const float* xyz,
+                          const float* rgb, int64_t capacity, uint8_t* out, int64_t* ref_offsets) {
+    const long long* tile_dst = nullptr; int tpr = 0, n_tiles = 0;
+    int rc = segment_scan(ctx, n_refs, H, W, table, ref_offsets, &tile_dst, &tpr, &n_tiles);
+    if (rc != LFD_OK) return rc;
+    if (capacity < 0 || (capacity > 0 && (!xyz || !rgb || !out))) return fail(ctx, LFD_ERR_INVALID, "bad arguments");
+    if (reinterpret_cast<uintptr_t>(out) & 3u) return fail(ctx, LFD_ERR_INVALID, "out must be 4-byte aligned");
+    if (capacity == 0) return LFD_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((capacity + 255) / 256, 4096);
+    hipLaunchKernelGGL(lfd_pack_ply_segments_kernel, dim3(grid), dim3(256), 0, ctx->stream, tile_dst, reinterpret_cast<const LfdTileSeg*>(table),
+                       (long long)H * W, tpr, n_tiles, xyz, rgb, (long long)capacity, out);
+    LFD_HIP(ctx, hipGetLastError());
+    return LFD_OK;
+}
+
+int lfd_pack_points3d_segments(lfd_context* ctx, int32_t n_refs, int32_t H, int32_t W, const lfd_tile_segment* table, const float* xyz,
+                               const float* rgb, const float* err, int64_t capacity, uint64_t id_base, uint8_t* out, int64_t* ref_offsets) {
+    const long long* tile_dst = nullptr; int tpr = 0, n_tiles = 0;
+    int rc = segment_scan(ctx, n_refs, H, W, table, ref_offsets, &tile_dst, &tpr, &n_tiles);
+    if (rc != LFD_OK) return rc;
+    if (capacity < 0 || (capacity > 0 && (!xyz || !rgb || !out))) return fail(ctx, LFD_ERR_INVALID, "bad arguments");
+    if (reinterpret_cast<uintptr_t>(out) & 3u) return fail(ctx, LFD_ERR_INVALID, "out must be 4-byte aligned");
+    if (capacity == 0) return LFD_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((capacity + 255) / 256, 4096);
+    hipLaunchKernelGGL(lfd_pack_points3d_segments_kernel, dim3(grid), dim3(256), 0, ctx->stream, tile_dst, reinterpret_cast<const LfdTileSeg*>(table),
+                       (long long)H * W, tpr, n_tiles, xyz, rgb, err, (long long)capacity, (unsigned long long)id_base, out);
+    LFD_HIP(ctx, hipGetLastError());
     return LFD_OK;
 }
 

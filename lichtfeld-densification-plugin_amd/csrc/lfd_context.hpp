@@ -83,6 +83,7 @@ struct lfd_context {
     // selection stage: legacy MT19937 stream (625 words) + scratch
     DeviceBuffer mt, sel_scratch, mt_batch;      // mt_batch: per-reference MT19937 states of lfd_triangulate_sampled_multi
     DeviceBuffer stamps;           // profiling builds: phase stamps of the dense kernel
+    DeviceBuffer seg_scan;         // tile segments: exclusive prefix of the last table handed to lfd_order_segments / lfd_pack_*_segments
     // N3 image preparation: coefficient / index tables of the last size pair
     DeviceBuffer img_tab, msk_tab;
     int img_key[4] = {0, 0, 0, 0}, img_ks[2] = {0, 0};

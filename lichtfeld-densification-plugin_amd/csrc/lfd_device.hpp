@@ -84,6 +84,8 @@ struct LfdSlotDesc {            // one per (reference, slot)
     int32_t pad;
 };
 
+struct LfdTileSeg { int32_t offset, count; };     // == lfd_tile_segment of the C-ABI
+
 struct LfdLaunch {              // kernel argument, passed by value
     const LfdCam* cams;
     const LfdRefDesc* refs;
@@ -124,6 +126,10 @@ struct LfdLaunch {              // kernel argument, passed by value
     const LfdColourCol* colour_cols;    // dense mode, analytic A-grid, two-channel warps: [W] / [H] colour tables (lfd_geometry.hpp), else null
     const LfdColourRow* colour_rows;
     unsigned long long* phase_stamps;   // profiling builds (-DLFD_DENSE_TIMING) with LFD_DENSE_TIMING set in the environment: [n_tiles][16] clock stamps, else null
+    // unordered retirement (lfd_triangulate_dense_segments): a tile claims room in ITS REFERENCE's region [r*H*W, (r+1)*H*W) of the output with
+    // one atomic on the reference's cursor and records where it went; no look-back.  Both null for the ordered kernels.
+    unsigned long long* ref_cursor;     // [n_refs] survivors claimed so far per reference (zeroed by the workgroup of tile 0, like seg_counts)
+    LfdTileSeg* tile_table;             // [n_refs * tiles_per_ref] {offset inside the reference's region, survivors} of every tile
 };
 
 // ---- S: on-device coverage sampling (lfd_select.hip) ---------------------------------------------

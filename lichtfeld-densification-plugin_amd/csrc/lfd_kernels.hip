@@ -486,8 +486,7 @@ struct DenseStage {                // per-tile results, indexed by the cell's sl
 struct __attribute__((packed, aligned(4))) LfdF3 { float a, b, c; };
 
 // records a thread of the copy-out waves handles: the tile's survivors are shared out over the waves that do NOT run the look-back
-constexpr int kCopyThreads = kBlock - 64;
-constexpr int kCopyRecords = (kTile + kCopyThreads - 1) / kCopyThreads;
+constexpr int kCopyThreadsOrdered = kBlock - 64;
 
 // phase stamps of the dense kernel (profiling builds only): lane 0 of waves 0 and 1 record the shader clock at the phase
 // boundaries of their tile; profiles/dense_phases.py turns them into a per-phase latency table
@@ -499,7 +498,10 @@ constexpr int kCopyRecords = (kTile + kCopyThreads - 1) / kCopyThreads;
 #define LFD_STAMP(i) do { } while (0)
 #endif
 
-template <bool kExactColour>
+// kUnordered (lfd_triangulate_dense_segments): no look-back.  A tile claims room in its reference's region of the output with one
+// atomic on the reference's cursor and records {offset, count} in the tile table; the consumers (lfd_order_segments, lfd_pack_*_segments)
+// walk the table and emit raster order.  Everything up to the retirement is the same code.
+template <bool kExactColour, bool kUnordered = false>
 __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
     // one LDS block, the per-pair constants first: S.pc[slot] is then addressed as slot * sizeof(LfdPairConst) + an instruction offset,
     // with no base to keep in a vector register across the geometry loop
@@ -572,8 +574,9 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
     __syncthreads();
     LFD_STAMP(1);
     const unsigned tile = s_ticket;
-    if (tile == 0 && L.seg_counts) {         // zero the per-(reference, slot) counters for this launch, then raise the flag
-        for (int i = tid; i < L.n_refs * L.k; i += kBlock) L.seg_counts[i] = 0;
+    if (tile == 0 && (L.seg_counts || kUnordered)) {         // zero the per-(reference, slot) counters (and the references' cursors) for this launch, then raise the flag
+        if (L.seg_counts) for (int i = tid; i < L.n_refs * L.k; i += kBlock) L.seg_counts[i] = 0;
+        if (kUnordered) for (int i = tid; i < L.n_refs; i += kBlock) L.ref_cursor[i] = 0ull;
         __threadfence();
         __syncthreads();
         if (tid == 0) __hip_atomic_store(L.seg_ready, L.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -837,11 +840,28 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
         //      look-back is covered by the workgroup's own arithmetic instead of idling all four waves.  After the
         //      barrier the same three waves write their records: consecutive threads write consecutive records, so
         //      every wave-wide store covers one contiguous span of the output arrays. -----------------------------
+        // (unordered retirement: nobody runs a look-back, so all four waves share the colour work and the stores)
+        constexpr int kCopyThreads = kUnordered ? kBlock : kCopyThreadsOrdered;
+        constexpr int kCopyRecords = (kTile + kCopyThreads - 1) / kCopyThreads;
         float rgb[kCopyRecords][3];
         int ctid = (int)threadIdx.x;               // thread index among the copy-out waves; taken from the hardware register again
         asm volatile("" : "+v"(ctid));             // here, so that no copy of it occupies a register across the geometry loop
-        ctid -= 64;
-        if (wave == 0) {
+        if (!kUnordered) ctid -= 64;
+        u64 claimed = 0;
+        if (kUnordered && tid == 0) {
+            // one returning atomic per tile on the reference's cursor (the tiles of a reference are in flight together, a few hundred per
+            // reference: ~12 ns each on one address), behind the flag that says tile 0's workgroup has zeroed the cursors.  Issued before
+            // the colour work, consumed after it: its round trip is covered
+            unsigned spins = 0;
+            unsigned ready = __hip_atomic_load(L.seg_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (ready != L.epoch) {
+                if (++spins > LFD_SPIN_LIMIT) { atomicExch(L.status, LFD_LAUNCH_TIMEOUT); break; }
+                __builtin_amdgcn_s_sleep(8);
+                ready = __hip_atomic_load(L.seg_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            claimed = atomicAdd(L.ref_cursor + r, (u64)block_total);
+        }
+        if (!kUnordered && wave == 0) {
 #if defined(LFD_ABLATE_LOOKBACK)
             const u64 excl = (u64)tile * kTile;
 #else
@@ -852,7 +872,8 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
                 if (tile_in_ref == 0) L.ref_offsets[r] = (long long)excl;
                 if (tile == n_tiles - 1u) L.ref_offsets[L.n_refs] = (long long)(excl + block_total);
             }
-        } else {
+        }
+        if (kUnordered || wave != 0) {
 #if !defined(LFD_ABLATE_STORES)
             const uint8_t* image = S.ref.image;
             const int n_loc = (int)block_total;
@@ -933,12 +954,17 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
             }
 #endif
         }
+        if (kUnordered && tid == 0) {
+            s_tile_excl = (u64)(unsigned)r * (u64)(unsigned)HW + claimed;
+            LfdTileSeg seg; seg.offset = (int32_t)claimed; seg.count = (int32_t)block_total;
+            L.tile_table[tile] = seg;
+        }
         LFD_STAMP(8);
         __syncthreads();                          // prefix known, colours in registers
         LFD_STAMP(9);
 
 #if !defined(LFD_ABLATE_STORES)
-        if (wave != 0) {
+        if (kUnordered || wave != 0) {
             // the tile's offset is the same for every lane: kept in scalar registers, so that a record's address is a scalar base
             // plus a 32-bit per-lane byte offset (no 64-bit vector multiply-adds: those run at a quarter of the rate)
             const u64 excl = s_tile_excl;
@@ -991,6 +1017,9 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
 extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_kernel(LfdLaunch L) { lfd_dense_body<false>(L); }
 // the same kernel with upstream's f64 colour arithmetic (bit-identical rgb; lfd_params.flags & LFD_FLAG_EXACT_COLOUR)
 extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_exact_kernel(LfdLaunch L) { lfd_dense_body<true>(L); }
+// unordered retirement (lfd_triangulate_dense_segments), both colour forms
+extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_segments_kernel(LfdLaunch L) { lfd_dense_body<false, true>(L); }
+extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_segments_exact_kernel(LfdLaunch L) { lfd_dense_body<true, true>(L); }
 
 // =================================================================================================
 // indexed mode, pass A on the whole chip: every selected cell is evaluated by its own thread (256 cells per workgroup,

@@ -55,7 +55,15 @@ def pose_world2cam(im) -> Tuple[np.ndarray, np.ndarray]:
 
 
 def load_reconstruction(sparse_dir: str):
-    import pycolmap
+    """``pycolmap.Reconstruction`` like upstream (densify.py:54-56) when pycolmap is installed; otherwise the same three files read by
+    core/colmap_io.py (cameras / images / points3D, .bin or .txt), which offers the attributes upstream touches."""
+    try:
+        import pycolmap
+    except ImportError:
+        from .core.colmap_io import Reconstruction
+        rec = Reconstruction(sparse_dir)
+        log.info(f"pycolmap is not installed: read {len(rec.images)} images / {len(rec.cameras)} cameras from {sparse_dir} with the built-in reader")
+        return rec, rec.cameras, rec.images
     rec = pycolmap.Reconstruction(sparse_dir)
     return rec, rec.cameras, rec.images
 
@@ -155,7 +163,7 @@ def _write_output(path: str, xyz, rgb, err, device_points=None) -> None:
     if d:
         os.makedirs(d, exist_ok=True)
     as_ply = path.lower().endswith(".ply")
-    if device_points is not None and int(device_points[0].shape[0]) == int(xyz.shape[0]):
+    if device_points is not None and device_points[0].is_cuda and int(device_points[0].shape[0]) == int(xyz.shape[0]):
         from .core import hip_backend as hb
         from .core.writers import write_ply_packed, write_points3D_bin_packed
         dens = hb.HipDensifier(device_points[0].device)

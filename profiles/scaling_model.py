@@ -7,7 +7,10 @@ NOT a measurement of N GPUs (a gpurun box has one): per-rank compute is MEASURED
     all-gather, direct (every rank sends its shard to every peer on that peer's own link): shard_bytes / link_bw;
     all-gather, ring (what a bandwidth-optimal ring costs when one link bounds each step): (N - 1) * shard_bytes / link_bw;
     gather to rank 0: the root receives N - 1 shards on N - 1 links at once: shard_bytes / link_bw.
-Usage: python profiles/scaling_model.py gpurun_out/scaling_inputs.jsonl"""
+Round 4 adds the OVERLAPPED schedule of core/distributed.py::OverlappedExchange / bench.py --gpus N: the rank's share in R rounds, round c's
+records (28-byte rows or 15-byte PLY vertex records) in an asynchronous collective beside the compute of round c + 1, the last round's
+exchange exposed:  t = c + (R - 1) max(c, x) + x  with c = compute / R and x = 2 LAT + shard_bytes / R / link_bw.
+Usage: python profiles/scaling_model.py gpurun_out/scaling_inputs.jsonl [rounds]"""
 import json
 import sys
 
@@ -33,3 +36,33 @@ for mode in ("dense", "sampled"):
             root = (2 * LAT + shard / LINK) * 1e3
         tot = r["step_ms"] + direct
         print(f"{n:5d}  {r['refs_per_rank']:9d}  {r['step_ms']:28.3f}   {direct:10.3f} | {ring:7.3f} | {root:7.3f}                 {tot:12.3f}   {t1 / tot:17.2f}   {total_pts / (tot * 1e-3):.3e}")
+
+
+ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+print(f"\n==== overlapped schedule, {ROUNDS} rounds per rank (direct all-gather / gather to root: one shard per link either way) ====")
+for mode in ("dense", "sampled"):
+    sel = sorted([r for r in rows if r["mode"] == mode], key=lambda r: r["ranks"])
+    if not sel:
+        continue
+    t1 = sel[0]["step_ms"]
+    total_pts = sel[0]["points"]
+    print(f"\n{mode} mode: {total_pts / 1e6:.2f} M surviving points = {total_pts * 28 / 1e6:.1f} MB as 28-byte rows, {total_pts * 15 / 1e6:.1f} MB as 15-byte PLY records")
+    print("ranks  compute ms   28 B end of run (round 3)   28 B overlapped   15 B overlapped   speed-up (28 B eor | 28 B ovl | 15 B ovl)   bound at 15 B")
+    for r in sel:
+        n = r["ranks"]
+        comp = r["step_ms"]
+        res = []
+        for nbytes, overlapped in ((28, False), (28, True), (15, True)):
+            if n == 1:
+                res.append(comp)
+                continue
+            shard = total_pts * nbytes / n
+            if not overlapped:
+                res.append(comp + (2 * LAT + shard / LINK) * 1e3)
+            else:
+                c = comp / ROUNDS
+                x = (2 * LAT + shard / ROUNDS / LINK) * 1e3
+                res.append(c + (ROUNDS - 1) * max(c, x) + x)
+        link_ms = 0.0 if n == 1 else total_pts * 15 / n / LINK * 1e3
+        bound = "compute" if n == 1 or comp >= link_ms else f"link ({link_ms:.3f} ms to move one shard)"
+        print(f"{n:5d}  {comp:10.3f}   {res[0]:25.3f}   {res[1]:15.3f}   {res[2]:15.3f}   {t1 / res[0]:10.2f} | {t1 / res[1]:8.2f} | {t1 / res[2]:8.2f}              {bound}")

@@ -117,3 +117,124 @@ def test_streamed_file_of_two_ranks_is_the_single_writer_file(tmp_path):
             if counts[g]:
                 w.append_packed(np.ascontiguousarray(pts[g].view(np.uint8).reshape(-1, 28)[:, :15]).tobytes())
     assert open(os.path.join(str(tmp_path), "stream.ply"), "rb").read() == open(ref, "rb").read()
+
+
+# ---- the exchange in rounds beside the compute (OverlappedExchange) ----------------------------------------------------------------------
+def _overlap_worker(rank, world, port, n_refs, per_round, form, record, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts, pts = _make_points(n_refs, seed=3)
+        mine = lfd_dist.shard_references(n_refs, rank, world)
+        ex = lfd_dist.OverlappedExchange(dist, n_refs, per_round, torch.device("cpu"), form=form, record=record)
+        for i, g in enumerate(mine):
+            if not counts[g]:
+                continue                                  # a reference without survivors is never pushed
+            t = torch.from_numpy(pts[g])
+            ex.push(i, t if record == "f32" else torch.from_numpy(np.ascontiguousarray(pts[g].view(np.uint8).reshape(-1, 28)[:, :15]).reshape(-1)))
+        recs, gcounts = ex.finish()
+        q.put((rank, recs.numpy(), gcounts, ex.n_rounds))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_refs,world,per_round,form,record", [
+    (7, 2, 1, "all_gather", "f32"), (7, 2, 2, "gather_to_root", "f32"), (10, 3, 2, "all_gather", "ply"), (5, 4, 1, "gather_to_root", "ply"),
+    (2, 3, 4, "all_gather", "f32"), (1, 2, 1, "gather_to_root", "f32"), (9, 2, 16, "all_gather", "ply")])
+def test_overlapped_exchange_is_the_single_process_sequence(n_refs, world, per_round, form, record):
+    """world 2 / 3 / 4, rounds of 1, 2, 4 and "everything in one round", uneven shards, a reference without survivors, a rank without any
+    reference: all_gather leaves the 1-rank sequence on every rank, gather_to_root on rank 0 (the others keep their shard)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, n_refs, per_round, form, record, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    counts, pts = _make_points(n_refs, seed=3)
+
+    def as_sent(parts):
+        if not parts:
+            return np.zeros((0, 7), np.float32) if record == "f32" else np.zeros((0,), np.uint8)
+        full = np.concatenate(parts, 0)
+        return full if record == "f32" else np.ascontiguousarray(full.view(np.uint8).reshape(-1, 28)[:, :15]).reshape(-1)
+    for rank, recs, gcounts, n_rounds in results:
+        np.testing.assert_array_equal(gcounts, counts)
+        assert n_rounds == -(-(-(-n_refs // world)) // per_round)
+        mine = lfd_dist.shard_references(n_refs, rank, world)
+        expect = as_sent(pts) if (form == "all_gather" or rank == 0) else as_sent([pts[g] for g in mine])
+        np.testing.assert_array_equal(recs, expect)
+
+
+def test_ply_records_give_back_positions_and_quantised_colours():
+    rs = np.random.RandomState(0)
+    xyz = rs.normal(size=(50, 3)).astype(np.float32)
+    rgb = rs.uniform(size=(50, 3)).astype(np.float32)
+    from lichtfeld_densification_plugin_amd.core.image_io import to_uint8_rgb
+    from lichtfeld_densification_plugin_amd.core.writers import ply_records
+    rec = torch.from_numpy(ply_records(xyz, to_uint8_rgb(rgb)).view(np.uint8).reshape(-1).copy())
+    x, c = lfd_dist.points_from_ply_records(rec)
+    np.testing.assert_array_equal(x.numpy(), xyz)
+    np.testing.assert_array_equal(to_uint8_rgb(c.numpy()), to_uint8_rgb(rgb))          # re-quantising gives the same bytes
+
+
+def test_backend_name_does_not_invent_a_backend():
+    """a group that was never initialised is an error, not "nccl" (which would send host tensors down the device branch)"""
+    assert not dist.is_initialized()
+    with pytest.raises(Exception):
+        lfd_dist._backend_name(dist)
+
+
+# ---- failure paths of the streamed sharded writer -----------------------------------------------------------------------------------------
+class _FailingWriter:
+    def __init__(self, fail_at):
+        self.calls, self.fail_at, self.kept = 0, fail_at, []
+
+    def append_packed(self, data):
+        self.calls += 1
+        if self.calls == self.fail_at:
+            raise OSError("disk full")
+        self.kept.append(bytes(data))
+
+
+def _writer_failure_worker(rank, world, port, n_refs, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts, pts = _make_points(n_refs)
+        mine = lfd_dist.shard_references(n_refs, rank, world)
+        writer = _FailingWriter(fail_at=2) if rank == 0 else None
+        stream = lfd_dist.ShardedPlyStream(dist, n_refs, writer, torch.device("cpu"))
+        raised = None
+        for i, g in enumerate(mine):
+            if counts[g]:
+                stream.push(i, torch.from_numpy(np.ascontiguousarray(pts[g].view(np.uint8).reshape(-1, 28)[:, :15]).reshape(-1)))
+        try:
+            stream.finish()
+        except OSError as exc:
+            raised = str(exc)
+        dist.barrier()                       # both ranks get here: nobody is left waiting for a receive that never comes
+        q.put((rank, raised, writer.calls if writer else None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_writer_that_fails_on_rank_0_drains_the_peers_and_raises_afterwards():
+    n_refs, world = 9, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_writer_failure_worker, args=(r, world, port, n_refs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0][1] == "disk full" and results[0][2] == 2          # the error, once; the writer was not called again
+    assert results[1][1] is None and results[2][1] is None

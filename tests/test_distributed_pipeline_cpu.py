@@ -57,8 +57,11 @@ def _rank(rank, world, port, tmp, cfg_kw, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,exchange", [("sampled", "all_gather"), ("sampled", "gather_to_root"), ("dense", "gather_to_root")])
-def test_two_host_ranks_equal_one_and_stream_the_same_file(g4, tmp_path, mode, exchange):
+@pytest.mark.parametrize("mode,exchange,overlap", [("sampled", "all_gather", True), ("sampled", "gather_to_root", True), ("dense", "gather_to_root", True),
+                                                   ("dense", "all_gather", True), ("sampled", "all_gather", False), ("dense", "gather_to_root", False)])
+def test_two_host_ranks_equal_one_and_stream_the_same_file(g4, tmp_path, mode, exchange, overlap):
+    """``overlap``: the exchange in rounds beside the compute (OverlappedExchange, rounds of ONE reference here so that several rounds run)
+    or the one exchange after the last reference"""
     import torch.multiprocessing as mp
     from lichtfeld_densification_plugin_amd.core import writers
     from lichtfeld_densification_plugin_amd.core.image_io import to_uint8_rgb
@@ -72,7 +75,7 @@ def test_two_host_ranks_equal_one_and_stream_the_same_file(g4, tmp_path, mode, e
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     out = os.path.join(tmp, "sharded.ply")
-    cfg_kw = dict(output_path=out, exchange=exchange, stream_output=True, **kw)
+    cfg_kw = dict(output_path=out, exchange=exchange, stream_output=True, exchange_overlap=overlap, exchange_round=1, **kw)
     procs = [ctx.Process(target=_rank, args=(r, 2, port, tmp, cfg_kw, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -97,3 +100,52 @@ def test_two_host_ranks_equal_one_and_stream_the_same_file(g4, tmp_path, mode, e
     ref_head, ref_body = open(os.path.join(tmp, "single.ply"), "rb").read().split(b"end_header\n", 1)
     assert body == ref_body
     assert [l for l in head.decode().split("\n") if l and not l.startswith("comment")] == [l for l in ref_head.decode().split("\n") if l]
+
+
+def _failing_rank(rank, world, port, tmp, cfg_kw, q):
+    import torch.distributed as dist
+    from conftest import load_golden
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cams, refs, nn, table = _scene(load_golden("g4_pipeline.npz"), tmp)
+        mine = [table[i] for i in range(len(refs)) if i % world == rank]
+        pl.has_cached_romav2_weights = lambda: True
+
+        def make_matcher(**_kw):          # the pipeline builds its own matcher (matcher=None): rank 1's constructor fails
+            if rank == 1:
+                raise RuntimeError("no model on this rank")
+            return _Replay(mine)
+        pl.RomaMatcher = make_matcher
+        try:
+            pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**cfg_kw))
+            q.put((rank, None))
+        except Exception as exc:
+            q.put((rank, f"{type(exc).__name__}: {exc}"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_a_rank_that_fails_before_the_loop_does_not_hang_the_others(g4, tmp_path, overlap):
+    """with a streamed sharded output, a rank whose matcher cannot even be constructed used to reach `finally` without a stream
+    object and went straight to the status agreement while rank 0 waited for its records.  The stream (and the overlapped exchange) now
+    exist before anything can fail: the failing rank sends empty references / closes empty rounds, everybody raises."""
+    import torch.multiprocessing as mp
+    tmp = str(tmp_path)
+    _scene(g4, tmp)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    cfg_kw = dict(output_path=os.path.join(tmp, "sharded.ply"), stream_output=True, exchange_overlap=overlap, exchange_round=1, nns_per_ref=2, seed=5,
+                  viz_interval=0, matches_per_ref=1200, triangulation_mode="sampled", per_reference_rng=True, backend="host", pack_workers=1)
+    procs = [ctx.Process(target=_failing_rank, args=(r, 2, port, tmp, cfg_kw, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[1] == "RuntimeError: no model on this rank"
+    assert results[0] == "RuntimeError: dense pipeline failed on another rank"

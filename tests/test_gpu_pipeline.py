@@ -207,37 +207,41 @@ def test_two_ranks_reproduce_the_single_process_sequence(g4, tmp_path, mode):
 
 
 def test_bench_starts_its_own_ranks(tmp_path):
-    """`python bench.py --gpus 2` without a launcher starts two fresh rank processes itself (here both on the one GPU of
-    the test box, LFD_BENCH_RANKS_PER_GPU=2, host collectives) and prints ONE line with n_gpus = 2, the whole-job value and
-    the separately timed ordered all-gather; with fewer GPUs than ranks and no sharing it refuses instead of silently
-    running one rank."""
+    """`python bench.py --gpus 2` without a launcher starts two fresh rank processes itself (here both on the one GPU of the test box,
+    LFD_BENCH_RANKS_PER_GPU=2, host collectives) and prints ONE line with n_gpus = 2.  The DEFAULT job of N > 1 is one scene (config 4's
+    shape) dealt over the ranks - strong scaling - with the exchange of the survivors inside `value`; compute-only is a side key.  With fewer
+    GPUs than ranks and no sharing it refuses instead of silently running one rank."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LFD_BENCH_RANKS_PER_GPU="2")
     env.pop("WORLD_SIZE", None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--refs", "4", "--preset", "turbo",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--refs", "6", "--preset", "turbo",
            "--light", "--spinup-s", "0.05"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["refs_total"] == 6 and d["config"]["refs_per_gpu"] == 3 and d["config"]["neighbours"] == 8 and "config[3]" in d["config"]["workload"]
     assert d["rccl_ranks"] == 0 and d["collective_backend"] == "gloo"          # two ranks on one GPU exchange through host buffers, and the line says so
-    assert d["exchange"]["points"] > 0 and d["exchange"]["allgather_ms"] > 0 and d["exchange"]["bytes_gathered"] == 28 * d["exchange"]["points"]
-    assert d["exchange"]["gather_to_root_ms"] > 0 and 0 < d["value_incl_exchange"] < d["value"] and d["value_incl_gather_to_root"] > 0
-    assert d["compute_ms"] >= d["kernel_ms"] > 0 and d["fresh_batch_ms"] >= 0 and d["config"]["batches_in_rotation"] == 3
-    assert d["end_to_end"] is None and "unmeasured" in d["end_to_end_note"] and "traffic_source" in d["roofline"]
-    # strong scaling: ONE scene (config 4's 56 references x 8 neighbours, here 6 x 8 at `turbo`) dealt over the ranks
-    cmd_s = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "config4", "--refs", "6",
-             "--preset", "turbo", "--scaling", "strong", "--light", "--spinup-s", "0.05"]
+    ex = d["exchange"]
+    assert ex["form"] == "all_gather" and ex["record_bytes"] == 15 and ex["overlapped"] and ex["rounds"] == 2 and ex["points"] > 0
+    assert ex["bytes_gathered"] == 15 * ex["points"] and ex["end_of_run_28B"]["allgather_ms"] > 0 and ex["end_of_run_28B"]["gather_to_root_ms"] > 0
+    assert "all_gather" in d["value_includes"] and 0 < d["value"] <= d["value_compute_only"] * 1.05        # the exchange is INSIDE value
+    assert d["compute_ms"] > 0 and d["kernel_ms"] > 0 and d["ms_per_step"] >= d["compute_ms"] * 0.95
+    assert d["sampled_mode"]["value"] > 0 and d["sampled_mode"]["points_per_scene"] > 0
+    assert d["end_to_end"] is None and "unmeasured" in d["end_to_end_note"] and "no multi-GPU node" in d["scaling_note"]
+    # the other forms: gather to the writer rank, 28-byte rows, weak scaling
+    cmd_s = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--refs", "3", "--preset", "turbo",
+             "--scaling", "weak", "--exchange", "gather_to_root", "--exchange-records", "f32", "--exchange-rounds", "3", "--light", "--spinup-s", "0.05"]
     res_s = subprocess.run(cmd_s, env=env, capture_output=True, text=True, timeout=600)
     assert res_s.returncode == 0, res_s.stderr[-2000:]
     ds = json.loads([l for l in res_s.stdout.splitlines() if l.startswith("{")][0])
-    assert ds["scaling"] == "strong" and ds["config"]["refs_total"] == 6 and ds["config"]["refs_per_gpu"] == 3 and ds["config"]["neighbours"] == 8
-    assert ds["exchange"]["points"] > 0 and ds["value_incl_exchange"] > 0
+    assert ds["scaling"] == "weak" and ds["config"]["refs_total"] == 6 and ds["config"]["refs_per_gpu"] == 3
+    assert ds["exchange"]["form"] == "gather_to_root" and ds["exchange"]["record_bytes"] == 28 and ds["exchange"]["rounds"] == 3 and ds["value"] > 0
     if torch.cuda.device_count() < 2:
         env2 = dict(os.environ)
         env2.pop("WORLD_SIZE", None)

@@ -50,6 +50,21 @@ SCRIPT = textwrap.dedent("""
             if b.numel(): stream.push(i, b)
         stream.finish()
         assert b"".join(sink.parts) == b"".join(b.cpu().numpy().tobytes() for b in bodies)
+        # the exchange in rounds (asynchronous collectives on the communicator's stream), both forms and both record kinds
+        parts = [torch.randn(c, 7, generator=g).to(dev) for c in counts]
+        for form in ("all_gather", "gather_to_root"):
+            ex = D.OverlappedExchange(dist, len(counts), 2, dev, form=form, record="f32")
+            assert ex.dev == dev and ex.n_rounds == 2
+            for i, p_ in enumerate(parts):
+                if p_.shape[0]: ex.push(i, p_)
+            recs, gc = ex.finish()
+            assert recs.device == dev and torch.equal(recs, torch.cat(parts)) and gc.tolist() == counts
+        recs15 = [torch.randint(0, 255, (c * 15,), generator=g, dtype=torch.uint8).to(dev) for c in counts]
+        ex = D.OverlappedExchange(dist, len(counts), 1, dev, form="all_gather", record="ply")
+        for i, p_ in enumerate(recs15):
+            if p_.numel(): ex.push(i, p_)
+        recs, gc = ex.finish()
+        assert torch.equal(recs, torch.cat(recs15)) and gc.tolist() == counts and ex.n_rounds == 4
         print("RCCL_OK", torch.cuda.get_device_name(0))
     finally:
         dist.destroy_process_group()
@@ -69,8 +84,9 @@ def test_exchange_helpers_on_device_buffers_through_rccl(tmp_path):
 
 @pytest.mark.gpu
 def test_bench_exchange_legs_through_rccl_on_one_rank():
-    """bench.py with LFD_BENCH_FORCE_DIST=1 creates the RCCL communicator for its one rank and runs both timed exchanges (ordered
-    all-gather, gather to the writer) on device buffers through it: the line then says `collective_backend: nccl`, `rccl_ranks: 1`."""
+    """bench.py with LFD_BENCH_FORCE_DIST=1 creates the RCCL communicator for its one rank and runs the sharded leg on device buffers through
+    it - the rounds of the overlapped exchange (counts + padded records, asynchronous collectives on the communicator's stream) and the
+    end-of-run exchanges: the line then says `collective_backend: nccl`."""
     import json
     import socket
     with socket.socket() as s:
@@ -78,12 +94,14 @@ def test_bench_exchange_legs_through_rccl_on_one_rank():
         port = s.getsockname()[1]
     env = dict(os.environ, LFD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--refs", "4", "--preset", "turbo", "--light",
-           "--spinup-s", "0.05"]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
-    assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
-    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
-    assert d["n_gpus"] == 1 and d["collective_backend"] == "nccl" and d["rccl_ranks"] == 1
-    ex = d["exchange"]
-    assert ex["points"] > 0 and ex["allgather_ms"] > 0 and ex["gather_to_root_ms"] > 0 and ex["bytes_gathered"] == 28 * ex["points"]
-    assert 0 < d["value_incl_exchange"] < d["value"]
+    for extra in ([], ["--exchange", "gather_to_root", "--exchange-records", "f32", "--exchange-rounds", "3"]):
+        cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "config4", "--refs", "4",
+               "--preset", "turbo", "--light", "--spinup-s", "0.05"] + extra
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+        assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
+        d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+        assert d["n_gpus"] == 1 and d["collective_backend"] == "nccl"
+        ex = d["exchange"]
+        assert ex["points"] > 0 and ex["overlapped"] and ex["end_of_run_28B"]["allgather_ms"] > 0 and ex["end_of_run_28B"]["gather_to_root_ms"] > 0
+        assert ex["rounds"] == (3 if extra else 2) and ex["record_bytes"] == (28 if extra else 15)
+        assert 0 < d["value"] and d["value_compute_only"] > 0
