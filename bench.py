@@ -134,6 +134,22 @@ def valu_busy_frac(args):
     return (t.get("valu") or {}).get("valu_busy_frac") if t else None
 
 
+def valu_roofline(args, kernel_ms):
+    """The OTHER bound of the fused kernel, stated beside the HBM one: the issue time of its vector instructions.  Instructions per cell by class
+    from the committed rocprofv3 --pmc passes of this command (profiles/traffic.json), real cycles per wave-instruction and the clock the chip
+    sustains under this arithmetic from profiles/microbench/clock_under_load.hip; `frac` = issue time / measured kernel time (1.0 = nothing but
+    vector issue)."""
+    t = _committed_pmc(args)
+    v = (t.get("valu") or {}) if t else {}
+    if not v.get("issue_ms"):
+        return None
+    return {"bound": "valu", "instructions_per_cell": v.get("instructions_per_cell"), "f64_per_cell": v.get("f64_per_cell"), "f32_per_cell": v.get("f32_per_cell"),
+            "conversions_per_cell": v.get("conversions_per_cell"), "integer_per_cell": v.get("integer_per_cell"),
+            "cycles_per_wave_instruction": v.get("cycles_per_wave_instruction"), "sustained_clock_GHz": v.get("sustained_clock_GHz"),
+            "issue_cycles_per_cell": v.get("issue_cycles_per_cell"), "issue_ms": v.get("issue_ms"), "frac": v["issue_ms"] / kernel_ms if kernel_ms else None,
+            "valu_busy_frac": v.get("valu_busy_frac"), "source": v.get("source")}
+
+
 def build_workload(args, rank, world, dev):
     """Global reference list dealt round-robin; this rank generates and keeps only its share.  weak scaling: --refs references per
     rank; strong scaling: --refs in total (BASELINE's metric is ONE scene at 1/2/4/8 GPUs)."""
@@ -170,7 +186,7 @@ def build_workload(args, rank, world, dev):
 _pads = []
 
 
-def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16):
+def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16, cams_for_hot=None):
     """Upstream-equivalent mode, reference after reference as the pipeline runs it: aggregate kernel ->
     on-device coverage sampling (M=10000) -> indexed kernels in one asynchronous call (lfd_triangulate_sampled),
     then the read-back of the counts.  Reported next to the headline (dense) number, not instead of it."""
@@ -209,6 +225,33 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16):
         dt2 = time.perf_counter() - t0
     assert pts2 == pts, (pts2, pts)
     res["pipelined_ms_per_reference"] = dt2 / len(todo) * 1e3
+    # the pipeline's DEFAULT configuration (upstream_normaliser: the weights normalised with torch's own CPU f32 sum, upstream's library call):
+    # reference i's aggregated map travels to the host on a side stream while the host sums reference i - 1's and launches its fused call
+    # (core/pipeline.py::_HotPath.begin_normaliser / finish_normaliser) - the launch stream never waits for the host
+    from lichtfeld_densification_plugin_amd.core.pipeline import _HotPath
+    hot = _HotPath(cams_for_hot, cfg, 0.9, wm, hm, dens.device, dens)
+    for warm in (True, False):
+        dens.seed_rng(cfg.seed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pts3, pend, fly = 0, [], []
+        for r in todo:
+            pend.append((r, hot.begin_normaliser(r, None)))
+            while len(pend) > 1:
+                r0, h0 = pend.pop(0)
+                fly.append(hot.launch_sampled(r0, None, None, s_override=hot.finish_normaliser(h0), batch=h0[0]))
+            while len(fly) > 1:
+                pts3 += fly.pop(0)[1].collect(indexed=True, check_selection=True).count
+        while pend:
+            r0, h0 = pend.pop(0)
+            fly.append(hot.launch_sampled(r0, None, None, s_override=hot.finish_normaliser(h0), batch=h0[0]))
+        while fly:
+            pts3 += fly.pop(0)[1].collect(indexed=True, check_selection=True).count
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t0
+    res["default_config_ms_per_reference"] = dt3 / len(todo) * 1e3
+    res["default_config_note"] = ("upstream_normaliser=True (the pipeline's default): upstream's torch f32 sum of every aggregated map on the host, the map copied on a "
+                                  "side stream while the neighbouring references are launched / collected")
     # several references per fused call (lfd_triangulate_sampled_multi), every reference on its own MT19937 stream - what sharded
     # runs use (core/pipeline.py, per_reference_rng): one aggregate launch, the selections of the group side by side in one
     # launch (a selection occupies 17 of the 256 CUs), one pair of indexed launches, one read-back
@@ -832,10 +875,11 @@ def main():
         if not args.light and world == 1:
             line["roofline"]["device_copy_GBps"] = device_copy_bandwidth(dev)      # what a plain device-to-device copy reaches on this box
         line["roofline"]["valu_busy_frac"] = valu_busy_frac(args)     # the f64 geometry makes the kernel vector-ALU-bound, not HBM-bound (same source as `traffic`)
+        line["roofline"]["valu"] = valu_roofline(args, kernel_ms)      # ... and that bound itself: issue time of the vector instructions / kernel time
         line["roofline"]["traffic_over_algorithmic"] = (line["roofline"]["traffic"] / algo_bytes) if line["roofline"]["traffic"] else None
         if not args.light and world == 1:     # the side legs (and the CPU baseline) belong to the N = 1 line; at N > 1 the other ranks are waiting
             line["with_d2h"] = d2h_inclusive_rate(dens, batch, params, out, dev)
-            line["sampled_mode"] = sampled_mode_rate(args, dens, refs, dims, cfg)
+            line["sampled_mode"] = sampled_mode_rate(args, dens, refs, dims, cfg, cams_for_hot=cams)
             line["secondary_kernels"] = secondary_kernels(args, dens, batch, refs, dims, cfg, res)
             par = parity_report(args, dens, cams, refs, srefs, dims, cfg)
             if par is not None:

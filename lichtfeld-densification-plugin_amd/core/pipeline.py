@@ -440,16 +440,61 @@ class _HotPath:
         exact_ok = cfg.no_filter or per_ref_rng or float(cfg.certainty_thresh) >= 2.0 ** -29 * H * W * max(self.sample_cap, 1e-6)
         return fusable and not need_best and exact_ok
 
-    def launch_sampled(self, ref: hb.ReferenceInputs, axes, device_seed: Optional[int]):
+    def launch_sampled(self, ref: hb.ReferenceInputs, axes, device_seed: Optional[int], s_override: float = 0.0, batch=None):
         """Enqueue one reference's fused call and the read-back of its counts; returns what ``finish_sampled`` needs."""
-        batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes, cameras=self.cams)
+        if batch is None:
+            batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes, cameras=self.cams)
         if device_seed is not None and not self.config.no_filter:
             self.dens.seed_rng(device_seed)
         M = self.config.matches_per_ref
         out = hb.OutputBuffers(int(M) + 24 * 24 + 64, 1, batch.k, self.dev)
-        self.dens.launch_sampled(batch, self.params, M, out, cap=self.sample_cap, border=2, tiles=24)
+        self.dens.launch_sampled(batch, self.params, M, out, cap=self.sample_cap, border=2, tiles=24, s_override=float(s_override))
         out.begin_collect(self.dens.stream)
         return batch, out
+
+    # -- upstream's normaliser without stalling the launch stream ---------------------------------------------------------------
+    def can_pipeline_normaliser(self, need_best: bool, per_ref_rng: bool, H: int, W: int) -> bool:
+        """The default single-stream sampled mode (``upstream_normaliser``): the aggregated map of reference i is copied to the host on
+        a SIDE stream while the host is busy with reference i - 1 (its torch sum, its fused launch) and the matcher with reference
+        i + 1; the launch stream never waits for the host.  Same preconditions as the launch-ahead (the device selection must not be
+        able to refuse its input), plus: one RNG stream, filter mode."""
+        cfg = self.config
+        if self.on_host or cfg.selection_backend != "device" or cfg.no_filter or per_ref_rng or need_best:
+            return False
+        if not bool(getattr(cfg, "upstream_normaliser", True)):
+            return False
+        return float(cfg.certainty_thresh) >= 2.0 ** -29 * H * W * max(self.sample_cap, 1e-6)
+
+    def begin_normaliser(self, ref: hb.ReferenceInputs, axes):
+        """Aggregate on the launch stream, then the 1 MB map to pinned host memory on the side stream, an event behind it."""
+        batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes, cameras=self.cams)
+        if getattr(self, "_norm_side", None) is None:
+            self._norm_side = torch.cuda.Stream(device=self.dev)
+            self._norm_free: list = []
+        H, W = batch.H, batch.W
+        slot = None
+        for i, cand in enumerate(self._norm_free):
+            if tuple(cand["best"].shape) == (1, H, W):
+                slot = self._norm_free.pop(i)
+                break
+        if slot is None:
+            slot = {"best": torch.empty((1, H, W), dtype=torch.float32, device=self.dev),
+                    "host": torch.empty((H, W), dtype=torch.float32).pin_memory(), "agg_done": torch.cuda.Event(), "copied": torch.cuda.Event()}
+        self.dens.launch_aggregate(batch, self.params, slot["best"], None)
+        slot["agg_done"].record(self.dens.stream)
+        with torch.cuda.stream(self._norm_side):
+            self._norm_side.wait_event(slot["agg_done"])
+            slot["host"].copy_(slot["best"][0], non_blocking=True)
+            slot["copied"].record(self._norm_side)
+        return batch, slot
+
+    def finish_normaliser(self, handle) -> float:
+        """upstream's torch f32 sum of the (capped, border-masked) map that has arrived; the slot goes back to the pool"""
+        _batch, slot = handle
+        slot["copied"].synchronize()
+        s_up = upstream_weight_sum(slot["host"], cap=self.sample_cap, border=2)
+        self._norm_free.append(slot)
+        return s_up if s_up > 0.0 else 0.0      # (a sum <= 0 is upstream's "nothing to sample" case, which the device stage reports from its exact sum)
 
     def launch_sampled_multi(self, refs: List[hb.ReferenceInputs], axes, seeds: List[int]):
         """``refs_per_launch`` references through ONE fused call, each on its own stream (per_reference_rng)."""
@@ -758,6 +803,23 @@ def run_dense_pipeline(
                     dev_parts.append((res.xyz[lo:hi].clone(), res.rgb[lo:hi].clone(), res.err[lo:hi].clone()))
                     emit(li, pk, None, None, None, None, dev_parts[-1])
 
+        pend_norm: List[Tuple[int, _PackedReference, hb.ReferenceInputs, object, object]] = []   # default sampled mode: aggregated map on its way to the host
+
+        def promote_one() -> None:
+            """The oldest reference whose aggregated map has reached the host: upstream's normaliser from it, then its fused call."""
+            li, pk, rf, ax_, handle = pend_norm.pop(0)
+            try:
+                s_up = hot.finish_normaliser(handle)
+                inflight.append((li, pk, hot.launch_sampled(rf, ax_, None, s_override=s_up, batch=handle[0])))
+            except Exception as ex:
+                log.error(f"Triangulation error for ref {pk.ref_uid}: {ex}")
+
+        def drain_pipelined() -> None:
+            while pend_norm:
+                promote_one()
+            while inflight:
+                finish_one()
+
         def finish_one() -> None:
             """Collect the oldest launched reference (sampled mode) and emit it: references are emitted in launch order."""
             li, pk, handle = inflight.pop(0)
@@ -827,6 +889,21 @@ def run_dense_pipeline(
                     flush_group()
                 continue
             flush_group()
+            if hot.can_pipeline_normaliser(want_debug, per_ref_rng, int(H), int(W)):
+                # upstream's normaliser (the default) without a host wait in the launch stream: this reference's aggregated map starts
+                # its way to the host; the reference before it - whose map has arrived meanwhile - gets its sum and its fused launch; the
+                # one before that is collected.  The fused calls are issued in reference order: one MT19937 stream, as upstream.
+                try:
+                    pend_norm.append((local_i, packed, ref, axes, hot.begin_normaliser(ref, axes)))
+                except Exception as ex:
+                    log.error(f"Triangulation error for ref {packed.ref_uid}: {ex}")
+                while len(pend_norm) > 1:
+                    promote_one()
+                while len(inflight) > 1:
+                    finish_one()
+                continue
+            while pend_norm:            # (a run that leaves the pipelined mode - a debug preview switched on - first issues what is pending, in order)
+                promote_one()
             if hot.can_launch_ahead(want_debug, per_ref_rng, int(H), int(W)):
                 # reference i is launched (asynchronously, counts read back behind an event) BEFORE reference i-1 is collected:
                 # the host side of one reference - packing, descriptor upload, Python - runs under the kernels of the other
@@ -853,8 +930,7 @@ def run_dense_pipeline(
             dev_parts.append((out.xyz.clone(), out.rgb.clone(), out.err.clone()))
             emit(local_i, packed, None, None, None, dbg, dev_parts[-1])
         flush_group()
-        while inflight:
-            finish_one()
+        drain_pipelined()
         flush_dense()
     except BaseException as exc:
         if world == 1:

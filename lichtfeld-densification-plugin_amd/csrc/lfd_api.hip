@@ -118,17 +118,21 @@ int slot_events(lfd_context* ctx, LfdBatchSlot& sl) {
     return LFD_OK;
 }
 
-// Build refs|slots|extra into one blob and find it a slot: a slot that already holds these tables is reused as it is; otherwise the
-// blob is uploaded - by a launch into the slot of the last launch, on the launch stream (stream order protects the kernels still
-// reading it); by lfd_prepare_batch (`ahead`) into the OTHER slot, on the preparation stream, behind the event that marks the end
+// Build refs|slots|fundamental matrices into one blob and find it a slot: a slot that already holds these tables is reused as it is;
+// otherwise the blob is uploaded - by a launch into the slot of the last launch, on the launch stream (stream order protects the kernels
+// still reading it); by lfd_prepare_batch (`ahead`) into the OTHER slot, on the preparation stream, behind the event that marks the end
 // of that slot's last user - so that it runs beside the kernels of the batch before it.
+// `extra` (the selection offsets of lfd_triangulate_indexed) is NOT part of what is cached and compared: it sits behind the tables and
+// is uploaded on its own, on the launch stream, by the launch that brings it - so a batch staged by lfd_prepare_batch serves the indexed
+// entry point as well (round 3 kept the offsets inside the blob: a staged batch then never matched).
 int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, size_t n_extra, bool ahead, int* slot_out, hipStream_t* stream_out,
                   const LfdRefDesc** d_refs, const LfdSlotDesc** d_slots, const long long** d_extra, const float** d_fund) {
     const size_t nr = (size_t)b->n_refs, ns = nr * (size_t)b->k;
     const size_t off_slots = (nr * sizeof(LfdRefDesc) + 15) & ~size_t(15);
-    const size_t off_extra = (off_slots + ns * sizeof(LfdSlotDesc) + 15) & ~size_t(15);
-    const size_t off_fund = (off_extra + n_extra * sizeof(long long) + 15) & ~size_t(15);
-    const size_t total = off_fund + (b->fundamental ? ns * 9 * sizeof(float) : 0);
+    const size_t off_fund = (off_slots + ns * sizeof(LfdSlotDesc) + 15) & ~size_t(15);
+    const size_t total = (off_fund + (b->fundamental ? ns * 9 * sizeof(float) : 0) + 15) & ~size_t(15);       // what is cached
+    const size_t off_extra = total;
+    const size_t extra_room = ((nr + 1) * sizeof(long long) + 15) & ~size_t(15);                              // always reserved: [n_refs + 1] offsets
     std::vector<unsigned char> blob(total, 0);
     LfdRefDesc* refs = reinterpret_cast<LfdRefDesc*>(blob.data());
     LfdSlotDesc* slots = reinterpret_cast<LfdSlotDesc*>(blob.data() + off_slots);
@@ -150,8 +154,8 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
             if (s.mask_b) refs[r].any_mask = 1;
         }
     }
-    if (n_extra) std::memcpy(blob.data() + off_extra, extra, n_extra * sizeof(long long));
     if (b->fundamental) std::memcpy(blob.data() + off_fund, b->fundamental, ns * 9 * sizeof(float));
+    if (n_extra * sizeof(long long) > extra_room) return fail(ctx, LFD_ERR_INVALID, "internal: selection offsets beyond the reserved room");
 
     int si = -1;
     for (int c = 0; c < 2; ++c) {
@@ -185,13 +189,13 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
             LFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.ready, 0));
             sl.ready_pending = false;
         }
-        rc = ensure(ctx, sl.desc, total);
+        rc = ensure(ctx, sl.desc, total + extra_room);
         if (rc != LFD_OK) return rc;
-        if (sl.pinned_bytes < total) {
+        if (sl.pinned_bytes < total + extra_room) {
             if (sl.pinned_in_flight) { LFD_HIP(ctx, hipEventSynchronize(sl.pinned_free)); sl.pinned_in_flight = false; }
             if (sl.pinned) LFD_HIP(ctx, hipHostFree(sl.pinned));
             sl.pinned = nullptr;
-            sl.pinned_bytes = std::max<size_t>(total * 2, 1 << 16);
+            sl.pinned_bytes = std::max<size_t>((total + extra_room) * 2, 1 << 16);
             LFD_HIP(ctx, hipHostMalloc(&sl.pinned, sl.pinned_bytes, hipHostMallocDefault));
         }
         if (sl.pinned_in_flight) { LFD_HIP(ctx, hipEventSynchronize(sl.pinned_free)); sl.pinned_in_flight = false; }
@@ -203,6 +207,24 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
         sl.consts_valid = false;
     }
     LfdBatchSlot& sl = ctx->slot[si];
+    if (n_extra) {
+        // this launch's selection offsets, behind the tables: a few dozen bytes, on the launch stream (the launch that reads them follows
+        // in the same stream; an earlier launch that read the previous offsets precedes the copy in it)
+        if (sl.desc.bytes < total + extra_room) return fail(ctx, LFD_ERR_STATE, "internal: batch slot without room for the selection offsets");
+        if (sl.x_in_flight) { LFD_HIP(ctx, hipEventSynchronize(sl.x_free)); sl.x_in_flight = false; }      // (the previous indexed launch into this slot: long through)
+        if (sl.pinned_x_bytes < extra_room) {
+            if (sl.pinned_x) LFD_HIP(ctx, hipHostFree(sl.pinned_x));
+            sl.pinned_x = nullptr;
+            sl.pinned_x_bytes = std::max<size_t>(extra_room * 2, 4096);
+            LFD_HIP(ctx, hipHostMalloc(&sl.pinned_x, sl.pinned_x_bytes, hipHostMallocDefault));
+        }
+        if (!sl.x_free) LFD_HIP(ctx, hipEventCreateWithFlags(&sl.x_free, hipEventDisableTiming));
+        std::memcpy(sl.pinned_x, extra, n_extra * sizeof(long long));
+        LFD_HIP(ctx, hipMemcpyAsync(static_cast<unsigned char*>(sl.desc.ptr) + off_extra, sl.pinned_x, n_extra * sizeof(long long), hipMemcpyHostToDevice,
+                                    ctx->stream));
+        LFD_HIP(ctx, hipEventRecord(sl.x_free, ctx->stream));
+        sl.x_in_flight = true;
+    }
     *slot_out = si;
     *stream_out = st;
     *d_refs = reinterpret_cast<const LfdRefDesc*>(sl.desc.ptr);
@@ -449,7 +471,8 @@ void lfd_destroy(lfd_context* ctx) {
         if (sl.desc.ptr) (void)hipFree(sl.desc.ptr);
         if (sl.consts.ptr) (void)hipFree(sl.consts.ptr);
         if (sl.pinned) (void)hipHostFree(sl.pinned);
-        for (hipEvent_t ev : {sl.pinned_free, sl.ready, sl.idle}) if (ev) (void)hipEventDestroy(ev);
+        if (sl.pinned_x) (void)hipHostFree(sl.pinned_x);
+        for (hipEvent_t ev : {sl.pinned_free, sl.ready, sl.idle, sl.x_free}) if (ev) (void)hipEventDestroy(ev);
     }
     for (hipEvent_t ev : ctx->kt_start) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->kt_stop) (void)hipEventDestroy(ev);

@@ -30,6 +30,10 @@ struct LfdBatchSlot {
     size_t pinned_bytes = 0;
     hipEvent_t pinned_free = nullptr;      // behind the upload that last read `pinned`
     bool pinned_in_flight = false;
+    void* pinned_x = nullptr;              // host staging of the selection offsets (lfd_triangulate_indexed), uploaded apart from the tables
+    size_t pinned_x_bytes = 0;
+    hipEvent_t x_free = nullptr;           // behind the upload that last read `pinned_x`
+    bool x_in_flight = false;
     hipEvent_t ready = nullptr;            // behind upload + setup issued on the preparation stream
     bool ready_pending = false;            // ... which the launch stream has not been told to wait for yet
     hipEvent_t idle = nullptr;             // on the launch stream, where the launch AFTER this slot's last user begins ...

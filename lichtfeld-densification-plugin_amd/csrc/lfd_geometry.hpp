@@ -197,6 +197,13 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
 #ifndef LFD_PACK_ROWS
 #define LFD_PACK_ROWS 0     /* bit 0: the reference view's DLT rows as packed f32 operations, bit 1: the neighbour's.  Measured: the packed forms need 2-6 registers more than the geometry loop has (scratch in the loop: 0.333-0.384 ms against 0.315), profiles/r2/ablation.txt */
 #endif
+#ifndef LFD_PARALLAX_EXACT
+#define LFD_PARALLAX_EXACT 4      /* upstream's own parallax sequence (normalised rays).  1: IEEE sqrtf, one IEEE reciprocal + three Markstein quotients per ray
+                                     on the device; 2: six IEEE divisions; 3: one-correction-step root / reciprocal (lfd_sqrt_rn_f32 ...); 4 (default): 3, run only
+                                     for cells within a derived rounding band of the threshold - everywhere else the cross-multiplied comparison provably is the
+                                     same decision; 0: the cross-multiplied test of rounds 1-3 alone.  Kernel time on the bench workload against 0: 1 +7.4 %,
+                                     2 +9.6 %, 3 +4.1 % (profiles/r4/ab_parallax_v1.txt, ab_parallax_v2.txt), 4: ab_parallax_v3.txt */
+#endif
 #ifndef LFD_NULLVEC_TOL
 /* direction change (relative, on x_i/x_3) of the last solve that counts as settled.  The change measures the error of the
  * PREVIOUS iterate; the one returned is q = (sigma4/sigma3)^2 times closer: within 1e-8 of v4 for sigma4/sigma3 <= 0.1.
@@ -421,6 +428,30 @@ LFD_HD float lfd_sqrt_f32(float x) {
 #endif
 }
 
+// Correctly rounded f32 square root / reciprocal from the hardware's 1-ulp instructions and ONE correction step (device only; for finite,
+// normal, positive x - the callers' arguments).  s = v_sqrt(x) is within an ulp; the residual x - s^2 is exact in an fma, and
+// s + (x - s^2) / (2 s) is the true root to ~2^-46, so its rounding is the correctly rounded root unless the root lies that close to a
+// rounding boundary.  The reciprocal likewise: one Newton step on v_rcp.
+LFD_HD float lfd_sqrt_rn_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float h = 0.5f * __builtin_amdgcn_rcpf(s);
+    const float r = fmaf(-s, s, x);
+    const float c = fmaf(r, h, s);
+    return (x > 0.0f && x < 3.0e38f) ? c : s;                   // zero, infinity, NaN, negative: the instruction's own (IEEE) answer
+#else
+    return sqrtf(x);
+#endif
+}
+LFD_HD float lfd_rcp_rn_f32(float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y = __builtin_amdgcn_rcpf(b);
+    return fmaf(fmaf(-b, y, 1.0f), y, y);
+#else
+    return 1.0f / b;
+#endif
+}
+
 // squared reprojection distance (core/geometry.py:91-104 without the final hypot: the caller takes ONE square
 // root of the larger of the two views' squares, which equals max(sqrt, sqrt) because sqrt is monotone)
 LFD_HD float lfd_reproj_sq(const float* P, float X0, float X1, float X2, float X3, float u, float v, float& pz) {
@@ -542,15 +573,71 @@ LFD_HD void lfd_eval_correspondence(const LfdRefConst& rc, const LfdPairConst& p
     }
     bool keep = (err <= kp.reproj_thresh) && (z1 > 0.0f) && (z2 > 0.0f);
     if (keep && kp.use_parallax) {
-        // core/geometry.py:113-119 normalises both rays and compares their dot product; here the same test is
-        // cross-multiplied: a.b <= dot_thresh * (|a| + 1e-12) * (|b| + 1e-12)  (no per-component divisions).  The two
-        // forms differ by a few f32 ulp of the dot product, i.e. only where upstream's own rounding decides.
         const float a0 = X0 - rc.C[0], a1 = X1 - rc.C[1], a2 = X2 - rc.C[2];
         const float b0 = X0 - pc.C[0], b1 = X1 - pc.C[1], b2 = X2 - pc.C[2];
+#if LFD_PARALLAX_EXACT
+        // Upstream's OWN operation sequence (core/geometry.py:113-119), operation for operation in f32: both rays normalised by
+        // (norm + 1e-12) - np.linalg.norm is sqrt((x0^2 + x1^2) + x2^2), every product and sum rounded - the three products of the
+        // unit rays summed in order, and the angle test as a comparison of that dot product with the largest f32 whose
+        // degrees(arccos(.)) is still >= min_deg (lfd_parallax_dot_threshold: clip / arccos / degrees are monotone).  For the same X
+        // the decision then is upstream's, bit for bit.  Round 3 tested  a.b <= thr (|a| + 1e-12)(|b| + 1e-12)  instead (no divisions):
+        // the two forms round differently in the last few ulp of the dot product, and with the whole ring scene within 0.1 degrees of
+        // the 0.5 degree threshold that decided 82 % of the cells the kernel and upstream disagreed on (profiles/parallax_attribution.py:
+        // 60 of 73 flips in 524 288 cells).  sqrtf and the reciprocals are the IEEE operations on both builds.
+#if LFD_PARALLAX_EXACT >= 3 && defined(__HIP_DEVICE_COMPILE__)
+        // the square root, the reciprocal and the quotients from the 1-ulp hardware instructions + one correction step each (lfd_sqrt_rn_f32,
+        // lfd_rcp_rn_f32, Markstein): on all 5.0e8 f32 values in [2^-20, 2^40) the reciprocal and the quotients ARE the IEEE results and the
+        // root differs on 30 values (profiles/microbench/rn_check.hip, profiles/r4/rn_check.txt), at a third of the instructions of the
+        // compiler's IEEE expansions (scaling for denormals and overflow, which squared ray lengths of a scene never are)
+        const float ss_a = (a0 * a0 + a1 * a1) + a2 * a2, ss_b = (b0 * b0 + b1 * b1) + b2 * b2;
+#if LFD_PARALLAX_EXACT == 4
+        // ... and only where it can matter.  The cross-multiplied form  a.b <= thr |a||b|  (1-ulp roots, no divisions) agrees with upstream's
+        // sequence whenever the two sides are farther apart than the rounding of BOTH evaluations can move them: the dot product of two
+        // nearly parallel rays has three positive terms (<= 3 x 2^-24 relative), each norm <= 3.5 x 2^-24, their product and the threshold
+        // one rounding each; upstream's normalised dot product <= 9 x 2^-24 - together below 1.3e-6 relative.  Outside a band of 2e-6 the
+        // cheap comparison IS upstream's decision; inside it (0.9 % of the cells of the ring scene, a lane of one wave step in six) the exact
+        // sequence below runs.  Tiny rays (the 1e-12 of upstream's norms would show) and NaN fall through to it as well.
+        const float nn = lfd_sqrt_f32(ss_a) * lfd_sqrt_f32(ss_b);
+        const float dotc = (a0 * b0 + a1 * b1) + a2 * b2;
+        const float rhs = kp.dot_thresh * nn, slack = 2e-6f * nn;
+        const bool sure_keep = (dotc < rhs - slack) && (nn > 1e-6f), sure_drop = (dotc > rhs + slack) && (nn > 1e-6f);
+        if (sure_keep || sure_drop) {
+            keep = sure_keep;
+        } else
+#endif
+        {
+        const float na = lfd_sqrt_rn_f32(ss_a) + 1e-12f;
+        const float nb = lfd_sqrt_rn_f32(ss_b) + 1e-12f;
+        const float ra = lfd_rcp_rn_f32(na), rb = lfd_rcp_rn_f32(nb);
+        const float ua0 = lfd_div_by_recip_f32(a0, na, ra), ua1 = lfd_div_by_recip_f32(a1, na, ra), ua2 = lfd_div_by_recip_f32(a2, na, ra);
+        const float ub0 = lfd_div_by_recip_f32(b0, nb, rb), ub1 = lfd_div_by_recip_f32(b1, nb, rb), ub2 = lfd_div_by_recip_f32(b2, nb, rb);
+        const float dot = (ua0 * ub0 + ua1 * ub1) + ua2 * ub2;
+        keep = dot <= kp.dot_thresh;
+        }
+#else
+        const float na = sqrtf((a0 * a0 + a1 * a1) + a2 * a2) + 1e-12f;
+        const float nb = sqrtf((b0 * b0 + b1 * b1) + b2 * b2) + 1e-12f;
+#if LFD_PARALLAX_EXACT == 2 || !defined(__HIP_DEVICE_COMPILE__)
+        const float ua0 = a0 / na, ua1 = a1 / na, ua2 = a2 / na;
+        const float ub0 = b0 / nb, ub1 = b1 / nb, ub2 = b2 / nb;
+#else
+        // one correctly rounded reciprocal per ray, three Markstein quotients from it: q' = RN(q + (a - b q) r) with r = RN(1/b) is the
+        // correctly rounded a / b (exact for every b whose significand is not all ones, i.e. all but 2^-23 of the norms)
+        const float ra = 1.0f / na, rb = 1.0f / nb;
+        const float ua0 = lfd_div_by_recip_f32(a0, na, ra), ua1 = lfd_div_by_recip_f32(a1, na, ra), ua2 = lfd_div_by_recip_f32(a2, na, ra);
+        const float ub0 = lfd_div_by_recip_f32(b0, nb, rb), ub1 = lfd_div_by_recip_f32(b1, nb, rb), ub2 = lfd_div_by_recip_f32(b2, nb, rb);
+#endif
+        const float dot = (ua0 * ub0 + ua1 * ub1) + ua2 * ub2;
+        keep = dot <= kp.dot_thresh;                  // == degrees(arccos(clip(dot, -1, 1))) >= min_deg; a NaN rejects in both forms
+#endif
+#else
+        // the same test cross-multiplied (no per-component divisions):  a.b <= dot_thresh * (|a| + 1e-12) * (|b| + 1e-12).  Differs from
+        // upstream's form by a few f32 ulp of the dot product.
         const float na = lfd_sqrt_f32((a0 * a0 + a1 * a1) + a2 * a2) + 1e-12f;
         const float nb = lfd_sqrt_f32((b0 * b0 + b1 * b1) + b2 * b2) + 1e-12f;
         const float dot = (a0 * b0 + a1 * b1) + a2 * b2;
-        keep = dot <= kp.dot_thresh * (na * nb);      // == degrees(arccos(clip(dot/(na nb),-1,1))) >= min_deg
+        keep = dot <= kp.dot_thresh * (na * nb);
+#endif
     }
     o.keep = keep ? 1 : 0;
 }

@@ -1,8 +1,9 @@
 #!/bin/bash
 # dense kernel on the other BASELINE.json configurations (synthetic stand-ins, same generator as bench.py)
+# (round 4: steady state - 400 steps after the spin-up, the dense kernel's own start / stop events - not the 30-step runs of round 3, which sat inside the clock transient)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 run() {
-  python $REPO/bench.py --light --steps 30 "$@" 2>&1 | python -c "
+  python $REPO/bench.py --light --steps ${LFD_OTHER_STEPS:-400} --cpu-sample-refs 0 --parity-refs 0 "$@" 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

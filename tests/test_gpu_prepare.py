@@ -104,3 +104,39 @@ def test_kernel_timing_reports_each_timed_launch_and_changes_nothing():
     assert dens.dense_kernel_times_ms().size == 0
     dens.check_launches()
     dens.close()
+
+
+def test_a_staged_batch_serves_the_indexed_entry_point_too():
+    """lfd_triangulate_indexed used to put its selection offsets INTO the cached table blob, so a batch staged by lfd_prepare_batch never
+    matched its launch (re-upload in the launch stream, the other slot's tables evicted).  The offsets now travel apart from the cached tables: staged
+    or not, the same result - and the slot staged for batch B still serves B after an indexed launch of batch A went through the other slot."""
+    dev = torch.device("cuda:0")
+    H = W = 128
+    cams = synthetic.ring_cameras(60, seed=0)
+    ga, gb = _refs(dev, cams, [0, 7, 14], 3, H, W), _refs(dev, cams, [3, 33], 3, H, W)
+    params = hb.make_params(lfd.DensePipelineConfig(output_path=""))
+    g = torch.Generator().manual_seed(1)
+    sel_a = [torch.sort(torch.randperm(H * W, generator=g)[:700]).values for _ in ga]
+    sel_b = [torch.sort(torch.randperm(H * W, generator=g)[:500]).values for _ in gb]
+
+    def run(prepare):
+        d = hb.HipDensifier(dev)
+        d.upload_cameras(cams)
+        ba, bb = hb.PreparedBatch(ga, W, H, cameras=cams), hb.PreparedBatch(gb, W, H, cameras=cams)
+        res = []
+        for rep in range(3):
+            for batch, sels in ((ba, sel_a), (bb, sel_b)):
+                if prepare:
+                    d.prepare(batch, params)
+                offs = np.concatenate([[0], np.cumsum([int(s.numel()) for s in sels])]).tolist()
+                if rep == 1:                      # other offsets for the same tables: only the offsets change
+                    sels = [s[:300] for s in sels]
+                    offs = np.concatenate([[0], np.cumsum([300] * len(sels))]).tolist()
+                o = d.triangulate_indexed(batch, params, torch.cat(sels).to(dev), offs)
+                res.append((o.count, o.xyz.clone(), o.rgb.clone(), o.err.clone(), o.ref_offsets.copy()))
+        d.close()
+        return res
+    plain, staged = run(False), run(True)
+    assert len(plain) == 6 and plain[0][0] > 500
+    for p, s in zip(plain, staged):
+        assert p[0] == s[0] and np.array_equal(p[4], s[4]) and torch.equal(p[1], s[1]) and torch.equal(p[2], s[2]) and torch.equal(p[3], s[3])

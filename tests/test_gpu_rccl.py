@@ -95,7 +95,7 @@ def test_bench_exchange_legs_through_rccl_on_one_rank():
     env = dict(os.environ, LFD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     for extra in ([], ["--exchange", "gather_to_root", "--exchange-records", "f32", "--exchange-rounds", "3"]):
-        cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "config4", "--refs", "4",
+        cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "config4", "--refs", "6",
                "--preset", "turbo", "--light", "--spinup-s", "0.05"] + extra
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
         assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
