@@ -241,12 +241,12 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16, cams_for_hot=None)
                 r0, h0 = pend.pop(0)
                 fly.append(hot.launch_sampled(r0, None, None, s_override=hot.finish_normaliser(h0), batch=h0[0]))
             while len(fly) > 1:
-                pts3 += fly.pop(0)[1].collect(indexed=True, check_selection=True).count
+                pts3 += getattr(hot.finish_sampled(fly.pop(0)), 'count', 0)
         while pend:
             r0, h0 = pend.pop(0)
             fly.append(hot.launch_sampled(r0, None, None, s_override=hot.finish_normaliser(h0), batch=h0[0]))
         while fly:
-            pts3 += fly.pop(0)[1].collect(indexed=True, check_selection=True).count
+            pts3 += getattr(hot.finish_sampled(fly.pop(0)), 'count', 0)
         torch.cuda.synchronize()
         dt3 = time.perf_counter() - t0
     res["default_config_ms_per_reference"] = dt3 / len(todo) * 1e3
@@ -273,6 +273,30 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16, cams_for_hot=None)
                       "pairs_per_s": reps * G * args.k / dtg, "points_per_s": ptsg / dtg,
                       "note": "per-reference MT19937 streams (sharded runs): the group's selections run side by side"}
     return res
+
+
+def unordered_rate(args, dens, batch, params, out, H, W, algo_bytes, launches=100):
+    """The same kernel with UNORDERED retirement (lfd_triangulate_dense_segments, opt-in: no look-back, one atomic per tile, a tile table for the
+    consumers that restore raster order): its own start / stop events over `launches` back-to-back launches of the headline batch."""
+    n = batch.n_refs
+    if out.capacity < n * H * W:
+        return None
+    tpr = (H * W + 1023) // 1024
+    table = torch.zeros((n * tpr, 2), dtype=torch.int32, device=dens.device)
+    counts = torch.zeros((n,), dtype=torch.int64, device=dens.device)
+    for _ in range(16):
+        dens.launch_dense_segments(batch, params, out, table, counts)
+    dens.time_dense_kernels(launches)
+    for _ in range(launches):
+        dens.launch_dense_segments(batch, params, out, table, counts)
+    ms = dens.dense_kernel_times_ms()
+    dens.time_dense_kernels(0)
+    dens.check_launches()
+    k_ms = float(np.mean(ms))
+    return {"kernel": "lfd_dense_segments_kernel", "kernel_ms": k_ms, "achieved": algo_bytes / (k_ms * 1e-3) / 1e9, "frac": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "survivors": int(counts.sum().item()),
+            "note": "opt-in (DensePipelineConfig.dense_tile_segments): tiles claim output room with one atomic instead of the ordered look-back; lfd_order_segments / "
+                    "lfd_pack_*_segments restore raster order from the tile table (bit-identical result, tests/test_gpu_segments.py; their cost: profiles/r4/ab_segments_v3_chunk_index.txt)"}
 
 
 def device_copy_bandwidth(dev, n_bytes=1 << 30, reps=10):
@@ -877,6 +901,8 @@ def main():
         line["roofline"]["valu_busy_frac"] = valu_busy_frac(args)     # the f64 geometry makes the kernel vector-ALU-bound, not HBM-bound (same source as `traffic`)
         line["roofline"]["valu"] = valu_roofline(args, kernel_ms)      # ... and that bound itself: issue time of the vector instructions / kernel time
         line["roofline"]["traffic_over_algorithmic"] = (line["roofline"]["traffic"] / algo_bytes) if line["roofline"]["traffic"] else None
+        if not args.light and world == 1:
+            line["unordered_retirement"] = unordered_rate(args, dens, batch, params, out, H, W, algo_bytes)
         if not args.light and world == 1:     # the side legs (and the CPU baseline) belong to the N = 1 line; at N > 1 the other ranks are waiting
             line["with_d2h"] = d2h_inclusive_rate(dens, batch, params, out, dev)
             line["sampled_mode"] = sampled_mode_rate(args, dens, refs, dims, cfg, cams_for_hot=cams)

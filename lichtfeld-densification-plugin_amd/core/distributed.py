@@ -324,12 +324,16 @@ class OverlappedExchange:
     ``record``: RECORD_F32 - ``records`` is an (n, 7) float32 tensor; RECORD_PLY - an (n * 15,) uint8 tensor of device-packed PLY records.
     ``finish()`` returns ``(records, counts)``: the records of ALL references in global reference order - the 1-rank sequence - as one tensor
     of the same kind ((N, 7) float32 / (N * 15,) uint8; on every rank for ``all_gather``, on ``root`` for ``gather_to_root``, where the other
-    ranks get their own shard back) and the (n_refs_global,) survivor counts."""
+    ranks get their own shard back) and the (n_refs_global,) survivor counts.
+
+    ``form="counts_only"``: nothing but the counts travels - every rank keeps its own shard and learns, round by round, where its references
+    sit in the global sequence (``_round_known`` is called with each round's table: ``SharedFilePlyStream`` writes its byte ranges of the
+    output file from there).  ``finish()`` then returns this rank's own records and the global counts."""
 
     def __init__(self, dist, n_refs_global: int, refs_per_round: int, device, form: str = "all_gather", record: str = RECORD_F32,
                  group=None, root: int = 0):
-        if form not in ("all_gather", "gather_to_root"):
-            raise ValueError("form must be 'all_gather' or 'gather_to_root'")
+        if form not in ("all_gather", "gather_to_root", "counts_only"):
+            raise ValueError("form must be 'all_gather', 'gather_to_root' or 'counts_only'")
         if record not in (RECORD_F32, RECORD_PLY):
             raise ValueError("record must be 'f32' or 'ply'")
         self.dist, self.group, self.root = dist, group, int(root)
@@ -392,8 +396,9 @@ class OverlappedExchange:
         # the gathered counts as a host table: a few dozen integers (under RCCL their copy is ordered behind the collective by wait())
         table = st["counts_out"].cpu().view(self.world, self.B).numpy().copy()
         st["table"] = table
+        self._round_known(c, table, st)
         rows = int(table.sum(axis=1).max())
-        if rows == 0:
+        if rows == 0 or self.form == "counts_only":
             return
         padded = torch.zeros((rows, self.cols), dtype=self.dtype, device=self.dev)
         if st["n_local"]:
@@ -412,6 +417,9 @@ class OverlappedExchange:
                                               group=self.group, async_op=True)
             else:
                 st["work"] = self.dist.gather(padded, None, dst=_global_rank(self.dist, self.group, self.root), group=self.group, async_op=True)
+
+    def _round_known(self, c: int, table: np.ndarray, st: dict) -> None:
+        """Hook: the counts of round ``c`` of every rank (``table[rank, j]``) have arrived (called in round order)."""
 
     def finish(self):
         """Close what is left (every rank runs ``n_rounds`` rounds), wait for the collectives, return the ordered records and counts."""
@@ -432,7 +440,7 @@ class OverlappedExchange:
                     g = r + (c * self.B + j) * self.world
                     if g < self.n_refs:
                         global_counts[g] = st["table"][r, j]
-        have_all = self.form == "all_gather" or self.rank == self.root
+        have_all = self.form == "all_gather" or (self.form == "gather_to_root" and self.rank == self.root)
         if not have_all:            # gather_to_root, another rank: its own shard, untouched
             own = [st["payload"] for st in self._rounds if st["n_local"]]
             mine = torch.cat(own, 0) if own else torch.empty((0, self.cols), dtype=self.dtype, device=self.home)
@@ -473,3 +481,83 @@ def points_from_ply_records(records: torch.Tensor):
     xyz = rec[:, :12].contiguous().view(torch.float32).reshape(-1, 3)
     rgb = rec[:, 12:15].to(torch.float32) / 255.0
     return xyz, rgb
+
+
+class SharedFilePlyStream(OverlappedExchange):
+    """The exchange-free streamed output of a sharded run on ONE node (a file system every rank sees): only the per-reference COUNTS cross a
+    link.  Every rank packs its finished references' 15-byte PLY records on its own GPU; when the counts of a round are known (one small
+    asynchronous all-gather per round, a round behind the compute like every OverlappedExchange) it knows the byte offset of each of its
+    references in the global reference order and writes them there itself (``os.pwrite``) - N ranks copy over N PCIe links and write N
+    disjoint byte ranges of one file; no survivor crosses xGMI.  Rank ``root`` creates the file (the fixed-width header of
+    ``StreamedPlyWriter``) before anybody writes and patches the vertex count into it at the end.  File bytes = the 1-rank ``write_ply``
+    output (``tests/test_distributed_cpu.py::test_shared_file_stream...``).  No upstream counterpart."""
+
+    def __init__(self, dist, n_refs_global: int, refs_per_round: int, path: str, device, group=None, root: int = 0):
+        super().__init__(dist, n_refs_global, refs_per_round, device, form="counts_only", record=RECORD_PLY, group=group, root=root)
+        import os
+        from .writers import ensure_dir, streamed_ply_header
+        self.path = path
+        self._base = 0                    # records of the rounds already placed
+        self._data_offset = len(streamed_ply_header(0))
+        self.error: Optional[BaseException] = None
+        self._fd = None
+        if self.rank == self.root:
+            try:
+                ensure_dir(path)
+                with open(path, "wb") as fh:
+                    fh.write(streamed_ply_header(0))
+            except BaseException as exc:               # noqa: BLE001 - kept: the collectives below must still match on every rank
+                self.error = exc
+        dist.barrier(group=group)                      # the file exists before anybody opens it
+        try:
+            self._fd = os.open(path, os.O_RDWR)
+        except BaseException as exc:                   # noqa: BLE001
+            self.error = self.error or exc
+
+    def _round_known(self, c: int, table: np.ndarray, st: dict) -> None:
+        import os
+        # global order inside a round: local index first, then rank (g = rank + local * world)
+        order = [(j, r) for j in range(self.B) for r in range(self.world)]
+        pos = self._base
+        mine = {}
+        for j, r in order:
+            if r == self.rank:
+                mine[j] = pos
+            pos += int(table[r, j])
+        self._base = pos
+        if self._fd is None or self.error is not None or not st["n_local"]:
+            return
+        try:
+            payload = st["payload"].reshape(-1).cpu().numpy()
+            off = 0
+            for j in range(self.B):
+                n = int(st["local_counts"][j])
+                if n:
+                    os.pwrite(self._fd, payload[off * 15:(off + n) * 15].tobytes(), self._data_offset + 15 * mine[j])
+                    off += n
+        except BaseException as exc:                   # noqa: BLE001 - the rounds go on (the counts must stay matched); raised by finish()
+            self.error = exc
+
+    def finish(self):
+        import os
+        recs, counts = super().finish()
+        if self._fd is not None:
+            try:
+                os.fsync(self._fd)
+            except OSError:
+                pass
+            os.close(self._fd)
+            self._fd = None
+        self.dist.barrier(group=self.group)            # every byte range is in place
+        if self.rank == self.root and self.error is None:
+            from .writers import streamed_ply_header
+            try:
+                with open(self.path, "r+b") as fh:     # the vertex count, patched into the fixed-width header
+                    fh.write(streamed_ply_header(int(counts.sum())))
+                    if int(counts.sum()) == 0:
+                        fh.truncate(self._data_offset)
+            except BaseException as exc:               # noqa: BLE001
+                self.error = exc
+        if self.error is not None:
+            raise self.error
+        return recs, counts

@@ -94,12 +94,26 @@ class _KeyedDescriptor(torch.nn.Module):
         except AttributeError:
             return getattr(super().__getattr__("inner"), name)
 
+    @staticmethod
+    def _frozen(levels):
+        """What the cache keeps: an immutable snapshot of the per-level LIST.  The model rebinds entries of the list it is handed - in
+        bidirectional settings ``_compute_head_preds`` does ``head_input[-1] = f_list[-1] + f_mv + match_emb`` on the NEIGHBOUR's list
+        (RoMaV2/src/romav2/matcher.py:57-59,179-186), i.e. on the very object ``self.f(img_B)`` returned - so a cached list handed out as it
+        is would come back with its last level replaced (found by tests/golden/check_matcher_contract.py against the real class, `high`).
+        The tensors themselves are never written in place."""
+        return levels if isinstance(levels, torch.Tensor) else tuple(levels)
+
+    @staticmethod
+    def _fresh(kept):
+        """... and what a call receives: a new list over the same tensors."""
+        return kept if isinstance(kept, torch.Tensor) else list(kept)
+
     def forward(self, img):
         if self.key is None or self.cache is None:
             return self.inner(img)
         variant = (int(img.shape[-2]), int(img.shape[-1]))
         if not isinstance(self.key, (list, tuple)):
-            return self.cache.get_or_compute(self.key, lambda: self.inner(img), variant=variant)
+            return self._fresh(self.cache.get_or_compute(self.key, lambda: self._frozen(self.inner(img)), variant=variant))
         # a batch of images, one key each (several pairs per forward): the cameras seen before come from the cache, the others go
         # through the backbone together - ONE pass - and are kept sample by sample
         keys = list(self.key)
@@ -113,7 +127,7 @@ class _KeyedDescriptor(torch.nn.Module):
             levels = [out] if self._returns_tensor else list(out)
             for j, i in enumerate(miss):
                 mine = [t[j:j + 1] for t in levels]
-                kept = mine[0] if self._returns_tensor else mine          # the same form the one-image path keeps
+                kept = mine[0] if self._returns_tensor else tuple(mine)          # the same (frozen) form the one-image path keeps
                 vals[i] = self.cache.store(keys[i], kept, variant) if keys[i] is not None else kept
         per_image = [[v] if isinstance(v, torch.Tensor) else list(v) for v in vals]
         stacked = [torch.cat([v[lv] for v in per_image], 0) for lv in range(len(per_image[0]))]

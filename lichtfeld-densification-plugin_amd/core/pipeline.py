@@ -447,10 +447,18 @@ class _HotPath:
         if device_seed is not None and not self.config.no_filter:
             self.dens.seed_rng(device_seed)
         M = self.config.matches_per_ref
-        out = hb.OutputBuffers(int(M) + 24 * 24 + 64, 1, batch.k, self.dev)
+        out = self._take_buffers(int(M) + 24 * 24 + 64, 1, batch.k)
         self.dens.launch_sampled(batch, self.params, M, out, cap=self.sample_cap, border=2, tiles=24, s_override=float(s_override))
         out.begin_collect(self.dens.stream)
         return batch, out
+
+    def _take_buffers(self, capacity: int, n_refs: int, k: int) -> hb.OutputBuffers:
+        """Survivor buffers of the fused sampled calls, recycled: a fresh OutputBuffers costs two device allocations and - on its first
+        read-back - a pinned host allocation (hipHostMalloc: milliseconds), per reference; ``finish_sampled`` hands a buffer back once the
+        reference's survivors have been copied out of it."""
+        pool = self.__dict__.setdefault("_buf_pool", {})
+        free = pool.setdefault((int(capacity), int(n_refs), int(k)), [])
+        return free.pop() if free else hb.OutputBuffers(int(capacity), int(n_refs), int(k), self.dev)
 
     # -- upstream's normaliser without stalling the launch stream ---------------------------------------------------------------
     def can_pipeline_normaliser(self, need_best: bool, per_ref_rng: bool, H: int, W: int) -> bool:
@@ -500,17 +508,25 @@ class _HotPath:
         """``refs_per_launch`` references through ONE fused call, each on its own stream (per_reference_rng)."""
         batch = hb.PreparedBatch(refs, self.w_match, self.h_match, axes=axes, cameras=self.cams)
         M = self.config.matches_per_ref
-        out = hb.OutputBuffers(len(refs) * (int(M) + 24 * 24 + 64), len(refs), batch.k, self.dev)
+        out = self._take_buffers(len(refs) * (int(M) + 24 * 24 + 64), len(refs), batch.k)
         self.dens.launch_sampled_multi(batch, self.params, M, out, seeds, cap=self.sample_cap, border=2, tiles=24)
         out.begin_collect(self.dens.stream)
         return batch, out
 
     def finish_sampled(self, handle) -> Optional[hb.TriangulationOutput]:
+        """Wait for the reference's counts, copy its survivors out of the (recycled) buffers: the result owns trimmed tensors."""
         _batch, out = handle
-        res = out.collect(indexed=True, check_selection=True)
-        if res.launch_status != 0:
-            self.dens.check_launches()
-        return res if res.count else None
+        try:
+            res = out.collect(indexed=True, check_selection=True)
+            if res.launch_status != 0:
+                self.dens.check_launches()
+            if not res.count:
+                return None
+            return dataclasses.replace(res, xyz=res.xyz.clone(), rgb=res.rgb.clone(), err=res.err.clone(),
+                                       cell=res.cell.clone() if res.cell is not None else None,
+                                       slot=res.slot.clone() if res.slot is not None else None, _packed=None)
+        finally:
+            self.__dict__.setdefault("_buf_pool", {}).setdefault((out.capacity, out._n_refs, out._k), []).append(out)
 
     def pack_ply_tensor(self, xyz: torch.Tensor, rgb: torch.Tensor) -> torch.Tensor:
         """The same records as a uint8 tensor that stays where the points are (what a sharded run sends to the writer rank)."""
@@ -640,12 +656,21 @@ def run_dense_pipeline(
                      and int(config.max_points) <= 0 and float(config.voxel_size) <= 0.0)
     xchg: Optional[lfd_dist.OverlappedExchange] = None
     xchg_result = None
+    shared_file: Optional[lfd_dist.SharedFilePlyStream] = None
     if world > 1:
-        if stream_wanted:
+        # The streamed output runs on a process group OF ITS OWN: its messages (point-to-point sends to rank 0, or its rounds of counts) and
+        # the rounds of the overlapped exchange are issued in different orders on different ranks (a rank with fewer references closes its
+        # last rounds in finish()), and operations on ONE communicator are matched - under RCCL also executed - in issue order.
+        stream_group = dist.new_group() if stream_wanted else None
+        if stream_wanted and bool(getattr(config, "stream_shared_file", False)):
+            # exchange-free streamed output on one node: only counts travel, every rank writes its own byte ranges of the file
+            per_round = int(getattr(config, "exchange_round", 0)) or max(int(config.refs_per_launch), 4)
+            shared_file = lfd_dist.SharedFilePlyStream(dist, len(refs_local), per_round, config.output_path, dev, group=stream_group)
+        elif stream_wanted:
             # sharded streamed output (BASELINE config 5): every rank packs its finished references' records on the device, rank 0 appends
             # them to the file in global reference order as they arrive.  Rank 0 opens the file inside the try: if that fails it still
             # receives (and drops) what the others send.
-            shard_stream = lfd_dist.ShardedPlyStream(dist, len(refs_local), None, dev)
+            shard_stream = lfd_dist.ShardedPlyStream(dist, len(refs_local), None, dev, group=stream_group)
         if bool(getattr(config, "exchange_overlap", True)):
             rec = str(getattr(config, "exchange_records", "f32"))
             if rec == "auto":
@@ -688,7 +713,7 @@ def run_dense_pipeline(
         inflight: List[Tuple[int, _PackedReference, object]] = []                       # sampled mode: launched, not yet read back
         if on_sequential_viz and viz_interval > 0 and intermediate_base:
             cum_body = CumulativePlyBody()
-        if stream_wanted:
+        if stream_wanted and shared_file is None:
             if rank == 0:
                 stream_writer = StreamedPlyWriter(config.output_path)
                 if shard_stream is not None:
@@ -703,12 +728,14 @@ def run_dense_pipeline(
             counts_local[local_i] = int(xyz.shape[0]) if xyz is not None else int(dev_pts[0].shape[0])
             refs_with_points += 1
             packed_t = None
-            if shard_stream is not None or (xchg is not None and xchg.record == lfd_dist.RECORD_PLY):
+            if shard_stream is not None or shared_file is not None or (xchg is not None and xchg.record == lfd_dist.RECORD_PLY):
                 packed_t = (hot.pack_ply_tensor(dev_pts[0], dev_pts[1]) if dev_pts is not None
                             else torch.from_numpy(ply_records(xyz, to_uint8_rgb(rgb)).view(np.uint8).reshape(-1).copy()))
             if shard_stream is not None:
                 # sharded streamed output: the records stay where they were packed until they travel to rank 0
                 shard_stream.push(local_i, packed_t)
+            if shared_file is not None:
+                shared_file.push(local_i, packed_t)      # ... or until this rank writes them into its own byte range of the file
             if xchg is not None:
                 # the overlapped exchange: this reference's records join the round being filled; a round that is complete leaves in an
                 # asynchronous collective while the next batch computes
@@ -792,7 +819,7 @@ def run_dense_pipeline(
                         log.error(f"Triangulation error for ref {pk.ref_uid}: {ex1}")
                         continue
                     if one is not None:
-                        dev_parts.append((one.xyz.clone(), one.rgb.clone(), one.err.clone()))
+                        dev_parts.append((one.xyz, one.rgb, one.err))
                         emit(li, pk, None, None, None, None, dev_parts[-1])
                 return
             if res is None:
@@ -830,9 +857,9 @@ def run_dense_pipeline(
                 return
             if res is None:
                 return
-            # the survivors stay where they are: the trimmed device copy is what the previews, the streamed output, the exchange and
-            # the device-side writers consume; the host arrays of the result are ONE copy at the end of the run
-            dev_parts.append((res.xyz.clone(), res.rgb.clone(), res.err.clone()))
+            # the survivors stay where they are: the trimmed device copy (finish_sampled) is what the previews, the streamed output, the exchange
+            # and the device-side writers consume; the host arrays of the result are ONE copy at the end of the run
+            dev_parts.append((res.xyz, res.rgb, res.err))
             emit(li, pk, None, None, None, None, dev_parts[-1])
 
         for local_i, packed in enumerate(prefetch):
@@ -959,6 +986,13 @@ def run_dense_pipeline(
                 log.error(f"The sharded output stream failed: {exc}")
                 if rank_status == 0:
                     rank_status, rank_error = 2, exc
+        if shared_file is not None:
+            try:
+                shared_file.finish()          # the rounds that are left, the last byte ranges, the vertex count in the header (rank 0)
+            except Exception as exc:
+                log.error(f"The shared-file output stream failed: {exc}")
+                if rank_status == 0:
+                    rank_status, rank_error = 2, exc
         if xchg is not None:
             try:
                 xchg_result = xchg.finish()   # closes the rounds that are left (empty ones on a rank that stopped early) and waits for the collectives
@@ -1042,4 +1076,4 @@ def run_dense_pipeline(
     return PipelineResult(xyz=xyz, rgb=rgb, err=err, elapsed_seconds=time.time() - t0,
                           pairs_processed=refs_with_points, pairs_matched=pair_counter, points_per_reference=counts,
                           device_points=device_points,
-                          streamed_path=config.output_path if (stream_writer is not None or shard_stream is not None) else None)
+                          streamed_path=config.output_path if (stream_writer is not None or shard_stream is not None or shared_file is not None) else None)

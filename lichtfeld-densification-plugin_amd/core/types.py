@@ -96,6 +96,9 @@ class DensePipelineConfig:
     # ``err`` zero - the written file is the same bytes); "auto": "ply" when the output is a .ply and no voxel filter has to see f32
     # colours, else "f32".  Only used by the overlapped exchange of a sharded run.
     exchange_records: str = "f32"
+    # sharded run + stream_output on ONE node: every rank writes its own byte ranges of the output file (core/distributed.py::SharedFilePlyStream) -
+    # only the per-reference counts cross a link - instead of sending its records to rank 0 (ShardedPlyStream).  Needs a file system all ranks see.
+    stream_shared_file: bool = False
     # dense mode: the kernel with UNORDERED retirement (lfd_triangulate_dense_segments: no look-back, ~6 % less kernel time); raster order is
     # restored from the tile table by lfd_order_segments (bit-identical result).  Opt-in.
     dense_tile_segments: bool = False

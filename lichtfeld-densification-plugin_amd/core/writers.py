@@ -57,26 +57,34 @@ def write_points3D_bin(path_out: str, xyz: np.ndarray, rgb_uint8: np.ndarray,
         rec.tofile(f)
 
 
+_STREAM_COUNT_WIDTH = 12
+
+
+def streamed_ply_header(n: int) -> bytes:
+    """Upstream's PLY header with the vertex count in a FIXED width (PLY allows comment lines: one pads the count), so that the data offset
+    does not depend on the count and the count can be patched in at the end.  What StreamedPlyWriter / SharedFilePlyStream write."""
+    head = ply_header(0).decode("ascii")
+    prefix = "ply\nformat binary_little_endian 1.0\n"
+    rest = head.split("element vertex 0\n", 1)[1]
+    count = str(int(n))
+    pad = "x" * (_STREAM_COUNT_WIDTH - len(count))
+    return (prefix + f"comment {pad}\n" + f"element vertex {count}\n" + rest).encode("ascii")
+
+
 class StreamedPlyWriter:
     """Append survivor segments as they complete; the vertex count in the header is patched on close
     (the header is padded so its length does not depend on the count)."""
 
-    _COUNT_WIDTH = 12
+    _COUNT_WIDTH = _STREAM_COUNT_WIDTH
 
     def __init__(self, path_out: str):
         ensure_dir(path_out)
         self._f = open(path_out, "wb")
         self._n = 0
-        head = ply_header(0).decode("ascii")
-        self._prefix = "ply\nformat binary_little_endian 1.0\n"
-        self._rest = head.split("element vertex 0\n", 1)[1]
         self._f.write(self._header_bytes(0))
 
     def _header_bytes(self, n: int) -> bytes:
-        # PLY allows comment lines: pad with one so the data offset is fixed
-        count = str(int(n))
-        pad = "x" * (self._COUNT_WIDTH - len(count))
-        return (self._prefix + f"comment {pad}\n" + f"element vertex {count}\n" + self._rest).encode("ascii")
+        return streamed_ply_header(n)
 
     def append(self, xyz: np.ndarray, rgb_uint8: np.ndarray) -> None:
         ply_records(xyz, rgb_uint8).tofile(self._f)

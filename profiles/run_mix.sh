@@ -20,7 +20,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if row["Kernel_Name"].startswith("lfd_dense"):
+        if row["Kernel_Name"].startswith("lfd_dense_kernel"):
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     v = acc[k]; print(f"{k:32s} n={len(v):3d} mean={sum(v)/len(v):.6g}")

@@ -238,3 +238,47 @@ def test_a_writer_that_fails_on_rank_0_drains_the_peers_and_raises_afterwards():
         assert p.exitcode == 0
     assert results[0][1] == "disk full" and results[0][2] == 2          # the error, once; the writer was not called again
     assert results[1][1] is None and results[2][1] is None
+
+
+# ---- exchange-free streamed output: only counts travel, every rank writes its own byte ranges of the file ---------------------------------
+def _shared_file_worker(rank, world, port, n_refs, per_round, path, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts, pts = _make_points(n_refs, seed=3)
+        mine = lfd_dist.shard_references(n_refs, rank, world)
+        st = lfd_dist.SharedFilePlyStream(dist, n_refs, per_round, path, torch.device("cpu"))
+        for i, g in enumerate(mine):
+            if counts[g]:
+                st.push(i, torch.from_numpy(np.ascontiguousarray(pts[g].view(np.uint8).reshape(-1, 28)[:, :15]).reshape(-1)))
+        recs, gcounts = st.finish()
+        q.put((rank, int(recs.numel()), gcounts))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_refs,world,per_round", [(7, 2, 2), (10, 3, 1), (5, 4, 3), (2, 3, 1)])
+def test_shared_file_stream_writes_the_single_writer_file(n_refs, world, per_round, tmp_path):
+    from lichtfeld_densification_plugin_amd.core.writers import StreamedPlyWriter
+    path = os.path.join(str(tmp_path), "out", "shared.ply")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_file_worker, args=(r, world, port, n_refs, per_round, path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    counts, pts = _make_points(n_refs, seed=3)
+    for rank, n_bytes, gcounts in results:
+        np.testing.assert_array_equal(gcounts, counts)
+        assert n_bytes == 15 * sum(counts[g] for g in lfd_dist.shard_references(n_refs, rank, world))      # every rank keeps its own shard
+    ref = os.path.join(str(tmp_path), "single.ply")
+    with StreamedPlyWriter(ref) as w:
+        for g in range(n_refs):
+            if counts[g]:
+                w.append_packed(np.ascontiguousarray(pts[g].view(np.uint8).reshape(-1, 28)[:, :15]).tobytes())
+    assert open(path, "rb").read() == open(ref, "rb").read()

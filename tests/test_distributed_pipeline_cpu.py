@@ -57,11 +57,13 @@ def _rank(rank, world, port, tmp, cfg_kw, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,exchange,overlap", [("sampled", "all_gather", True), ("sampled", "gather_to_root", True), ("dense", "gather_to_root", True),
-                                                   ("dense", "all_gather", True), ("sampled", "all_gather", False), ("dense", "gather_to_root", False)])
-def test_two_host_ranks_equal_one_and_stream_the_same_file(g4, tmp_path, mode, exchange, overlap):
+@pytest.mark.parametrize("mode,exchange,overlap,shared", [("sampled", "all_gather", True, False), ("sampled", "gather_to_root", True, False),
+                                                          ("dense", "gather_to_root", True, False), ("dense", "all_gather", True, True),
+                                                          ("sampled", "all_gather", False, False), ("dense", "gather_to_root", False, True)])
+def test_two_host_ranks_equal_one_and_stream_the_same_file(g4, tmp_path, mode, exchange, overlap, shared):
     """``overlap``: the exchange in rounds beside the compute (OverlappedExchange, rounds of ONE reference here so that several rounds run)
-    or the one exchange after the last reference"""
+    or the one exchange after the last reference; ``shared``: the streamed file written by both ranks into their own byte ranges (only counts travel)
+    instead of sent to rank 0"""
     import torch.multiprocessing as mp
     from lichtfeld_densification_plugin_amd.core import writers
     from lichtfeld_densification_plugin_amd.core.image_io import to_uint8_rgb
@@ -75,7 +77,7 @@ def test_two_host_ranks_equal_one_and_stream_the_same_file(g4, tmp_path, mode, e
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     out = os.path.join(tmp, "sharded.ply")
-    cfg_kw = dict(output_path=out, exchange=exchange, stream_output=True, exchange_overlap=overlap, exchange_round=1, **kw)
+    cfg_kw = dict(output_path=out, exchange=exchange, stream_output=True, exchange_overlap=overlap, exchange_round=1, stream_shared_file=shared, **kw)
     procs = [ctx.Process(target=_rank, args=(r, 2, port, tmp, cfg_kw, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -11,7 +11,8 @@ differently from the oracle (= upstream's arithmetic on this machine):
     f32 rounding noise (f64 SVD of the same f32 matrix, f64 reprojection / depth / angle), widened by the first-order
     bound of ONE f32 evaluation of that formula  (oracle.classify_flips states the band per reject reason).
 
-Zero flips outside the band are allowed, on any shape; the flip RATE is also bounded at 2x what was measured.
+Zero flips outside the band are allowed, on any shape; the flip RATE is also bounded at 2x what was measured (round 4, with the parallax test
+evaluated by upstream's own operation sequence: 0 .. 6.7e-5 per shape, 2.2e-5 overall - profiles/r4/flip_table.txt; rounds 1-3: 1-1.5e-4).
 The kernels receive upstream's own fundamental matrices (lfd_batch.fundamental), so the Sampson gate has no band at all
 beyond f64 association order (1e-12).
 """
@@ -31,30 +32,30 @@ pytestmark = pytest.mark.gpu
 SHAPES = {
     # BASELINE config 2, GUI defaults: fast 512^2, k=3, reproj 0.8
     "fast_k3_gui": dict(cams=(185, 1297, 840, 960.0), grid=(512, 512, 512, 512), k=3, refs=(0, 60), noise=0.5, outl=0.05,
-                        patch=None, reproj=0.8, sample=None, rate=3e-4),
+                        patch=None, reproj=0.8, sample=None, rate=1.4e-4),
     # BASELINE config 2, CLI defaults: k=4, reproj 1.5 (densify.py:318-415)
     "fast_k4_cli": dict(cams=(185, 1297, 840, 960.0), grid=(512, 512, 512, 512), k=4, refs=(30,), noise=1.0, outl=0.05,
-                        patch=None, reproj=1.5, sample=None, rate=3e-4),
+                        patch=None, reproj=1.5, sample=None, rate=1.2e-4),
     # BASELINE config 3: `high` = 960^2 grid over 640-px match images, bicycle-sized cameras, 10 % gross outliers and a
     # patch whose parallax falls through 0.5 degrees
     "high_k3_patch": dict(cams=(194, 1237, 822, 915.0), grid=(960, 960, 640, 640), k=3, refs=(10,), noise=1.0, outl=0.10,
-                          patch=(0.3, 0.6, 0.2, 0.8), reproj=0.8, sample=None, rate=4e-4),
+                          patch=(0.3, 0.6, 0.2, 0.8), reproj=0.8, sample=None, rate=1.2e-4),
     # BASELINE config 4, one rank's shape: fast, 8 neighbours, several references in one launch
     "fast_k8_multi": dict(cams=(185, 1297, 840, 960.0), grid=(512, 512, 512, 512), k=8, refs=(5, 90, 150), noise=0.5, outl=0.05,
-                          patch=None, reproj=0.8, sample=None, rate=3e-4),
+                          patch=None, reproj=0.8, sample=None, rate=1.2e-4),
     # BASELINE config 5: `precise` = 1280^2 grid over 800-px match images, 8 neighbours, ROI subset of 12 cameras
     "precise_k8_roi": dict(cams=(12, 1297, 840, 960.0), grid=(1280, 1280, 800, 800), k=8, refs=(5,), noise=0.5, outl=0.05,
-                           patch=None, reproj=0.8, sample=None, rate=3e-4),
+                           patch=None, reproj=0.8, sample=None, rate=1.2e-4),
     # wide baselines (40 cameras on the ring: 9 degrees apart, parallax 5-10 degrees - the parallax test is out of play), 1.5 px of
     # matching noise around the 0.8 px reprojection threshold, and a second neighbour that looks SIDEWAYS (yawed by 70 degrees), so
     # that its principal plane cuts through the visible ground: depths in that view pass through zero and the reprojection blows up
     # next to it.  Here the reprojection and cheirality tests decide, and their bands carry the weight.
     "wide_k2_plane": dict(cams=(40, 1297, 840, 960.0), grid=(512, 512, 512, 512), k=2, refs=(3, 21), noise=1.5, outl=0.05,
-                          patch=None, reproj=0.8, sample=None, rate=3e-4, yaw_nbr=70.0, expect=("reproj", "cheirality")),
+                          patch=None, reproj=0.8, sample=None, rate=1.2e-4, yaw_nbr=70.0, expect=("reproj", "cheirality")),
     # masks on the reference and on every neighbour + upstream's four-channel warps [xA yA xB yB]: the masked four-cells-at-a-time
     # front end and the four-channel loads of the dense kernel at full size (core/pipeline.py:405-430)
     "fast_k3_masks_c4": dict(cams=(185, 1297, 840, 960.0), grid=(512, 512, 512, 512), k=3, refs=(40, 100), noise=0.5, outl=0.05,
-                             patch=None, reproj=0.8, sample=None, rate=3e-4, masks=True, channels=4),
+                             patch=None, reproj=0.8, sample=None, rate=1.2e-4, masks=True, channels=4),
 }
 
 

@@ -241,3 +241,43 @@ def test_several_pairs_per_forward_equal_one_pair_per_forward(monkeypatch, share
             assert len(a) == len(b)
             for (wa, ca), (wb, cb) in zip(a, b):
                 assert torch.equal(wa, wb) and torch.equal(ca, cb)
+
+
+class _RebindingStubRoMa(_StubRoMa):
+    """... whose forward REBINDS the last level of the neighbour's feature list, as the real model does in bidirectional settings
+    (``_compute_head_preds``: ``head_input = f_list; head_input[-1] = f_list[-1] + ...`` on the list ``self.f(img_B_lr)`` returned,
+    RoMaV2/src/romav2/matcher.py:57-59,179-186)."""
+
+    def _forward_from_features(self, f_list_A, img_A_lr, img_B_lr):
+        f_b = self.f(img_B_lr)
+        shift = (f_list_A[0] - f_b[0]).mean()
+        f_b[-1] = f_b[-1] + 1000.0                    # what the head's input assembly does to the caller's list
+        warp = torch.zeros((1, self.H_lr, self.W_lr, 2), device=img_B_lr.device) + shift
+        return {"warp_AB": warp, "overlap_AB": torch.full((1, self.H_lr, self.W_lr, 1), 0.5, device=img_B_lr.device)}
+
+
+def test_cached_features_survive_a_model_that_rebinds_its_feature_lists(monkeypatch):
+    """Round 4, found by tests/golden/check_matcher_contract.py on the real class (`high`): a cached per-level list handed out as it is came
+    back from a bidirectional forward with its last level replaced, and the camera's next use was matched on the wrong features.  The cache
+    keeps an immutable snapshot and every call gets a fresh list."""
+    from PIL import Image
+    stub = types.ModuleType("romav2")
+    stub.RoMaV2 = _RebindingStubRoMa
+    monkeypatch.setitem(sys.modules, "romav2", stub)
+    from lichtfeld_densification_plugin_amd.core import matcher as mm
+    rs = np.random.RandomState(5)
+    images = {i: Image.fromarray(rs.randint(0, 256, (40, 48, 3)).astype(np.uint8)) for i in range(3)}
+    work = [(0, [1, 2]), (1, [0, 2]), (2, [0, 1])]
+
+    def run(keys):
+        m = mm.RomaMatcher(device="cpu", setting="turbo")
+        if keys:
+            m.set_feature_cache(FeatureCache({0: 9, 1: 9, 2: 9}))
+        return [m.match_grids_batch(images[r], [images[n] for n in nbrs], **({"keys": (r, nbrs)} if keys else {})) for r, nbrs in work], m.model.backbone_calls
+
+    plain, calls_plain = run(False)
+    shared, calls_shared = run(True)
+    assert calls_plain == 9 and calls_shared == 3
+    for a, b in zip(plain, shared):
+        for (wa, ca), (wb, cb) in zip(a, b):
+            assert torch.equal(wa, wb) and torch.equal(ca, cb)
