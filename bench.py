@@ -299,6 +299,28 @@ def unordered_rate(args, dens, batch, params, out, H, W, algo_bytes, launches=10
                     "lfd_pack_*_segments restore raster order from the tile table (bit-identical result, tests/test_gpu_segments.py; their cost: profiles/r4/ab_segments_v3_chunk_index.txt)"}
 
 
+def ply_output_rate(args, dens, batch, params, H, W, cells, s_frac, launches=100):
+    """The same kernel writing the file payload itself (lfd_triangulate_dense_ply: 15-byte PLY vertex records instead of the 28-byte arrays): its own
+    start / stop events, against lfd_triangulate_dense + lfd_pack_ply - the pair it replaces for a consumer that writes or ships the PLY."""
+    n = batch.n_refs
+    rec = torch.empty((n * H * W * 15,), dtype=torch.uint8, device=dens.device)
+    offs = torch.zeros((n + 1,), dtype=torch.int64, device=dens.device)
+    for _ in range(16):
+        dens.launch_dense_ply(batch, params, rec, offs)
+    dens.time_dense_kernels(launches)
+    for _ in range(launches):
+        dens.launch_dense_ply(batch, params, rec, offs)
+    ms = dens.dense_kernel_times_ms()
+    dens.time_dense_kernels(0)
+    dens.check_launches()
+    k_ms = float(np.mean(ms))
+    bytes_ply = cells * (4 * args.k + 11 + 15 * s_frac)
+    return {"kernel": "lfd_dense_ply_kernel", "kernel_ms": k_ms, "bytes_per_cell": 4 * args.k + 11 + 15 * s_frac, "achieved": bytes_ply / (k_ms * 1e-3) / 1e9,
+            "frac": bytes_ply / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "survivors": int(offs[-1].item()),
+            "note": "15-byte records from the kernel itself: replaces lfd_triangulate_dense + lfd_pack_ply (secondary_kernels.lfd_pack_ply_kernel.ms) where the consumer "
+                    "is the PLY writer / the exchange; bytes equal the packer's (tests/test_gpu_segments.py)"}
+
+
 def device_copy_bandwidth(dev, n_bytes=1 << 30, reps=10):
     """HBM bytes moved per second by a device-to-device copy of 1 GiB (read + write counted), the practical ceiling beside the
     8 TB/s of the data sheet."""
@@ -903,6 +925,7 @@ def main():
         line["roofline"]["traffic_over_algorithmic"] = (line["roofline"]["traffic"] / algo_bytes) if line["roofline"]["traffic"] else None
         if not args.light and world == 1:
             line["unordered_retirement"] = unordered_rate(args, dens, batch, params, out, H, W, algo_bytes)
+            line["ply_output"] = ply_output_rate(args, dens, batch, params, H, W, cells, s_frac)
         if not args.light and world == 1:     # the side legs (and the CPU baseline) belong to the N = 1 line; at N > 1 the other ranks are waiting
             line["with_d2h"] = d2h_inclusive_rate(dens, batch, params, out, dev)
             line["sampled_mode"] = sampled_mode_rate(args, dens, refs, dims, cfg, cams_for_hot=cams)

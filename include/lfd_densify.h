@@ -143,6 +143,14 @@ int lfd_aggregate(lfd_context* ctx, const lfd_batch* batch, const lfd_params* pa
 int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params,
                           const lfd_points* out, int64_t* ref_offsets, int32_t* seg_counts);
 
+/* The same kernel writing the FILE PAYLOAD itself: survivors leave as 15-byte PLY vertex records (x y z f32 LE, r g b u8 quantised like
+ * upstream's to_uint8_rgb - what lfd_pack_ply makes of lfd_triangulate_dense's arrays, byte for byte) in raster order per reference, so a run
+ * whose consumer is the PLY writer (streamed output, the exchange of a sharded run) needs no packing pass and writes 15 instead of 28 bytes
+ * per survivor.  records: device u8 [capacity * 15]; the reprojection error is not part of a PLY vertex and is not produced; cell / slot:
+ * optional as in the lfd_points structure - NULL to skip.  Replaces core/pipeline.py:753-780 + core/writers.py:29-46 for that consumer. */
+int lfd_triangulate_dense_ply(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, uint8_t* records, int64_t capacity,
+                              int64_t* ref_offsets, int32_t* seg_counts, int32_t* cell, uint8_t* slot);
+
 /* The same kernel with UNORDERED RETIREMENT (opt-in; the default entry point above stays ordered).  The ordered kernel makes a tile wait
  * for the survivor counts of every tile before it (a decoupled look-back: a fifth of a tile's life on the benchmark shape); here a tile
  * claims room with ONE atomic on its reference's cursor and records where it went:
@@ -274,6 +282,10 @@ float lfd_parallax_dot_threshold(float min_deg);
  * (core/geometry.py:122-130). */
 int lfd_host_fundamental(const float* K1, const float* R1, const float* t1, const float* K2,
                          const float* R2, const float* t2, float* F_out);
+/* Upstream's sampling weights before their normalisation (core/sampling.py:13,23-26): out = min(cert, cap) * inside(border) in f32, one pass,
+ * element by element the values torch.clamp(max=cap) * inside.float() gives (NaN propagates).  Host arrays [H*W].  The Python mirror sums them
+ * with torch (upstream's own reduction) for the `upstream_normaliser` of the device selection. */
+int lfd_host_capped_border_weights(const float* cert, int32_t H, int32_t W, float cap, int32_t border, float* out);
 /* Smallest right singular vector of a row-major 4x4 f32 matrix, the routine the kernels triangulate with
  * (f64 inverse iteration on A^T A), on the HOST build of the same source; out4 is un-normalised.  Returns the
  * number of solves made (>= 3) or a negative lfd_status.  CPU unit tests compare it with an f64 SVD. */

@@ -92,6 +92,8 @@ def load_library() -> C.CDLL:
     lib.lfd_aggregate.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p, C.c_void_p]
     lib.lfd_triangulate_dense.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.POINTER(lfd_points),
                                           C.c_void_p, C.c_void_p]
+    lib.lfd_triangulate_dense_ply.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]
     lib.lfd_dense_tiles_per_ref.argtypes = [C.c_int32, C.c_int32]
     lib.lfd_triangulate_dense_segments.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.POINTER(lfd_points),
                                                    C.c_void_p, C.c_void_p, C.c_void_p]
@@ -136,12 +138,14 @@ def load_library() -> C.CDLL:
     lib.lfd_parallax_dot_threshold.argtypes = [C.c_float]
     lib.lfd_parallax_dot_threshold.restype = C.c_float
     lib.lfd_host_fundamental.argtypes = [fptr] * 7
+    lib.lfd_host_capped_border_weights.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
+    lib.lfd_host_capped_border_weights.restype = C.c_int
     lib.lfd_host_null_vector.argtypes = [fptr, C.POINTER(C.c_double)]
     lib.lfd_host_null_vector.restype = C.c_int
     lib.lfd_host_eval_correspondence.argtypes = [fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                                  C.c_int32, C.POINTER(lfd_params), fptr]
     for name in ("lfd_create", "lfd_set_stream", "lfd_reload_env", "lfd_kernel_timing", "lfd_kernel_timing_read", "lfd_upload_cameras", "lfd_prepare_batch", "lfd_aggregate", "lfd_triangulate_dense",
-                 "lfd_dense_tiles_per_ref", "lfd_triangulate_dense_segments", "lfd_order_segments", "lfd_pack_ply_segments", "lfd_pack_points3d_segments",
+                 "lfd_triangulate_dense_ply", "lfd_dense_tiles_per_ref", "lfd_triangulate_dense_segments", "lfd_order_segments", "lfd_pack_ply_segments", "lfd_pack_points3d_segments",
                  "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_triangulate_sampled_multi", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
                  "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_identity_axis",
                  "lfd_host_fundamental", "lfd_get_pair_fundamental", "lfd_create_host", "lfd_aggregate_host",
@@ -228,6 +232,15 @@ def fundamental_from_world2cam(K1, R1, t1, K2, R2, t2) -> np.ndarray:
     cross = np.array([[0, -tz, ty], [tz, 0, -tx], [-ty, tx, 0]], dtype=np.float32)
     E = cross @ R
     return np.linalg.inv(K2).T @ E @ np.linalg.inv(K1)
+
+
+def host_capped_border_weights(cert: np.ndarray, cap: float, border: int, out: np.ndarray) -> np.ndarray:
+    """out = min(cert, cap) * inside(border), f32, one pass (lfd_host_capped_border_weights): upstream's un-normalised sampling weights."""
+    H, W = cert.shape
+    rc = load_library().lfd_host_capped_border_weights(cert.ctypes.data, int(H), int(W), C.c_float(cap), int(border), out.ctypes.data)
+    if rc != 0:
+        raise HipBackendError("lfd_host_capped_border_weights failed")
+    return out
 
 
 def host_null_vector(A) -> "tuple[np.ndarray, int]":
@@ -730,6 +743,28 @@ class HipDensifier:
                                                     out.ref_offsets.data_ptr(),
                                                     out.seg_counts.data_ptr() if out.with_segments else None),
                     "lfd_triangulate_dense")
+
+    # -- the file payload straight from the kernel ----------------------------------------------------------------------------------------
+    def launch_dense_ply(self, batch: PreparedBatch, params: lfd_params, records: torch.Tensor, ref_offsets: torch.Tensor,
+                         seg_counts: Optional[torch.Tensor] = None) -> None:
+        """lfd_triangulate_dense_ply: ``records`` (uint8, capacity * 15) receives the 15-byte PLY vertex records of the survivors in raster
+        order per reference; ``ref_offsets`` (int64, n_refs + 1) their exclusive prefix.  Asynchronous."""
+        self._same_device(batch, None, records, ref_offsets, seg_counts)
+        if records.dtype != torch.uint8 or ref_offsets.dtype != torch.int64 or not records.is_contiguous():
+            raise ValueError("records must be a contiguous uint8 tensor, ref_offsets int64")
+        self._check(self._lib.lfd_triangulate_dense_ply(self._ctx, C.byref(batch.c), C.byref(params), records.data_ptr(), int(records.numel()) // 15,
+                                                        ref_offsets.data_ptr(), seg_counts.data_ptr() if seg_counts is not None else None, None, None),
+                    "lfd_triangulate_dense_ply")
+
+    def triangulate_dense_ply(self, batch: PreparedBatch, params: lfd_params):
+        """(PLY body as a uint8 device tensor, ref_offsets host int64): what pack_ply makes of triangulate_dense's result, from one kernel."""
+        cap = batch.n_refs * batch.H * batch.W
+        rec = torch.empty((max(cap * 15, 4),), dtype=torch.uint8, device=self.device)
+        offs = torch.zeros((batch.n_refs + 1,), dtype=torch.int64, device=self.device)
+        self.launch_dense_ply(batch, params, rec, offs)
+        self.check_launches()
+        h = offs.cpu().numpy()
+        return rec[:int(h[-1]) * 15], h
 
     # -- unordered retirement (opt-in): tiles claim room with one atomic, the consumers restore raster order from the tile table ------------
     def launch_dense_segments(self, batch: PreparedBatch, params: lfd_params, out: OutputBuffers, table: torch.Tensor,

@@ -17,6 +17,8 @@
 extern "C" __global__ void lfd_aggregate_kernel(LfdLaunch L, float* best_cert, uint8_t* best_slot);
 extern "C" __global__ void lfd_dense_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_dense_exact_kernel(LfdLaunch L);
+extern "C" __global__ void lfd_dense_ply_kernel(LfdLaunch L);
+extern "C" __global__ void lfd_dense_ply_exact_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_dense_segments_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_dense_segments_exact_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_segment_scan_kernel(const LfdTileSeg* table, int n_tiles, int tiles_per_ref, int n_refs, long long* tile_dst, long long* ref_offsets);
@@ -619,13 +621,17 @@ int lfd_aggregate(lfd_context* ctx, const lfd_batch* batch, const lfd_params* pa
 
 // the dense launch in its two forms: ordered (ref_offsets; ref_counts / table null) and unordered retirement (ref_counts + table)
 static int dense_launch(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, const lfd_points* out,
-                        int64_t* ref_offsets, int32_t* seg_counts, int64_t* ref_counts, lfd_tile_segment* table) {
+                        int64_t* ref_offsets, int32_t* seg_counts, int64_t* ref_counts, lfd_tile_segment* table, uint8_t* ply = nullptr) {
     const bool unordered = table != nullptr;
     LfdLaunch L;
     int rc = prepare_launch(ctx, batch, params, nullptr, 0, L, nullptr);
     if (rc != LFD_OK) return rc;
-    rc = check_points(ctx, out, reinterpret_cast<long long*>(unordered ? ref_counts : ref_offsets));
-    if (rc != LFD_OK) return rc;
+    if (ply) {                         // file-payload output: the records go to `ply`; out carries the capacity (and optionally cell / slot)
+        if (!out || out->capacity < 0 || !ref_offsets) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_dense_ply: out (capacity) and ref_offsets are required");
+    } else {
+        rc = check_points(ctx, out, reinterpret_cast<long long*>(unordered ? ref_counts : ref_offsets));
+        if (rc != LFD_OK) return rc;
+    }
     if (unordered && out->capacity < (int64_t)batch->n_refs * batch->H * batch->W)
         return fail(ctx, LFD_ERR_CAPACITY, "lfd_triangulate_dense_segments: capacity must be n_refs * H * W (every reference owns a region of H * W records)");
     const size_t n_tiles = (size_t)batch->n_refs * (size_t)L.tiles_per_ref;
@@ -640,6 +646,7 @@ static int dense_launch(lfd_context* ctx, const lfd_batch* batch, const lfd_para
     static_assert(sizeof(lfd_tile_segment) == sizeof(LfdTileSeg), "lfd_tile_segment is the kernels' LfdTileSeg");
     L.ref_cursor = reinterpret_cast<unsigned long long*>(ref_counts);      // (zeroed the same way)
     L.tile_table = reinterpret_cast<LfdTileSeg*>(table);
+    L.ply = ply;
     size_t extra_lds = 0;                     // profiling switch: dynamic LDS lowers the number of resident workgroups
     extra_lds = ctx->env.dense_extra_lds;
 #if defined(LFD_DENSE_TIMING)            // profiling builds: per-tile phase stamps, dumped to the file named by LFD_DENSE_TIMING
@@ -668,7 +675,8 @@ static int dense_launch(lfd_context* ctx, const lfd_batch* batch, const lfd_para
     if (rc != LFD_OK) return rc;
     hipEvent_t t_start = nullptr, t_stop = used_slot.idle;
     if (ctx->kt_used < ctx->kt_start.size()) { t_start = ctx->kt_start[ctx->kt_used]; t_stop = ctx->kt_stop[ctx->kt_used]; ++ctx->kt_used; }
-    auto kernel = unordered ? (exact_colour ? lfd_dense_segments_exact_kernel : lfd_dense_segments_kernel)
+    auto kernel = ply ? (exact_colour ? lfd_dense_ply_exact_kernel : lfd_dense_ply_kernel)
+                : unordered ? (exact_colour ? lfd_dense_segments_exact_kernel : lfd_dense_segments_kernel)
                             : (exact_colour ? lfd_dense_exact_kernel : lfd_dense_kernel);
     hipExtLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), (unsigned)extra_lds, ctx->stream, t_start, t_stop, 0, L);
     LFD_HIP(ctx, hipGetLastError());
@@ -688,6 +696,17 @@ static int dense_launch(lfd_context* ctx, const lfd_batch* batch, const lfd_para
 int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, const lfd_points* out,
                           int64_t* ref_offsets, int32_t* seg_counts) {
     return dense_launch(ctx, batch, params, out, ref_offsets, seg_counts, nullptr, nullptr);
+}
+
+int lfd_triangulate_dense_ply(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, uint8_t* records, int64_t capacity,
+                              int64_t* ref_offsets, int32_t* seg_counts, int32_t* cell, uint8_t* slot) {
+    if (ctx && !records) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_dense_ply: records is null");
+    lfd_points out;
+    std::memset(&out, 0, sizeof(out));
+    out.capacity = capacity;
+    out.cell = cell;
+    out.slot = slot;
+    return dense_launch(ctx, batch, params, &out, ref_offsets, seg_counts, nullptr, nullptr, records);
 }
 
 int lfd_dense_tiles_per_ref(int32_t H, int32_t W) {
@@ -1190,6 +1209,22 @@ static void unpack_cam(const float* v, LfdCam& c) {
     std::memcpy(c.K, v, 9 * 4); std::memcpy(c.R, v + 9, 9 * 4); std::memcpy(c.t, v + 18, 3 * 4);
     std::memcpy(c.P, v + 21, 12 * 4); std::memcpy(c.C, v + 33, 3 * 4);
     c.w = (int32_t)v[36]; c.h = (int32_t)v[37]; c.pad[0] = c.pad[1] = 0;
+}
+
+int lfd_host_capped_border_weights(const float* cert, int32_t H, int32_t W, float cap, int32_t border, float* out) {
+    if (!cert || !out || H <= 0 || W <= 0 || border < 0) return LFD_ERR_INVALID;
+    // (the inner loops are branch-free over contiguous spans, so that the host compiler vectorises them: compare + blend, 8-16 cells at a time)
+    const int x_lo = std::min(border, W), x_hi = std::max(x_lo, W - border);       // columns [x_lo, x_hi) are inside
+    for (int y = 0; y < H; ++y) {
+        const bool row_in = y >= border && y <= H - 1 - border;
+        const float* __restrict__ src = cert + (size_t)y * W;
+        float* __restrict__ dst = out + (size_t)y * W;
+        const int a = row_in ? x_lo : W, b = row_in ? x_hi : W;                      // [0, a) and [b, W) are outside: weight = clamp(c) * 0
+        for (int x = 0; x < a; ++x) dst[x] = (src[x] > cap ? cap : src[x]) * 0.0f;   // (not a plain 0: NaN * 0 and -inf * 0 are NaN upstream too)
+        for (int x = a; x < b; ++x) dst[x] = src[x] > cap ? cap : src[x];            // torch.clamp(max=cap) * 1: a NaN stays a NaN
+        for (int x = b; x < W; ++x) dst[x] = (src[x] > cap ? cap : src[x]) * 0.0f;
+    }
+    return LFD_OK;
 }
 
 int lfd_host_null_vector(const float* A16, double* out4) {

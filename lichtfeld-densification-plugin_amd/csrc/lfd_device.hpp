@@ -130,6 +130,8 @@ struct LfdLaunch {              // kernel argument, passed by value
     // one atomic on the reference's cursor and records where it went; no look-back.  Both null for the ordered kernels.
     unsigned long long* ref_cursor;     // [n_refs] survivors claimed so far per reference (zeroed by the workgroup of tile 0, like seg_counts)
     LfdTileSeg* tile_table;             // [n_refs * tiles_per_ref] {offset inside the reference's region, survivors} of every tile
+    // file-payload output (lfd_triangulate_dense_ply): 15-byte PLY vertex records [capacity * 15] instead of xyz / rgb / err (those are null then)
+    unsigned char* ply;
 };
 
 // ---- S: on-device coverage sampling (lfd_select.hip) ---------------------------------------------

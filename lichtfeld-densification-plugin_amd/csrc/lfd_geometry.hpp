@@ -836,6 +836,13 @@ __device__ __forceinline__ void lfd_bilinear_eval_f32(LfdTapRows t, unsigned sh0
 }
 #endif
 
+// upstream's colour quantisation (core/image_utils.py:24-26): np.clip(np.round(c * 255), 0, 255).astype(uint8) - f32 multiply, round half to even
+LFD_HD unsigned char lfd_quantise_u8(float c) {
+    const float v = rintf(c * 255.0f);
+    if (!(v == v)) return 0;                      // NaN -> 0 (the x86 float->int conversion upstream runs on)
+    return (unsigned char)fminf(fmaxf(v, 0.0f), 255.0f);
+}
+
 // ---- certainty prologue pieces (core/pipeline.py:361-382,405-430) --------------------------------
 LFD_HD float lfd_cert_floor(float c, float thresh) { return (c < thresh) ? thresh : c; }   // NaN stays NaN
 

@@ -501,7 +501,9 @@ constexpr int kCopyThreadsOrdered = kBlock - 64;
 // kUnordered (lfd_triangulate_dense_segments): no look-back.  A tile claims room in its reference's region of the output with one
 // atomic on the reference's cursor and records {offset, count} in the tile table; the consumers (lfd_order_segments, lfd_pack_*_segments)
 // walk the table and emit raster order.  Everything up to the retirement is the same code.
-template <bool kExactColour, bool kUnordered = false>
+// kPly (lfd_triangulate_dense_ply): the survivors leave as 15-byte PLY vertex records (xyz f32 LE + the colour quantised like upstream's
+// to_uint8_rgb) instead of the 28-byte structure of arrays: the packer's pass over the cloud disappears for streamed / exchanged output.
+template <bool kExactColour, bool kUnordered = false, bool kPly = false>
 __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
     // one LDS block, the per-pair constants first: S.pc[slot] is then addressed as slot * sizeof(LfdPairConst) + an instruction offset,
     // with no base to keep in a vector register across the geometry loop
@@ -973,6 +975,30 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
             long long room = L.capacity - base;          // beyond capacity: counted, not written
             int n = (int)block_total;
             if (room < (long long)n) n = room > 0 ? (int)room : 0;
+            if (kPly) {
+                // one record per thread and step: 12 bytes of position + 3 bytes of colour at byte 15 (base + i) - unaligned 12 / 2 / 1-byte
+                // stores; a wave's 64 records are 960 contiguous bytes of the file payload
+                unsigned char* gp = L.ply + 15 * base;
+#pragma unroll
+                for (int u = 0; u < kCopyRecords; ++u) {
+                    const int i = ctid + u * kCopyThreads;
+                    if (i < n) {
+                        const int sl = (int)stage_order[i];
+                        const float* sxyz = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(stage.xyz) + lfd_slot_bytes12(sl));
+                        struct __attribute__((packed, aligned(1))) F3u { float a, b, c; };
+                        struct __attribute__((packed, aligned(1))) U16u { unsigned short v; };
+                        F3u p; p.a = sxyz[0]; p.b = sxyz[1]; p.c = sxyz[2];
+                        const unsigned o15 = (unsigned)i * 15u;
+                        const unsigned q0 = lfd_quantise_u8(rgb[u][0]), q1 = lfd_quantise_u8(rgb[u][1]), q2 = lfd_quantise_u8(rgb[u][2]);
+                        *reinterpret_cast<F3u*>(gp + o15) = p;
+                        U16u rg; rg.v = (unsigned short)(q0 | (q1 << 8));
+                        *reinterpret_cast<U16u*>(gp + o15 + 12u) = rg;
+                        gp[o15 + 14u] = (unsigned char)q2;
+                        if (L.cell) L.cell[base + i] = tile_cell0 + sl;
+                        if (L.slot) L.slot[base + i] = stage.slot[sl];
+                    }
+                }
+            } else {
             unsigned char* gx = reinterpret_cast<unsigned char*>(L.xyz + 3 * base);
             unsigned char* gc = reinterpret_cast<unsigned char*>(L.rgb + 3 * base);
             unsigned char* ge = reinterpret_cast<unsigned char*>(L.err + base);
@@ -1004,6 +1030,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
             }
         }
 #endif
+            }
 #if defined(LFD_DENSE_TIMING)
         LFD_STAMP(10);
         if (L.phase_stamps && lane == 0 && wave < 2) {
@@ -1018,6 +1045,9 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
 // the same kernel with upstream's f64 colour arithmetic (bit-identical rgb; lfd_params.flags & LFD_FLAG_EXACT_COLOUR)
 extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_exact_kernel(LfdLaunch L) { lfd_dense_body<true>(L); }
 // unordered retirement (lfd_triangulate_dense_segments), both colour forms
+// file-payload output (lfd_triangulate_dense_ply), both colour forms
+extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_ply_kernel(LfdLaunch L) { lfd_dense_body<false, false, true>(L); }
+extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_ply_exact_kernel(LfdLaunch L) { lfd_dense_body<true, false, true>(L); }
 extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_segments_kernel(LfdLaunch L) { lfd_dense_body<false, true>(L); }
 extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_segments_exact_kernel(LfdLaunch L) { lfd_dense_body<true, true>(L); }
 

@@ -12,11 +12,7 @@
 
 namespace {
 
-__device__ __forceinline__ unsigned char quantise_u8(float c) {
-    const float v = rintf(c * 255.0f);            // np.round: half to even, in f32
-    if (!(v == v)) return 0;                      // NaN -> 0 (x86 float->int conversion upstream runs on)
-    return (unsigned char)fminf(fmaxf(v, 0.0f), 255.0f);
-}
+__device__ __forceinline__ unsigned char quantise_u8(float c) { return lfd_quantise_u8(c); }
 
 template <int REC>
 __device__ __forceinline__ void flush_records(const unsigned char* lds, unsigned char* out, long long first_point,

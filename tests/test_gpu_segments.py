@@ -98,3 +98,32 @@ def test_capacity_below_a_region_per_reference_is_refused(dev):
     with pytest.raises(hb.HipBackendError, match="capacity"):
         dens.launch_dense_segments(batch, hb.make_params(cfg), out, table, counts)
     dens.close()
+
+
+@pytest.mark.parametrize("name,exact", [("fast_k3_gui", False), ("fast_k3_gui", True), ("high_k3_patch", False), ("fast_k3_masks_c4", False), ("fast_k8_multi", False)])
+def test_dense_ply_kernel_writes_the_packers_bytes(dev, name, exact):
+    """lfd_triangulate_dense_ply: the kernel's own 15-byte records = lfd_pack_ply of lfd_triangulate_dense's arrays, byte for byte (the same
+    colour arithmetic, quantised like upstream's to_uint8_rgb), with the same per-reference offsets - and, with the f64 colour flag, the bytes of
+    upstream's writer for upstream's colours."""
+    spec = SHAPES[name]
+    H, W, wm, hm = spec["grid"]
+    cams, _srefs, refs = _scene(spec, dev)
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    cfg = lfd.DensePipelineConfig(output_path="", reproj_thresh=spec["reproj"], nns_per_ref=spec["k"])
+    params = hb.make_params(cfg, exact_colour=exact)
+    batch = hb.PreparedBatch(refs, wm, hm, cameras=cams)
+    ordered = dens.triangulate_dense(batch, params)
+    body, offs = dens.triangulate_dense_ply(batch, params)
+    np.testing.assert_array_equal(offs, ordered.ref_offsets)
+    assert torch.equal(body, dens.pack_ply(ordered.xyz, ordered.rgb))
+    # a buffer that is too small: counted, not written beyond
+    small = ordered.count // 2
+    rec = torch.full((small * 15 + 64,), 0xAB, dtype=torch.uint8, device=dev)
+    off2 = torch.zeros((batch.n_refs + 1,), dtype=torch.int64, device=dev)
+    dens._check(dens._lib.lfd_triangulate_dense_ply(dens._ctx, __import__("ctypes").byref(batch.c), __import__("ctypes").byref(params), rec.data_ptr(), small,
+                                                    off2.data_ptr(), None, None, None), "lfd_triangulate_dense_ply")
+    dens.check_launches()
+    np.testing.assert_array_equal(off2.cpu().numpy(), ordered.ref_offsets)           # the counts are still the full ones
+    assert torch.equal(rec[:small * 15], body[:small * 15]) and bool((rec[small * 15:] == 0xAB).all())
+    dens.close()
