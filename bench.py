@@ -88,6 +88,9 @@ def parse_args():
     ap.add_argument("--spinup-s", type=float, default=0.25, help="untimed spin-up (bursts of 32 back-to-back launches) before the warm-up steps")
     ap.add_argument("--light", action="store_true", help="headline only: skip the secondary legs (profiling passes)")
     ap.add_argument("--parity-refs", type=int, default=2, help="references of the workload checked cell by cell against the oracle (0 = skip)")
+    ap.add_argument("--scene-root", default=os.environ.get("LFD_SCENE_ROOT"),
+                    help="a COLMAP scene (images*/ + sparse/0/) for the END-TO-END leg: dense_init through the real RoMa-v2 matcher; needs the `romav2` package "
+                         "and its weights (torch hub cache, or LFD_ROMA_WEIGHTS=path/to/romav2.pt); without them `end_to_end` stays null with the reason")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc run of this same command (profiles/)")
     args = ap.parse_args()
@@ -541,8 +544,8 @@ def parity_report(args, dens, cams, refs, srefs, dims, cfg):
 def run_sharded(args, world, rank, dev, dist, backend):
     """--gpus N > 1 (or one rank with LFD_BENCH_FORCE_DIST=1): ONE scene dealt round-robin over the ranks, and the exchange of the survivors
     INSIDE the timed region.  A step = the rank's share of the scene in ``--exchange-rounds`` launches of the fused dense kernel, every
-    launch's survivors packed on the device and handed - on a side stream, while the next launch computes - to the round's asynchronous
-    collective (core/distributed.py::OverlappedExchange), then the wait for the last round: when a step ends the ordered cloud of the whole
+    launch's survivors (15-byte PLY records written by the kernel itself, lfd_triangulate_dense_ply; or the 28-byte rows) handed - on a side stream,
+    while the next launch computes - to the round's asynchronous collective (core/distributed.py::OverlappedExchange), then the wait for the last round: when a step ends the ordered cloud of the whole
     scene is where the collective puts it (every rank: all_gather; rank 0: gather_to_root).  `value` = the scene's survivors / that time.
     Beside it: the same steps without any exchange (`value_compute_only`), the end-of-run exchanges of round 3 on the same survivors, and the
     upstream-equivalent sampled mode (M = 10000 per reference) through the same exchange."""
@@ -556,32 +559,46 @@ def run_sharded(args, world, rank, dev, dist, backend):
     dens = hb.HipDensifier(dev)
     dens.upload_cameras(cams)
     side = torch.cuda.Stream(device=dev)
-    packer = hb.HipDensifier(dev, stream=side)          # lfd_pack_ply of a finished launch runs on the side stream, beside the next launch
     n_local_max = (total_refs + world - 1) // world
     per_round = max(1, -(-n_local_max // max(1, args.exchange_rounds)))
     n_rounds = -(-n_local_max // per_round)
     chunks = [refs[c * per_round:(c + 1) * per_round] for c in range(n_rounds)]
     batches = [hb.PreparedBatch(ch, wm, hm, cameras=cams) if ch else None for ch in chunks]
-    outs = [hb.OutputBuffers(len(ch) * H * W, len(ch), args.k, dev, with_cell=False, with_segments=False) if ch else None for ch in chunks]
     ply = args.exchange_records == "ply"
     rec_bytes = 15 if ply else 28
     cdev = dev if backend != "gloo" else torch.device("cpu")
+    # "ply": the kernel writes the 15-byte records itself (lfd_triangulate_dense_ply - no packing pass); "f32": the 28-byte arrays, made into rows
+    outs = [hb.OutputBuffers(len(ch) * H * W, len(ch), args.k, dev, with_cell=False, with_segments=False) if (ch and not ply) else None for ch in chunks]
+    recs_dev = [torch.empty((len(ch) * H * W * 15,), dtype=torch.uint8, device=dev) if (ch and ply) else None for ch in chunks]
+    offs_dev = [torch.zeros((len(ch) + 1,), dtype=torch.int64, device=dev) if ch else None for ch in chunks]
+    offs_host = [torch.zeros((len(ch) + 1,), dtype=torch.int64).pin_memory() if ch else None for ch in chunks]
+    done = [torch.cuda.Event() if ch else None for ch in chunks]
 
     def barrier():
         torch.cuda.synchronize(dev)
         dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def launch(c):
+        if ply:
+            dens.launch_dense_ply(batches[c], params, recs_dev[c], offs_dev[c])
+        else:
+            dens.launch_dense(batches[c], params, outs[c])
+            offs_dev[c].copy_(outs[c].ref_offsets)
+        with torch.cuda.stream(dens.stream):
+            offs_host[c].copy_(offs_dev[c], non_blocking=True)       # the counts of this launch, behind it on the launch stream
+            done[c].record(dens.stream)
+
     def retire(c, ex):
-        """launch c is through (its counts behind their own event): pack its survivors on the side stream, hand every reference to the round"""
+        """launch c is through (its counts behind their own event): hand every reference's records to the round, on the side stream"""
         if batches[c] is None:
             return 0
-        res = outs[c].collect()
-        offs = res.ref_offsets
-        with torch.cuda.stream(side):
-            side.wait_event(outs[c]._meta_event)             # recorded behind launch c's counts on the launch stream
-            if ex is not None:
-                body = packer.pack_ply(res.xyz, res.rgb) if ply else lfd_dist.rows_from_points(res.xyz, res.rgb, res.err)
+        done[c].synchronize()
+        offs = offs_host[c].numpy().copy()
+        if ex is not None:
+            with torch.cuda.stream(side):
+                side.wait_event(done[c])
+                body = recs_dev[c] if ply else lfd_dist.rows_from_points(outs[c].xyz[:int(offs[-1])], outs[c].rgb[:int(offs[-1])], outs[c].err[:int(offs[-1])])
                 for i in range(len(chunks[c])):
                     lo, hi = int(offs[i]), int(offs[i + 1])
                     ex.push(c * per_round + i, (body[lo * 15:hi * 15] if ply else body[lo:hi]) if hi > lo else None)
@@ -592,8 +609,7 @@ def run_sharded(args, world, rank, dev, dist, backend):
         pts = 0
         for c in range(n_rounds):
             if batches[c] is not None:
-                dens.launch_dense(batches[c], params, outs[c])
-                outs[c].begin_collect(dens.stream)
+                launch(c)
             if c >= 1:
                 pts += retire(c - 1, ex)
         pts += retire(n_rounds - 1, ex)
@@ -640,6 +656,11 @@ def run_sharded(args, world, rank, dev, dist, backend):
 
     # round 3's end-of-run exchanges (28-byte rows, one collective after the last reference) on this scene's survivors, for comparison
     end_of_run = {}
+    if ply:                            # (the 28-byte arrays of the same survivors, for the comparison only)
+        outs = [hb.OutputBuffers(len(ch) * H * W, len(ch), args.k, dev, with_cell=False, with_segments=False) if ch else None for ch in chunks]
+        for c in range(n_rounds):
+            if batches[c] is not None:
+                dens.launch_dense(batches[c], params, outs[c])
     res_all = [outs[c].collect() for c in range(n_rounds) if batches[c] is not None]
     lx = torch.cat([r.xyz for r in res_all]) if res_all else torch.zeros((0, 3), device=dev)
     lc = torch.cat([r.rgb for r in res_all]) if res_all else torch.zeros((0, 3), device=dev)
@@ -694,7 +715,8 @@ def run_sharded(args, world, rank, dev, dist, backend):
     if rank == 0:
         cells_rank = len(refs) * H * W
         s_frac = (n_pts / cells_rank) if cells_rank else 0.0
-        bytes_per_cell = 4 * args.k + 11 + 28 * s_frac
+        bytes_per_cell = 4 * args.k + 11 + (15 if ply else 28) * s_frac        # what this launch moves at least: k certainties, the winner's warp, a texel; 15 / 28 B per survivor
+        kname = "lfd_dense_ply_kernel" if ply else "lfd_dense_kernel"
         rccl = world if backend == "nccl" else 0
         step_ms = elapsed / args.steps * 1e3
         line = {
@@ -706,7 +728,7 @@ def run_sharded(args, world, rank, dev, dist, backend):
             "config": {"workload": f"{WORKLOADS[args.workload]['what']}: ring of {WORKLOADS[args.workload]['n_cams']} cameras 1297x840, `{args.preset}` grid {H}x{W}, "
                                    f"{args.refs} reference views x {args.k} neighbours {'per GPU' if args.scaling == 'weak' else 'in total, dealt over the ranks'}, "
                                    f"default thresholds (certainty 0.2 / sampson 5.0 / reproj 0.8 / parallax 0.5 deg), noise {args.noise_px} px, {args.outliers:.0%} outliers",
-                       "kernel": "fused dense filter+triangulate kernel (lfd_dense_kernel)", "mode": "dense", "refs_per_gpu": len(refs), "refs_total": total_refs,
+                       "kernel": f"fused dense filter+triangulate kernel ({kname})", "mode": "dense", "refs_per_gpu": len(refs), "refs_total": total_refs,
                        "neighbours": args.k, "grid": [H, W], "sharding": f"references round-robin over {world} rank(s)",
                        "launches_per_step": launches_per_step, "refs_per_round": per_round},
             "pairs_per_s": total_refs * args.k * args.steps / elapsed,
@@ -719,7 +741,7 @@ def run_sharded(args, world, rank, dev, dist, backend):
             "exchange": {"form": args.exchange, "record_bytes": rec_bytes, "rounds": n_rounds, "overlapped": True, "points": total_pts,
                          "bytes_per_rank_sent": int(rec_bytes * n_pts), "bytes_gathered": int(rec_bytes * total_pts), "backend": backend,
                          "order": "global reference position (1-GPU sequence)", "end_of_run_28B": end_of_run},
-            "roofline": {"bound": "hbm", "kernel": "lfd_dense_kernel", "kernel_ms": kernel_ms_step,
+            "roofline": {"bound": "hbm", "kernel": kname, "kernel_ms": kernel_ms_step,
                          "achieved": (cells_rank * bytes_per_cell / (kernel_ms_step * 1e-3) / 1e9) if kernel_ms_step > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (cells_rank * bytes_per_cell / (kernel_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms_step > 0 else None,
                          "traffic": None, "bytes_per_cell": bytes_per_cell,
@@ -734,8 +756,49 @@ def run_sharded(args, world, rank, dev, dist, backend):
         print(json.dumps(line), flush=True)
     dist.barrier()
     dist.destroy_process_group()
-    packer.close()
     dens.close()
+
+
+def end_to_end(args):
+    """SURVEY 8d iii: points/s INCLUDING the RoMa-v2 forward, on a real scene.  Runs only where everything it needs exists; otherwise (None, why)."""
+    missing = []
+    if not args.scene_root:
+        missing.append("no --scene-root / LFD_SCENE_ROOT (a COLMAP scene with images)")
+    elif not os.path.isdir(os.path.join(args.scene_root, "sparse", "0")):
+        missing.append(f"{args.scene_root}/sparse/0 not found")
+    try:
+        from lichtfeld_densification_plugin_amd.core import matcher as mm
+        mm._import_romav2()
+    except Exception as exc:
+        missing.append(f"RoMa-v2 is not importable ({str(exc).splitlines()[0][:120]})")
+        mm = None
+    weights = os.environ.get("LFD_ROMA_WEIGHTS")
+    if mm is not None and not (weights and os.path.isfile(weights)) and not mm.has_cached_romav2_weights():
+        missing.append("romav2.pt not found (torch hub cache / LFD_ROMA_WEIGHTS)")
+    if missing:
+        return None, "points/s including the RoMa-v2 forward (SURVEY 8d iii) is unmeasured: " + "; ".join(missing)
+    from lichtfeld_densification_plugin_amd import densify
+    if weights:                                    # where torch.hub looks for it
+        import shutil
+        dst = os.path.join(torch.hub.get_dir(), "checkpoints", "romav2.pt")
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        if not os.path.exists(dst):
+            shutil.copyfile(weights, dst)
+    argv = ["--scene_root", args.scene_root, "--roma_setting", args.preset, "--out_name", "points3D_dense_bench.ply"]
+    for sub in ("images_4", "images_2", "images"):
+        if os.path.isdir(os.path.join(args.scene_root, sub)):
+            argv += ["--images_subdir", sub]
+            break
+    a = densify.build_argparser().parse_args(argv)
+    seen = {}
+    t0 = time.perf_counter()
+    rc = densify.dense_init(a, progress_callback=lambda p, m: seen.__setitem__("last", m))
+    dt = time.perf_counter() - t0
+    if rc != 0:
+        return None, f"dense_init returned {rc}"
+    n = int(str(seen.get("last", "0")).split("!")[-1].split("points")[0].replace(",", "").strip() or 0)
+    return {"points_per_s": n / dt, "seconds": dt, "points": n, "scene": args.scene_root, "setting": args.preset,
+            "note": "densify.dense_init (CLI defaults): COLMAP read, image loading, RoMa-v2 forward, sampled-mode hot path, PLY written"}, None
 
 
 def launch_ranks(args):
@@ -924,6 +987,12 @@ def main():
         line["roofline"]["valu"] = valu_roofline(args, kernel_ms)      # ... and that bound itself: issue time of the vector instructions / kernel time
         line["roofline"]["traffic_over_algorithmic"] = (line["roofline"]["traffic"] / algo_bytes) if line["roofline"]["traffic"] else None
         if not args.light and world == 1:
+            e2e, why = end_to_end(args)
+            line["end_to_end"] = e2e
+            if why:
+                line["end_to_end_note"] = why
+            else:
+                line.pop("end_to_end_note", None)
             line["unordered_retirement"] = unordered_rate(args, dens, batch, params, out, H, W, algo_bytes)
             line["ply_output"] = ply_output_rate(args, dens, batch, params, H, W, cells, s_frac)
         if not args.light and world == 1:     # the side legs (and the CPU baseline) belong to the N = 1 line; at N > 1 the other ranks are waiting

@@ -282,10 +282,6 @@ float lfd_parallax_dot_threshold(float min_deg);
  * (core/geometry.py:122-130). */
 int lfd_host_fundamental(const float* K1, const float* R1, const float* t1, const float* K2,
                          const float* R2, const float* t2, float* F_out);
-/* Upstream's sampling weights before their normalisation (core/sampling.py:13,23-26): out = min(cert, cap) * inside(border) in f32, one pass,
- * element by element the values torch.clamp(max=cap) * inside.float() gives (NaN propagates).  Host arrays [H*W].  The Python mirror sums them
- * with torch (upstream's own reduction) for the `upstream_normaliser` of the device selection. */
-int lfd_host_capped_border_weights(const float* cert, int32_t H, int32_t W, float cap, int32_t border, float* out);
 /* Smallest right singular vector of a row-major 4x4 f32 matrix, the routine the kernels triangulate with
  * (f64 inverse iteration on A^T A), on the HOST build of the same source; out4 is un-normalised.  Returns the
  * number of solves made (>= 3) or a negative lfd_status.  CPU unit tests compare it with an f64 SVD. */

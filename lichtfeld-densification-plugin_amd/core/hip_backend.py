@@ -138,8 +138,6 @@ def load_library() -> C.CDLL:
     lib.lfd_parallax_dot_threshold.argtypes = [C.c_float]
     lib.lfd_parallax_dot_threshold.restype = C.c_float
     lib.lfd_host_fundamental.argtypes = [fptr] * 7
-    lib.lfd_host_capped_border_weights.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
-    lib.lfd_host_capped_border_weights.restype = C.c_int
     lib.lfd_host_null_vector.argtypes = [fptr, C.POINTER(C.c_double)]
     lib.lfd_host_null_vector.restype = C.c_int
     lib.lfd_host_eval_correspondence.argtypes = [fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
@@ -232,15 +230,6 @@ def fundamental_from_world2cam(K1, R1, t1, K2, R2, t2) -> np.ndarray:
     cross = np.array([[0, -tz, ty], [tz, 0, -tx], [-ty, tx, 0]], dtype=np.float32)
     E = cross @ R
     return np.linalg.inv(K2).T @ E @ np.linalg.inv(K1)
-
-
-def host_capped_border_weights(cert: np.ndarray, cap: float, border: int, out: np.ndarray) -> np.ndarray:
-    """out = min(cert, cap) * inside(border), f32, one pass (lfd_host_capped_border_weights): upstream's un-normalised sampling weights."""
-    H, W = cert.shape
-    rc = load_library().lfd_host_capped_border_weights(cert.ctypes.data, int(H), int(W), C.c_float(cap), int(border), out.ctypes.data)
-    if rc != 0:
-        raise HipBackendError("lfd_host_capped_border_weights failed")
-    return out
 
 
 def host_null_vector(A) -> "tuple[np.ndarray, int]":

@@ -16,45 +16,30 @@ import numpy as np
 import torch
 
 
-_INSIDE_CACHE: dict = {}
-
-
-def _inside_mask_f32(H: int, W: int, border: int) -> np.ndarray:
-    key = (int(H), int(W), int(border))
-    m = _INSIDE_CACHE.get(key)
-    if m is None:
-        ys = np.arange(H).reshape(H, 1)
-        xs = np.arange(W).reshape(1, W)
-        m = ((xs >= border) & (xs <= W - 1 - border) & (ys >= border) & (ys <= H - 1 - border)).astype(np.float32)
-        if len(_INSIDE_CACHE) > 16:
-            _INSIDE_CACHE.clear()
-        _INSIDE_CACHE[key] = m
-    return m
+_NORMALISER_CACHE: dict = {}
 
 
 def upstream_weight_sum(cert_map, cap: float = 0.9, border: int = 2) -> float:
     """Upstream's normaliser of the sampling weights (core/sampling.py:23-31 there): the torch CPU f32 ``sum`` of the capped,
-    border-masked certainty map - the same library call on the same values, so the same rounding as upstream on this machine.
-    Only the REDUCTION depends on the library (its chunking); the cap and the 0 / 1 border mask are exactly rounded element by element in
-    any library, so they are applied in ONE pass by the library's host helper (lfd_host_capped_border_weights; torch would wake its whole
-    thread pool for each of a dozen small elementwise operations - 0.6 ms per map on a 128-thread host)."""
-    cert = torch.as_tensor(cert_map).detach().to("cpu", torch.float32).contiguous()
+    border-masked certainty map - the same library calls on the same values (``clamp(max=cap)``, ``* inside.float()``, ``sum``), so the same
+    rounding as upstream on this machine.  The 0 / 1 border mask is built once per grid size and the two elementwise steps write into a
+    kept buffer: three torch operations per map instead of a dozen (each one wakes torch's whole thread pool: 0.6 ms per map on a
+    128-thread host with the dozen; single-threaded passes are slower still there - profiles/r4/sampled_default_breakdown.txt)."""
+    cert = torch.as_tensor(cert_map).detach().to("cpu", torch.float32)
     H, W = int(cert.shape[0]), int(cert.shape[1])
-    buf = _INSIDE_CACHE.get(("scratch", H, W))
-    if buf is None:
-        if len(_INSIDE_CACHE) > 16:
-            _INSIDE_CACHE.clear()
-        buf = _INSIDE_CACHE[("scratch", H, W)] = torch.empty((H * W,), dtype=torch.float32)       # (one caller at a time per process: the pipeline's driver thread)
-    global _WEIGHTS_FN
-    if _WEIGHTS_FN is None:
-        from .hip_backend import load_library
-        _WEIGHTS_FN = load_library().lfd_host_capped_border_weights
-    if _WEIGHTS_FN(cert.data_ptr(), H, W, cap, int(border), buf.data_ptr()) != 0:                  # torch.clamp(max=cap) * inside.float(), one pass
-        raise ValueError("lfd_host_capped_border_weights refused its arguments")
-    return float(buf.sum())
-
-
-_WEIGHTS_FN = None
+    key = (H, W, int(border))
+    kept = _NORMALISER_CACHE.get(key)
+    if kept is None:
+        ys = torch.arange(H).view(H, 1)
+        xs = torch.arange(W).view(1, W)
+        inside = (xs >= border) & (xs <= W - 1 - border) & (ys >= border) & (ys <= H - 1 - border)
+        if len(_NORMALISER_CACHE) > 8:
+            _NORMALISER_CACHE.clear()
+        kept = _NORMALISER_CACHE[key] = (inside.to(torch.float32), torch.empty((H, W), dtype=torch.float32))     # (one caller at a time: the driver thread)
+    mask, buf = kept
+    torch.clamp(cert, max=cap, out=buf)
+    buf.mul_(mask)
+    return float(buf.reshape(-1).sum())
 
 
 def select_samples_with_coverage(cert_map, M: int, cap: float = 0.9, border: int = 2, tiles: int = 24,

@@ -1211,22 +1211,6 @@ static void unpack_cam(const float* v, LfdCam& c) {
     c.w = (int32_t)v[36]; c.h = (int32_t)v[37]; c.pad[0] = c.pad[1] = 0;
 }
 
-int lfd_host_capped_border_weights(const float* cert, int32_t H, int32_t W, float cap, int32_t border, float* out) {
-    if (!cert || !out || H <= 0 || W <= 0 || border < 0) return LFD_ERR_INVALID;
-    // (the inner loops are branch-free over contiguous spans, so that the host compiler vectorises them: compare + blend, 8-16 cells at a time)
-    const int x_lo = std::min(border, W), x_hi = std::max(x_lo, W - border);       // columns [x_lo, x_hi) are inside
-    for (int y = 0; y < H; ++y) {
-        const bool row_in = y >= border && y <= H - 1 - border;
-        const float* __restrict__ src = cert + (size_t)y * W;
-        float* __restrict__ dst = out + (size_t)y * W;
-        const int a = row_in ? x_lo : W, b = row_in ? x_hi : W;                      // [0, a) and [b, W) are outside: weight = clamp(c) * 0
-        for (int x = 0; x < a; ++x) dst[x] = (src[x] > cap ? cap : src[x]) * 0.0f;   // (not a plain 0: NaN * 0 and -inf * 0 are NaN upstream too)
-        for (int x = a; x < b; ++x) dst[x] = src[x] > cap ? cap : src[x];            // torch.clamp(max=cap) * 1: a NaN stays a NaN
-        for (int x = b; x < W; ++x) dst[x] = (src[x] > cap ? cap : src[x]) * 0.0f;
-    }
-    return LFD_OK;
-}
-
 int lfd_host_null_vector(const float* A16, double* out4) {
     if (!A16 || !out4) return -LFD_ERR_INVALID;
     return lfd_null_vector(A16, out4);
