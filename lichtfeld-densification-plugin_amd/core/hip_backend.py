@@ -229,7 +229,23 @@ def fundamental_from_world2cam(K1, R1, t1, K2, R2, t2) -> np.ndarray:
     tx, ty, tz = t
     cross = np.array([[0, -tz, ty], [tz, 0, -tx], [-ty, tx, 0]], dtype=np.float32)
     E = cross @ R
-    return np.linalg.inv(K2).T @ E @ np.linalg.inv(K1)
+    return _inv_intrinsics(K2).T @ E @ _inv_intrinsics(K1)
+
+
+_KINV_CACHE: dict = {}
+
+
+def _inv_intrinsics(K: np.ndarray) -> np.ndarray:
+    """``np.linalg.inv(K)`` (upstream's call, LAPACK sgetrf/sgetri), remembered by the matrix's bytes: a run has a few hundred cameras and every
+    pair asks for both inverses - the same LAPACK call on the same bytes gives the same bytes, so the cache changes no result, only the count
+    of LAPACK calls in the per-reference loop (six per reference of three neighbours otherwise)."""
+    key = K.tobytes()
+    inv = _KINV_CACHE.get(key)
+    if inv is None:
+        if len(_KINV_CACHE) > 4096:
+            _KINV_CACHE.clear()
+        inv = _KINV_CACHE[key] = np.linalg.inv(K)
+    return inv
 
 
 def host_null_vector(A) -> "tuple[np.ndarray, int]":

@@ -474,33 +474,45 @@ class _HotPath:
         return float(cfg.certainty_thresh) >= 2.0 ** -29 * H * W * max(self.sample_cap, 1e-6)
 
     def begin_normaliser(self, ref: hb.ReferenceInputs, axes):
-        """Aggregate on the launch stream, then the 1 MB map to pinned host memory on the side stream, an event behind it."""
+        """Aggregate on the launch stream; the capped, border-masked WEIGHTS (upstream's ``clamp(max=cap) * inside.float()``: exactly rounded
+        element by element, so the device gives the host's values) right behind it; then the 1 MB weight map to pinned host memory on the side
+        stream, an event behind it.  What is left for the host is upstream's one library-dependent step: torch's f32 ``sum``."""
         batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes, cameras=self.cams)
         if getattr(self, "_norm_side", None) is None:
             self._norm_side = torch.cuda.Stream(device=self.dev)
             self._norm_free: list = []
+            self._norm_masks: dict = {}
         H, W = batch.H, batch.W
+        mask = self._norm_masks.get((H, W))
+        if mask is None:
+            ys = torch.arange(H, device=self.dev).view(H, 1)
+            xs = torch.arange(W, device=self.dev).view(1, W)
+            mask = ((xs >= 2) & (xs <= W - 1 - 2) & (ys >= 2) & (ys <= H - 1 - 2)).to(torch.float32)          # border = 2 (core/pipeline.py:642-649 upstream)
+            self._norm_masks[(H, W)] = mask
         slot = None
         for i, cand in enumerate(self._norm_free):
             if tuple(cand["best"].shape) == (1, H, W):
                 slot = self._norm_free.pop(i)
                 break
         if slot is None:
-            slot = {"best": torch.empty((1, H, W), dtype=torch.float32, device=self.dev),
+            slot = {"best": torch.empty((1, H, W), dtype=torch.float32, device=self.dev), "w": torch.empty((H, W), dtype=torch.float32, device=self.dev),
                     "host": torch.empty((H, W), dtype=torch.float32).pin_memory(), "agg_done": torch.cuda.Event(), "copied": torch.cuda.Event()}
         self.dens.launch_aggregate(batch, self.params, slot["best"], None)
-        slot["agg_done"].record(self.dens.stream)
+        with torch.cuda.stream(self.dens.stream):
+            torch.clamp(slot["best"][0], max=self.sample_cap, out=slot["w"])
+            slot["w"].mul_(mask)
+            slot["agg_done"].record(self.dens.stream)
         with torch.cuda.stream(self._norm_side):
             self._norm_side.wait_event(slot["agg_done"])
-            slot["host"].copy_(slot["best"][0], non_blocking=True)
+            slot["host"].copy_(slot["w"], non_blocking=True)
             slot["copied"].record(self._norm_side)
         return batch, slot
 
     def finish_normaliser(self, handle) -> float:
-        """upstream's torch f32 sum of the (capped, border-masked) map that has arrived; the slot goes back to the pool"""
+        """upstream's torch f32 sum (core/sampling.py:27 there) of the weight map that has arrived; the slot goes back to the pool"""
         _batch, slot = handle
         slot["copied"].synchronize()
-        s_up = upstream_weight_sum(slot["host"], cap=self.sample_cap, border=2)
+        s_up = float(slot["host"].reshape(-1).sum())
         self._norm_free.append(slot)
         return s_up if s_up > 0.0 else 0.0      # (a sum <= 0 is upstream's "nothing to sample" case, which the device stage reports from its exact sum)
 
