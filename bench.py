@@ -604,8 +604,8 @@ def run_sharded(args, world, rank, dev, dist, backend):
                     ex.push(c * per_round + i, (body[lo * 15:hi * 15] if ply else body[lo:hi]) if hi > lo else None)
         return int(offs[-1])
 
-    def scene(with_exchange=True):
-        ex = lfd_dist.OverlappedExchange(dist, total_refs, per_round, dev, form=args.exchange, record="ply" if ply else "f32") if with_exchange else None
+    def scene(with_exchange=True, form=None):
+        ex = lfd_dist.OverlappedExchange(dist, total_refs, per_round, dev, form=form or args.exchange, record="ply" if ply else "f32") if with_exchange else None
         pts = 0
         for c in range(n_rounds):
             if batches[c] is not None:
@@ -649,10 +649,20 @@ def run_sharded(args, world, rank, dev, dist, backend):
         scene(with_exchange=False)
     barrier()
     elapsed_compute = time.perf_counter() - t1
+    # ... and with the counts only on the wire: the cloud stays sharded over the ranks' HBM, every rank knows where its references sit in the
+    # 1-GPU sequence (what a data-parallel consumer or the byte-range writer of core/distributed.py::SharedFilePlyStream needs)
+    scene(form="counts_only")
+    barrier()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        _n, own_recs, counts_co = scene(form="counts_only")
+    barrier()
+    elapsed_resident = time.perf_counter() - t2
+    assert int(counts_co.sum()) == total_pts and own_recs.numel() == n_pts * (15 if ply else 7)
 
-    stats = torch.tensor([elapsed, elapsed_compute, kernel_ms_step], dtype=torch.float64, device=cdev)
+    stats = torch.tensor([elapsed, elapsed_compute, kernel_ms_step, elapsed_resident], dtype=torch.float64, device=cdev)
     dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-    elapsed, elapsed_compute, kernel_ms_max = (float(v) for v in stats.tolist())
+    elapsed, elapsed_compute, kernel_ms_max, elapsed_resident = (float(v) for v in stats.tolist())
 
     # round 3's end-of-run exchanges (28-byte rows, one collective after the last reference) on this scene's survivors, for comparison
     end_of_run = {}
@@ -736,6 +746,9 @@ def run_sharded(args, world, rank, dev, dist, backend):
             "survivor_fraction": s_frac,
             "value_compute_only": total_pts * args.steps / elapsed_compute, "compute_ms": elapsed_compute / args.steps * 1e3,
             "kernel_ms": kernel_ms_max, "exchange_ms_exposed": (elapsed - elapsed_compute) / args.steps * 1e3,
+            "value_sharded_resident": total_pts * args.steps / elapsed_resident,
+            "value_sharded_resident_note": "the same steps with only the per-reference counts exchanged (form counts_only): the ordered cloud stays sharded over the "
+                                           "ranks' HBM with every reference's global offset known on every rank - comparable to N = 1, whose result also stays in HBM",
             "end_to_end": None,
             "end_to_end_note": "points/s including the RoMa-v2 forward (SURVEY 8d iii) is unmeasured: neither the RoMa-v2 weights nor torchvision are on the box",
             "exchange": {"form": args.exchange, "record_bytes": rec_bytes, "rounds": n_rounds, "overlapped": True, "points": total_pts,

@@ -47,7 +47,7 @@ for mode in ("dense", "sampled"):
     t1 = sel[0]["step_ms"]
     total_pts = sel[0]["points"]
     print(f"\n{mode} mode: {total_pts / 1e6:.2f} M surviving points = {total_pts * 28 / 1e6:.1f} MB as 28-byte rows, {total_pts * 15 / 1e6:.1f} MB as 15-byte PLY records")
-    print("ranks  compute ms   28 B end of run (round 3)   28 B overlapped   15 B overlapped   speed-up (28 B eor | 28 B ovl | 15 B ovl)   bound at 15 B")
+    print("ranks  compute ms   28 B end of run (round 3)   28 B overlapped   15 B overlapped   speed-up (28 B eor | 28 B ovl | 15 B ovl)   bound at 15 B   counts only: ms, speed-up (cloud left sharded in HBM)")
     for r in sel:
         n = r["ranks"]
         comp = r["step_ms"]
@@ -65,4 +65,5 @@ for mode in ("dense", "sampled"):
                 res.append(c + (ROUNDS - 1) * max(c, x) + x)
         link_ms = 0.0 if n == 1 else total_pts * 15 / n / LINK * 1e3
         bound = "compute" if n == 1 or comp >= link_ms else f"link ({link_ms:.3f} ms to move one shard)"
-        print(f"{n:5d}  {comp:10.3f}   {res[0]:25.3f}   {res[1]:15.3f}   {res[2]:15.3f}   {t1 / res[0]:10.2f} | {t1 / res[1]:8.2f} | {t1 / res[2]:8.2f}              {bound}")
+        resident = comp if n == 1 else comp + LAT * 1e3          # the rounds' count all-gathers ride beside the launches; the last one is waited for
+        print(f"{n:5d}  {comp:10.3f}   {res[0]:25.3f}   {res[1]:15.3f}   {res[2]:15.3f}   {t1 / res[0]:10.2f} | {t1 / res[1]:8.2f} | {t1 / res[2]:8.2f}              {bound:42s} {resident:.3f}  {t1 / resident:.2f}")

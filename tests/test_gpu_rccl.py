@@ -104,4 +104,4 @@ def test_bench_exchange_legs_through_rccl_on_one_rank():
         ex = d["exchange"]
         assert ex["points"] > 0 and ex["overlapped"] and ex["end_of_run_28B"]["allgather_ms"] > 0 and ex["end_of_run_28B"]["gather_to_root_ms"] > 0
         assert ex["rounds"] == (3 if extra else 2) and ex["record_bytes"] == (28 if extra else 15)
-        assert 0 < d["value"] and d["value_compute_only"] > 0
+        assert 0 < d["value"] and d["value_compute_only"] > 0 and d["value_sharded_resident"] > 0
