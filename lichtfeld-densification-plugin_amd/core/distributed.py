@@ -533,7 +533,13 @@ class SharedFilePlyStream(OverlappedExchange):
             for j in range(self.B):
                 n = int(st["local_counts"][j])
                 if n:
-                    os.pwrite(self._fd, payload[off * 15:(off + n) * 15].tobytes(), self._data_offset + 15 * mine[j])
+                    view = memoryview(payload[off * 15:(off + n) * 15])
+                    at, done = self._data_offset + 15 * mine[j], 0
+                    while done < len(view):            # pwrite may write less than asked (signals, 2 GiB limit)
+                        w = os.pwrite(self._fd, view[done:], at + done)
+                        if w <= 0:
+                            raise OSError(f"pwrite wrote {w} bytes at offset {at + done} of {self.path}")
+                        done += w
                     off += n
         except BaseException as exc:                   # noqa: BLE001 - the rounds go on (the counts must stay matched); raised by finish()
             self.error = exc
@@ -548,7 +554,12 @@ class SharedFilePlyStream(OverlappedExchange):
                 pass
             os.close(self._fd)
             self._fd = None
-        self.dist.barrier(group=self.group)            # every byte range is in place
+        # every byte range is in place - or somebody failed: the ranks agree (one small all-reduce instead of a barrier), and the vertex count is
+        # patched into the header only for a complete file (a failed run leaves "element vertex 0": no reader takes the holes for points)
+        flag = torch.tensor([0 if self.error is None else 1], dtype=torch.int32, device=self.dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX, group=self.group)
+        if int(flag.item()) and self.error is None:
+            self.error = RuntimeError(f"another rank failed to write its records into {self.path}")
         if self.rank == self.root and self.error is None:
             from .writers import streamed_ply_header
             try:

@@ -776,7 +776,7 @@ int lfd_pack_points3d_segments(lfd_context* ctx, int32_t n_refs, int32_t H, int3
     const long long* tile_dst = nullptr; int tpr = 0, n_tiles = 0;
     int rc = segment_scan(ctx, n_refs, H, W, table, ref_offsets, &tile_dst, &tpr, &n_tiles);
     if (rc != LFD_OK) return rc;
-    if (capacity < 0 || (capacity > 0 && (!xyz || !rgb || !out))) return fail(ctx, LFD_ERR_INVALID, "bad arguments");
+    if (capacity < 0 || (capacity > 0 && (!xyz || !rgb || !err || !out))) return fail(ctx, LFD_ERR_INVALID, "bad arguments");
     if (reinterpret_cast<uintptr_t>(out) & 3u) return fail(ctx, LFD_ERR_INVALID, "out must be 4-byte aligned");
     if (capacity == 0) return LFD_OK;
     const unsigned grid = (unsigned)std::min<int64_t>((capacity + 255) / 256, 4096);

@@ -282,3 +282,47 @@ def test_shared_file_stream_writes_the_single_writer_file(n_refs, world, per_rou
             if counts[g]:
                 w.append_packed(np.ascontiguousarray(pts[g].view(np.uint8).reshape(-1, 28)[:, :15]).tobytes())
     assert open(path, "rb").read() == open(ref, "rb").read()
+
+
+def _shared_file_failure_worker(rank, world, port, n_refs, path, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts, pts = _make_points(n_refs, seed=3)
+        mine = lfd_dist.shard_references(n_refs, rank, world)
+        st = lfd_dist.SharedFilePlyStream(dist, n_refs, 2, path, torch.device("cpu"))
+        if rank == 1:                                   # this rank's descriptor goes bad under it (disk error, file removed and the mount gone ...)
+            os.close(st._fd)
+            st._fd = os.open(os.devnull, os.O_RDONLY)   # pwrite on a read-only descriptor: EBADF
+        for i, g in enumerate(mine):
+            if counts[g]:
+                st.push(i, torch.from_numpy(np.ascontiguousarray(pts[g].view(np.uint8).reshape(-1, 28)[:, :15]).reshape(-1)))
+        try:
+            st.finish()
+            q.put((rank, None))
+        except BaseException as exc:                    # noqa: BLE001
+            q.put((rank, type(exc).__name__ + ": " + str(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shared_file_stream_with_a_rank_that_cannot_write_raises_everywhere_and_leaves_an_empty_cloud(tmp_path):
+    """one rank's writes fail: the rounds still match (nobody hangs), EVERY rank raises, and the header keeps `element vertex 0` - no reader
+    takes the holes of an incomplete file for points"""
+    n_refs, world = 9, 3
+    path = os.path.join(str(tmp_path), "shared.ply")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_file_failure_worker, args=(r, world, port, n_refs, path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "OSError" in results[1] or "Errno" in results[1], results
+    assert "another rank failed" in results[0] and "another rank failed" in results[2], results
+    head = open(path, "rb").read(200)
+    assert int(head.split(b"element vertex")[1].split(b"\n")[0]) == 0          # (the count field is fixed-width, blank-padded)
