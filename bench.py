@@ -74,6 +74,9 @@ def parse_args():
     ap.add_argument("--exchange-records", default="ply", choices=["ply", "f32"],
                     help="what travels: the 15-byte PLY vertex records packed on the device (the point cloud as it is written: xyz f32 + rgb u8) or the "
                          "28-byte f32 rows (xyz, rgb, err)")
+    ap.add_argument("--replicate", default="auto",
+                    help="--gpus > 1: references computed by EVERY rank instead of exchanged (recompute instead of communicate): a count, or `auto` - "
+                         "core/distributed.py::plan_replication from this run's own measurements (per-reference compute, all-gather bandwidth)")
     ap.add_argument("--exchange-rounds", type=int, default=2, help="rounds a rank's share of the scene is cut into (one launch + one exchange round each)")
     ap.add_argument("--refs", type=int, default=None, help="reference views resident per GPU (weak) / in total (strong)")
     ap.add_argument("--k", type=int, default=None, help="neighbours per reference (GUI default 3)")
@@ -153,9 +156,9 @@ def valu_roofline(args, kernel_ms):
             "valu_busy_frac": v.get("valu_busy_frac"), "source": v.get("source")}
 
 
-def build_workload(args, rank, world, dev):
-    """Global reference list dealt round-robin; this rank generates and keeps only its share.  weak scaling: --refs references per
-    rank; strong scaling: --refs in total (BASELINE's metric is ONE scene at 1/2/4/8 GPUs)."""
+def build_workload(args, rank, world, dev, positions=None):
+    """Global reference list dealt round-robin; this rank generates and keeps only its share (``positions``: these positions of the global
+    list instead).  weak scaling: --refs references per rank; strong scaling: --refs in total (BASELINE's metric is ONE scene at 1/2/4/8 GPUs)."""
     h_lr, w_lr, H, W = synthetic.ROMA_PRESETS[args.preset]
     wl = WORKLOADS[args.workload]
     n_cams = wl["n_cams"]
@@ -163,7 +166,7 @@ def build_workload(args, rank, world, dev):
     total_refs = args.refs * world if args.scaling == "weak" else args.refs
     step = 3 if n_cams >= 3 * total_refs or n_cams % 3 else 1
     ref_ids = [(i * step) % n_cams for i in range(total_refs)]          # spread over the ring
-    mine = [i for i in range(total_refs) if i % world == rank]
+    mine = [i for i in range(total_refs) if i % world == rank] if positions is None else [int(g) for g in positions]
     k = min(args.k, n_cams - 1)
     refs, srefs = [], []
     for gi in mine:
@@ -541,137 +544,342 @@ def parity_report(args, dens, cams, refs, srefs, dims, cfg):
 
 
 
+class _Pieces:
+    """A rank's own records as the list of buffers they sit in (nothing concatenated); numel() is all the bench needs of it."""
+
+    def __init__(self, parts):
+        self.parts = parts
+
+    def numel(self):
+        return sum(int(p.numel()) for p in self.parts)
+
+
 def run_sharded(args, world, rank, dev, dist, backend):
-    """--gpus N > 1 (or one rank with LFD_BENCH_FORCE_DIST=1): ONE scene dealt round-robin over the ranks, and the exchange of the survivors
-    INSIDE the timed region.  A step = the rank's share of the scene in ``--exchange-rounds`` launches of the fused dense kernel, every
-    launch's survivors (15-byte PLY records written by the kernel itself, lfd_triangulate_dense_ply; or the 28-byte rows) handed - on a side stream,
-    while the next launch computes - to the round's asynchronous collective (core/distributed.py::OverlappedExchange), then the wait for the last round: when a step ends the ordered cloud of the whole
-    scene is where the collective puts it (every rank: all_gather; rank 0: gather_to_root).  `value` = the scene's survivors / that time.
-    Beside it: the same steps without any exchange (`value_compute_only`), the end-of-run exchanges of round 3 on the same survivors, and the
-    upstream-equivalent sampled mode (M = 10000 per reference) through the same exchange."""
+    """--gpus N > 1 (or one rank with LFD_BENCH_FORCE_DIST=1): ONE scene over the ranks, and the exchange of the survivors INSIDE the timed region.
+    The scene's references are split (core/distributed.py::plan_replication, from THIS run's own measurements) into a sharded prefix - dealt
+    round-robin, each rank's share in ``--exchange-rounds`` launches of the fused dense kernel, every launch's survivors (15-byte PLY records written
+    by the kernel itself, lfd_triangulate_dense_ply; or the 28-byte rows) handed on a side stream to the round's asynchronous collective
+    (core/distributed.py::OverlappedExchange) - and a replicated suffix that every rank that receives the cloud computes itself while the rounds
+    travel: one GPU triangulates a reference faster than its survivors cross an xGMI link, so recomputing part of the scene is cheaper than moving
+    it.  When a step ends the ordered cloud of the whole scene is one contiguous buffer on every rank (all_gather) / on rank 0 (gather_to_root).
+    `value` = the scene's survivors, each counted ONCE, / that time.  Beside it: the pure-sharding schedule (`value_pure_sharding`), the same steps
+    without any exchange, with the counts only, the end-of-run exchanges of round 3, and the upstream-equivalent sampled mode through the exchange."""
     from lichtfeld_densification_plugin_amd.core import distributed as lfd_dist
-    cams, refs, srefs, dims, mine, total_refs = build_workload(args, rank, world, dev)
-    H, W, wm, hm = dims
-    cfg = lfd.DensePipelineConfig(output_path="", roma_setting=args.preset, nns_per_ref=args.k)
-    params = hb.make_params(cfg)
+    h_lr, w_lr, H, W = synthetic.ROMA_PRESETS[args.preset]
+    wm, hm = w_lr, h_lr
+    total_refs = args.refs * world if args.scaling == "weak" else args.refs
     if total_refs < world:
         raise SystemExit(f"--refs {args.refs} ({args.scaling} scaling) leaves a rank without a reference view: {total_refs} references over {world} ranks")
-    dens = hb.HipDensifier(dev)
-    dens.upload_cameras(cams)
-    side = torch.cuda.Stream(device=dev)
-    n_local_max = (total_refs + world - 1) // world
-    per_round = max(1, -(-n_local_max // max(1, args.exchange_rounds)))
-    n_rounds = -(-n_local_max // per_round)
-    chunks = [refs[c * per_round:(c + 1) * per_round] for c in range(n_rounds)]
-    batches = [hb.PreparedBatch(ch, wm, hm, cameras=cams) if ch else None for ch in chunks]
     ply = args.exchange_records == "ply"
-    rec_bytes = 15 if ply else 28
+    rec_bytes, cols, rdtype = (15, 15, torch.uint8) if ply else (28, 7, torch.float32)
     cdev = dev if backend != "gloo" else torch.device("cpu")
-    # "ply": the kernel writes the 15-byte records itself (lfd_triangulate_dense_ply - no packing pass); "f32": the 28-byte arrays, made into rows
-    outs = [hb.OutputBuffers(len(ch) * H * W, len(ch), args.k, dev, with_cell=False, with_segments=False) if (ch and not ply) else None for ch in chunks]
-    recs_dev = [torch.empty((len(ch) * H * W * 15,), dtype=torch.uint8, device=dev) if (ch and ply) else None for ch in chunks]
-    offs_dev = [torch.zeros((len(ch) + 1,), dtype=torch.int64, device=dev) if ch else None for ch in chunks]
-    offs_host = [torch.zeros((len(ch) + 1,), dtype=torch.int64).pin_memory() if ch else None for ch in chunks]
-    done = [torch.cuda.Event() if ch else None for ch in chunks]
+    consumes_cloud = args.exchange == "all_gather" or rank == 0
+    side = torch.cuda.Stream(device=dev)
+    cache = {}                                     # global position -> ReferenceInputs (generated once per rank)
+    cams_box = []
+
+    def refs_at(positions):
+        need = [g for g in positions if g not in cache]
+        if need or not cams_box:
+            cams, refs, _srefs, _dims, mine, _tot = build_workload(args, rank, world, dev, positions=need)
+            if not cams_box:
+                cams_box.append(cams)
+            for g, r in zip(mine, refs):
+                cache[g] = r
+        return [cache[g] for g in positions]
 
     def barrier():
         torch.cuda.synchronize(dev)
         dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def launch(c):
-        if ply:
-            dens.launch_dense_ply(batches[c], params, recs_dev[c], offs_dev[c])
-        else:
-            dens.launch_dense(batches[c], params, outs[c])
-            offs_dev[c].copy_(outs[c].ref_offsets)
-        with torch.cuda.stream(dens.stream):
-            offs_host[c].copy_(offs_dev[c], non_blocking=True)       # the counts of this launch, behind it on the launch stream
-            done[c].record(dens.stream)
+    def max_over_ranks(vals):
+        t = torch.tensor(list(vals), dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
 
-    def retire(c, ex):
-        """launch c is through (its counts behind their own event): hand every reference's records to the round, on the side stream"""
-        if batches[c] is None:
-            return 0
-        done[c].synchronize()
-        offs = offs_host[c].numpy().copy()
-        if ex is not None:
+    cfg = lfd.DensePipelineConfig(output_path="", roma_setting=args.preset, nns_per_ref=args.k)
+    refs_at(lfd_dist.shard_references(total_refs, rank, world))          # (also fixes args.k and the camera ring)
+    cams = cams_box[0]
+    cfg = lfd.DensePipelineConfig(output_path="", roma_setting=args.preset, nns_per_ref=args.k)
+    params = hb.make_params(cfg)
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+
+    class Schedule:
+        """One way of running the scene: the last `n_rep` references replicated, the others sharded in rounds."""
+
+        def __init__(self, n_rep):
+            self.n_rep = int(n_rep)
+            mine, self.n_sh = lfd_dist.split_replicated(total_refs, self.n_rep, rank, world, replicas_here=consumes_cloud)
+            self.sh_pos = [g for g in mine if g < self.n_sh]
+            self.rep_pos = [g for g in mine if g >= self.n_sh]
+            n_local_max = (self.n_sh + world - 1) // world
+            self.per_round = max(1, -(-n_local_max // max(1, args.exchange_rounds))) if self.n_sh else 1
+            self.n_rounds = -(-n_local_max // self.per_round) if self.n_sh else 0
+            sh_refs = refs_at(self.sh_pos)
+            self.chunks = [sh_refs[c * self.per_round:(c + 1) * self.per_round] for c in range(self.n_rounds)]
+            self.batches = [hb.PreparedBatch(ch, wm, hm, cameras=cams) if ch else None for ch in self.chunks]
+            self.rep_batch = hb.PreparedBatch(refs_at(self.rep_pos), wm, hm, cameras=cams) if self.rep_pos else None
+            # "ply": the kernel writes the 15-byte records itself (lfd_triangulate_dense_ply - no packing pass); "f32": the 28-byte arrays, made into rows
+            self.outs = [hb.OutputBuffers(len(ch) * H * W, len(ch), args.k, dev, with_cell=False, with_segments=False) if (ch and not ply) else None for ch in self.chunks]
+            self.recs_dev = [torch.empty((len(ch) * H * W * 15,), dtype=torch.uint8, device=dev) if (ch and ply) else None for ch in self.chunks]
+            self.offs_dev = [torch.zeros((len(ch) + 1,), dtype=torch.int64, device=dev) if ch else None for ch in self.chunks]
+            self.offs_host = [torch.zeros((len(ch) + 1,), dtype=torch.int64).pin_memory() if ch else None for ch in self.chunks]
+            self.done = [torch.cuda.Event() if ch else None for ch in self.chunks]
+            # the cloud of a rank that consumes it: ONE buffer; the sharded part ends at row `cap_sh` (the exchange places its ordered records
+            # there, finish(place=...)), the replicated part starts there (the kernel writes it in place): contiguous, in global reference order
+            self.cap_sh = self.n_sh * H * W
+            self.cloud = None
+            if consumes_cloud and (self.rep_pos or self.n_sh):
+                self.cloud = torch.empty(((self.cap_sh + len(self.rep_pos) * H * W) * cols,), dtype=rdtype, device=dev)
+            self.rep_out = (hb.OutputBuffers(len(self.rep_pos) * H * W, len(self.rep_pos), args.k, dev, with_cell=False, with_segments=False)
+                            if (self.rep_pos and not ply) else None)
+            self.rep_offs_dev = torch.zeros((len(self.rep_pos) + 1,), dtype=torch.int64, device=dev) if self.rep_pos else None
+            self.rep_offs_host = torch.zeros((len(self.rep_pos) + 1,), dtype=torch.int64).pin_memory() if self.rep_pos else None
+            self.launches_per_step = sum(1 for b in self.batches if b is not None) + (1 if self.rep_batch is not None else 0)
+
+        def launch(self, c):
+            if ply:
+                dens.launch_dense_ply(self.batches[c], params, self.recs_dev[c], self.offs_dev[c])
+            else:
+                dens.launch_dense(self.batches[c], params, self.outs[c])
+                self.offs_dev[c].copy_(self.outs[c].ref_offsets)
+            with torch.cuda.stream(dens.stream):
+                self.offs_host[c].copy_(self.offs_dev[c], non_blocking=True)       # the counts of this launch, behind it on the launch stream
+                self.done[c].record(dens.stream)
+
+        def launch_replicated(self):
+            """the replicated references, in place: records straight into the cloud buffer behind the sharded part"""
+            if ply:
+                dens.launch_dense_ply(self.rep_batch, params, self.cloud[self.cap_sh * 15:], self.rep_offs_dev)
+            else:
+                dens.launch_dense(self.rep_batch, params, self.rep_out)
+                self.rep_offs_dev.copy_(self.rep_out.ref_offsets)
+            with torch.cuda.stream(dens.stream):
+                self.rep_offs_host.copy_(self.rep_offs_dev, non_blocking=True)
+
+        def retire(self, c, ex):
+            """launch c is through (its counts behind their own event): hand every reference's records to the round, on the side stream"""
+            if self.batches[c] is None:
+                return 0
+            self.done[c].synchronize()
+            offs = self.offs_host[c].numpy().copy()
+            if ex is not None:
+                with torch.cuda.stream(side):
+                    side.wait_event(self.done[c])
+                    o = self.outs[c]
+                    body = self.recs_dev[c] if ply else lfd_dist.rows_from_points(o.xyz[:int(offs[-1])], o.rgb[:int(offs[-1])], o.err[:int(offs[-1])])
+                    ex.push_many(c * self.per_round, body, np.diff(offs))          # views of the launch's own buffer: nothing is copied
+            return int(offs[-1])
+
+        def scene(self, with_exchange=True, form=None):
+            """-> (this rank's sharded survivors, replicated survivors, the cloud (or this rank's shard), global counts of the sharded part)"""
+            the_form = form or args.exchange
+            on_device = cdev == dev                          # RCCL: the records never leave HBM; gloo (ranks sharing a GPU): through host tensors
+            # nothing replicated: the ordered records are placed from row 0 of the cloud as the rounds complete; with a replicated part behind
+            # them their place is only known at the end (finish(place=...)): they must END where the replicated part begins
+            early = with_exchange and consumes_cloud and on_device and self.rep_batch is None and the_form != "counts_only" and self.cloud is not None
+            ex = (lfd_dist.OverlappedExchange(dist, self.n_sh, self.per_round, dev, form=the_form, record="ply" if ply else "f32", eager=True,
+                                              dest=self.cloud.view(-1, cols) if early else None)
+                  if (with_exchange and self.n_sh) else None)
+            pts = 0
+            for c in range(self.n_rounds):
+                if self.batches[c] is not None:
+                    self.launch(c)
+                if c >= 1:
+                    pts += self.retire(c - 1, ex)
+            if self.rep_batch is not None:
+                self.launch_replicated()                     # computes while the rounds travel
+            if self.n_rounds:
+                pts += self.retire(self.n_rounds - 1, ex)
+            n_rep_pts = 0
+            if self.rep_batch is not None:
+                dens.stream.synchronize()
+                n_rep_pts = int(self.rep_offs_host[-1])
+                if not ply:                                  # the rows of the replicated part, behind the sharded part
+                    with torch.cuda.stream(dens.stream):
+                        dst = self.cloud.view(-1, 7)[self.cap_sh:self.cap_sh + n_rep_pts]
+                        dst[:, 0:3] = self.rep_out.xyz[:n_rep_pts]; dst[:, 3:6] = self.rep_out.rgb[:n_rep_pts]; dst[:, 6] = self.rep_out.err[:n_rep_pts]
+            if ex is None:
+                if with_exchange and self.rep_batch is not None:        # everything replicated: the cloud is what this rank computed, nothing travels
+                    dens.stream.synchronize()
+                    return pts, n_rep_pts, self.cloud[self.cap_sh * cols:(self.cap_sh + n_rep_pts) * cols], np.zeros((0,), np.int64)
+                return pts, n_rep_pts, None, None
+            placed = {}
+
+            def place(n_rows):
+                placed["n"] = n_rows
+                return self.cloud.view(-1, cols)[self.cap_sh - n_rows:self.cap_sh]
+            in_place = consumes_cloud and on_device and the_form != "counts_only" and not early
             with torch.cuda.stream(side):
-                side.wait_event(done[c])
-                body = recs_dev[c] if ply else lfd_dist.rows_from_points(outs[c].xyz[:int(offs[-1])], outs[c].rgb[:int(offs[-1])], outs[c].err[:int(offs[-1])])
-                for i in range(len(chunks[c])):
-                    lo, hi = int(offs[i]), int(offs[i + 1])
-                    ex.push(c * per_round + i, (body[lo * 15:hi * 15] if ply else body[lo:hi]) if hi > lo else None)
-        return int(offs[-1])
+                recs, counts = ex.finish(place=place if in_place else None, concat=False)
+            if isinstance(recs, list):                       # this rank's own shard, where the launches left it
+                recs = _Pieces(recs)
+            side.synchronize()
+            if self.rep_batch is not None:
+                dens.stream.synchronize()
+            if in_place:                                     # sharded part | replicated part: one contiguous slice, global reference order
+                m_sh = placed.get("n", 0)
+                recs = self.cloud[(self.cap_sh - m_sh) * cols:(self.cap_sh + n_rep_pts) * cols]
+            elif consumes_cloud and self.rep_batch is not None and (form or args.exchange) != "counts_only":      # (gloo: the records came back through the host)
+                recs = torch.cat([recs.reshape(-1), self.cloud[self.cap_sh * cols:(self.cap_sh + n_rep_pts) * cols]])
+            return pts, n_rep_pts, recs, counts
 
-    def scene(with_exchange=True, form=None):
-        ex = lfd_dist.OverlappedExchange(dist, total_refs, per_round, dev, form=form or args.exchange, record="ply" if ply else "f32") if with_exchange else None
-        pts = 0
-        for c in range(n_rounds):
-            if batches[c] is not None:
-                launch(c)
-            if c >= 1:
-                pts += retire(c - 1, ex)
-        pts += retire(n_rounds - 1, ex)
-        if ex is None:
-            return pts, None, None
-        with torch.cuda.stream(side):
-            recs, counts = ex.finish()
-        side.synchronize()
-        return pts, recs, counts
+    def timed(sched, steps, **kw):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = sched.scene(**kw)
+        barrier()
+        return time.perf_counter() - t0, r
 
-    # spin-up + warm-up (also creates the communicator's channels), then the timed region: EXACTLY K steps
+    # ---- 1. the pure-sharding schedule: spin-up, warm-up (also creates the communicator's channels), K steps -----------------------------------
+    pure = Schedule(0)
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < args.spinup_s:
-        scene(with_exchange=False)
+        pure.scene(with_exchange=False)
     for _ in range(max(args.warmup, 1)):
-        n_pts, recs, counts = scene()
-    launches_per_step = sum(1 for b in batches if b is not None)
-    dens.time_dense_kernels(args.steps * launches_per_step)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_pts, recs, counts = scene()
-    barrier()
-    elapsed = time.perf_counter() - t0
+        pure.scene()
+    dens.time_dense_kernels(args.steps * pure.launches_per_step)
+    if os.environ.get("LFD_BENCH_CPROFILE"):          # where the host's time of a step goes (profiles/r4/exchange_overhead.txt)
+        import cProfile
+        import pstats
+        for label, kw in (("all_gather", {}), ("counts_only", {"form": "counts_only"}), ("no exchange", {"with_exchange": False})):
+            pr = cProfile.Profile()
+            pr.enable()
+            el_p, _r = timed(pure, args.steps, **kw)
+            pr.disable()
+            print(f"==== {label}: {el_p / args.steps * 1e3:.3f} ms per step ====", file=sys.stderr)
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(22)
+    el_pure, (n_pts_pure, _z, recs, counts) = timed(pure, args.steps)
     per_launch = [float(x) for x in dens.dense_kernel_times_ms()]
     dens.time_dense_kernels(0)
     kernel_ms_step = float(np.sum(per_launch) / max(args.steps, 1))
     dens.check_launches()
     total_pts = int(counts.sum())
-    have_cloud = args.exchange == "all_gather" or rank == 0
-    if have_cloud:
-        assert recs.numel() == total_pts * (15 if ply else 7), (recs.shape, total_pts)
-    # the same K steps without any exchange
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        scene(with_exchange=False)
-    barrier()
-    elapsed_compute = time.perf_counter() - t1
+    if consumes_cloud:
+        assert recs.numel() == total_pts * cols, (recs.shape, total_pts)
+    el_compute, _r = timed(pure, args.steps, with_exchange=False)                    # the same K steps without any exchange
     # ... and with the counts only on the wire: the cloud stays sharded over the ranks' HBM, every rank knows where its references sit in the
     # 1-GPU sequence (what a data-parallel consumer or the byte-range writer of core/distributed.py::SharedFilePlyStream needs)
-    scene(form="counts_only")
-    barrier()
-    t2 = time.perf_counter()
-    for _ in range(args.steps):
-        _n, own_recs, counts_co = scene(form="counts_only")
-    barrier()
-    elapsed_resident = time.perf_counter() - t2
-    assert int(counts_co.sum()) == total_pts and own_recs.numel() == n_pts * (15 if ply else 7)
+    pure.scene(form="counts_only")
+    el_resident, (_n, _z, own_recs, counts_co) = timed(pure, args.steps, form="counts_only")
+    assert int(counts_co.sum()) == total_pts and own_recs.numel() == n_pts_pure * cols
+    el_pure, el_compute, kernel_ms_max, el_resident = max_over_ranks([el_pure, el_compute, kernel_ms_step, el_resident])
 
-    stats = torch.tensor([elapsed, elapsed_compute, kernel_ms_step, elapsed_resident], dtype=torch.float64, device=cdev)
-    dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-    elapsed, elapsed_compute, kernel_ms_max, elapsed_resident = (float(v) for v in stats.tolist())
+    # ---- 2. what this machine does per reference and per byte: the plan's inputs, measured here ------------------------------------------------
+    n_loc = len(pure.sh_pos)
+    # one launch of n references = launch_ms + ref_ms * n: two points of the line, back-to-back launches of the whole share and of half of it
+    def launch_time(n):
+        b = hb.PreparedBatch(refs_at(pure.sh_pos[:n]), wm, hm, cameras=cams)
+        rec = torch.empty((n * H * W * 15,), dtype=torch.uint8, device=dev) if ply else None
+        o = hb.OutputBuffers(n * H * W, n, args.k, dev, with_cell=False, with_segments=False) if not ply else None
+        off = torch.zeros((n + 1,), dtype=torch.int64, device=dev)
 
-    # round 3's end-of-run exchanges (28-byte rows, one collective after the last reference) on this scene's survivors, for comparison
+        def go():
+            if ply:
+                dens.launch_dense_ply(b, params, rec, off)
+            else:
+                dens.launch_dense(b, params, o)
+        for _ in range(3):
+            go()
+        torch.cuda.synchronize(dev)
+        t_0 = time.perf_counter()
+        reps_l = max(5, min(args.steps, 50))
+        for _ in range(reps_l):
+            go()
+        torch.cuda.synchronize(dev)
+        dens.check_launches()
+        return (time.perf_counter() - t_0) / reps_l * 1e3
+    n_hi, n_lo = n_loc, max(1, n_loc // 2)
+    t_hi = launch_time(n_hi)
+    if n_hi > n_lo:
+        t_lo = launch_time(n_lo)
+        ref_ms = max((t_hi - t_lo) / (n_hi - n_lo), 1e-6)
+        launch_ms = max(t_lo - ref_ms * n_lo, 0.0)
+    else:
+        ref_ms, launch_ms = t_hi / max(n_hi, 1), 0.0
+    ref_bytes = rec_bytes * total_pts / max(total_refs, 1)
+    # the all-gather of one rank's share of the records as this backend moves it: per-peer bandwidth and the fixed cost
+    shard_rows = max(1, int(total_pts / world))
+    ag_in = torch.zeros((shard_rows * cols,), dtype=rdtype, device=cdev)
+    ag_out = torch.empty((world * shard_rows * cols,), dtype=rdtype, device=cdev)
+    small_in = torch.zeros((cols,), dtype=rdtype, device=cdev)
+    small_out = torch.empty((world * cols,), dtype=rdtype, device=cdev)
+    t_ag = {}
+    for name, (i_, o_) in (("big", (ag_in, ag_out)), ("small", (small_in, small_out))):
+        dist.all_gather_into_tensor(o_, i_)
+        barrier()
+        ta = time.perf_counter()
+        for _ in range(3):
+            dist.all_gather_into_tensor(o_, i_)
+        barrier()
+        t_ag[name] = (time.perf_counter() - ta) / 3 * 1e3
+    del ag_in, ag_out
+    t_big, t_small = max_over_ranks([t_ag["big"], t_ag["small"]])
+    link_gbps = shard_rows * rec_bytes / max(t_big - t_small, 1e-3) / 1e6 if world > 1 else 122.0
+    cp_src = torch.empty((64 << 20,), dtype=torch.uint8, device=dev)
+    cp_dst = torch.empty_like(cp_src)
+    cp_dst.copy_(cp_src)
+    torch.cuda.synchronize(dev)
+    tc0 = time.perf_counter()
+    for _ in range(5):
+        cp_dst.copy_(cp_src)
+    torch.cuda.synchronize(dev)
+    copy_gbps = 5 * (64 << 20) / (time.perf_counter() - tc0) / 1e9
+    del cp_src, cp_dst
+    ref_ms, launch_ms, link_inv, copy_inv, coll_ms = max_over_ranks([ref_ms, launch_ms, 1.0 / link_gbps, 1.0 / copy_gbps, t_small])
+    plan = lfd_dist.plan_replication(total_refs, world, ref_ms, ref_bytes, launch_ms=launch_ms, link_gbps=1.0 / link_inv, collective_ms=2 * coll_ms,
+                                     copy_gbps=1.0 / copy_inv)
+    if args.replicate != "auto":
+        plan = dict(plan, n_replicated=max(0, min(int(args.replicate), total_refs)), forced=True)
+        plan["n_sharded"] = total_refs - plan["n_replicated"]
+    elif world == 1:
+        plan = dict(plan, n_replicated=0, n_sharded=total_refs)
+    # The model knows the link and the kernel, not the software around them: `auto` MEASURES the candidates - the model's pick, nothing / a quarter /
+    # half / three quarters / everything replicated - a few steps each, and takes the fastest (pure sharding and "every rank computes everything"
+    # are always among them: the planned schedule is never slower than either).  The ranks agree on the times (MAX), hence on the choice.
+    measured = {0: el_pure / args.steps * 1e3}
+    if args.replicate == "auto" and world > 1:
+        probe_steps = max(4, min(args.steps, 15))
+        for cand in sorted({int(plan["n_replicated"]), total_refs // 4, total_refs // 2, (3 * total_refs) // 4, total_refs} - {0}):
+            trial = Schedule(cand)
+            trial.scene()
+            el_c, _r = timed(trial, probe_steps)
+            (el_c,) = max_over_ranks([el_c])
+            measured[cand] = el_c / probe_steps * 1e3
+            del trial
+            torch.cuda.empty_cache()
+        best = min(measured, key=lambda c_: (measured[c_], c_))
+        plan = dict(plan, model_n_replicated=int(plan["n_replicated"]), n_replicated=int(best), n_sharded=total_refs - int(best))
+
+    # ---- 3. the planned schedule: `value` ----------------------------------------------------------------------------------------------------------
+    n_rep = int(plan["n_replicated"])
+    if n_rep > 0:
+        sched = Schedule(n_rep)
+        for _ in range(max(args.warmup, 1)):
+            sched.scene()
+        el_value, (n_sh_pts, n_rep_pts, recs_v, counts_v) = timed(sched, args.steps)
+        (el_value,) = max_over_ranks([el_value])
+        sh_total = int(counts_v.sum()) if counts_v is not None else 0
+        rep_t = torch.tensor([n_rep_pts], dtype=torch.int64, device=cdev)
+        dist.all_reduce(rep_t, op=dist.ReduceOp.MAX)                 # (a rank that does not consume the cloud computed no replicated part)
+        assert sh_total + int(rep_t.item()) == total_pts, (sh_total, int(rep_t.item()), total_pts)          # the same scene, every point once
+        if consumes_cloud:
+            assert recs_v.numel() == total_pts * cols, (recs_v.numel(), total_pts)
+            if recs is not None and recs.numel() == recs_v.numel():
+                assert torch.equal(recs_v.reshape(-1).to(recs.device), recs.reshape(-1)), "the planned schedule's cloud differs from the pure-sharding one"
+    else:
+        sched, el_value = pure, el_pure
+
+    # round 3's end-of-run exchanges (28-byte rows, one collective after the last reference) on the pure-sharding survivors, for comparison
     end_of_run = {}
-    if ply:                            # (the 28-byte arrays of the same survivors, for the comparison only)
-        outs = [hb.OutputBuffers(len(ch) * H * W, len(ch), args.k, dev, with_cell=False, with_segments=False) if ch else None for ch in chunks]
-        for c in range(n_rounds):
-            if batches[c] is not None:
-                dens.launch_dense(batches[c], params, outs[c])
-    res_all = [outs[c].collect() for c in range(n_rounds) if batches[c] is not None]
+    outs = [hb.OutputBuffers(len(ch) * H * W, len(ch), args.k, dev, with_cell=False, with_segments=False) if ch else None for ch in pure.chunks]
+    for c in range(pure.n_rounds):
+        if pure.batches[c] is not None:
+            dens.launch_dense(pure.batches[c], params, outs[c])
+    res_all = [outs[c].collect() for c in range(pure.n_rounds) if pure.batches[c] is not None]
     lx = torch.cat([r.xyz for r in res_all]) if res_all else torch.zeros((0, 3), device=dev)
     lc = torch.cat([r.rgb for r in res_all]) if res_all else torch.zeros((0, 3), device=dev)
     le = torch.cat([r.err for r in res_all]) if res_all else torch.zeros((0,), device=dev)
@@ -679,13 +887,13 @@ def run_sharded(args, world, rank, dev, dist, backend):
     for name, fn in (("allgather_ms", lfd_dist.all_gather_by_reference), ("gather_to_root_ms", lfd_dist.gather_to_root_by_reference)):
         fn(lx, lc, le, counts_local, total_refs, dist)
         barrier()
-        t_ag = time.perf_counter()
+        t_e = time.perf_counter()
         g = fn(lx, lc, le, counts_local, total_refs, dist)
         barrier()
-        ag = torch.tensor([time.perf_counter() - t_ag], dtype=torch.float64, device=cdev)
-        dist.all_reduce(ag, op=dist.ReduceOp.MAX)
-        end_of_run[name] = float(ag[0].item()) * 1e3
+        (dt_e,) = max_over_ranks([time.perf_counter() - t_e])
+        end_of_run[name] = dt_e * 1e3
         assert int(g[3].sum()) == total_pts
+    del outs, res_all, lx, lc, le
 
     # the upstream-equivalent mode through the same exchange: every reference's ~9.1k selected cells (M = 10000), per-reference RNG streams,
     # the rank's share in ONE fused call, f32 rows in one round
@@ -693,10 +901,12 @@ def run_sharded(args, world, rank, dev, dist, backend):
     if not args.light or world > 1:
         M = cfg.matches_per_ref
         capn = M + 24 * 24 + 64
-        G = len(refs)
-        bg = hb.PreparedBatch(refs, wm, hm, cameras=cams)
+        my_refs = refs_at(pure.sh_pos)
+        G = len(my_refs)
+        bg = hb.PreparedBatch(my_refs, wm, hm, cameras=cams)
         outg = hb.OutputBuffers(capn * G, G, args.k, dev)
-        seeds = [(cfg.seed * 2654435761 + gi) & 0xFFFFFFFF for gi in mine]
+        seeds = [(cfg.seed * 2654435761 + gi) & 0xFFFFFFFF for gi in pure.sh_pos]
+        n_local_max = (total_refs + world - 1) // world
 
         def sampled_scene():
             ex = lfd_dist.OverlappedExchange(dist, total_refs, n_local_max, dev, form=args.exchange, record="f32")
@@ -714,58 +924,69 @@ def run_sharded(args, world, rank, dev, dist, backend):
         for _ in range(reps):
             srecs, scounts = sampled_scene()
         barrier()
-        dts = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=cdev)
-        dist.all_reduce(dts, op=dist.ReduceOp.MAX)
-        dts = float(dts[0].item())
+        (dts,) = max_over_ranks([time.perf_counter() - ts])
         sampled = {"value": float(scounts.sum()) * reps / dts, "unit": "points/s", "ms_per_scene": dts / reps * 1e3, "points_per_scene": int(scounts.sum()),
                    "pairs_per_s": total_refs * args.k * reps / dts, "matches_per_ref": M,
                    "note": "upstream-equivalent mode (coverage sampling, ~9.1k cells per reference) on the same scene and shards, 28-byte rows through "
-                           "the same collective in one round, INSIDE the time"}
+                           "the same collective in one round, INSIDE the time (never replicated: its exchange is small)"}
 
     if rank == 0:
-        cells_rank = len(refs) * H * W
-        s_frac = (n_pts / cells_rank) if cells_rank else 0.0
+        n_rank_refs = len(pure.sh_pos)
+        cells_rank = n_rank_refs * H * W
+        s_frac = (n_pts_pure / cells_rank) if cells_rank else 0.0
         bytes_per_cell = 4 * args.k + 11 + (15 if ply else 28) * s_frac        # what this launch moves at least: k certainties, the winner's warp, a texel; 15 / 28 B per survivor
         kname = "lfd_dense_ply_kernel" if ply else "lfd_dense_kernel"
         rccl = world if backend == "nccl" else 0
-        step_ms = elapsed / args.steps * 1e3
+        step_ms = el_value / args.steps * 1e3
+        n_sh = int(plan["n_sharded"])
         line = {
             "metric": "triangulated points/sec + pairs/sec, MipNeRF360 garden @fast, 1/2/4/8 GPU",
-            "value": total_pts * args.steps / elapsed, "unit": "points/s", "n_gpus": world, "rccl_ranks": rccl, "collective_backend": backend,
+            "value": total_pts * args.steps / el_value, "unit": "points/s", "n_gpus": world, "rccl_ranks": rccl, "collective_backend": backend,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32 (+f64 Sampson/DLT solve)", "data": "synthetic",
-            "value_includes": f"compute + the {args.exchange} of the survivors ({rec_bytes}-byte records), in {n_rounds} round(s) beside the compute",
+            "value_includes": (f"every point of the scene ONCE: compute + the {args.exchange} of the survivors ({rec_bytes}-byte records) of {n_sh} sharded "
+                               f"references in {sched.n_rounds} round(s) beside the compute; {n_rep} references replicated (computed by every rank that "
+                               "receives the cloud instead of travelling); the ordered cloud ends up contiguous where the collective delivers it"),
             "config": {"workload": f"{WORKLOADS[args.workload]['what']}: ring of {WORKLOADS[args.workload]['n_cams']} cameras 1297x840, `{args.preset}` grid {H}x{W}, "
                                    f"{args.refs} reference views x {args.k} neighbours {'per GPU' if args.scaling == 'weak' else 'in total, dealt over the ranks'}, "
                                    f"default thresholds (certainty 0.2 / sampson 5.0 / reproj 0.8 / parallax 0.5 deg), noise {args.noise_px} px, {args.outliers:.0%} outliers",
-                       "kernel": f"fused dense filter+triangulate kernel ({kname})", "mode": "dense", "refs_per_gpu": len(refs), "refs_total": total_refs,
-                       "neighbours": args.k, "grid": [H, W], "sharding": f"references round-robin over {world} rank(s)",
-                       "launches_per_step": launches_per_step, "refs_per_round": per_round},
-            "pairs_per_s": total_refs * args.k * args.steps / elapsed,
-            "cells_per_s": total_refs * H * W * args.steps / elapsed,
+                       "kernel": f"fused dense filter+triangulate kernel ({kname})", "mode": "dense", "refs_per_gpu": n_rank_refs, "refs_total": total_refs,
+                       "neighbours": args.k, "grid": [H, W], "sharding": f"{n_sh} references round-robin over {world} rank(s), {n_rep} replicated",
+                       "launches_per_step": sched.launches_per_step, "refs_per_round": sched.per_round},
+            "pairs_per_s": total_refs * args.k * args.steps / el_value,
+            "cells_per_s": total_refs * H * W * args.steps / el_value,
             "survivor_fraction": s_frac,
-            "value_compute_only": total_pts * args.steps / elapsed_compute, "compute_ms": elapsed_compute / args.steps * 1e3,
-            "kernel_ms": kernel_ms_max, "exchange_ms_exposed": (elapsed - elapsed_compute) / args.steps * 1e3,
-            "value_sharded_resident": total_pts * args.steps / elapsed_resident,
-            "value_sharded_resident_note": "the same steps with only the per-reference counts exchanged (form counts_only): the ordered cloud stays sharded over the "
+            "replication": {"n_replicated": n_rep, "n_sharded": n_sh, "planned_step_ms": plan["step_ms"], "planned_pure_sharding_ms": plan["pure_sharding_ms"],
+                            "planned_single_rank_ms": plan["single_rank_ms"], "inputs_measured_in_this_run": plan["inputs"], "forced": bool(plan.get("forced")),
+                            "model_n_replicated": plan.get("model_n_replicated"), "candidates_measured_ms": {str(k_): v_ for k_, v_ in sorted(measured.items())},
+                            "redundant_cells_per_step": n_rep * H * W * (world - 1 if args.exchange == "all_gather" else 0),
+                            "note": "core/distributed.py::plan_replication: the references whose recomputation on every rank is cheaper than their "
+                                    "survivors' trip over a link; with a matcher in the loop (tens of ms per pair) the plan is 0"},
+            "value_pure_sharding": total_pts * args.steps / el_pure, "pure_sharding_ms": el_pure / args.steps * 1e3,
+            "value_compute_only": total_pts * args.steps / el_compute, "compute_ms": el_compute / args.steps * 1e3,
+            "kernel_ms": kernel_ms_max, "exchange_ms_exposed": (el_pure - el_compute) / args.steps * 1e3,
+            "value_sharded_resident": total_pts * args.steps / el_resident,
+            "value_sharded_resident_note": "the pure-sharding steps with only the per-reference counts exchanged (form counts_only): the ordered cloud stays sharded over the "
                                            "ranks' HBM with every reference's global offset known on every rank - comparable to N = 1, whose result also stays in HBM",
             "end_to_end": None,
             "end_to_end_note": "points/s including the RoMa-v2 forward (SURVEY 8d iii) is unmeasured: neither the RoMa-v2 weights nor torchvision are on the box",
-            "exchange": {"form": args.exchange, "record_bytes": rec_bytes, "rounds": n_rounds, "overlapped": True, "points": total_pts,
-                         "bytes_per_rank_sent": int(rec_bytes * n_pts), "bytes_gathered": int(rec_bytes * total_pts), "backend": backend,
-                         "order": "global reference position (1-GPU sequence)", "end_of_run_28B": end_of_run},
+            "exchange": {"form": args.exchange, "record_bytes": rec_bytes, "rounds": sched.n_rounds, "overlapped": True, "points": total_pts,
+                         "bytes_per_rank_sent": int(rec_bytes * n_pts_pure), "bytes_gathered": int(rec_bytes * total_pts), "backend": backend,
+                         "order": "global reference position (1-GPU sequence)", "end_of_run_28B": end_of_run,
+                         "allgather_GBps_per_peer_measured": 1.0 / link_inv, "collective_ms_measured": coll_ms, "note": "bytes_*: the pure-sharding schedule"},
             "roofline": {"bound": "hbm", "kernel": kname, "kernel_ms": kernel_ms_step,
                          "achieved": (cells_rank * bytes_per_cell / (kernel_ms_step * 1e-3) / 1e9) if kernel_ms_step > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (cells_rank * bytes_per_cell / (kernel_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms_step > 0 else None,
                          "traffic": None, "bytes_per_cell": bytes_per_cell,
-                         "note": f"rank 0's {launches_per_step} launch(es) per step ({len(refs)} reference views), HIP start/stop events of each launch"},
+                         "note": f"rank 0's {pure.launches_per_step} launch(es) per pure-sharding step ({n_rank_refs} reference views), HIP start/stop events of each launch"},
         }
         if sampled is not None:
             line["sampled_mode"] = sampled
         if world > 1:
             line["scaling_note"] = ("no multi-GPU node was available to the builder: when this line comes from N real GPUs it is the first measurement. In dense mode ONE "
-                                    "GPU triangulates the scene faster than its survivors can cross an xGMI link (DESIGN 5), so `value` at 2 and 4 GPUs is bound by "
-                                    "the link, not by the kernel; `sampled_mode` is the upstream-equivalent job, whose exchange is small")
+                                    "GPU triangulates the scene faster than its survivors can cross an xGMI link (DESIGN 5): `value_pure_sharding` is bound by the link, "
+                                    "`value` recomputes what is cheaper to recompute than to move (the plan's inputs are measured in this run); `sampled_mode` is the "
+                                    "upstream-equivalent job, whose exchange is small")
         print(json.dumps(line), flush=True)
     dist.barrier()
     dist.destroy_process_group()

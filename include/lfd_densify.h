@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LFD_ABI_VERSION 5
+#define LFD_ABI_VERSION 6
 #define LFD_MAX_SLOTS 16 /* neighbours per reference handled by one launch */
 
 enum lfd_status {
@@ -243,6 +243,16 @@ int lfd_pack_ply(lfd_context* ctx, const float* xyz, const float* rgb, int64_t n
 int lfd_pack_points3d(lfd_context* ctx, const float* xyz, const float* rgb, const float* err, int64_t n,
                       uint64_t id_base, uint8_t* out);
 int lfd_quantise_rgb(lfd_context* ctx, const float* rgb, int64_t n, uint8_t* out);
+
+/* (e) multi-GPU exchange, placement step (no upstream counterpart - upstream has no multi-GPU code): n copies
+ * dst[dst_offset .. +nbytes) = src[src_offset .. +nbytes) in ONE launch on `hip_stream` of device `device_index` (offsets and lengths in
+ * bytes, no alignment required: 15-byte PLY records).  The overlapped exchange receives every rank's records of a round as one padded block
+ * per rank; this puts each reference's records at its place in the ordered cloud (core/distributed.py::OverlappedExchange).  Needs no
+ * context; segments must not overlap each other's destination.  Asynchronous. */
+typedef struct lfd_copy_segment {
+    int64_t src_offset, dst_offset, nbytes;
+} lfd_copy_segment;
+int lfd_copy_segments(void* hip_stream, int32_t device_index, const void* src, void* dst, const lfd_copy_segment* segs, int32_t n);
 
 /* Debug / test read-back: the f64-widened fundamental matrices the kernels of the LAST prepared batch used, one
  * row-major 3x3 per (reference, slot) pair (n_pairs = n_refs * k of that batch; rows of unused slots are unspecified).

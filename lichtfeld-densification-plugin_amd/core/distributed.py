@@ -17,6 +17,11 @@ finished references' records are handed to an asynchronous collective (all-gathe
 computes; the result is the same ordered sequence.  When the consumer is the PLY writer the 15-byte device-packed records travel
 instead of the 28-byte rows.
 
+``plan_replication`` / ``split_replicated``: recompute instead of communicate.  One GPU triangulates a reference faster than its survivors cross an
+xGMI link, so a sharded dense run is bound by the link; the references of a scene are therefore split into a SHARDED prefix (dealt over the ranks,
+exchanged) and a REPLICATED suffix (computed by every rank that needs the cloud, never sent), sized so that the redundant compute and the exchange of
+the rest take the same time.  With a matcher in the loop (tens of ms per pair) the plan is "shard everything"; for the bare hot path it is not.
+
 ``ShardedPlyStream`` is the streamed writer of a sharded run (BASELINE config 5): every rank packs the PLY records of its
 finished references on the device and rank 0 appends them to the output file in global reference order as they arrive.
 
@@ -36,6 +41,55 @@ def shard_references(n_refs: int, rank: int, world: int) -> List[int]:
     """Positions (in the global reference list) owned by ``rank``: round-robin, which balances the
     k-centres ordering of the list."""
     return list(range(rank, n_refs, world))
+
+
+def split_replicated(n_refs: int, n_replicated: int, rank: int, world: int, replicas_here: bool = True) -> Tuple[List[int], int]:
+    """Positions this rank processes when the LAST ``n_replicated`` references of the global list are computed by every rank instead of
+    exchanged: its round-robin share of the sharded prefix ``[0, n_sharded)`` followed by the whole replicated suffix (``replicas_here=False``:
+    a rank that does not consume the cloud - ``gather_to_root``, not the root - skips the suffix).  Returns ``(positions, n_sharded)``."""
+    n_rep = max(0, min(int(n_replicated), int(n_refs)))
+    n_sh = int(n_refs) - n_rep
+    mine = shard_references(n_sh, rank, world)
+    if replicas_here:
+        mine = mine + list(range(n_sh, int(n_refs)))
+    return mine, n_sh
+
+
+def plan_replication(n_refs: int, world: int, ref_ms: float, ref_bytes: float, *, launch_ms: float = 0.0, link_gbps: float = 122.0,
+                     collective_ms: float = 0.05, copy_gbps: float = 2000.0) -> dict:
+    """How many of a scene's ``n_refs`` references to REPLICATE (compute on every rank) instead of exchanging them, for an all-gather (or a
+    gather to one rank) of the survivors over point-to-point links.
+
+    Cost model (one step = the scene once; the sharded part is launched first, its rounds travel while the replicated part computes):
+        compute(n)   = launch_ms + ref_ms * n                              one rank's launches over n references
+        exchange(m)  = collective_ms + m * ref_bytes / link                one rank's shard of m references crossing ONE link - what a direct
+                                                                           all-gather and a gather need, every peer on its own link at once
+        merge(n)     = n * ref_bytes / copy                                the gathered records copied to their ordered place
+        T(n_sh)      = compute(ceil(n_sh / world)) + max(compute(n_refs - n_sh), exchange(ceil(n_sh / world))) + merge(n_sh)
+    Returns the ``n_sh`` of the smallest T (ties: the larger sharded part - less redundant work) as
+    ``{"n_sharded", "n_replicated", "step_ms", "pure_sharding_ms", "single_rank_ms", "inputs"}``.  ``ref_ms`` is the per-reference cost of
+    EVERYTHING a rank does for a reference (with a matcher in the loop: tens of ms - the plan is then n_replicated = 0); ``link_gbps`` the
+    measured all-gather bandwidth per peer.  world == 1: nothing is exchanged, nothing replicated."""
+    n_refs, world = int(n_refs), max(1, int(world))
+    link = max(float(link_gbps), 1e-6) * 1e6          # bytes per ms
+    copy = max(float(copy_gbps), 1e-6) * 1e6
+
+    def compute(n):
+        return (float(launch_ms) + float(ref_ms) * n) if n > 0 else 0.0
+
+    def step(n_sh):
+        m = -(-n_sh // world)
+        ex = (float(collective_ms) + m * float(ref_bytes) / link) if n_sh > 0 else 0.0
+        return compute(m) + max(compute(n_refs - n_sh), ex) + n_sh * float(ref_bytes) / copy
+
+    inputs = {"n_refs": n_refs, "world": world, "ref_ms": float(ref_ms), "ref_bytes": float(ref_bytes), "launch_ms": float(launch_ms),
+              "link_gbps": float(link_gbps), "collective_ms": float(collective_ms), "copy_gbps": float(copy_gbps)}
+    single = compute(n_refs)
+    if world == 1 or n_refs == 0:
+        return {"n_sharded": n_refs, "n_replicated": 0, "step_ms": single, "pure_sharding_ms": single, "single_rank_ms": single, "inputs": inputs}
+    best = min(range(n_refs + 1), key=lambda n_sh: (round(step(n_sh), 9), -n_sh))
+    return {"n_sharded": best, "n_replicated": n_refs - best, "step_ms": step(best), "pure_sharding_ms": step(n_refs), "single_rank_ms": single,
+            "inputs": inputs}
 
 
 def _pack(xyz: torch.Tensor, rgb: torch.Tensor, err: torch.Tensor, rows: int) -> torch.Tensor:
@@ -326,12 +380,23 @@ class OverlappedExchange:
     of the same kind ((N, 7) float32 / (N * 15,) uint8; on every rank for ``all_gather``, on ``root`` for ``gather_to_root``, where the other
     ranks get their own shard back) and the (n_refs_global,) survivor counts.
 
+    Nothing is copied that need not be: records pushed as consecutive views of one buffer (what a launch of the fused kernel leaves: the references
+    of a batch one after the other) travel from where they are - no concatenation - and, when that buffer has room for the round's padded size
+    (it has: a launch's buffer holds H * W records per reference), without a padded copy either; the receivers never look beyond the counts.
+    ``push_many`` hands over such a run of references in one call.  The gathered blocks reach their ordered places in ONE launch per exchange
+    (``lfd_copy_segments`` through ``hip_backend.copy_segments``; per-reference tensor copies on host tensors).
+
     ``form="counts_only"``: nothing but the counts travels - every rank keeps its own shard and learns, round by round, where its references
     sit in the global sequence (``_round_known`` is called with each round's table: ``SharedFilePlyStream`` writes its byte ranges of the
     output file from there).  ``finish()`` then returns this rank's own records and the global counts."""
 
     def __init__(self, dist, n_refs_global: int, refs_per_round: int, device, form: str = "all_gather", record: str = RECORD_F32,
-                 group=None, root: int = 0):
+                 group=None, root: int = 0, eager: bool = False, dest: Optional[torch.Tensor] = None):
+        """``eager``: a round's records leave as soon as the round is complete - its counts are waited for on the spot (a host wait of one small
+        collective) instead of a round later; for a caller whose next launch is already queued (bench.py), so that the records travel while it
+        runs.  ``dest``: a (rows, cols) tensor on the exchange's device with room for every record: the ordered records are placed into it FROM
+        ROW 0 as the rounds complete (each round's placement queued behind its collective) instead of all at the end into a new tensor; ``finish``
+        then returns ``dest[:total]``."""
         if form not in ("all_gather", "gather_to_root", "counts_only"):
             raise ValueError("form must be 'all_gather', 'gather_to_root' or 'counts_only'")
         if record not in (RECORD_F32, RECORD_PLY):
@@ -347,6 +412,14 @@ class OverlappedExchange:
         self.n_local = len(shard_references(self.n_refs, self.rank, self.world))
         n_local_max = (self.n_refs + self.world - 1) // self.world
         self.n_rounds = (n_local_max + self.B - 1) // self.B
+        self.eager = bool(eager)
+        self._dest = dest
+        if dest is not None and (dest.dim() != 2 or dest.shape[1] != self.cols or dest.dtype != self.dtype or not dest.is_contiguous()
+                                 or dest.device != self.dev):
+            raise ValueError(f"dest must be a contiguous (rows, {self.cols}) {self.dtype} tensor on {self.dev}")
+        self._placed = 0                   # rounds whose records are at their ordered place in dest already
+        self._placed_rows = 0
+        self._block: dict = {}             # round -> (records of the whole round as one view, per-reference counts): push_many's fast path
         self._open: dict = {}              # local index -> records of the round being filled
         self._cur = 0                      # round being filled
         self._rounds: list = []            # closed rounds: dict(counts_out, counts_work, payload, n_local, work, gathered, table)
@@ -370,39 +443,125 @@ class OverlappedExchange:
             if rec.dtype != self.dtype:
                 raise ValueError(f"records must be {self.dtype} with {self.cols} columns per point")
             self._open[li] = rec
+        if self._cur < self.n_rounds and li == min((self._cur + 1) * self.B, self.n_local) - 1:
+            self._close_round()                # the round is complete: its counts leave now, not when the next round's first reference arrives
+
+    def push_many(self, first_local_index: int, records: torch.Tensor, counts: Sequence[int]) -> None:
+        """``len(counts)`` consecutive local references at once: ``records`` holds their records one after the other (``counts[i]`` each) - the
+        buffer a launch of the fused kernel wrote.  The same as one ``push`` per reference with the corresponding slice (views: nothing is copied);
+        a run that is exactly one round is taken over as ONE view."""
+        rec = records.reshape(-1, self.cols)
+        first, m = int(first_local_index), len(counts)
+        c = first // self.B if self.B else 0
+        whole_round = (m > 0 and first == c * self.B and first + m == min((c + 1) * self.B, self.n_local) and first == self._last_local + 1
+                       and not self.finished and rec.dtype == self.dtype)
+        if not whole_round:
+            lo = 0
+            for i, n in enumerate(counts):
+                n = int(n)
+                self.push(first + i, rec[lo:lo + n] if n else None)
+                lo += n
+            return
+        while self._cur < c:
+            self._close_round()
+        cnt = np.zeros(self.B, np.int64)
+        cnt[:m] = np.asarray(counts, np.int64)
+        self._block[c] = (rec[:int(cnt.sum())], cnt)
+        self._last_local = first + m - 1
+        self._close_round()
+
+    def _joined(self, parts):
+        """One (rows, cols) tensor of the parts in order: a VIEW when they already lie one after the other in one buffer, else a concatenation."""
+        if len(parts) == 1:
+            return parts[0]
+        es = parts[0].element_size()
+        run = all(p.is_contiguous() for p in parts) and all(
+            parts[i + 1].untyped_storage().data_ptr() == parts[0].untyped_storage().data_ptr()
+            and parts[i + 1].data_ptr() == parts[i].data_ptr() + parts[i].numel() * es for i in range(len(parts) - 1))
+        if run:
+            rows = sum(int(p.shape[0]) for p in parts)
+            return torch.as_strided(parts[0], (rows, self.cols), (self.cols, 1))
+        return torch.cat(parts, 0)
 
     def _close_round(self) -> None:
         c = self._cur
-        counts = torch.zeros(self.B, dtype=torch.int64)
-        parts = []
-        for j in range(self.B):
-            rec = self._open.pop(c * self.B + j, None)
-            if rec is not None:
-                counts[j] = rec.shape[0]
-                parts.append(rec)
-        payload = (torch.cat(parts, 0) if len(parts) > 1 else parts[0]) if parts else torch.empty((0, self.cols), dtype=self.dtype, device=self.home)
+        blk = self._block.pop(c, None)
+        if blk is not None:
+            payload, counts = blk[0], torch.from_numpy(blk[1])
+        else:
+            counts = torch.zeros(self.B, dtype=torch.int64)
+            parts = []
+            for j in range(self.B):
+                rec = self._open.pop(c * self.B + j, None)
+                if rec is not None:
+                    counts[j] = rec.shape[0]
+                    parts.append(rec)
+            payload = self._joined(parts) if parts else torch.empty((0, self.cols), dtype=self.dtype, device=self.home)
         cnt_in = counts.to(self.dev)
         cnt_out = torch.empty(self.world * self.B, dtype=torch.int64, device=self.dev)
         work = self.dist.all_gather_into_tensor(cnt_out, cnt_in, group=self.group, async_op=True)
         self._rounds.append(dict(counts_in=cnt_in, counts_out=cnt_out, counts_work=work, payload=payload, n_local=int(counts.sum()),
                                  local_counts=counts, work=None, gathered=None, table=None, padded=None))
         self._cur += 1
-        if c >= 1:
+        if self.eager:
+            self._send_round(c)               # (waits for the counts it has just sent off: the caller's next launch is already queued)
+        elif c >= 1:
             self._send_round(c - 1)           # its counts were gathered a whole round ago
+
+    def _round_segments(self, c: int, base_row: int, row_bytes: int):
+        """(source byte offset in the round's gathered block, destination byte offset, bytes) of every reference of round ``c``; the round's
+        references are consecutive in the global order (local index first, then rank), the first of them at ``base_row``."""
+        st = self._rounds[c]
+        table = st["table"]
+        within = np.concatenate([np.zeros((self.world, 1), np.int64), np.cumsum(table, axis=1)], axis=1)
+        rows = int(st["gathered"].shape[1])
+        segs, at = [], int(base_row)
+        for j in range(self.B):
+            for r in range(self.world):
+                n = int(table[r, j])
+                if n and r + (c * self.B + j) * self.world < self.n_refs:
+                    segs.append(((r * rows + int(within[r, j])) * row_bytes, at * row_bytes, n * row_bytes))
+                    at += n
+        return segs
+
+    def _place_round(self, c: int) -> None:
+        """Round ``c``'s records to their ordered place in ``dest`` (queued behind the round's collective; rounds are placed in order)."""
+        st = self._rounds[c]
+        if st["gathered"] is not None:
+            st["work"].wait()
+            self._place(st["gathered"], self._dest, self._round_segments(c, self._placed_rows, self.cols * self._dest.element_size()))
+        self._placed_rows += int(st["table"].sum())
+        self._placed += 1
 
     def _send_round(self, c: int) -> None:
         st = self._rounds[c]
+        if st.get("sent"):
+            return
+        st["sent"] = True
         st["counts_work"].wait()
         # the gathered counts as a host table: a few dozen integers (under RCCL their copy is ordered behind the collective by wait())
         table = st["counts_out"].cpu().view(self.world, self.B).numpy().copy()
         st["table"] = table
         self._round_known(c, table, st)
         rows = int(table.sum(axis=1).max())
+        early = self._dest is not None and (self.form == "all_gather" or (self.form == "gather_to_root" and self.rank == self.root))
+        if early:
+            if int(self._placed_rows + sum(int(self._rounds[i]["table"].sum()) for i in range(self._placed, c + 1))) > int(self._dest.shape[0]):
+                raise ValueError("dest has no room for the records gathered so far")
+            while self._placed < c:                 # the rounds before this one: their collectives were launched a round ago
+                self._place_round(self._placed)
         if rows == 0 or self.form == "counts_only":
             return
-        padded = torch.zeros((rows, self.cols), dtype=self.dtype, device=self.dev)
-        if st["n_local"]:
-            padded[:st["n_local"]] = st["payload"].to(self.dev)
+        pay = st["payload"]
+        room = (pay.untyped_storage().nbytes() - pay.storage_offset() * pay.element_size()) // (self.cols * pay.element_size()) if st["n_local"] else 0
+        if st["n_local"] and pay.device == self.dev and pay.is_contiguous() and room >= rows:
+            # the records' own buffer has room for the round's padded size: they travel from where they are (what lies behind them is
+            # whatever the buffer held - the receivers never look beyond the counts)
+            padded = torch.as_strided(pay, (rows, self.cols), (self.cols, 1))
+        else:
+            padded = torch.zeros((rows, self.cols), dtype=self.dtype, device=self.dev)
+            if st["n_local"]:
+                padded[:st["n_local"]] = pay.to(self.dev)
         st["padded"] = padded
         self.bytes_sent += padded.numel() * padded.element_size()
         if self.form == "all_gather":
@@ -421,8 +580,12 @@ class OverlappedExchange:
     def _round_known(self, c: int, table: np.ndarray, st: dict) -> None:
         """Hook: the counts of round ``c`` of every rank (``table[rank, j]``) have arrived (called in round order)."""
 
-    def finish(self):
-        """Close what is left (every rank runs ``n_rounds`` rounds), wait for the collectives, return the ordered records and counts."""
+    def finish(self, place=None, concat: bool = True):
+        """Close what is left (every rank runs ``n_rounds`` rounds), wait for the collectives, return the ordered records and counts.
+        ``concat=False``: where this rank only gets its own shard back (``counts_only``, or ``gather_to_root`` off the root) the records are
+        returned as the list of the rounds' payloads, where they are, instead of one concatenated copy.
+        ``place(n_rows)``: optional, returns the (n_rows, cols) tensor on this exchange's device the ordered records are to be written INTO (a
+        slice of a larger buffer: the caller's own records sit next to it) instead of a new allocation; used where this rank assembles the cloud."""
         if self.finished:
             raise RuntimeError("finish called twice")
         self.finished = True
@@ -443,21 +606,41 @@ class OverlappedExchange:
         have_all = self.form == "all_gather" or (self.form == "gather_to_root" and self.rank == self.root)
         if not have_all:            # gather_to_root, another rank: its own shard, untouched
             own = [st["payload"] for st in self._rounds if st["n_local"]]
-            mine = torch.cat(own, 0) if own else torch.empty((0, self.cols), dtype=self.dtype, device=self.home)
+            if not concat:
+                return [self._shape(p_.to(self.home)) for p_ in own], global_counts
+            mine = (torch.cat(own, 0) if len(own) > 1 else own[0]) if own else torch.empty((0, self.cols), dtype=self.dtype, device=self.home)
             return self._shape(mine.to(self.home)), global_counts
+        if self._dest is not None:
+            while self._placed < len(self._rounds):
+                self._place_round(self._placed)
+            return self._shape(self._dest[:self._placed_rows].to(self.home)), global_counts
         offsets = np.concatenate([[0], np.cumsum(global_counts)])
-        out = torch.empty((int(offsets[-1]), self.cols), dtype=self.dtype, device=self.dev)
+        if place is not None:
+            out = place(int(offsets[-1]))
+            if tuple(out.shape) != (int(offsets[-1]), self.cols) or out.dtype != self.dtype or out.device != self.dev:
+                raise ValueError(f"place() must return a ({int(offsets[-1])}, {self.cols}) {self.dtype} tensor on {self.dev}")
+        else:
+            out = torch.empty((int(offsets[-1]), self.cols), dtype=self.dtype, device=self.dev)
+        row_bytes = self.cols * out.element_size()
+        base = 0
         for c, st in enumerate(self._rounds):
-            if st["gathered"] is None:
-                continue
-            within = np.concatenate([np.zeros((self.world, 1), np.int64), np.cumsum(st["table"], axis=1)], axis=1)
-            for r in range(self.world):
-                for j in range(self.B):
-                    g = r + (c * self.B + j) * self.world
-                    n = int(st["table"][r, j])
-                    if g < self.n_refs and n:
-                        out[int(offsets[g]):int(offsets[g]) + n] = st["gathered"][r, int(within[r, j]):int(within[r, j]) + n]
+            if st["gathered"] is not None:
+                self._place(st["gathered"], out, self._round_segments(c, base, row_bytes))
+            base += int(st["table"].sum())
         return self._shape(out.to(self.home)), global_counts
+
+    def _place(self, src: torch.Tensor, dst: torch.Tensor, segs) -> None:
+        """dst.bytes[d : d + n] = src.bytes[s : s + n] for every (s, d, n): one launch on the device, tensor copies on the host."""
+        if not segs:
+            return
+        if src.is_cuda:
+            from . import hip_backend as hb
+            # (dst may be a view into a larger buffer - finish(place=...): offsets are relative to ITS first byte)
+            hb.copy_segments(src, dst, segs)
+            return
+        sb, db = src.reshape(-1).view(torch.uint8), dst.reshape(-1).view(torch.uint8)
+        for s_, d_, n_ in segs:
+            db[d_:d_ + n_] = sb[s_:s_ + n_]
 
     def _shape(self, t: torch.Tensor) -> torch.Tensor:
         return t if self.record == RECORD_F32 else t.reshape(-1)

@@ -18,7 +18,7 @@ import torch
 from .types import CameraRecord, DensePipelineConfig
 
 LFD_MAX_SLOTS = 16
-LFD_ABI_VERSION = 5
+LFD_ABI_VERSION = 6
 LFD_FLAG_EXACT_COLOUR = 1     # lfd_params.flags: dense mode blends colours with upstream's f64 arithmetic (bit-identical rgb)
 LFD_FLAG_TILE_SEGMENTS = 2    # informational: the caller takes the unordered-retirement route (lfd_triangulate_dense_segments)
 _LIB_NAME = "liblfd_densify.so"
@@ -115,6 +115,7 @@ def load_library() -> C.CDLL:
     lib.lfd_pack_ply.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.lfd_pack_points3d.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]
     lib.lfd_quantise_rgb.argtypes = [ctxp, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.lfd_copy_segments.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.lfd_launch_status.argtypes = [ctxp, C.POINTER(C.c_int32)]
     lib.lfd_get_pair_fundamental.argtypes = [ctxp, C.c_int32, C.POINTER(C.c_double)]
     lib.lfd_rng_seed.argtypes = [ctxp, C.c_uint32]
@@ -145,7 +146,7 @@ def load_library() -> C.CDLL:
     for name in ("lfd_create", "lfd_set_stream", "lfd_reload_env", "lfd_kernel_timing", "lfd_kernel_timing_read", "lfd_upload_cameras", "lfd_prepare_batch", "lfd_aggregate", "lfd_triangulate_dense",
                  "lfd_triangulate_dense_ply", "lfd_dense_tiles_per_ref", "lfd_triangulate_dense_segments", "lfd_order_segments", "lfd_pack_ply_segments", "lfd_pack_points3d_segments",
                  "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_triangulate_sampled_multi", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
-                 "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_identity_axis",
+                 "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_copy_segments", "lfd_identity_axis",
                  "lfd_host_fundamental", "lfd_get_pair_fundamental", "lfd_create_host", "lfd_aggregate_host",
                  "lfd_triangulate_dense_host", "lfd_triangulate_indexed_host", "lfd_prepare_image", "lfd_prepare_mask",
                  "lfd_host_resize_tables", "lfd_host_nearest_indices",
@@ -181,6 +182,24 @@ def identity_axis(n: int) -> np.ndarray:
     if rc != 0:
         raise HipBackendError("lfd_identity_axis failed")
     return out
+
+
+def copy_segments(src: torch.Tensor, dst: torch.Tensor, segments, stream: Optional["torch.cuda.Stream"] = None) -> None:
+    """lfd_copy_segments: ``dst.bytes[d : d + n] = src.bytes[s : s + n]`` for every row ``(s, d, n)`` of ``segments`` (int64, byte offsets into the two
+    contiguous device tensors' storage views) in ONE launch on ``stream`` (default: torch's current stream of that device).  Asynchronous."""
+    segs = np.ascontiguousarray(np.asarray(segments, np.int64).reshape(-1, 3))
+    if segs.shape[0] == 0:
+        return
+    if not (src.is_cuda and dst.is_cuda and src.device == dst.device and src.is_contiguous() and dst.is_contiguous()):
+        raise ValueError("copy_segments needs two contiguous tensors on one GPU")
+    sb, db = src.numel() * src.element_size(), dst.numel() * dst.element_size()
+    if segs.min() < 0 or int((segs[:, 0] + segs[:, 2]).max()) > sb or int((segs[:, 1] + segs[:, 2]).max()) > db:
+        raise ValueError("copy_segments: a segment leaves its tensor")
+    st = stream if stream is not None else torch.cuda.current_stream(src.device)
+    rc = load_library().lfd_copy_segments(C.c_void_p(st.cuda_stream), int(src.device.index or 0), C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()),
+                                          segs.ctypes.data_as(C.c_void_p), int(segs.shape[0]))
+    if rc != 0:
+        raise HipBackendError(f"lfd_copy_segments failed ({rc})")
 
 
 def parallax_dot_threshold(min_deg: float) -> float:

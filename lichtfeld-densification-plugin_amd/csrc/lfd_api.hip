@@ -35,6 +35,7 @@ extern "C" __global__ void lfd_select_filter_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_pack_ply_kernel(const float* xyz, const float* rgb, long long n, unsigned char* out);
 extern "C" __global__ void lfd_pack_points3d_kernel(const float* xyz, const float* rgb, const float* err, long long n,
                                                     unsigned long long id_base, unsigned char* out);
+extern "C" __global__ void lfd_copy_segments_kernel(LfdCopyArgs A, const unsigned char* src, unsigned char* dst);
 extern "C" __global__ void lfd_quantise_rgb_kernel(const float* rgb, long long n3, unsigned char* out);
 extern "C" __global__ void lfd_select_topm_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_select_filter_mw_kernel(LfdSelectArgs A);
@@ -1157,6 +1158,34 @@ int lfd_pack_points3d(lfd_context* ctx, const float* xyz, const float* rgb, cons
     hipLaunchKernelGGL(lfd_pack_points3d_kernel, dim3(grid), dim3(256), 0, ctx->stream, xyz, rgb, err, (long long)n,
                        (unsigned long long)id_base, out);
     LFD_HIP(ctx, hipGetLastError());
+    return LFD_OK;
+}
+
+int lfd_copy_segments(void* hip_stream, int32_t device_index, const void* src, void* dst, const lfd_copy_segment* segs, int32_t n) {
+    if (n < 0 || (n > 0 && (!src || !dst || !segs))) return LFD_ERR_INVALID;
+    if (n == 0) return LFD_OK;
+    if (hipSetDevice(device_index) != hipSuccess) return LFD_ERR_HIP;
+    for (int32_t first = 0; first < n;) {
+        LfdCopyArgs A;
+        int m = 0;
+        long long chunks = 0;
+        A.chunk0[0] = 0;
+        for (; first < n && m < LFD_COPY_MAX_SEGS; ++first) {
+            const lfd_copy_segment& sg = segs[first];
+            if (sg.nbytes < 0 || sg.src_offset < 0 || sg.dst_offset < 0) return LFD_ERR_INVALID;
+            if (sg.nbytes == 0) continue;
+            const long long c = (sg.nbytes + LFD_COPY_CHUNK - 1) / LFD_COPY_CHUNK;
+            if (chunks + c > 0x7fffffffLL) { if (m == 0) return LFD_ERR_INVALID; break; }       // (one launch's grid is full: the rest goes into the next)
+            A.src[m] = sg.src_offset; A.dst[m] = sg.dst_offset; A.n[m] = sg.nbytes;
+            chunks += c;
+            A.chunk0[++m] = (int)chunks;
+        }
+        if (m == 0) continue;
+        A.n_segs = m;
+        hipLaunchKernelGGL(lfd_copy_segments_kernel, dim3((unsigned)chunks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), A,
+                           static_cast<const unsigned char*>(src), static_cast<unsigned char*>(dst));
+        if (hipGetLastError() != hipSuccess) return LFD_ERR_HIP;
+    }
     return LFD_OK;
 }
 

@@ -84,6 +84,14 @@ struct LfdSlotDesc {            // one per (reference, slot)
     int32_t pad;
 };
 
+#define LFD_COPY_MAX_SEGS 96
+#define LFD_COPY_CHUNK 32768       // bytes one workgroup of lfd_copy_segments_kernel moves
+struct LfdCopyArgs {               // by value in the kernel arguments (2.7 KB): no upload, no allocation
+    long long src[LFD_COPY_MAX_SEGS], dst[LFD_COPY_MAX_SEGS], n[LFD_COPY_MAX_SEGS];
+    int chunk0[LFD_COPY_MAX_SEGS + 1];      // first workgroup of every segment (exclusive prefix of ceil(n / LFD_COPY_CHUNK))
+    int n_segs;
+};
+
 struct LfdTileSeg { int32_t offset, count; };     // == lfd_tile_segment of the C-ABI
 
 struct LfdLaunch {              // kernel argument, passed by value

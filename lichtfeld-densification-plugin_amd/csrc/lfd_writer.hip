@@ -294,3 +294,39 @@ extern "C" __global__ void lfd_quantise_rgb_kernel(const float* __restrict__ rgb
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (long long)gridDim.x * blockDim.x)
         out[i] = quantise_u8(rgb[i]);
 }
+
+
+// ---- lfd_copy_segments: many (source offset, destination offset, bytes) copies in ONE launch -------------------------------------------------------
+// The overlapped exchange of a sharded run (core/distributed.py) receives every rank's records of a round as one padded block per rank and owes
+// each reference's records their place in the ordered cloud: world x references-per-round copies per round, a few MB each.  As separate copies they
+// cost more host time than the kernel that produced the records; here they are one launch.  Offsets and lengths are in BYTES and need no alignment
+// (15-byte PLY records): the destination is written in aligned 16-byte units, the source read with whatever alignment it has.
+struct __attribute__((packed, aligned(1))) LfdU4u { unsigned x, y, z, w; };
+
+extern "C" __global__ void __launch_bounds__(256) lfd_copy_segments_kernel(LfdCopyArgs A, const unsigned char* __restrict__ src, unsigned char* __restrict__ dst) {
+    const int tid = (int)threadIdx.x;
+    const int b = (int)blockIdx.x;
+    int lo = 0, hi = A.n_segs;                     // chunk0[lo] <= b < chunk0[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (A.chunk0[mid] <= b) lo = mid; else hi = mid;
+    }
+    const long long off = (long long)(b - A.chunk0[lo]) * LFD_COPY_CHUNK;
+    long long len = A.n[lo] - off;
+    if (len > LFD_COPY_CHUNK) len = LFD_COPY_CHUNK;
+    if (len <= 0) return;
+    const unsigned char* s = src + A.src[lo] + off;
+    unsigned char* d = dst + A.dst[lo] + off;
+    int head = (int)((16u - (unsigned)(reinterpret_cast<unsigned long long>(d) & 15u)) & 15u);
+    if (head > len) head = (int)len;
+    if (tid < head) d[tid] = s[tid];
+    const long long body = (len - head) >> 4;
+    const LfdU4u* sv = reinterpret_cast<const LfdU4u*>(s + head);
+    uint4* dv = reinterpret_cast<uint4*>(d + head);
+    for (long long i = tid; i < body; i += 256) {
+        const LfdU4u v = sv[i];
+        dv[i] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    const long long done = head + (body << 4);
+    if (tid < len - done) d[done + tid] = s[done + tid];
+}

@@ -326,3 +326,144 @@ def test_shared_file_stream_with_a_rank_that_cannot_write_raises_everywhere_and_
     assert "another rank failed" in results[0] and "another rank failed" in results[2], results
     head = open(path, "rb").read(200)
     assert int(head.split(b"element vertex")[1].split(b"\n")[0]) == 0          # (the count field is fixed-width, blank-padded)
+
+
+# ---- records that travel from where they are (views of one launch buffer), placement into a caller's buffer, replication plan ----------------------
+def _view_worker(rank, world, port, n_refs, n_rep, per_round, record, q):
+    """What bench.py's sharded leg does, on host tensors: the last n_rep references are computed by every rank (written in place behind the
+    exchanged part of ONE cloud buffer), the others are sharded; every round's records are consecutive views of one roomy buffer handed over
+    with push_many (nothing concatenated, nothing padded); finish(place=...) puts the ordered records in front of the replicated ones."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts, pts = _make_points(n_refs, seed=5)
+        cols, dt = (7, torch.float32) if record == "f32" else (15, torch.uint8)
+
+        def rec_of(g):
+            return pts[g] if record == "f32" else np.ascontiguousarray(pts[g].view(np.uint8).reshape(-1, 28)[:, :15])
+        mine, n_sh = lfd_dist.split_replicated(n_refs, n_rep, rank, world)
+        sh = [g for g in mine if g < n_sh]
+        rep = [g for g in mine if g >= n_sh]
+        cap_sh = 40 * n_sh
+        cloud = torch.zeros((cap_sh + 40 * len(rep), cols), dtype=dt)
+        n_rep_rows = 0
+        for g in rep:                                                     # "the kernel writes the replicated part in place"
+            r = torch.from_numpy(rec_of(g))
+            cloud[cap_sh + n_rep_rows:cap_sh + n_rep_rows + r.shape[0]] = r
+            n_rep_rows += r.shape[0]
+        ex = lfd_dist.OverlappedExchange(dist, n_sh, per_round, torch.device("cpu"), form="all_gather", record=record)
+        views = 0
+        for c0 in range(0, len(sh), per_round):
+            chunk = sh[c0:c0 + per_round]
+            buf = torch.full((40 * per_round + 7, cols), 77, dtype=dt)    # a launch's buffer: room for H * W records per reference, stale bytes behind
+            cs = [int(counts[g]) for g in chunk]
+            lo = 0
+            for g in chunk:
+                buf[lo:lo + counts[g]] = torch.from_numpy(rec_of(g))
+                lo += counts[g]
+            ex.push_many(c0, buf, cs)
+        placed = {}
+
+        def place(n_rows):
+            placed["n"] = n_rows
+            return cloud[cap_sh - n_rows:cap_sh]
+        recs, gcounts = ex.finish(place=place)
+        for st in ex._rounds:                                             # every payload is a view of its launch buffer, never a copy
+            if st["n_local"] and st["padded"] is not None:
+                views += int(st["padded"].untyped_storage().data_ptr() == st["payload"].untyped_storage().data_ptr())
+        out = cloud[cap_sh - placed.get("n", 0):cap_sh + n_rep_rows]
+        q.put((rank, out.numpy().copy(), gcounts, views, sum(1 for st in ex._rounds if st["n_local"] and st["padded"] is not None)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_refs,n_rep,world,per_round,record", [(9, 3, 2, 2, "ply"), (9, 0, 2, 2, "f32"), (11, 5, 3, 1, "ply"), (6, 6, 2, 2, "f32"), (8, 2, 4, 1, "f32")])
+def test_views_placement_and_replication_give_the_single_process_cloud(n_refs, n_rep, world, per_round, record):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_view_worker, args=(r, world, port, n_refs, n_rep, per_round, record, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    counts, pts = _make_points(n_refs, seed=5)
+    full = np.concatenate(pts, 0)
+    expect = full if record == "f32" else np.ascontiguousarray(full.view(np.uint8).reshape(-1, 28)[:, :15])
+    for rank, cloud, gcounts, views, sent in results:
+        np.testing.assert_array_equal(gcounts, counts[:n_refs - n_rep])
+        np.testing.assert_array_equal(cloud, expect)                      # sharded part | replicated part: the 1-rank sequence, contiguous
+        assert views == sent                                              # no round was copied into a padded buffer
+
+
+def test_replication_plan():
+    P = lfd_dist.plan_replication
+    # the bare hot path on config 4 (one reference 5 us of kernel, 3.6 MB of survivors, 122 GB/s per peer): moving costs more than recomputing
+    p2, p8 = P(56, 2, 0.0054, 3.57e6, launch_ms=0.01), P(56, 8, 0.0054, 3.57e6, launch_ms=0.01)
+    assert p2["n_replicated"] > p8["n_replicated"] > 0 and p2["n_sharded"] + p2["n_replicated"] == 56
+    for p in (p2, p8):
+        assert p["step_ms"] <= p["pure_sharding_ms"] and p["step_ms"] <= p["single_rank_ms"] * 1.000001      # never worse than either extreme
+    # a faster link shifts the plan towards sharding, a slower one towards replication; no link at all -> every rank computes everything
+    assert P(56, 8, 0.0054, 3.57e6, link_gbps=1000.0)["n_sharded"] > p8["n_sharded"] > P(56, 8, 0.0054, 3.57e6, link_gbps=10.0)["n_sharded"]
+    assert P(56, 4, 0.0054, 3.57e6, link_gbps=1e-3)["n_sharded"] == 0
+    # with a matcher in the loop (8 pairs x 30 ms per reference) nothing is worth recomputing
+    assert P(56, 8, 240.0, 3.57e6)["n_replicated"] == 0 and P(148, 2, 90.0, 3.4e6)["n_replicated"] == 0
+    # one rank: nothing to exchange
+    p1 = P(56, 1, 0.0054, 3.57e6)
+    assert p1["n_replicated"] == 0 and p1["step_ms"] == p1["single_rank_ms"]
+    assert lfd_dist.split_replicated(10, 4, 1, 3) == ([1, 4, 6, 7, 8, 9], 6) and lfd_dist.split_replicated(10, 4, 1, 3, replicas_here=False) == ([1, 4], 6)
+    assert lfd_dist.split_replicated(5, 9, 0, 2) == ([0, 1, 2, 3, 4], 0)
+
+
+def _eager_worker(rank, world, port, n_refs, per_round, form, record, use_dest, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts, pts = _make_points(n_refs, seed=9)
+        cols, dt = (7, torch.float32) if record == "f32" else (15, torch.uint8)
+        mine = lfd_dist.shard_references(n_refs, rank, world)
+        dest = torch.full((int(counts.sum()) + 3, cols), 9, dtype=dt) if use_dest else None
+        ex = lfd_dist.OverlappedExchange(dist, n_refs, per_round, torch.device("cpu"), form=form, record=record, eager=True, dest=dest)
+        for i, g in enumerate(mine):
+            if counts[g]:
+                ex.push(i, torch.from_numpy(pts[g] if record == "f32" else np.ascontiguousarray(pts[g].view(np.uint8).reshape(-1, 28)[:, :15]).reshape(-1)))
+        recs, gcounts = ex.finish()
+        shares = use_dest and (form == "all_gather" or rank == 0) and recs.numel() > 0 and recs.untyped_storage().data_ptr() == dest.untyped_storage().data_ptr()
+        q.put((rank, recs.numpy().copy(), gcounts, bool(shares)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_refs,world,per_round,form,record,use_dest", [
+    (7, 2, 1, "all_gather", "f32", True), (7, 2, 2, "gather_to_root", "ply", True), (10, 3, 2, "all_gather", "ply", False), (5, 4, 1, "gather_to_root", "f32", False),
+    (9, 2, 16, "all_gather", "ply", True), (2, 3, 1, "all_gather", "f32", True)])
+def test_eager_rounds_and_early_placement_are_the_same_sequence(n_refs, world, per_round, form, record, use_dest):
+    """eager=True (a round's records leave as soon as it is complete) and dest= (ordered records placed from row 0 of the caller's buffer as the
+    rounds complete): the 1-rank sequence, in the caller's buffer where one was given"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eager_worker, args=(r, world, port, n_refs, per_round, form, record, use_dest, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    counts, pts = _make_points(n_refs, seed=9)
+
+    def as_sent(parts):
+        if not parts:
+            return np.zeros((0, 7), np.float32) if record == "f32" else np.zeros((0,), np.uint8)
+        full = np.concatenate(parts, 0)
+        return full if record == "f32" else np.ascontiguousarray(full.view(np.uint8).reshape(-1, 28)[:, :15]).reshape(-1)
+    for rank, recs, gcounts, shares in results:
+        np.testing.assert_array_equal(gcounts, counts)
+        have = form == "all_gather" or rank == 0
+        np.testing.assert_array_equal(recs, as_sent(pts) if have else as_sent([pts[g] for g in lfd_dist.shard_references(n_refs, rank, world)]))
+        if use_dest and have and int(counts.sum()):
+            assert shares                                  # the result IS the caller's buffer, not a copy

@@ -219,11 +219,12 @@ def test_bench_starts_its_own_ranks(tmp_path):
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--refs", "6", "--preset", "turbo",
            "--light", "--spinup-s", "0.05"]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    res = subprocess.run(cmd + ["--replicate", "0"], env=env, capture_output=True, text=True, timeout=600)       # the pure-sharding schedule
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
+    assert d["replication"]["n_replicated"] == 0 and d["replication"]["forced"] and d["value"] == d["value_pure_sharding"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["refs_total"] == 6 and d["config"]["refs_per_gpu"] == 3 and d["config"]["neighbours"] == 8 and "config[3]" in d["config"]["workload"]
     assert d["rccl_ranks"] == 0 and d["collective_backend"] == "gloo"          # two ranks on one GPU exchange through host buffers, and the line says so
@@ -235,12 +236,34 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert d["value_sharded_resident"] > 0 and "counts_only" in d["value_sharded_resident_note"]         # the cloud left sharded: counts on the wire only
     assert d["sampled_mode"]["value"] > 0 and d["sampled_mode"]["points_per_scene"] > 0
     assert d["end_to_end"] is None and "unmeasured" in d["end_to_end_note"] and "no multi-GPU node" in d["scaling_note"]
+    # recompute instead of communicate: the last two references computed by both ranks, four exchanged - the cloud is the pure-sharding one bit
+    # for bit (bench.py asserts it) and every point counts once; then the plan from the run's own measurements (whatever it decides here)
+    res_r = subprocess.run(cmd + ["--replicate", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert res_r.returncode == 0, res_r.stderr[-2000:]
+    dr = json.loads([l for l in res_r.stdout.splitlines() if l.startswith("{")][0])
+    rp = dr["replication"]
+    assert rp["n_replicated"] == 2 and rp["n_sharded"] == 4 and rp["forced"] and rp["redundant_cells_per_step"] == 2 * dr["config"]["grid"][0] * dr["config"]["grid"][1]
+    assert dr["exchange"]["points"] == ex["points"] and dr["exchange"]["rounds"] == 2 and dr["value"] > 0 and dr["value_pure_sharding"] > 0
+    assert "2 references replicated" in dr["value_includes"] and "4 references round-robin" in dr["config"]["sharding"]
+    res_a = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res_a.returncode == 0, res_a.stderr[-2000:]
+    da = json.loads([l for l in res_a.stdout.splitlines() if l.startswith("{")][0])
+    ra = da["replication"]
+    assert not ra["forced"] and ra["n_replicated"] + ra["n_sharded"] == 6 and ra["inputs_measured_in_this_run"]["ref_ms"] > 0 and da["exchange"]["points"] == ex["points"]
+    assert ra["inputs_measured_in_this_run"]["link_gbps"] > 0 and ra["planned_step_ms"] <= ra["planned_pure_sharding_ms"] + 1e-9
+    cm = {int(k_): v_ for k_, v_ in ra["candidates_measured_ms"].items()}
+    assert 0 in cm and 6 in cm and ra["n_replicated"] in cm and cm[ra["n_replicated"]] == min(cm.values())      # measured, and the fastest one taken
     # the other forms: gather to the writer rank, 28-byte rows, weak scaling
     cmd_s = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--refs", "3", "--preset", "turbo",
-             "--scaling", "weak", "--exchange", "gather_to_root", "--exchange-records", "f32", "--exchange-rounds", "3", "--light", "--spinup-s", "0.05"]
+             "--scaling", "weak", "--exchange", "gather_to_root", "--exchange-records", "f32", "--exchange-rounds", "3", "--light", "--spinup-s", "0.05",
+             "--replicate", "0"]
     res_s = subprocess.run(cmd_s, env=env, capture_output=True, text=True, timeout=600)
     assert res_s.returncode == 0, res_s.stderr[-2000:]
     ds = json.loads([l for l in res_s.stdout.splitlines() if l.startswith("{")][0])
+    res_g = subprocess.run(cmd_s[:-1] + ["3"], env=env, capture_output=True, text=True, timeout=600)       # ... with half of the scene replicated: on the root only
+    assert res_g.returncode == 0, res_g.stderr[-2000:]
+    dg = json.loads([l for l in res_g.stdout.splitlines() if l.startswith("{")][0])
+    assert dg["replication"]["n_replicated"] == 3 and dg["replication"]["redundant_cells_per_step"] == 0 and dg["exchange"]["points"] == ds["exchange"]["points"]
     assert ds["scaling"] == "weak" and ds["config"]["refs_total"] == 6 and ds["config"]["refs_per_gpu"] == 3
     assert ds["exchange"]["form"] == "gather_to_root" and ds["exchange"]["record_bytes"] == 28 and ds["exchange"]["rounds"] == 3 and ds["value"] > 0
     if torch.cuda.device_count() < 2:

@@ -94,7 +94,9 @@ def test_bench_exchange_legs_through_rccl_on_one_rank():
         port = s.getsockname()[1]
     env = dict(os.environ, LFD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for extra in ([], ["--exchange", "gather_to_root", "--exchange-records", "f32", "--exchange-rounds", "3"]):
+    # (the third run: two of the six references "replicated" - their records written in place behind the exchanged part of the one cloud buffer,
+    # the exchange placing its ordered records in front of them: the placement path device collectives take, bench.py asserts the cloud's bytes)
+    for extra in ([], ["--exchange", "gather_to_root", "--exchange-records", "f32", "--exchange-rounds", "3"], ["--replicate", "2"]):
         cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "config4", "--refs", "6",
                "--preset", "turbo", "--light", "--spinup-s", "0.05"] + extra
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
@@ -103,5 +105,9 @@ def test_bench_exchange_legs_through_rccl_on_one_rank():
         assert d["n_gpus"] == 1 and d["collective_backend"] == "nccl"
         ex = d["exchange"]
         assert ex["points"] > 0 and ex["overlapped"] and ex["end_of_run_28B"]["allgather_ms"] > 0 and ex["end_of_run_28B"]["gather_to_root_ms"] > 0
-        assert ex["rounds"] == (3 if extra else 2) and ex["record_bytes"] == (28 if extra else 15)
+        assert ex["rounds"] == (3 if "gather_to_root" in extra else 2) and ex["record_bytes"] == (28 if "f32" in extra else 15)
         assert 0 < d["value"] and d["value_compute_only"] > 0 and d["value_sharded_resident"] > 0
+        if "--replicate" in extra:
+            assert d["replication"]["n_replicated"] == 2 and d["replication"]["forced"] and d["value_pure_sharding"] > 0
+        else:
+            assert d["replication"]["n_replicated"] == 0 and d["value"] == d["value_pure_sharding"]        # one rank: nothing to exchange, nothing to replicate

@@ -47,3 +47,37 @@ def test_packing_matches_oracle_writer_for_ragged_sizes(dens, n):
     assert head + dens.pack_ply(tx, tc).cpu().numpy().tobytes() == orc.ply_bytes(xyz, u8)
     assert np.uint64(n).tobytes() + dens.pack_points3d(tx, tc, te).cpu().numpy().tobytes() == orc.points3d_bin_bytes(xyz, u8, err)
     assert np.uint64(n).tobytes() + dens.pack_points3d(tx, tc, None).cpu().numpy().tobytes() == orc.points3d_bin_bytes(xyz, u8, None)
+
+
+@pytest.mark.gpu
+def test_copy_segments_places_byte_ranges_in_one_launch():
+    """lfd_copy_segments: arbitrary byte offsets and lengths (15-byte records: nothing is aligned), empty segments, more segments than one
+    launch's argument block holds, a segment longer than one workgroup's chunk - against the same copies done one by one"""
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(4)
+    src = torch.from_numpy(rs.randint(0, 256, size=3_000_000, dtype=np.uint8)).to(dev)
+    for n_seg in (1, 7, 96, 97, 250):
+        lens = rs.randint(0, 20000, size=n_seg).astype(np.int64)
+        lens[0] = 150_001                                            # several chunks, odd length
+        if n_seg > 3:
+            lens[3] = 0
+        s_off = np.sort(rs.choice(3_000_000 - 160_000, size=n_seg, replace=False)).astype(np.int64)
+        gaps = rs.randint(0, 23, size=n_seg).astype(np.int64)       # destinations: packed with small odd gaps
+        d_off = np.cumsum(gaps + np.concatenate([[0], lens[:-1]]))
+        total = int(d_off[-1] + lens[-1]) + 5
+        dst = torch.full((total,), 0xEE, dtype=torch.uint8, device=dev)
+        exp = np.full(total, 0xEE, np.uint8)
+        host = src.cpu().numpy()
+        for s_, d_, n_ in zip(s_off, d_off, lens):
+            exp[d_:d_ + n_] = host[s_:s_ + n_]
+        hb.copy_segments(src, dst, np.stack([s_off, d_off, lens], 1))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(dst.cpu().numpy(), exp)
+    # typed tensors (28-byte rows), a destination that is a view into a larger buffer
+    rows = torch.arange(7 * 1000, dtype=torch.float32, device=dev).reshape(1000, 7)
+    big = torch.zeros((2000, 7), dtype=torch.float32, device=dev)
+    hb.copy_segments(rows, big[500:1500], [(100 * 28, 0, 50 * 28), (0, 50 * 28, 100 * 28)])
+    torch.cuda.synchronize()
+    assert torch.equal(big[500:550], rows[100:150]) and torch.equal(big[550:650], rows[0:100]) and float(big[:500].abs().sum()) == 0.0 and float(big[650:].abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        hb.copy_segments(rows, big[500:1500], [(0, 999 * 28, 2 * 28)])            # leaves the destination view
