@@ -640,7 +640,19 @@ def run_dense_pipeline(
 
     per_ref_rng = bool(config.per_reference_rng) or world > 1
     stream_rng = np.random.RandomState(int(config.seed))     # upstream: np.random.seed(config.seed), global stream
-    my_positions = lfd_dist.shard_references(len(refs_local), rank, world)
+    # Sharded runs may REPLICATE the last references of the list (config.exchange_replicate: computed by every rank that receives the cloud, never
+    # sent - core/distributed.py::plan_replication says when that pays: never with a real matcher in the loop); the others are dealt round-robin.
+    stream_wanted = (bool(getattr(config, "stream_output", False)) and str(config.output_path).lower().endswith(".ply")
+                     and int(config.max_points) <= 0 and float(config.voxel_size) <= 0.0)
+    consumes_cloud = world == 1 or str(getattr(config, "exchange", "all_gather")) == "all_gather" or rank == 0
+    n_rep = 0
+    if world > 1 and bool(getattr(config, "exchange_overlap", True)) and not stream_wanted:
+        n_rep = int(round(float(getattr(config, "exchange_replicate", 0.0)) * len(refs_local)))
+    my_positions, n_sharded = lfd_dist.split_replicated(len(refs_local), n_rep, rank, world, replicas_here=consumes_cloud)
+    n_sharded_mine = sum(1 for g in my_positions if g < n_sharded)
+    rep_parts: List[torch.Tensor] = []                     # replicated references' records (the exchange's format), in reference order
+    rep_refs_with_points = 0
+    rep_pairs = 0
 
     xyz_parts: List[np.ndarray] = []
     rgb_parts: List[np.ndarray] = []
@@ -664,8 +676,6 @@ def run_dense_pipeline(
     # anything can fail: every rank then reaches the matching finish() in `finally` whatever went wrong on it (a matcher that cannot be
     # built, no memory for the context, a cancellation) - it sends empty references / closes empty rounds - and nobody is left blocked
     # in a receive or a collective ahead of the status agreement.
-    stream_wanted = (bool(getattr(config, "stream_output", False)) and str(config.output_path).lower().endswith(".ply")
-                     and int(config.max_points) <= 0 and float(config.voxel_size) <= 0.0)
     xchg: Optional[lfd_dist.OverlappedExchange] = None
     xchg_result = None
     shared_file: Optional[lfd_dist.SharedFilePlyStream] = None
@@ -688,7 +698,7 @@ def run_dense_pipeline(
             if rec == "auto":
                 rec = "ply" if (str(config.output_path).lower().endswith(".ply") and float(config.voxel_size) <= 0.0) else "f32"
             per_round = int(getattr(config, "exchange_round", 0)) or max(int(config.refs_per_launch), 4)
-            xchg = lfd_dist.OverlappedExchange(dist, len(refs_local), per_round, dev, form=str(getattr(config, "exchange", "all_gather")), record=rec)
+            xchg = lfd_dist.OverlappedExchange(dist, n_sharded, per_round, dev, form=str(getattr(config, "exchange", "all_gather")), record=rec)
     try:
         cached = has_cached_romav2_weights() if own_matcher else True
         msg = "Initializing RoMa v2 model..." if cached else "Installing model weights..."
@@ -732,7 +742,10 @@ def run_dense_pipeline(
                     shard_stream.writer = stream_writer
 
         def emit(local_i: int, packed: _PackedReference, xyz, rgb, err, dbg, dev_pts=None) -> None:
-            nonlocal refs_with_points
+            nonlocal refs_with_points, rep_refs_with_points
+            replicated = local_i >= n_sharded_mine
+            if replicated:
+                rep_refs_with_points += 1
             # (dense mode hands over the device tensors only: the host arrays of the result are one copy at the end of the run)
             xyz_parts.append(xyz)
             rgb_parts.append(rgb)
@@ -752,11 +765,15 @@ def run_dense_pipeline(
                 # the overlapped exchange: this reference's records join the round being filled; a round that is complete leaves in an
                 # asynchronous collective while the next batch computes
                 if xchg.record == lfd_dist.RECORD_PLY:
-                    xchg.push(local_i, packed_t)
+                    rec_t = packed_t
                 elif dev_pts is not None:
-                    xchg.push(local_i, lfd_dist.rows_from_points(dev_pts[0], dev_pts[1], dev_pts[2]))
+                    rec_t = lfd_dist.rows_from_points(dev_pts[0], dev_pts[1], dev_pts[2])
                 else:
-                    xchg.push(local_i, lfd_dist.rows_from_points(torch.from_numpy(xyz), torch.from_numpy(rgb), torch.from_numpy(err)).to(dev))
+                    rec_t = lfd_dist.rows_from_points(torch.from_numpy(xyz), torch.from_numpy(rgb), torch.from_numpy(err)).to(dev)
+                if replicated:
+                    rep_parts.append(rec_t.to(dev))         # a replicated reference: every rank that receives the cloud has it already
+                else:
+                    xchg.push(local_i, rec_t)
             if cum_body is not None or (stream_writer is not None and shard_stream is None):
                 # this reference's PLY records, packed once (on the device when the points are there): the previews and the
                 # streamed output are made of these bytes, nothing is re-concatenated or re-quantised later
@@ -903,6 +920,8 @@ def run_dense_pipeline(
                 continue
             first_pair = pair_counter + 1
             pair_counter += len(results)
+            if local_i >= n_sharded_mine:
+                rep_pairs += len(results)
             warps, certs = _as_device_maps(results, dev)
             H, W = certs[0].shape
             axes = None
@@ -1053,6 +1072,14 @@ def run_dense_pipeline(
     if world > 1 and xchg_result is not None:
         # the rounds travelled beside the compute; what is left is to name the parts of the ordered records
         recs, counts = xchg_result
+        if n_rep and consumes_cloud:
+            # sharded part | replicated part: the replicated references are the LAST of the list, so the ordered cloud is a concatenation
+            recs = torch.cat([recs.reshape(-1)] + [r_.reshape(-1) for r_ in rep_parts]) if rep_parts else recs
+            if xchg.record != lfd_dist.RECORD_PLY:
+                recs = recs.reshape(-1, 7)
+            counts = np.concatenate([counts, np.asarray(counts_local[n_sharded_mine:], np.int64)])
+        elif n_rep:
+            counts = np.concatenate([counts, np.zeros(n_rep, np.int64)])      # (a rank that does not receive the cloud did not compute them)
         if xchg.record == lfd_dist.RECORD_PLY:
             gx, gc_ = lfd_dist.points_from_ply_records(recs)
             ge = torch.zeros((int(gx.shape[0]),), dtype=torch.float32, device=gx.device)
@@ -1061,7 +1088,9 @@ def run_dense_pipeline(
         xyz, rgb, err = gx.cpu().numpy(), gc_.cpu().numpy(), ge.cpu().numpy()
         device_points = (gx, gc_, ge)
         n_points_global = int(counts.sum())
-        t = torch.tensor([refs_with_points, pair_counter], dtype=torch.int64, device=lfd_dist._collective_device(gx, dist))
+        # (replicated references were processed by several ranks: they count once, on rank 0)
+        mine_once = (refs_with_points - (rep_refs_with_points if rank else 0), pair_counter - (rep_pairs if rank else 0))
+        t = torch.tensor(list(mine_once), dtype=torch.int64, device=lfd_dist._collective_device(gx, dist))
         dist.all_reduce(t)
         refs_with_points, pair_counter = int(t[0].item()), int(t[1].item())
     elif world > 1:       # the one exchange step: the survivors travel over RCCL from where they already are (HBM), ordered by reference

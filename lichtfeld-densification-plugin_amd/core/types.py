@@ -96,6 +96,11 @@ class DensePipelineConfig:
     # ``err`` zero - the written file is the same bytes); "auto": "ply" when the output is a .ply and no voxel filter has to see f32
     # colours, else "f32".  Only used by the overlapped exchange of a sharded run.
     exchange_records: str = "f32"
+    # sharded runs: the fraction of the reference list (its LAST references) computed by EVERY rank that receives the cloud instead of being
+    # exchanged - recompute instead of communicate.  core/distributed.py::plan_replication says when it pays: for the bare hot path (one GPU
+    # triangulates a reference faster than its survivors cross an xGMI link), never with a real matcher in the loop (default 0).  Needs the
+    # overlapped exchange; ignored with stream_output.  The result is the same sequence.
+    exchange_replicate: float = 0.0
     # sharded run + stream_output on ONE node: every rank writes its own byte ranges of the output file (core/distributed.py::SharedFilePlyStream) -
     # only the per-reference counts cross a link - instead of sending its records to rank 0 (ShardedPlyStream).  Needs a file system all ranks see.
     stream_shared_file: bool = False
@@ -119,6 +124,8 @@ class DensePipelineConfig:
             raise ValueError("exchange_records must be 'f32', 'ply' or 'auto'")
         if int(self.exchange_round) < 0:
             raise ValueError("exchange_round must be >= 0")
+        if not (0.0 <= float(self.exchange_replicate) <= 1.0):
+            raise ValueError("exchange_replicate must be a fraction in [0, 1]")
 
 
 @dataclasses.dataclass

@@ -67,3 +67,28 @@ for mode in ("dense", "sampled"):
         bound = "compute" if n == 1 or comp >= link_ms else f"link ({link_ms:.3f} ms to move one shard)"
         resident = comp if n == 1 else comp + LAT * 1e3          # the rounds' count all-gathers ride beside the launches; the last one is waited for
         print(f"{n:5d}  {comp:10.3f}   {res[0]:25.3f}   {res[1]:15.3f}   {res[2]:15.3f}   {t1 / res[0]:10.2f} | {t1 / res[1]:8.2f} | {t1 / res[2]:8.2f}              {bound:42s} {resident:.3f}  {t1 / resident:.2f}")
+
+
+# ---- round 4: recompute instead of communicate (core/distributed.py::plan_replication) ---------------------------------------------------------------
+# the same inputs through the planner bench.py uses: per-reference compute and launch cost from the measured dense rows (a line through the
+# 56 / 28 / 14 / 7-reference launches), 15-byte records, one link per peer, 0.1 ms of collectives per round trip, the placement copy at 3.5 TB/s
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+try:
+    from lichtfeld_densification_plugin_amd.core import distributed as _d
+    dense = sorted([r for r in rows if r["mode"] == "dense"], key=lambda r: r["ranks"])
+    if len(dense) >= 2:
+        n_total = dense[0]["refs_per_rank"] if "refs_per_rank" in dense[0] else 56
+        xs = [r.get("refs_per_rank", n_total // r["ranks"]) for r in dense]
+        ys = [r["step_ms"] for r in dense]
+        mx, my = sum(xs) / len(xs), sum(ys) / len(ys)
+        b = sum((x - mx) * (y - my) for x, y in zip(xs, ys)) / sum((x - mx) ** 2 for x in xs)
+        a = my - b * mx
+        ref_bytes = dense[0]["points"] * 15 / n_total
+        print(f"\n==== replicated suffix + sharded prefix (plan_replication): launch {a:.4f} ms + {b:.5f} ms per reference, {ref_bytes / 1e6:.2f} MB of records per reference ====")
+        print("ranks  sharded  replicated   step ms   speed-up vs 1 GPU   | pure sharding: ms, speed-up")
+        for n in (1, 2, 4, 8):
+            p = _d.plan_replication(n_total, n, b, ref_bytes, launch_ms=a, link_gbps=LINK / 1e9, collective_ms=0.1, copy_gbps=3500.0)
+            print(f"{n:5d}  {p['n_sharded']:7d}  {p['n_replicated']:10d}   {p['step_ms']:.3f}     {p['single_rank_ms'] / p['step_ms']:.2f}                | "
+                  f"{p['pure_sharding_ms']:.3f}  {p['single_rank_ms'] / p['pure_sharding_ms']:.2f}")
+except ImportError as exc:          # (the model's first part needs nothing but the input file)
+    print(f"(replication plan skipped: {exc})")

@@ -151,3 +151,61 @@ def test_a_rank_that_fails_before_the_loop_does_not_hang_the_others(g4, tmp_path
         assert p.exitcode == 0
     assert results[1] == "RuntimeError: no model on this rank"
     assert results[0] == "RuntimeError: dense pipeline failed on another rank"
+
+
+def _rank_replicating(rank, world, port, tmp, cfg_kw, q):
+    import torch.distributed as dist
+    from conftest import load_golden
+    from lichtfeld_densification_plugin_amd.core import distributed as lfd_dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cams, refs, nn, table = _scene(load_golden("g4_pipeline.npz"), tmp)
+        cfg = lfd.DensePipelineConfig(**cfg_kw)
+        n_rep = int(round(cfg.exchange_replicate * len(refs)))
+        positions, _n_sh = lfd_dist.split_replicated(len(refs), n_rep, rank, world, replicas_here=(cfg.exchange == "all_gather" or rank == 0))
+        res = pl.run_dense_pipeline(cams, refs, nn, cfg, matcher=_Replay([table[g] for g in positions]))       # the matcher sees exactly these references
+        q.put((rank, res.xyz, res.rgb, res.err, res.points_per_reference, res.pairs_processed, res.pairs_matched, len(positions)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,exchange,records,frac", [("dense", "all_gather", "f32", 0.5), ("sampled", "gather_to_root", "f32", 0.34), ("dense", "all_gather", "ply", 1.0),
+                                                        ("sampled", "all_gather", "f32", 0.5)])
+def test_replicated_references_give_the_single_process_result(g4, tmp_path, mode, exchange, records, frac):
+    """config.exchange_replicate: the last references of the list are computed by every rank that receives the cloud and never sent; the others are
+    sharded and exchanged in rounds.  Same sequence, same counts, every reference and pair counted once."""
+    import torch.multiprocessing as mp
+    from lichtfeld_densification_plugin_amd.core.image_io import to_uint8_rgb
+    tmp = str(tmp_path)
+    cams, refs, nn, table = _scene(g4, tmp)
+    kw = dict(nns_per_ref=2, seed=5, viz_interval=0, matches_per_ref=1200, triangulation_mode=mode, per_reference_rng=True, backend="host", pack_workers=1)
+    single = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(output_path=os.path.join(tmp, "single.ply"), **kw), matcher=_Replay(table))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    cfg_kw = dict(output_path=os.path.join(tmp, "sharded.ply"), exchange=exchange, exchange_round=1, exchange_records=records, exchange_replicate=frac, **kw)
+    procs = [ctx.Process(target=_rank_replicating, args=(r, 2, port, tmp, cfg_kw, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n_rep = int(round(frac * len(refs)))
+    assert n_rep >= 1
+    for rank, xyz, rgb, err, counts, n_refs, n_pairs, n_mine in results:
+        assert n_refs == single.pairs_processed and n_pairs == single.pairs_matched            # replicated references and their pairs count once
+        if exchange == "all_gather" or rank == 0:
+            assert n_mine == len(range(rank, len(refs) - n_rep, 2)) + n_rep
+            np.testing.assert_array_equal(counts, single.points_per_reference)
+            np.testing.assert_array_equal(xyz, single.xyz)
+            if records == "ply":                                                               # 15-byte records: colours as the writer quantises them, no error column
+                np.testing.assert_array_equal(to_uint8_rgb(rgb), to_uint8_rgb(single.rgb))
+            else:
+                np.testing.assert_array_equal(rgb, single.rgb)
+                np.testing.assert_array_equal(err, single.err)
+        else:
+            assert n_mine == len(range(rank, len(refs) - n_rep, 2))                            # not a consumer of the cloud: its share of the sharded part only
+            np.testing.assert_array_equal(counts[:len(refs) - n_rep], single.points_per_reference[:len(refs) - n_rep])
