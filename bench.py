@@ -609,13 +609,14 @@ def run_sharded(args, world, rank, dev, dist, backend):
     class Schedule:
         """One way of running the scene: the last `n_rep` references replicated, the others sharded in rounds."""
 
-        def __init__(self, n_rep):
+        def __init__(self, n_rep, rounds=None):
             self.n_rep = int(n_rep)
+            rounds = int(rounds) if rounds else int(args.exchange_rounds)
             mine, self.n_sh = lfd_dist.split_replicated(total_refs, self.n_rep, rank, world, replicas_here=consumes_cloud)
             self.sh_pos = [g for g in mine if g < self.n_sh]
             self.rep_pos = [g for g in mine if g >= self.n_sh]
             n_local_max = (self.n_sh + world - 1) // world
-            self.per_round = max(1, -(-n_local_max // max(1, args.exchange_rounds))) if self.n_sh else 1
+            self.per_round = max(1, -(-n_local_max // max(1, rounds))) if self.n_sh else 1
             self.n_rounds = -(-n_local_max // self.per_round) if self.n_sh else 0
             sh_refs = refs_at(self.sh_pos)
             self.chunks = [sh_refs[c * self.per_round:(c + 1) * self.per_round] for c in range(self.n_rounds)]
@@ -840,24 +841,29 @@ def run_sharded(args, world, rank, dev, dist, backend):
     # The model knows the link and the kernel, not the software around them: `auto` MEASURES the candidates - the model's pick, nothing / a quarter /
     # half / three quarters / everything replicated - a few steps each, and takes the fastest (pure sharding and "every rank computes everything"
     # are always among them: the planned schedule is never slower than either).  The ranks agree on the times (MAX), hence on the choice.
-    measured = {0: el_pure / args.steps * 1e3}
+    # (a round costs a chain of two collectives and a look at the counts - ~0.2 ms through RCCL, profiles/r4/exchange_overhead.txt - so the
+    # candidates with a replicated part, whose compute is what the exchange hides behind, run ONE round; pure sharding is tried both ways)
+    measured = {(0, pure.n_rounds): el_pure / args.steps * 1e3}
+    best_rounds = pure.n_rounds
     if args.replicate == "auto" and world > 1:
         probe_steps = max(4, min(args.steps, 15))
-        for cand in sorted({int(plan["n_replicated"]), total_refs // 4, total_refs // 2, (3 * total_refs) // 4, total_refs} - {0}):
-            trial = Schedule(cand)
+        cands = [(0, 1)] if pure.n_rounds != 1 else []
+        cands += [(c_, 1) for c_ in sorted({int(plan["n_replicated"]), total_refs // 4, total_refs // 2, (3 * total_refs) // 4, total_refs} - {0})]
+        for cand, rnd in cands:
+            trial = Schedule(cand, rnd)
             trial.scene()
             el_c, _r = timed(trial, probe_steps)
             (el_c,) = max_over_ranks([el_c])
-            measured[cand] = el_c / probe_steps * 1e3
+            measured[(cand, trial.n_rounds)] = el_c / probe_steps * 1e3
             del trial
             torch.cuda.empty_cache()
-        best = min(measured, key=lambda c_: (measured[c_], c_))
+        best, best_rounds = min(measured, key=lambda c_: (measured[c_], c_))
         plan = dict(plan, model_n_replicated=int(plan["n_replicated"]), n_replicated=int(best), n_sharded=total_refs - int(best))
 
     # ---- 3. the planned schedule: `value` ----------------------------------------------------------------------------------------------------------
     n_rep = int(plan["n_replicated"])
-    if n_rep > 0:
-        sched = Schedule(n_rep)
+    if n_rep > 0 or best_rounds != pure.n_rounds:
+        sched = Schedule(n_rep, best_rounds if args.replicate == "auto" else None)
         for _ in range(max(args.warmup, 1)):
             sched.scene()
         el_value, (n_sh_pts, n_rep_pts, recs_v, counts_v) = timed(sched, args.steps)
@@ -958,7 +964,7 @@ def run_sharded(args, world, rank, dev, dist, backend):
             "survivor_fraction": s_frac,
             "replication": {"n_replicated": n_rep, "n_sharded": n_sh, "planned_step_ms": plan["step_ms"], "planned_pure_sharding_ms": plan["pure_sharding_ms"],
                             "planned_single_rank_ms": plan["single_rank_ms"], "inputs_measured_in_this_run": plan["inputs"], "forced": bool(plan.get("forced")),
-                            "model_n_replicated": plan.get("model_n_replicated"), "candidates_measured_ms": {str(k_): v_ for k_, v_ in sorted(measured.items())},
+                            "model_n_replicated": plan.get("model_n_replicated"), "candidates_measured_ms": {f"{k_[0]} replicated, {k_[1]} round(s)": v_ for k_, v_ in sorted(measured.items())},
                             "redundant_cells_per_step": n_rep * H * W * (world - 1 if args.exchange == "all_gather" else 0),
                             "note": "core/distributed.py::plan_replication: the references whose recomputation on every rank is cheaper than their "
                                     "survivors' trip over a link; with a matcher in the loop (tens of ms per pair) the plan is 0"},
