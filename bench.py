@@ -236,8 +236,9 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16, cams_for_hot=None)
     # (core/pipeline.py::_HotPath.begin_normaliser / finish_normaliser) - the launch stream never waits for the host
     from lichtfeld_densification_plugin_amd.core.pipeline import _HotPath
     hot = _HotPath(cams_for_hot, cfg, 0.9, wm, hm, dens.device, dens)
-    for warm in (True, False):
-        dens.seed_rng(cfg.seed)
+    passes_ms = []
+    for warm in (True, False, False, False, False, False):      # one warm pass, five timed ones: the host side of this path (torch's CPU reduction on
+        dens.seed_rng(cfg.seed)                                  # the host's thread pool) depends on what else runs on the host - the pool's four GPU slots share it
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pts3, pend, fly = 0, [], []
@@ -255,7 +256,10 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16, cams_for_hot=None)
             pts3 += getattr(hot.finish_sampled(fly.pop(0)), 'count', 0)
         torch.cuda.synchronize()
         dt3 = time.perf_counter() - t0
-    res["default_config_ms_per_reference"] = dt3 / len(todo) * 1e3
+        if not warm:
+            passes_ms.append(dt3 / len(todo) * 1e3)
+    res["default_config_ms_per_reference"] = min(passes_ms)
+    res["default_config_passes_ms_per_reference"] = passes_ms
     res["default_config_note"] = ("upstream_normaliser=True (the pipeline's default): upstream's torch f32 sum of every aggregated map on the host, the map copied on a "
                                   "side stream while the neighbouring references are launched / collected")
     # several references per fused call (lfd_triangulate_sampled_multi), every reference on its own MT19937 stream - what sharded
@@ -974,6 +978,7 @@ def run_sharded(args, world, rank, dev, dist, backend):
             "value_sharded_resident": total_pts * args.steps / el_resident,
             "value_sharded_resident_note": "the pure-sharding steps with only the per-reference counts exchanged (form counts_only): the ordered cloud stays sharded over the "
                                            "ranks' HBM with every reference's global offset known on every rank - comparable to N = 1, whose result also stays in HBM",
+            "host": getattr(args, "host", None),
             "end_to_end": None,
             "end_to_end_note": "points/s including the RoMa-v2 forward (SURVEY 8d iii) is unmeasured: neither the RoMa-v2 weights nor torchvision are on the box",
             "exchange": {"form": args.exchange, "record_bytes": rec_bytes, "rounds": sched.n_rounds, "overlapped": True, "points": total_pts,
@@ -1079,6 +1084,11 @@ def main():
                          "without a launcher, which starts them itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # torch sizes its intra-op pool by the CPUs it sees (256 on the pool's boxes), the container may use 16: the spinning workers would burn the CFS
+    # quota and the kernel would stop the whole process for most of every 100 ms (profiles/r4/sampled_sustained.txt)
+    from lichtfeld_densification_plugin_amd.core import hostenv
+    host_threads = hostenv.fit_threads_to_quota()
+    args.host = {"torch_threads": host_threads, "cpu_quota_cores": hostenv.cpu_quota(), "cpus_visible": os.cpu_count()}
     shared_gpu = int(os.environ.get("LFD_BENCH_RANKS_PER_GPU", "1")) > 1     # functional check: several ranks on one GPU -> gloo
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -1208,6 +1218,7 @@ def main():
             "survivor_fraction": s_frac,
             # one step = lfd_prepare_batch (descriptor upload + per-pair constants of a batch the context has not just seen) + the dense kernel
             "compute_ms": elapsed / args.steps * 1e3, "kernel_ms": kernel_ms, "fresh_batch_ms": fresh_batch_ms,
+            "host": getattr(args, "host", None),
             "end_to_end": None,
             "end_to_end_note": "points/s including the RoMa-v2 forward (SURVEY 8d iii) is unmeasured: neither the RoMa-v2 weights nor torchvision are on the box",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -342,5 +342,14 @@ def build_argparser() -> argparse.ArgumentParser:
     return ap
 
 
+def main(argv=None) -> int:
+    """The command line (upstream densify.py:418-420).  As its own process it fits torch's intra-op threads to the container's CPU quota first
+    (core/hostenv.py: a pool sized by the CPUs the container SEES gets the whole process throttled); inside LichtFeld Studio - ``dense_init`` /
+    ``dense_init_from_lfs`` called by the plugin - process-wide settings are the host application's and nothing is touched."""
+    from .core import hostenv
+    hostenv.fit_threads_to_quota(log=log.info)
+    return dense_init(build_argparser().parse_args(argv))
+
+
 if __name__ == "__main__":
-    raise SystemExit(dense_init(build_argparser().parse_args()))
+    raise SystemExit(main())

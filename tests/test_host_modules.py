@@ -213,3 +213,38 @@ def test_host_arrays_slices_the_packed_buffer_like_three_copies():
                                   ref_offsets=np.array([0, n], np.int64), seg_counts=np.zeros((1, 3), np.int32))
     for a, b in zip(out2.host_arrays(), (hx, hc, he)):
         np.testing.assert_array_equal(a, b)
+
+
+def test_host_threads_fit_the_container_quota(monkeypatch, tmp_path):
+    """core/hostenv.py: the cgroup quota is read (v2 `cpu.max`), torch's intra-op threads are lowered to it and never raised, and a user's
+    OMP_NUM_THREADS wins"""
+    import builtins
+    import torch
+    from lichtfeld_densification_plugin_amd.core import hostenv
+    real_open = builtins.open
+
+    def fake_open(path, *a, **kw):
+        if path == "/sys/fs/cgroup/cpu.max":
+            return real_open(str(tmp_path / "cpu.max"), *a, **kw)
+        return real_open(path, *a, **kw)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    (tmp_path / "cpu.max").write_text("300000 100000\n")
+    assert hostenv.cpu_quota() == 3.0 and hostenv.usable_cores() <= 3
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert hostenv.cpu_quota() is None
+    before = torch.get_num_threads()
+    try:
+        (tmp_path / "cpu.max").write_text("200000 100000\n")
+        monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+        monkeypatch.delenv("MKL_NUM_THREADS", raising=False)
+        torch.set_num_threads(max(before, 4))
+        msgs = []
+        assert hostenv.fit_threads_to_quota(log=msgs.append) == min(2, hostenv.usable_cores()) and torch.get_num_threads() <= 2 and msgs
+        (tmp_path / "cpu.max").write_text("6400000 100000\n")           # a quota above what torch uses: nothing is raised
+        assert hostenv.fit_threads_to_quota() == torch.get_num_threads() <= 2
+        torch.set_num_threads(max(before, 4))
+        monkeypatch.setenv("OMP_NUM_THREADS", "4")                       # the user's setting wins
+        (tmp_path / "cpu.max").write_text("100000 100000\n")
+        assert hostenv.fit_threads_to_quota() == max(before, 4)
+    finally:
+        torch.set_num_threads(before)
