@@ -1060,7 +1060,7 @@ def launch_ranks(args):
     sock.close()
     procs = []
     for rank in range(args.gpus):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank // share if share > 1 else rank), WORLD_SIZE=str(args.gpus),
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
@@ -1089,7 +1089,9 @@ def main():
     from lichtfeld_densification_plugin_amd.core import hostenv
     host_threads = hostenv.fit_threads_to_quota()
     args.host = {"torch_threads": host_threads, "cpu_quota_cores": hostenv.cpu_quota(), "cpus_visible": os.cpu_count()}
-    shared_gpu = int(os.environ.get("LFD_BENCH_RANKS_PER_GPU", "1")) > 1     # functional check: several ranks on one GPU -> gloo
+    share = max(1, int(os.environ.get("LFD_BENCH_RANKS_PER_GPU", "1")))
+    shared_gpu = share > 1                        # functional check: several ranks on one GPU -> gloo (own launcher or torch.distributed.run alike)
+    local_rank //= share
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

@@ -276,6 +276,31 @@ def test_bench_starts_its_own_ranks(tmp_path):
         assert res2.returncode != 0 and "GPU(s) visible" in (res2.stderr + res2.stdout)
 
 
+def test_bench_under_the_drivers_launcher(tmp_path):
+    """the form the round-end driver uses: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` (here two ranks on
+    the one GPU of the test box: LFD_BENCH_RANKS_PER_GPU=2 maps both local ranks to device 0 and the collectives to gloo): one JSON line from rank 0"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, LFD_BENCH_RANKS_PER_GPU="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k_, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--refs", "6", "--preset", "turbo", "--light", "--spinup-s", "0.05"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong" and d["value"] > 0 and d["collective_backend"] == "gloo"
+    assert d["replication"]["n_replicated"] + d["replication"]["n_sharded"] == 6 and d["host"]["torch_threads"] >= 1
+
+
 @pytest.mark.parametrize("mode", ["sampled", "dense"])
 def test_streamed_output_and_previews_are_the_host_writer_bytes(g4, tmp_path, mode):
     """config.stream_output: the PLY grows while the run proceeds (records packed on the device, appended per reference, vertex
