@@ -37,3 +37,5 @@ def test_single_gpu_bench_line_contract():
     s = d["sampled_mode"]
     assert s["ms_per_reference"] > 0 and s["pipelined_ms_per_reference"] > 0 and s["default_config_ms_per_reference"] > 0 and s["grouped"]["ms_per_reference"] > 0
     assert d["end_to_end"] is None and "unmeasured" in d["end_to_end_note"]
+    assert len(s["default_config_passes_ms_per_reference"]) == 5 and s["default_config_ms_per_reference"] == min(s["default_config_passes_ms_per_reference"])
+    assert d["host"]["torch_threads"] >= 1 and d["host"]["cpus_visible"] >= d["host"]["torch_threads"]       # threads fitted to the container's quota (core/hostenv.py)
