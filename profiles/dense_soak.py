@@ -39,4 +39,34 @@ for (n_refs, H, W, k) in ((64, 512, 512, 3), (7, 90, 126, 2), (24, 320, 320, 4))
             assert first.setdefault(i % 3, sig) == sig, (i, sig[:1], first[i % 3][:1])
     torch.cuda.synchronize()
     print(f"{n_refs} refs x {k} nbrs x {H}x{W}: {n_launch} launches over 3 rotating batches, {first[0][0]} survivors each time, {time.time() - t0:.1f} s")
+    # round 4: the same soak over the other two forms of the kernel, INTERLEAVED with the ordered one on one context (they share the tile-state
+    # words, the ticket counters and the per-reference cursors): unordered retirement + the table consumers, and the kernel-written PLY records -
+    # every sampled launch against the ordered kernel's result of the same batch
+    ref_ply = {j: dens.pack_ply(*(lambda r: (r.xyz, r.rgb))(dens.triangulate_dense(batches[j], params))).clone() for j in range(3)}
+    tpr = (H * W + 1023) // 1024
+    table = torch.zeros((n_refs * tpr, 2), dtype=torch.int32, device=dev)
+    counts = torch.zeros((n_refs,), dtype=torch.int64, device=dev)
+    rec = torch.empty((n_refs * H * W * 15,), dtype=torch.uint8, device=dev)
+    offs = torch.zeros((n_refs + 1,), dtype=torch.int64, device=dev)
+    t1 = time.time()
+    n2 = max(n_launch // 2, 30)
+    for i in range(n2):
+        j = i % 3
+        form = i % 4
+        if form == 0:
+            dens.launch_dense(batches[j], params, out)
+        elif form in (1, 3):
+            dens.launch_dense_segments(batches[j], params, out, table, counts)
+        else:
+            dens.launch_dense_ply(batches[j], params, rec, offs)
+        if i % 40 in (1, 2, 3) or i == n2 - 1:
+            dens.check_launches()
+            if form in (1, 3):
+                body, _o = dens.pack_ply_segments(hb.SegmentedOutput(out, table, counts, n_refs, H, W, k))
+                assert torch.equal(body, ref_ply[j]), (i, "segments")
+            elif form == 2:
+                n = int(offs[-1].item())
+                assert torch.equal(rec[:n * 15], ref_ply[j]), (i, "ply")
+    torch.cuda.synchronize()
+    print(f"   + {n2} launches alternating ordered / unordered / PLY-record forms on the same context: every sampled result = the ordered kernel's bytes, {time.time() - t1:.1f} s")
     dens.close()
