@@ -955,7 +955,11 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
         {
             const int tile = std::max(1, W / tiles);
             const long long nbins = (long long)((W - 1) / tile + 1) * ((H - 1) / tile + 1);
-            if (nbins > LFD_SELECT_MAX_BINS) return fail(ctx, LFD_ERR_INVALID, "selection: too many coverage bins");
+            if (nbins > LFD_SELECT_MAX_BINS)
+                return fail(ctx, LFD_ERR_INVALID, "selection: too many coverage bins: a " + std::to_string(H) + " x " + std::to_string(W) + " grid with " +
+                            std::to_string(tiles) + " tiles per side has " + std::to_string(nbins) + " coverage tiles, the device stage holds " +
+                            std::to_string((int)LFD_SELECT_MAX_BINS) + " (RoMa's square grids of 320 ... 1280 cells per side have 576 ... 625); the host selection "
+                            "stage (selection_backend=\"host\" in the Python mirror: upstream's own library calls) has no such limit");
         }
         const bool timing_mw = timing && ctx->env.select_timing == 2;     // 2: stamps of workgroup 0 of the multi-workgroup kernel
         if (n_wg >= 2 && (!timing || timing_mw)) {

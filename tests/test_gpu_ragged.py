@@ -124,3 +124,83 @@ def test_every_output_form_agrees_on_ragged_shapes(dev, case):
             assert np.abs(ordered.rgb.cpu().numpy()[id_] - host.rgb.numpy()[ih_]).max() <= 1e-6
     twin.close()
     dens.close()
+
+
+def _coverage_tiles(H, W, tiles=24):
+    t = max(1, W // tiles)
+    return ((W - 1) // t + 1) * ((H - 1) // t + 1)
+
+
+def test_a_grid_beyond_the_coverage_limit_is_refused_with_a_message_that_says_so(dev):
+    """the device selection holds 1024 coverage tiles (RoMa's grids need at most 625): 65 x 63 has 33 x 32 of them - refused, loudly"""
+    assert _coverage_tiles(65, 63) == 1056 and max(_coverage_tiles(n, n) for n in (320, 512, 640, 960, 1280)) == 625
+    dens = hb.HipDensifier(dev)
+    dens.seed_rng(0)
+    with pytest.raises(hb.HipBackendError, match="1056 coverage tiles.*holds 1024.*host selection"):
+        dens.select_samples(torch.rand((65, 63), device=dev), 500, cap=0.9, border=2, tiles=24)
+    dens.close()
+
+
+@pytest.mark.parametrize("case", [c for c in _cases() if c["H"] >= 31 and c["W"] >= 31 and _coverage_tiles(c["H"], c["W"]) <= 1024], ids=lambda c: f"{c['id']}-{c['H']}x{c['W']}-k{c['k']}-c{c['channels']}{'-m' if c['masks'] else ''}")
+def test_the_upstream_equivalent_path_on_ragged_shapes(dev, case):
+    """Sampled mode (what upstream runs) on the same ragged grids, one reference at a time on ONE MT19937 stream like upstream: the fused call
+    (lfd_triangulate_sampled) = aggregate + selection + indexed as three calls, bit for bit, stream position included; and the indexed result =
+    the CPU twin's on the same selection (same groups in the same order; survivors up to a threshold's last bit, coordinates within 1e-5)."""
+    H, W, k = case["H"], case["W"], case["k"]
+    cams, refs_dev, refs_host, wm, hm = _build(case, dev)
+    M = max(64, min(2000, H * W // 3))
+    cfg = lfd.DensePipelineConfig(output_path="", nns_per_ref=k, reproj_thresh=1.5, matches_per_ref=M)
+    params = hb.make_params(cfg)
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    twin = hb.HostDensifier(2)
+    twin.upload_cameras(cams)
+    got = {}
+    for mode in ("three", "fused"):
+        dens.seed_rng(9)
+        res = []
+        for r in refs_dev:
+            b = hb.PreparedBatch([r], wm, hm, cameras=cams)
+            try:
+                if mode == "three":
+                    best, _ = dens.aggregate(b, params)
+                    sel = dens.select_samples(best[0], M, cap=0.9, border=2, tiles=24)
+                    out = dens.triangulate_indexed(b, params, sel, [0, int(sel.numel())])
+                    res.append(("ok", int(sel.numel()), out, sel))
+                else:
+                    out = dens.triangulate_sampled(b, params, M, cap=0.9, border=2, tiles=24)
+                    res.append(("ok", out.n_selected, out, None))
+            except ValueError as exc:                       # upstream's np.random.choice refusals (fewer non-zero weights than draws ...)
+                res.append(("refused", str(exc)[:40], None, None))
+        got[mode] = (res, dens.rng_state())
+    assert got["three"][1][1] == got["fused"][1][1]
+    np.testing.assert_array_equal(got["three"][1][0], got["fused"][1][0])
+    n_ok = 0
+    for ri, (a, b) in enumerate(zip(got["three"][0], got["fused"][0])):
+        assert a[0] == b[0], (a[:2], b[:2])
+        if a[0] != "ok":
+            continue
+        n_ok += 1
+        assert a[1] == b[1] and a[1] > 0
+        for f in ("xyz", "rgb", "err", "cell", "slot"):
+            assert torch.equal(getattr(a[2], f), getattr(b[2], f)), f
+        np.testing.assert_array_equal(a[2].ref_offsets, b[2].ref_offsets)
+        np.testing.assert_array_equal(a[2].seg_counts, b[2].seg_counts)
+        np.testing.assert_array_equal(a[2].seg_order, b[2].seg_order)
+        # ... and the CPU twin on the same selection
+        sel = a[3].cpu()
+        hbatch = hb.PreparedBatch([refs_host[ri]], wm, hm, cameras=cams)
+        host = twin.triangulate_indexed(hbatch, params, sel, [0, int(sel.numel())])
+        cd, ch = a[2].cell.cpu().numpy().astype(np.int64), host.cell.numpy().astype(np.int64)
+        common, id_, ih_ = np.intersect1d(cd, ch, return_indices=True)
+        assert cd.size + ch.size - 2 * common.size <= max(2, int(2e-3 * max(cd.size, 1)))
+        np.testing.assert_array_equal(a[2].slot.cpu().numpy()[id_], host.slot.numpy()[ih_])
+        groups = lambda s_: [int(g) for g in s_[np.concatenate([[True], s_[1:] != s_[:-1]])]] if s_.size else []
+        gd, gh = groups(a[2].slot.cpu().numpy()), groups(host.slot.numpy())
+        assert len(set(gd)) == len(gd) and [g for g in gd if g in gh] == [g for g in gh if g in gd]          # contiguous groups, the same order
+        if common.size:
+            xd, xh = a[2].xyz.cpu().numpy()[id_], host.xyz.numpy()[ih_]
+            assert np.abs(xd - xh).max() <= 1e-5 * max(1.0, float(np.abs(xh).max()))
+    assert n_ok >= 1 or case["masks"]
+    twin.close()
+    dens.close()
