@@ -169,7 +169,9 @@ int upload_tables(lfd_context* ctx, const lfd_batch* b, const long long* extra, 
     if (si >= 0) {                                   // the tables are (or are about to be) in place
         LfdBatchSlot& sl = ctx->slot[si];
         if (!ahead && sl.ready_pending) {            // staged ahead on the preparation stream: the launch stream waits for that, once
+#if !defined(LFD_EXPERIMENT_NO_READY_WAIT)           // (measurement only, UNSAFE: what the wait packet costs a step - profiles/r4/ab_ready_wait.txt)
             LFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.ready, 0));
+#endif
             sl.ready_pending = false;
         }
         if (ahead && sl.ready_pending) st = ctx->prep_stream;      // (a second lfd_prepare_batch of the same batch: stay behind the first)
