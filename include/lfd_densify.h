@@ -220,9 +220,10 @@ int lfd_triangulate_sampled_multi(lfd_context* ctx, const lfd_batch* batch, cons
  * under which upstream's np.random.choice raises ValueError; 4.. internal) are returned on the host.
  * s_override > 0 replaces the normaliser sum(weights) (upstream's is a torch f32 reduction whose
  * rounding depends on the host's thread count; the device uses the correctly rounded exact sum).
- * Limit: the coverage pass holds at most 1024 tiles (tile = max(1, W / tiles) cells per side, ceil(W / tile) * ceil(H / tile) of
- * them): RoMa's square grids of 320 ... 1280 cells per side have 576 ... 625; a grid beyond the limit (e.g. 47 x 47, or 65 x 63)
- * is refused with LFD_ERR_INVALID and a message that says so - the host selection stage has no such limit. */
+ * Limit: the coverage pass holds at most 2304 tiles (tile = max(1, W / tiles) cells per side, ceil(W / tile) * ceil(H / tile) of
+ * them): every square grid fits (47 x 47 has the most, 2209; RoMa's grids of 320 ... 1280 cells per side have 576 ... 625); a grid
+ * beyond the limit (much taller than wide: 24 x 200) is refused with LFD_ERR_INVALID and a message that says so - the host
+ * selection stage has no such limit. */
 int lfd_rng_seed(lfd_context* ctx, uint32_t seed);
 int lfd_rng_get_state(lfd_context* ctx, uint32_t* key624_host, int32_t* pos_host);
 int lfd_rng_set_state(lfd_context* ctx, const uint32_t* key624_host, int32_t pos);

@@ -960,7 +960,7 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
             if (nbins > LFD_SELECT_MAX_BINS)
                 return fail(ctx, LFD_ERR_INVALID, "selection: too many coverage bins: a " + std::to_string(H) + " x " + std::to_string(W) + " grid with " +
                             std::to_string(tiles) + " tiles per side has " + std::to_string(nbins) + " coverage tiles, the device stage holds " +
-                            std::to_string((int)LFD_SELECT_MAX_BINS) + " (RoMa's square grids of 320 ... 1280 cells per side have 576 ... 625); the host selection "
+                            std::to_string((int)LFD_SELECT_MAX_BINS) + " (every square grid fits; RoMa's, 320 ... 1280 cells per side, have 576 ... 625); the host selection "
                             "stage (selection_backend=\"host\" in the Python mirror: upstream's own library calls) has no such limit");
         }
         const bool timing_mw = timing && ctx->env.select_timing == 2;     // 2: stamps of workgroup 0 of the multi-workgroup kernel

@@ -144,7 +144,7 @@ struct LfdLaunch {              // kernel argument, passed by value
 
 // ---- S: on-device coverage sampling (lfd_select.hip) ---------------------------------------------
 #define LFD_SELECT_BLOCK 1024
-#define LFD_SELECT_MAX_BINS 1024
+#define LFD_SELECT_MAX_BINS 2304     // coverage tiles a map may have: every SQUARE grid fits (the most: 47 x 47 at one cell per tile; RoMa's grids have 576 ... 625)
 #define LFD_SELECT_TOPM_MAX 16384    // no_filter: winners sorted in LDS (128 KiB)
 #ifndef LFD_SELECT_DEFAULT_WG
 #define LFD_SELECT_DEFAULT_WG 16      // compute workgroups the selection uses by default (0: single-workgroup kernel)

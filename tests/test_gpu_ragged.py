@@ -132,16 +132,18 @@ def _coverage_tiles(H, W, tiles=24):
 
 
 def test_a_grid_beyond_the_coverage_limit_is_refused_with_a_message_that_says_so(dev):
-    """the device selection holds 1024 coverage tiles (RoMa's grids need at most 625): 65 x 63 has 33 x 32 of them - refused, loudly"""
-    assert _coverage_tiles(65, 63) == 1056 and max(_coverage_tiles(n, n) for n in (320, 512, 640, 960, 1280)) == 625
+    """the device selection holds 2304 coverage tiles - every square grid fits (47 x 47 has the most), RoMa's need at most 625; a grid much taller
+    than wide (24 x 200: one cell per tile, 4800 of them) is refused, loudly"""
+    assert max(_coverage_tiles(n, n) for n in range(1, 1400)) == 2209 and max(_coverage_tiles(n, n) for n in (320, 512, 640, 960, 1280)) == 625
+    assert _coverage_tiles(200, 24) == 4800
     dens = hb.HipDensifier(dev)
     dens.seed_rng(0)
-    with pytest.raises(hb.HipBackendError, match="1056 coverage tiles.*holds 1024.*host selection"):
-        dens.select_samples(torch.rand((65, 63), device=dev), 500, cap=0.9, border=2, tiles=24)
+    with pytest.raises(hb.HipBackendError, match="4800 coverage tiles.*holds 2304.*host selection"):
+        dens.select_samples(torch.rand((200, 24), device=dev), 500, cap=0.9, border=2, tiles=24)
     dens.close()
 
 
-@pytest.mark.parametrize("case", [c for c in _cases() if c["H"] >= 31 and c["W"] >= 31 and _coverage_tiles(c["H"], c["W"]) <= 1024], ids=lambda c: f"{c['id']}-{c['H']}x{c['W']}-k{c['k']}-c{c['channels']}{'-m' if c['masks'] else ''}")
+@pytest.mark.parametrize("case", [c for c in _cases() if c["H"] >= 31 and c["W"] >= 31 and _coverage_tiles(c["H"], c["W"]) <= 2304], ids=lambda c: f"{c['id']}-{c['H']}x{c['W']}-k{c['k']}-c{c['channels']}{'-m' if c['masks'] else ''}")
 def test_the_upstream_equivalent_path_on_ragged_shapes(dev, case):
     """Sampled mode (what upstream runs) on the same ragged grids, one reference at a time on ONE MT19937 stream like upstream: the fused call
     (lfd_triangulate_sampled) = aggregate + selection + indexed as three calls, bit for bit, stream position included; and the indexed result =

@@ -56,7 +56,9 @@ def test_device_selection_reproduces_upstream_golden(g2, dens):
         np.testing.assert_array_equal(_numpy_state_after(dens).random_sample(2), g2[f"c{ci}_f_next_doubles"])
 
 
-@pytest.mark.parametrize("h,w,M,seed", [(64, 64, 1000, 3), (96, 80, 2500, 11), (320, 320, 10000, 5), (512, 512, 12000, 7)])
+@pytest.mark.parametrize("h,w,M,seed", [(64, 64, 1000, 3), (96, 80, 2500, 11), (320, 320, 10000, 5), (512, 512, 12000, 7),
+                                        # one cell per coverage tile (W < 48): 2209 and 2080 tiles, the most a square / near-square grid has
+                                        (47, 47, 600, 2), (65, 63, 900, 4), (33, 40, 300, 9)])
 def test_device_selection_with_its_own_normaliser_equals_oracle(dens, h, w, M, seed):
     cert = _tiefree(h, w, 1000 + seed)
     dens.seed_rng(seed)
