@@ -138,7 +138,9 @@ int lfd_aggregate(lfd_context* ctx, const lfd_batch* batch, const lfd_params* pa
 
 /* Fused dense kernel: every grid cell -> floor/masks/arg-max -> Sampson -> DLT -> reprojection,
  * cheirality, parallax -> colour -> ordered compaction.  Survivors are emitted per reference in
- * raster order.  ref_offsets: device i64 [n_refs+1] (exclusive prefix of survivors per reference;
+ * raster order.  Candidates are the cells upstream's sampler could draw (core/sampling.py:24-27, 41-43:
+ * a cell whose best certainty after floor and masks is <= 0 - masked out - has weight 0 there) plus the
+ * two-cell border upstream keeps out of its draw; a masked-out cell is never triangulated.  ref_offsets: device i64 [n_refs+1] (exclusive prefix of survivors per reference;
  * last = total); seg_counts: device i32 [n_refs*k] survivors per (reference, slot) or NULL. */
 int lfd_triangulate_dense(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params,
                           const lfd_points* out, int64_t* ref_offsets, int32_t* seg_counts);

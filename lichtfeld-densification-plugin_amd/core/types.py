@@ -38,7 +38,8 @@ class DensePipelineConfig:
     pack_workers: int = 4
     # ---- extensions of this implementation (not present upstream) --------------------------
     # "sampled": upstream behaviour - coverage sampling picks ~0.85*M+tiles cells per reference and
-    #            only those are triangulated.  "dense": every grid cell goes through the fused kernel.
+    #            only those are triangulated.  "dense": every grid cell upstream's sampler COULD draw (best certainty after
+    #            floor and masks not <= 0: a masked-out cell never is) goes through the fused kernel.
     triangulation_mode: str = "sampled"
     # references whose RoMa outputs are kept resident and triangulated by ONE kernel launch
     refs_per_launch: int = 1

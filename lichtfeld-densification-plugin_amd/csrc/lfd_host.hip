@@ -197,11 +197,14 @@ void host_cell_best(const HostLaunch& L, int r, int cell, float& best, int& bj) 
 struct HostPoint { float x, y, z, r, g, b, err; int cell; int slot; };
 
 // one cell through arg-max -> geometry -> colour; returns false when the cell does not survive
-bool host_eval_cell(const HostLaunch& L, const HostRef& R, int r, int cell, HostPoint& o, int& bj_out) {
+bool host_eval_cell(const HostLaunch& L, const HostRef& R, int r, int cell, HostPoint& o, int& bj_out, bool need_weight = false) {
     const lfd_batch* b = L.b;
     float best; int bj;
     host_cell_best(L, r, cell, best, bj);
     bj_out = bj;
+    // dense mode: only cells upstream's sampler could ever draw - a weight that is not <= 0 after floor and masks (core/sampling.py:24-27, 41-43 upstream:
+    // p = weights / sum, the coverage pass stops at weights <= 0); a masked-out cell is not a candidate.  Indexed mode: the caller selected.
+    if (need_weight && best <= 0.0f) return false;
     const float* wp = b->warp[(size_t)r * b->k + bj] + (size_t)cell * b->warp_channels;
     float xan, yan, xbn, ybn;
     if (b->warp_channels == 4) { xan = wp[0]; yan = wp[1]; xbn = wp[2]; ybn = wp[3]; }
@@ -301,7 +304,7 @@ int lfd_triangulate_dense_host(lfd_context* ctx, const lfd_batch* b, const lfd_p
             HostPoint* v = stage + (size_t)c * kChunk;
             int n = 0, bj;
             for (int cell = c0; cell < c1; ++cell)
-                if (host_eval_cell(L, refs[(size_t)r], r, cell, v[n], bj)) ++n;
+                if (host_eval_cell(L, refs[(size_t)r], r, cell, v[n], bj, true)) ++n;
             kept[(size_t)c] = n;
             if (seg_counts) {
                 int* cnt = per_slot.data() + (size_t)c * LFD_MAX_SLOTS;

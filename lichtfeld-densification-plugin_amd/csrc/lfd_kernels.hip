@@ -620,6 +620,11 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
 
         // ---- stage 1: certainty floor + arg-max over the neighbour slots (coalesced 16-B loads) -----
         int bj[kCpt];
+        // cells whose best certainty is <= 0 (masked out; a floor of 0 with a certainty of 0): not candidates - upstream's sampler cannot draw
+        // them (core/sampling.py:24-27, 41-43 upstream).  Four bits that live until the coordinates are parked: a dead cell is parked with a NaN
+        // neighbour coordinate, which every branch of the per-cell routine rejects (Sampson `<`, reprojection `<=`, isfinite) - the geometry loop
+        // carries no flag and no test for it.
+        unsigned dead = 0;
 #if LFD_DENSE_ALL_WARPS
         // Up to four neighbours, two-channel warps, no masks: the warps of ALL slots are requested together with the certainty
         // planes (dense 16-byte loads) and the winner's is picked in registers, instead of a second, dependent round trip for the
@@ -655,6 +660,8 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
                 }
             }
             have_warps = true;
+            if (!(th > 0.0f))          // (a floored certainty is >= the floor: with a positive floor - a scalar test - no cell of an unmasked reference is dead)
+                dead = (unsigned)(best.x <= 0.0f) | ((unsigned)(best.y <= 0.0f) << 1) | ((unsigned)(best.z <= 0.0f) << 2) | ((unsigned)(best.w <= 0.0f) << 3);
         } else
 #endif
         if (!any_mask && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW) {
@@ -682,16 +689,20 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
                     }
                 }
             }
+            if (!(th > 0.0f))
+                dead = (unsigned)(best.x <= 0.0f) | ((unsigned)(best.y <= 0.0f) << 1) | ((unsigned)(best.z <= 0.0f) << 2) | ((unsigned)(best.w <= 0.0f) << 3);
         } else if ((L.W & 3) == 0 && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW) {      // masks present
             int dy, x0;
             lfd_divmod_local(tile_x0 + tid * kCpt, L.W, L.inv_w, L.w_log2, dy, x0);
             float b4[4];
             cells4_best_masked(L, S, cell0, tile_y0 + dy, x0, b4, bj);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dead |= (unsigned)(b4[e] <= 0.0f) << e;
         } else {
 #pragma unroll
             for (int e = 0; e < kCpt; ++e) {
                 bj[e] = 0;
-                if (cell0 + e < HW) { float b; cell_best(L, S, cell0 + e, b, bj[e]); }
+                if (cell0 + e < HW) { float b; cell_best(L, S, cell0 + e, b, bj[e]); dead |= (unsigned)(b <= 0.0f) << e; }
             }
         }
 
@@ -747,6 +758,11 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
                 stage.err[sl] = ybn;
                 bj_packed |= (unsigned)bj[e] << (8 * e);
             }
+        }
+        if (dead) {                               // (rare: masks, or a floor of 0)
+#pragma unroll
+            for (int e = 0; e < kCpt; ++e)
+                if ((dead >> e) & 1u) stage.xyz[3 * (tid * kCpt + e) + 2] = __builtin_nanf("");
         }
         *reinterpret_cast<unsigned*>(&stage.slot[tid * kCpt]) = bj_packed;
 

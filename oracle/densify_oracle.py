@@ -512,13 +512,17 @@ def triangulate_reference(cert_list, warp_list, img_a, cam_a, cams_b, w_match, h
 
 def triangulate_dense(cert_list, warp_list, img_a, cam_a, cams_b, w_match, h_match,
                       params: OracleParams, mask_a=None, mask_b_list=None, axes=None):
-    """Dense extension used by the fused kernel: every grid cell is "selected" (the selection stage
-    is skipped; certainty only decides the winning neighbour).  Survivors are returned in raster
-    order together with their cell index and neighbour slot.  With upstream's rules this is exactly
-    ``triangulate_selected(arange(H*W))`` re-sorted by cell."""
+    """Dense extension used by the fused kernel: every grid cell upstream's sampler could ever draw is "selected" - the cells whose
+    best certainty after floor and masks is not <= 0 (core/sampling.py:24-27, 41-43 upstream: p = weights / sum, the coverage
+    pass stops at weights <= 0; a masked-out cell has weight 0; the border upstream excludes from sampling stays in) - the selection
+    stage is skipped, certainty otherwise only decides the winning neighbour.  Survivors are returned in raster order together
+    with their cell index and neighbour slot.  With upstream's rules this is exactly
+    ``triangulate_selected(nonzero(~(best_cert <= 0)))`` re-sorted by cell."""
     best_cert, best_k, agg = prepare_reference(cert_list, warp_list, params, mask_a, mask_b_list)
     h, w = best_cert.shape
-    res = triangulate_selected(np.arange(h * w, dtype=np.int64), best_cert, best_k, agg, img_a, cam_a,
+    with np.errstate(invalid="ignore"):
+        candidates = np.nonzero(~(best_cert.reshape(-1) <= 0))[0].astype(np.int64)      # (a NaN best certainty stays a candidate, as before)
+    res = triangulate_selected(candidates, best_cert, best_k, agg, img_a, cam_a,
                                cams_b, w_match, h_match, params, axes=axes)
     cell = res.cell
     order = np.argsort(cell, kind="stable")

@@ -84,7 +84,8 @@ def flip_report(kept_cells, sref, cams, w_match, h_match, params, axes, sample=N
             cells = np.arange(H * W, dtype=np.int64)
         else:
             cells = np.sort(np.random.RandomState(seed).choice(H * W, size=int(sample), replace=False)).astype(np.int64)
-        res = orc.triangulate_selected(cells, best_cert, best_k, agg, sref.image.cpu().numpy(), ca, cbs, w_match, h_match,
+        cand = cells[~(best_cert.reshape(-1)[cells] <= 0)]      # dense mode's candidates: best certainty not <= 0 (orc.triangulate_dense)
+        res = orc.triangulate_selected(cand, best_cert, best_k, agg, sref.image.cpu().numpy(), ca, cbs, w_match, h_match,
                                        params, axes=axes)
     keep_orc = np.zeros(H * W, bool)
     keep_orc[res.cell] = True

@@ -127,3 +127,52 @@ def test_dense_ply_kernel_writes_the_packers_bytes(dev, name, exact):
     np.testing.assert_array_equal(off2.cpu().numpy(), ordered.ref_offsets)           # the counts are still the full ones
     assert torch.equal(rec[:small * 15], body[:small * 15]) and bool((rec[small * 15:] == 0xAB).all())
     dens.close()
+
+
+@pytest.mark.parametrize("fill", ["nothing", "one cell", "non-finite"])
+def test_degenerate_inputs_through_the_unordered_and_ply_forms(dev, fill):
+    """every cell masked out (zero survivors everywhere), exactly one cell left by the mask, and NaN / Inf in warps and certainties: the three
+    forms of the kernel agree (empty tables and payloads, offsets all zero; the one record; non-finite cells rejected, nothing fatal)"""
+    from lichtfeld_densification_plugin_amd import synthetic
+    H, W, k = 70, 90, 3
+    cams = synthetic.ring_cameras(24, seed=1)
+    refs = []
+    for ref in (2, 9):
+        nbrs = synthetic.ring_neighbours(24, ref, k)
+        s = synthetic.synth_reference(cams, ref, nbrs, H, W, W, H, noise_px=0.2, outlier_frac=0.0, channels=2, seed=ref, cert_mode="tiefree")
+        cert = [c.clone() for c in s.cert]
+        warp = [w.clone().contiguous() for w in s.warp]
+        mask_a = None
+        if fill in ("nothing", "one cell"):
+            # (upstream's certainty "floor" LIFTS low certainties to the threshold - every cell stays a candidate; what removes cells is a mask)
+            mask_a = torch.zeros((H, W), dtype=torch.uint8)
+            if fill == "one cell" and ref == 9:
+                mask_a[H // 2, W // 2] = 1
+        else:
+            cert[0][3, :] = float("nan"); cert[1][:, 5] = float("inf"); warp[2][10:20, 10:20, :] = float("nan"); warp[0][30, 30, 0] = float("-inf")
+        refs.append(hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=[c.to(dev) for c in cert], warp=[w.to(dev) for w in warp], image=s.image.to(dev),
+                                       mask_a=None if mask_a is None else mask_a.to(dev)))
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    params = hb.make_params(lfd.DensePipelineConfig(output_path="", nns_per_ref=k, reproj_thresh=1.5))
+    batch = hb.PreparedBatch(refs, W, H, cameras=cams)
+    ordered = dens.triangulate_dense(batch, params)
+    if fill == "nothing":
+        assert ordered.count == 0
+    elif fill == "one cell":
+        assert ordered.count <= 1 and int(ordered.ref_offsets[1]) == 0
+    else:
+        assert ordered.count > 1000 and bool(torch.isfinite(ordered.xyz).all()) and bool(torch.isfinite(ordered.err).all())
+    seg = dens.triangulate_dense_segments(batch, params)
+    np.testing.assert_array_equal(seg.ref_counts.cpu().numpy(), np.diff(ordered.ref_offsets))
+    again = dens.order_segments(seg)
+    np.testing.assert_array_equal(again.ref_offsets, ordered.ref_offsets)
+    assert torch.equal(again.xyz, ordered.xyz) and torch.equal(again.rgb, ordered.rgb) and torch.equal(again.cell, ordered.cell)
+    ply_ref = dens.pack_ply(ordered.xyz, ordered.rgb)
+    body_s, offs_s = dens.pack_ply_segments(seg)
+    body_k, offs_k = dens.triangulate_dense_ply(batch, params)
+    np.testing.assert_array_equal(offs_s, ordered.ref_offsets)
+    np.testing.assert_array_equal(offs_k, ordered.ref_offsets)
+    assert body_s.numel() == body_k.numel() == ply_ref.numel() == 15 * ordered.count
+    assert torch.equal(body_s, ply_ref) and torch.equal(body_k, ply_ref)
+    dens.close()
