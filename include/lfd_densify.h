@@ -268,7 +268,8 @@ int lfd_get_pair_fundamental(lfd_context* ctx, int32_t n_pairs, double* F_out_ho
 /* ---- N3: image preparation on the device (core/image_utils.py:40-91, core/pipeline.py:163-171) ------------------- */
 /* Decoding stays on the host (PIL); the decoded u8 arrays are uploaded and prepared here, bit for bit like Pillow 12:
  * lfd_prepare_image:  dst = Image.resize((w_out, h_out), BILINEAR) of the (h_in, w_in, 3) u8 image src (8-bit two-pass
- *                     fixed-point convolution, horizontal first), then masked pixels black (mask01: device u8 {0,1}
+ *                     fixed-point convolution, horizontal first - vertical first where Pillow's Image.resize does that: an
+ *                     image more than 100 times taller than wide that shrinks vertically), then masked pixels black (mask01: device u8 {0,1}
  *                     [h_out*w_out] or NULL) as apply_mask_to_rgb does.  dst: device u8 [h_out*w_out*3].
  * lfd_prepare_mask:   dst01 = load_mask_resized_np after the "L" conversion: Image.resize(NEAREST) of the (h_in, w_in) u8
  *                     mask, then (v / 255 as f32) > threshold, optionally inverted; dst01: device u8 {0,1} [h_out*w_out].

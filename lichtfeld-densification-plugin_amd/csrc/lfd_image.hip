@@ -83,6 +83,47 @@ __device__ __forceinline__ int clip8(int acc) {
 
 }  // namespace
 
+// The same resize with the passes in the other order - vertical first, the vertically resampled pixel of every source column rounded to 8 bits,
+// then horizontal: what Pillow's Image.resize does for an image more than 100 times taller than wide that shrinks vertically (PIL/Image.py:
+// two resize calls).  tab as below.
+extern "C" __global__ void __launch_bounds__(256) lfd_resize_bilinear_vfirst_kernel(const uint8_t* __restrict__ src, int w_in, int h_in,
+                                                                                    uint8_t* __restrict__ dst, int w_out, int h_out,
+                                                                                    const int32_t* __restrict__ tab, int ks_x, int ks_y,
+                                                                                    const uint8_t* __restrict__ mask01) {
+    const int ox = (int)(blockIdx.x * 64 + (threadIdx.x & 63));
+    const int oy = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+    if (ox >= w_out || oy >= h_out) return;
+    const int32_t* bx = tab;
+    const int32_t* kx = bx + 2 * w_out;
+    const int32_t* by = kx + (size_t)w_out * ks_x;
+    const int32_t* ky = by + 2 * h_out;
+    const bool horiz = w_out != w_in;                 // (vertical: always - the caller's rule)
+    const int xmin = horiz ? bx[2 * ox] : ox, xcnt = horiz ? bx[2 * ox + 1] : 1;
+    const int ymin = by[2 * oy], ycnt = by[2 * oy + 1];
+    int a0 = 1 << (kPrecisionBits - 1), a1 = a0, a2 = a0;
+    int o0 = 0, o1 = 0, o2 = 0;
+    for (int tx = 0; tx < xcnt; ++tx) {
+        const uint8_t* col = src + ((size_t)ymin * w_in + (xmin + tx)) * 3;
+        int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0;
+        for (int ty = 0; ty < ycnt; ++ty) {
+            const int k = ky[(size_t)oy * ks_y + ty];
+            const uint8_t* px = col + (size_t)ty * w_in * 3;
+            s0 += (int)px[0] * k; s1 += (int)px[1] * k; s2 += (int)px[2] * k;
+        }
+        const int v0 = clip8(s0), v1 = clip8(s1), v2 = clip8(s2);
+        if (horiz) {
+            const int k = kx[(size_t)ox * ks_x + tx];
+            a0 += v0 * k; a1 += v1 * k; a2 += v2 * k;
+        } else {
+            o0 = v0; o1 = v1; o2 = v2;
+        }
+    }
+    if (horiz) { o0 = clip8(a0); o1 = clip8(a1); o2 = clip8(a2); }
+    if (mask01 && mask01[(size_t)oy * w_out + ox] == 0) o0 = o1 = o2 = 0;
+    uint8_t* d = dst + ((size_t)oy * w_out + ox) * 3;
+    d[0] = (uint8_t)o0; d[1] = (uint8_t)o1; d[2] = (uint8_t)o2;
+}
+
 // tab: [bounds_x (2*w_out) | kk_x (w_out*ks_x) | bounds_y (2*h_out) | kk_y (h_out*ks_y)]
 extern "C" __global__ void __launch_bounds__(256) lfd_resize_bilinear_kernel(const uint8_t* __restrict__ src, int w_in, int h_in,
                                                                              uint8_t* __restrict__ dst, int w_out, int h_out,
@@ -179,8 +220,10 @@ int lfd_prepare_image(lfd_context* ctx, const uint8_t* src_rgb, int32_t w_in, in
         ctx->img_key[0] = w_in; ctx->img_key[1] = h_in; ctx->img_key[2] = w_out; ctx->img_key[3] = h_out;
     }
     const dim3 grid((unsigned)((w_out + 63) / 64), (unsigned)((h_out + 3) / 4));
-    hipLaunchKernelGGL(lfd_resize_bilinear_kernel, grid, dim3(256), 0, ctx->stream, src_rgb, w_in, h_in, dst_rgb, w_out, h_out,
-                       static_cast<const int32_t*>(ctx->img_tab.ptr), ctx->img_ks[0], ctx->img_ks[1], mask01);
+    // Pillow's Image.resize: "if self.size[1] > self.size[0] * 100 and size[1] < self.size[1]" - vertical pass first
+    const bool vfirst = (long long)h_in > (long long)w_in * 100 && h_out < h_in;
+    hipLaunchKernelGGL(vfirst ? lfd_resize_bilinear_vfirst_kernel : lfd_resize_bilinear_kernel, grid, dim3(256), 0, ctx->stream, src_rgb, w_in, h_in,
+                       dst_rgb, w_out, h_out, static_cast<const int32_t*>(ctx->img_tab.ptr), ctx->img_ks[0], ctx->img_ks[1], mask01);
     LFD_IMG_HIP(ctx, hipGetLastError());
     return LFD_OK;
 }

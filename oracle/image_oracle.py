@@ -87,6 +87,16 @@ def resize_bilinear_u8(img: np.ndarray, size_wh: Tuple[int, int]) -> np.ndarray:
     w_out, h_out = int(size_wh[0]), int(size_wh[1])
     h_in, w_in = img.shape[:2]
     cur = img
+    if h_in > w_in * 100 and h_out < h_in:
+        # Pillow's Image.resize (PIL/Image.py, "if self.size[1] > self.size[0] * 100 and size[1] < self.size[1]"): an image more than 100 times
+        # taller than wide that shrinks vertically is resampled VERTICALLY FIRST, then horizontally - two resize calls, the intermediate
+        # image rounded to 8 bits like every pass
+        bv, kv, _ = bilinear_coeffs(h_in, h_out)
+        cur = _pass(cur, bv, kv, axis=0)
+        if w_out != w_in:
+            bh, kh, _ = bilinear_coeffs(w_in, w_out)
+            cur = _pass(cur, bh, kh, axis=1)
+        return np.ascontiguousarray(cur)
     if w_out != w_in:
         bh, kh, _ = bilinear_coeffs(w_in, w_out)
         if h_out != h_in:           # Pillow resamples only the rows the vertical pass will read

@@ -36,7 +36,10 @@ def test_oracle_equals_pillow_on_random_sizes():
     """The restatement against the library itself (Pillow is what upstream calls), sizes up to the garden / bicycle images."""
     from PIL import Image
     rs = np.random.RandomState(3)
-    for h, w, wo, ho in [(37, 53, 31, 29), (29, 31, 53, 37), (840, 1297, 512, 512), (100, 100, 100, 37), (17, 400, 9, 17)]:
+    for h, w, wo, ho in [(37, 53, 31, 29), (29, 31, 53, 37), (840, 1297, 512, 512), (100, 100, 100, 37), (17, 400, 9, 17),
+                         # Pillow's Image.resize resamples VERTICALLY FIRST when the image is more than 100 times taller than wide and shrinks
+                         # vertically (PIL/Image.py): both sides of that rule
+                         (1201, 12, 53, 37), (1200, 12, 53, 37), (1201, 12, 12, 37), (1300, 12, 30, 1301), (301, 3, 3, 300), (997, 3, 31, 31)]:
         img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
         np.testing.assert_array_equal(io.resize_bilinear_u8(img, (wo, ho)), np.asarray(Image.fromarray(img).resize((wo, ho), Image.BILINEAR)))
         m = rs.randint(0, 256, (h, w)).astype(np.uint8)
@@ -106,3 +109,35 @@ def test_decode_cache_is_bounded_by_bytes(tmp_path, monkeypatch):
     image_io.decode_rgb_u8(paths[1])
     assert image_io.decode_rgb_u8.cache_info()["entries"] == 0
     image_io.decode_rgb_u8.cache_clear()
+
+
+@pytest.mark.gpu
+def test_device_image_prep_equals_pillow_on_random_sizes():
+    """The device resize / mask kernels against the LIBRARY upstream calls (Pillow itself, not the restatement): 40 seeded size pairs - odd sizes,
+    up- and down-scaling (down to 1 pixel, up 8x), extreme aspect ratios, identity - images, masks with both thresholds, and the black-out."""
+    from PIL import Image
+    dev = torch.device("cuda:0")
+    dens = hb.HipDensifier(dev)
+    rs = np.random.RandomState(11)
+    sizes = [(1, 1, 1, 1), (1, 7, 5, 1), (3, 3, 24, 24), (64, 64, 64, 64), (997, 3, 31, 31), (2, 1300, 640, 2),
+             (1201, 12, 53, 37), (1200, 12, 53, 37), (1201, 12, 12, 37), (1300, 12, 30, 1301), (301, 3, 3, 300), (2001, 20, 7, 13)]      # Pillow's vertical-first rule, both sides
+    while len(sizes) < 40:
+        h, w = int(rs.randint(1, 600)), int(rs.randint(1, 900))
+        sizes.append((h, w, int(rs.randint(1, 700)), int(rs.randint(1, 700))))
+    for h, w, wo, ho in sizes:
+        img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        want = np.asarray(Image.fromarray(img).resize((wo, ho), Image.BILINEAR))
+        got = dens.prepare_image(torch.from_numpy(img).to(dev), (wo, ho)).cpu().numpy()
+        np.testing.assert_array_equal(got, want, err_msg=f"image {h}x{w} -> {ho}x{wo}")
+        m = rs.randint(0, 256, (h, w)).astype(np.uint8)
+        near = np.asarray(Image.fromarray(m, mode="L").resize((wo, ho), Image.NEAREST))
+        for thr, inv in ((0.5, False), (0.3, True)):
+            m01 = ((near.astype(np.float32) / 255.0) > thr)
+            m01 = (~m01 if inv else m01).astype(np.uint8)                       # upstream load_mask_resized_np (core/image_utils.py:64-91)
+            got_m = dens.prepare_mask(torch.from_numpy(m).to(dev), (wo, ho), threshold=thr, invert=inv).cpu().numpy()
+            np.testing.assert_array_equal(got_m, m01, err_msg=f"mask {h}x{w} -> {ho}x{wo} thr {thr} inv {inv}")
+        keep = ((near.astype(np.float32) / 255.0) > 0.5).astype(np.uint8)
+        black = want * keep[..., None]                                          # apply_mask_to_rgb
+        got_b = dens.prepare_image(torch.from_numpy(img).to(dev), (wo, ho), torch.from_numpy(keep).to(dev)).cpu().numpy()
+        np.testing.assert_array_equal(got_b, black, err_msg=f"black-out {h}x{w} -> {ho}x{wo}")
+    dens.close()
