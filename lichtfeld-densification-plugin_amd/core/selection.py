@@ -30,11 +30,12 @@ def select_cameras_by_visibility(rec, k: int) -> List[int]:
     """Greedy set cover over the sparse model's 3-D points (needs a pycolmap Reconstruction)."""
     if not rec.points3D:
         raise ValueError("Visibility-based selection requires a sparse point cloud.")
-    seen_by: Dict[int, set] = {
-        img.image_id: {p.point3D_id for p in img.points2D if p.has_point3D() and p.point3D_id != -1}
-        for img in rec.images.values()}
+    observed = {img.image_id: [p.point3D_id for p in img.points2D if p.has_point3D() and p.point3D_id != -1] for img in rec.images.values()}
+    seen_by: Dict[int, set] = {iid: set(pts) for iid, pts in observed.items()}
     k = min(k, len(seen_by))
-    gain = {iid: len(pts) for iid, pts in seen_by.items()}
+    # upstream's first scores count OBSERVATIONS (a list: a 3-D point observed twice in one image counts twice), the later ones distinct
+    # uncovered points (core/selection.py:14-33 upstream) - found by tests/golden/check_oracle_fuzz.py
+    gain = {iid: len(pts) for iid, pts in observed.items()}
     covered: set = set()
     picked: List[int] = []
     for _ in range(k):

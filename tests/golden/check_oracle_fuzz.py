@@ -158,6 +158,32 @@ def main():
                     ns.writers.write_points3D_bin(p3, xyz, u8, err) if "err" in ns.writers.write_points3D_bin.__code__.co_varnames else ns.writers.write_points3D_bin(p3, xyz, u8)
                     t.check("write_points3D_bin", np.frombuffer(open(p3, "rb").read(), np.uint8),
                             np.frombuffer(orc.points3d_bin_bytes(xyz, u8, err if "err" in ns.writers.write_points3D_bin.__code__.co_varnames else None), np.uint8))
+        # ---- camera selection (product host code, lichtfeld-densification-plugin_amd/core/selection.py, against upstream core/selection.py) ------
+        from lichtfeld_densification_plugin_amd.core import selection as sel_mine
+        import types as _types
+        for c in range(max(args.cases // 3, 30)):
+            n = int(rs.choice([1, 2, 3, 17, 60, 185]))
+            poses = rs.normal(0, rs.choice([1.0, 5.0]), (n, 12)).astype(np.float32)
+            if c % 4 == 1 and n > 3:
+                poses[1] = poses[0]; poses[3] = poses[2]                       # coincident cameras: distance ties
+            if c % 4 == 2:
+                poses[:, 5] = 1.0                                              # a constant column (sigma -> 1e-8)
+            for k in (1, 3, 8, n, n + 5):
+                t.check("select_cameras_kcenters", np.asarray(ns.selection.select_cameras_kcenters(poses, k), np.int64),
+                        np.asarray(sel_mine.select_cameras_kcenters(poses, k), np.int64))
+                t.check("nearest_neighbors", ns.selection.nearest_neighbors(poses, k), sel_mine.nearest_neighbors(poses, k))
+            # visibility: a reconstruction as far as the function looks at one (images with points2D that may or may not have a 3-D point)
+            n_img, n_pts = int(rs.randint(1, 30)), int(rs.randint(1, 200))
+
+            def p2d(pid):
+                return _types.SimpleNamespace(point3D_id=int(pid), has_point3D=lambda pid=pid: pid != -1 and pid != 2 ** 64 - 1)
+            images = {int(iid): _types.SimpleNamespace(image_id=int(iid), points2D=[p2d(pid) for pid in rs.choice(np.concatenate([[-1, -1], np.arange(n_pts)]),
+                                                                                                     size=int(rs.randint(0, 80)))])
+                      for iid in rs.choice(1000, n_img, replace=False)}
+            rec = _types.SimpleNamespace(images=images, points3D={i: None for i in range(n_pts)})
+            for k in (1, 4, n_img, n_img + 3):
+                t.check("select_cameras_by_visibility", np.asarray(ns.selection.select_cameras_by_visibility(rec, k), np.int64),
+                        np.asarray(sel_mine.select_cameras_by_visibility(rec, k), np.int64))
     total, bad = sum(t.cases.values()), sum(t.bad.values())
     for k in sorted(t.cases):
         print(f"{k:48s} {t.cases[k]:6d} cases  {t.bad.get(k, 0)} mismatches")
