@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""The driver loop against UPSTREAM'S OWN ``run_dense_pipeline`` on seeded scenes - development container only (it imports /root/reference through
+tests/golden/ref_import.py; nothing of it is copied, the GPU box never sees it).
+
+    python tests/golden/check_pipeline_fuzz.py [--scenes 16] [--write]
+
+Golden g4 pins the loop on ONE scene in two configurations.  Here: scenes of 4-9 cameras, 1-3 neighbours, different reference subsets, square and
+rectangular grids, filter and no_filter, different matches_per_ref / seeds / viz intervals, a reference whose matcher call fails - upstream's
+``run_dense_pipeline`` (its matcher class replaced by a table of prepared warps, exactly like make_golden.py) against this package's, on the CPU twin
+(``backend="host"``: the host build of the kernels' per-cell source + upstream's own host sampling stage).  Compared: per-reference survivor counts
+and the processed / matched counters (exact), colours (bit for bit: the same f64 blend), positions (1e-5: the twin's f64 null vector against
+LAPACK's f32 SVD) and errors, the sequence of progress percentages and message heads, the intermediate preview files (names, vertex counts, bodies
+to the same tolerances).  ``--write`` stores the tally as tests/golden/g10_pipeline_fuzz.json."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+from ref_import import load_reference  # noqa: E402
+import lichtfeld_densification_plugin_amd as lfd  # noqa: E402
+from lichtfeld_densification_plugin_amd import synthetic  # noqa: E402
+from lichtfeld_densification_plugin_amd.core import pipeline as mine  # noqa: E402
+
+
+class Table:
+    """Duck-typed stand-in for RomaMatcher: the prepared (warp HxWx4, cert HxW) tensors, reference by reference; ``fail_at``: that call raises."""
+    sample_thresh = 0.9
+
+    def __init__(self, wm, hm, table, fail_at=-1):
+        self.w_resized, self.h_resized, self.table, self.calls, self.fail_at = wm, hm, table, 0, fail_at
+
+    def match_grids_batch(self, imA, imB_list, **_kw):
+        i = self.calls
+        self.calls += 1
+        if i == self.fail_at:
+            raise RuntimeError("matcher failed on this reference")
+        return [(w.clone(), c.clone()) for (w, c) in self.table[i]]
+
+    def close(self):
+        pass
+
+
+def read_ply(path):
+    head, body = open(path, "rb").read().split(b"end_header\n", 1)
+    n = int([l for l in head.decode().split("\n") if l.startswith("element vertex")][0].split()[-1])
+    rec = np.frombuffer(body, np.dtype([("p", "<f4", 3), ("c", "u1", 3)]), count=n)
+    return n, rec["p"].copy(), rec["c"].copy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scenes", type=int, default=16)
+    ap.add_argument("--write", action="store_true")
+    args = ap.parse_args()
+    from PIL import Image
+    ns = load_reference()
+    P = ns.pipeline
+    rs = np.random.RandomState(77)
+    tally = {"scenes": 0, "count_mismatch": 0, "counter_mismatch": 0, "rgb_mismatch": 0, "xyz_out_of_tol": 0, "err_out_of_tol": 0, "progress_mismatch": 0,
+             "preview_mismatch": 0, "raised_differently": 0, "points": 0, "max_xyz_rel": 0.0}
+    for sc in range(args.scenes):
+        n_cams = int(rs.randint(4, 10))
+        H, W = [(64, 64), (48, 80), (40, 40), (72, 56)][sc % 4]
+        wm, hm = W, H
+        k = int(rs.randint(1, 4))
+        cams = synthetic.ring_cameras(n_cams, seed=100 + sc, arc=0.9)
+        refs_local = sorted(int(r) for r in rs.choice(n_cams, size=int(rs.randint(1, min(n_cams, 4) + 1)), replace=False))
+        nn_table = ns.selection.nearest_neighbors(np.stack([c.flat_pose() for c in cams]), k)
+        no_filter = bool(sc % 3 == 1)
+        cfg_kw = dict(nns_per_ref=k, seed=int(rs.randint(0, 1000)), viz_interval=int(rs.choice([0, 1, 2])), pack_workers=1, no_filter=no_filter,
+                      matches_per_ref=int(rs.choice([200, 900, 2500])), reproj_thresh=float(rs.choice([0.8, 1.5])), min_parallax_deg=float(rs.choice([0.5, 0.0])))
+        fail_at = 1 if (sc % 5 == 4 and len(refs_local) > 1) else -1
+        with tempfile.TemporaryDirectory() as d:
+            for i, c in enumerate(cams):
+                c.image_path = os.path.join(d, f"im{i:02d}.png")
+                Image.fromarray(synthetic.synth_image(hm, wm, 500 + 10 * sc + i).numpy()).save(c.image_path)
+            table = []
+            for r in refs_local:
+                nbrs = [int(n) for n in nn_table[r][:k]]
+                s = synthetic.synth_reference(cams, r, nbrs, H, W, wm, hm, noise_px=float(rs.choice([0.2, 0.6])), outlier_frac=0.05, channels=4,
+                                              seed=900 + sc, cert_mode=str(rs.choice(["tiefree", "smooth"])))
+                table.append([(s.warp[j], s.cert[j]) for j in range(len(nbrs))])
+            out = {}
+            for who in ("upstream", "mine"):
+                fm = Table(wm, hm, table, fail_at)
+                progress, viz = [], []
+                sub = os.path.join(d, who)
+                try:
+                    with np.errstate(all="ignore"):
+                        if who == "upstream":
+                            P.RomaMatcher = lambda device="cpu", mode="outdoor", setting="fast", _fm=fm: _fm
+                            P.has_cached_romav2_weights = lambda: True
+                            cfg = ns.config.DensePipelineConfig(output_path=os.path.join(sub, "dense.ply"), roma_setting="fast", **cfg_kw)
+                            res = P.run_dense_pipeline(cams, refs_local, nn_table, cfg, progress_callback=lambda p, m: progress.append((p, m)),
+                                                       on_sequential_viz=lambda path: viz.append(path))
+                        else:
+                            cfg = lfd.DensePipelineConfig(output_path=os.path.join(sub, "dense.ply"), roma_setting="fast", backend="host", **cfg_kw)
+                            res = mine.run_dense_pipeline(cams, refs_local, nn_table, cfg, progress_callback=lambda p, m: progress.append((p, m)),
+                                                          on_sequential_viz=lambda path: viz.append(path), matcher=fm)
+                    previews = [(os.path.basename(v),) + read_ply(v) for v in viz]
+                    out[who] = dict(xyz=res.xyz, rgb=res.rgb, err=res.err, processed=int(res.pairs_processed), matched=int(getattr(res, "pairs_matched", -1)),
+                                    progress=[(round(float(p), 6), m.split(" | ")[0]) for p, m in progress], previews=previews, error=None)
+                except Exception as exc:                      # noqa: BLE001 - "No points triangulated" and friends: both sides must agree
+                    out[who] = dict(error=f"{type(exc).__name__}: {str(exc)[:80]}")
+            tally["scenes"] += 1
+            u, m = out["upstream"], out["mine"]
+            if (u["error"] is None) != (m["error"] is None) or (u["error"] is not None and u["error"] != m["error"]):
+                tally["raised_differently"] += 1
+                print(f"scene {sc}: raised differently: upstream {u['error']!r}, mine {m['error']!r}")
+                continue
+            if u["error"] is not None:
+                continue
+            tally["points"] += int(u["xyz"].shape[0])
+            if u["xyz"].shape != m["xyz"].shape:
+                tally["count_mismatch"] += 1
+                print(f"scene {sc}: {u['xyz'].shape[0]} points upstream, {m['xyz'].shape[0]} here ({cfg_kw})")
+                continue
+            if (u["processed"], u["matched"]) != (m["processed"], m["matched"]) and u["matched"] >= 0:
+                tally["counter_mismatch"] += 1
+                print(f"scene {sc}: counters {(u['processed'], u['matched'])} vs {(m['processed'], m['matched'])}")
+            if not np.array_equal(u["rgb"], m["rgb"]):
+                tally["rgb_mismatch"] += 1
+            scale = np.maximum(1.0, np.abs(u["xyz"]).max(axis=1, keepdims=True)) if u["xyz"].size else np.ones((0, 1))
+            rel = float((np.abs(u["xyz"] - m["xyz"]) / scale).max()) if u["xyz"].size else 0.0
+            tally["max_xyz_rel"] = max(tally["max_xyz_rel"], rel)
+            tally["xyz_out_of_tol"] += int(rel > 1e-5)
+            tally["err_out_of_tol"] += int(u["err"].size and not np.allclose(m["err"], u["err"], rtol=1e-4, atol=2e-3))      # (no_filter keeps outliers: errors of 1e4 px)
+            if u["progress"] != m["progress"]:
+                tally["progress_mismatch"] += 1
+                print(f"scene {sc}: progress differs\n  upstream {u['progress'][:6]} ...\n  mine     {m['progress'][:6]} ...")
+            ok = len(u["previews"]) == len(m["previews"])
+            for a, b in zip(u["previews"], m["previews"]):
+                ok &= a[0] == b[0] and a[1] == b[1] and np.array_equal(a[3], b[3]) and (a[1] == 0 or float(np.abs(a[2] - b[2]).max()) <= 1e-4)
+            tally["preview_mismatch"] += int(not ok)
+    print(json.dumps(tally, indent=1))
+    bad = sum(v for k_, v in tally.items() if k_.endswith(("mismatch", "out_of_tol", "differently")))
+    if args.write:
+        tally["comment"] = ("tests/golden/check_pipeline_fuzz.py: upstream's run_dense_pipeline (imported from /root/reference in the development container) against "
+                            "this package's on the CPU twin, seeded scenes")
+        tally["numpy"], tally["torch"] = np.__version__, torch.__version__
+        with open(os.path.join(HERE, "g10_pipeline_fuzz.json"), "w") as fh:
+            json.dump(tally, fh, indent=1, sort_keys=True)
+        print("wrote g10_pipeline_fuzz.json")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

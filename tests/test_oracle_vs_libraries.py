@@ -72,3 +72,14 @@ def test_the_record_of_the_fuzz_against_upstream_reports_no_mismatch():
                "MT19937 position after a selection", "to_uint8_rgb", "write_ply body", "write_points3D_bin",
                "select_cameras_kcenters", "nearest_neighbors", "select_cameras_by_visibility"):
         assert rec["cases"].get(fn, 0) > 0, fn
+
+
+def test_the_record_of_the_driver_loop_against_upstreams_reports_no_mismatch():
+    """tests/golden/check_pipeline_fuzz.py (development container): upstream's run_dense_pipeline against this package's (CPU twin) on seeded scenes -
+    counts, counters, colours, positions, progress sequence, previews, error behaviour; its tally is committed"""
+    import json
+    import os
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_pipeline_fuzz.json")))
+    assert rec["scenes"] >= 20 and rec["points"] > 30000 and rec["max_xyz_rel"] <= 1e-5
+    for k in ("count_mismatch", "counter_mismatch", "rgb_mismatch", "xyz_out_of_tol", "err_out_of_tol", "progress_mismatch", "preview_mismatch", "raised_differently"):
+        assert rec[k] == 0, k
