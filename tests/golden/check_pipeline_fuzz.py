@@ -5,7 +5,7 @@ tests/golden/ref_import.py; nothing of it is copied, the GPU box never sees it).
     python tests/golden/check_pipeline_fuzz.py [--scenes 16] [--write]
 
 Golden g4 pins the loop on ONE scene in two configurations.  Here: scenes of 4-9 cameras, 1-3 neighbours, different reference subsets, square and
-rectangular grids, filter and no_filter, different matches_per_ref / seeds / viz intervals, a reference whose matcher call fails - upstream's
+rectangular grids, filter and no_filter, different matches_per_ref / seeds / viz intervals, mask files (match-sized, other sizes, unreadable), a reference whose matcher call fails - upstream's
 ``run_dense_pipeline`` (its matcher class replaced by a table of prepared warps, exactly like make_golden.py) against this package's, on the CPU twin
 (``backend="host"``: the host build of the kernels' per-cell source + upstream's own host sampling stage).  Compared: per-reference survivor counts
 and the processed / matched counters (exact), colours (bit for bit: the same f64 blend), positions (1e-5: the twin's f64 null vector against
@@ -85,6 +85,18 @@ def main():
             for i, c in enumerate(cams):
                 c.image_path = os.path.join(d, f"im{i:02d}.png")
                 Image.fromarray(synthetic.synth_image(hm, wm, 500 + 10 * sc + i).numpy()).save(c.image_path)
+                c.mask_path = None
+                if sc % 2 == 1 and rs.rand() < 0.6:            # mask files: match size, another size (resized NEAREST), one that cannot be read
+                    mh, mw = (hm, wm) if rs.rand() < 0.5 else (int(rs.randint(20, 200)), int(rs.randint(20, 200)))
+                    blob = np.full((mh, mw), 255, np.uint8)
+                    for _ in range(4):
+                        y, x = int(rs.randint(0, mh)), int(rs.randint(0, mw))
+                        blob[y:y + mh // 3, x:x + mw // 4] = int(rs.choice([0, 90, 140]))          # grey levels on both sides of the 0.5 threshold
+                    c.mask_path = os.path.join(d, f"mask{i:02d}.png")
+                    if rs.rand() < 0.12:
+                        open(c.mask_path, "wb").write(b"not an image")
+                    else:
+                        Image.fromarray(blob, mode="L").save(c.mask_path)
             table = []
             for r in refs_local:
                 nbrs = [int(n) for n in nn_table[r][:k]]
