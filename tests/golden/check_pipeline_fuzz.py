@@ -155,6 +155,86 @@ def main():
             for a, b in zip(u["previews"], m["previews"]):
                 ok &= a[0] == b[0] and a[1] == b[1] and np.array_equal(a[3], b[3]) and (a[1] == 0 or float(np.abs(a[2] - b[2]).max()) <= 1e-4)
             tally["preview_mismatch"] += int(not ok)
+    # ---- the GUI entry point (densify.py:215-316 upstream): camera nodes -> records -> k-centres references -> neighbours -> pipeline -> point cap ->
+    # PLY, against upstream's, on fake scene nodes: nodes without a camera, masks switched off, fractions and counts of references, more neighbours
+    # than cameras (clamped), a point cap, a single camera (code 1), a cancellation after a few progress calls (code 2)
+    import types as _types
+    from lichtfeld_densification_plugin_amd import densify as mine_densify
+    D = sys.modules[ns.pipeline.__name__.rsplit(".core.", 1)[0] + ".densify"] if (ns.pipeline.__name__.rsplit(".core.", 1)[0] + ".densify") in sys.modules else None
+    if D is None:
+        import importlib
+        D = importlib.import_module(ns.pipeline.__name__.rsplit(".core.", 1)[0] + ".densify")
+    tally.update({"lfs_cases": 0, "lfs_return_mismatch": 0, "lfs_file_mismatch": 0, "lfs_progress_mismatch": 0})
+    for sc in range(max(args.scenes // 2, 6)):
+        n_cams = 1 if sc == 3 else int(rs.randint(3, 8))
+        H = W = 48
+        cams = synthetic.ring_cameras(max(n_cams, 2), seed=300 + sc, arc=0.9)[:n_cams]
+        cfg_kw = dict(num_refs=float(rs.choice([0.5, 0.8, 1.0, 2.0, 3.0])), nns_per_ref=int(rs.choice([1, 2, 12])), seed=int(rs.randint(0, 99)), viz_interval=0,
+                      pack_workers=1, matches_per_ref=int(rs.choice([300, 1500])), max_points=int(rs.choice([0, 0, 700])), use_masks=bool(sc % 2))
+        cancel_after = 4 if sc == 5 else -1
+        with tempfile.TemporaryDirectory() as d:
+            nodes = []
+            for i, c in enumerate(cams):
+                path = os.path.join(d, f"im{i:02d}.png")
+                Image.fromarray(synthetic.synth_image(H, W, 700 + 10 * sc + i).numpy()).save(path)
+                mpath = os.path.join(d, f"mask{i:02d}.png")
+                blob = np.full((H, W), 255, np.uint8)
+                blob[: H // 3, : W // 2] = 0
+                Image.fromarray(blob, mode="L").save(mpath)
+                nodes.append(_types.SimpleNamespace(has_camera=True, camera_width=c.width, camera_height=c.height, camera_focal_x=float(c.K[0, 0]),
+                                                    camera_focal_y=float(c.K[1, 1]), camera_R=np.asarray(c.R), camera_T=np.asarray(c.t).reshape(3),
+                                                    camera_uid=int(c.uid), image_path=path, mask_path=mpath, has_mask=bool(i % 2)))
+                if i == 1:
+                    nodes.append(_types.SimpleNamespace(has_camera=False))
+            recs = D.extract_cameras_from_lfs(nodes)
+            table = []
+            if len(recs) >= 2:
+                flat = np.stack([r.flat_pose() for r in recs])
+                n_refs = int(round(cfg_kw["num_refs"] * len(recs))) if cfg_kw["num_refs"] <= 1.0 else int(cfg_kw["num_refs"])
+                refs_local = ns.selection.select_cameras_kcenters(flat, max(1, n_refs))
+                k_eff = max(1, min(cfg_kw["nns_per_ref"], len(recs) - 1))
+                nn_table = ns.selection.nearest_neighbors(flat, k_eff)
+                by_uid = {int(c.uid): j for j, c in enumerate(cams)}
+                for r in refs_local:
+                    nbrs = [int(n) for n in nn_table[r][:k_eff]]
+                    s = synthetic.synth_reference(cams, by_uid[int(recs[r].uid)], [by_uid[int(recs[n].uid)] for n in nbrs], H, W, W, H, noise_px=0.3, outlier_frac=0.05,
+                                                  channels=4, seed=40 + sc, cert_mode="tiefree")
+                    table.append([(s.warp[j], s.cert[j]) for j in range(len(nbrs))])
+            got = {}
+            for who in ("upstream", "mine"):
+                fm = Table(W, H, table)
+                progress = []
+                out_path = os.path.join(d, who, "dense.ply")
+                os.makedirs(os.path.dirname(out_path), exist_ok=True)          # (upstream's writer expects the directory to exist)
+                calls = {"n": 0}
+
+                def cancel():
+                    calls["n"] += 1
+                    return cancel_after >= 0 and calls["n"] > cancel_after
+                with np.errstate(all="ignore"):
+                    if who == "upstream":
+                        P.RomaMatcher = lambda device="cpu", mode="outdoor", setting="fast", _fm=fm: _fm
+                        P.has_cached_romav2_weights = lambda: True
+                        cfg = ns.config.DensePipelineConfig(output_path=out_path, roma_setting="fast", **cfg_kw)
+                        ret = D.dense_init_from_lfs(nodes, cfg, progress_callback=lambda p, m: progress.append((round(float(p), 6), m.split(" | ")[0])), cancel_requested=cancel)
+                    else:
+                        cfg = lfd.DensePipelineConfig(output_path=out_path, roma_setting="fast", backend="host", **cfg_kw)
+                        ret = mine_densify.dense_init_from_lfs(nodes, cfg, progress_callback=lambda p, m: progress.append((round(float(p), 6), m.split(" | ")[0])),
+                                                               cancel_requested=cancel, matcher=fm)
+                ply = read_ply(out_path) if (ret[0] == 0 and os.path.exists(out_path)) else None
+                got[who] = (ret[0], (ret[1] or "").replace(os.path.join(d, who), "<out>"), ply, progress)
+            tally["lfs_cases"] += 1
+            u, m = got["upstream"], got["mine"]
+            if u[:2] != m[:2]:
+                tally["lfs_return_mismatch"] += 1
+                print(f"lfs case {sc}: returned {u[:2]} upstream, {m[:2]} here ({cfg_kw})")
+            if (u[2] is None) != (m[2] is None) or (u[2] is not None and not (u[2][0] == m[2][0] and np.array_equal(u[2][2], m[2][2]) and
+                                                                                (u[2][0] == 0 or float(np.abs(u[2][1] - m[2][1]).max()) <= 1e-4))):
+                tally["lfs_file_mismatch"] += 1
+                print(f"lfs case {sc}: output files differ ({None if u[2] is None else u[2][0]} vs {None if m[2] is None else m[2][0]} vertices, {cfg_kw})")
+            if u[3] != m[3]:
+                tally["lfs_progress_mismatch"] += 1
+                print(f"lfs case {sc}: progress differs\n  upstream {u[3]}\n  mine     {m[3]}")
     print(json.dumps(tally, indent=1))
     bad = sum(v for k_, v in tally.items() if k_.endswith(("mismatch", "out_of_tol", "differently")))
     if args.write:

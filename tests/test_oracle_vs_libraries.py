@@ -81,5 +81,7 @@ def test_the_record_of_the_driver_loop_against_upstreams_reports_no_mismatch():
     import os
     rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_pipeline_fuzz.json")))
     assert rec["scenes"] >= 20 and rec["points"] > 30000 and rec["max_xyz_rel"] <= 1e-5
-    for k in ("count_mismatch", "counter_mismatch", "rgb_mismatch", "xyz_out_of_tol", "err_out_of_tol", "progress_mismatch", "preview_mismatch", "raised_differently"):
+    assert rec["lfs_cases"] >= 10             # ... and the GUI entry point dense_init_from_lfs on fake scene nodes (return codes, output files, progress)
+    for k in ("count_mismatch", "counter_mismatch", "rgb_mismatch", "xyz_out_of_tol", "err_out_of_tol", "progress_mismatch", "preview_mismatch", "raised_differently",
+              "lfs_return_mismatch", "lfs_file_mismatch", "lfs_progress_mismatch"):
         assert rec[k] == 0, k
