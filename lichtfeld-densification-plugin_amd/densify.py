@@ -28,11 +28,15 @@ def K_from_camera(cam) -> np.ndarray:
     parameters are ignored exactly as upstream ignores them."""
     model = str(cam.model.name).upper()
     p = np.asarray(cam.params, dtype=np.float32)
-    if ("PINHOLE" in model and "SIMPLE" not in model) or "OPENCV" in model or "FISHEYE" in model:
+    # upstream's chain IN ITS ORDER (core/geometry.py:15-30): SIMPLE_RADIAL_FISHEYE is a SIMPLE_RADIAL before it is a FISHEYE
+    # (found by tests/golden/check_oracle_fuzz.py: the two 4-parameter tests had been merged in front of the 3-parameter ones)
+    if "PINHOLE" in model and "SIMPLE" not in model:
         fx, fy, cx, cy = p[0], p[1], p[2], p[3]
     elif "SIMPLE_PINHOLE" in model or "SIMPLE_RADIAL" in model or model == "RADIAL":
         fx = fy = p[0]
         cx, cy = p[1], p[2]
+    elif "OPENCV" in model or "FISHEYE" in model:
+        fx, fy, cx, cy = p[0], p[1], p[2], p[3]
     else:
         fx = fy = p[0]
         cx = p[1] if len(p) > 1 else cam.width / 2

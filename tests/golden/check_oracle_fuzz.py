@@ -184,6 +184,28 @@ def main():
             for k in (1, 4, n_img, n_img + 3):
                 t.check("select_cameras_by_visibility", np.asarray(ns.selection.select_cameras_by_visibility(rec, k), np.int64),
                         np.asarray(sel_mine.select_cameras_by_visibility(rec, k), np.int64))
+        # ---- COLMAP cameras / images -> K, R, t (product host code densify.py against upstream core/geometry.py:10-50): every COLMAP model name
+        from lichtfeld_densification_plugin_amd import densify as dens_mine
+        models = {"SIMPLE_PINHOLE": 3, "PINHOLE": 4, "SIMPLE_RADIAL": 4, "RADIAL": 5, "OPENCV": 8, "OPENCV_FISHEYE": 8, "FULL_OPENCV": 12, "FOV": 5,
+                  "SIMPLE_RADIAL_FISHEYE": 4, "RADIAL_FISHEYE": 5, "THIN_PRISM_FISHEYE": 12, "RAD_TAN_THIN_PRISM_FISHEYE": 16, "SOMETHING_ELSE": 1, "simple_pinhole": 3}
+        for name, npar in models.items():
+            for rep in range(3):
+                cam = _types.SimpleNamespace(model=_types.SimpleNamespace(name=name), params=rs.uniform(100, 2000, npar), width=int(rs.randint(100, 4000)), height=int(rs.randint(100, 4000)))
+                t.check("K_from_camera", G.K_from_camera(cam), dens_mine.K_from_camera(cam))
+        for rep in range(30):
+            q = rs.normal(size=4); q /= np.linalg.norm(q)
+            w_, x_, y_, z_ = q
+            Rm = np.array([[1 - 2 * (y_ * y_ + z_ * z_), 2 * (x_ * y_ - z_ * w_), 2 * (x_ * z_ + y_ * w_)], [2 * (x_ * y_ + z_ * w_), 1 - 2 * (x_ * x_ + z_ * z_), 2 * (y_ * z_ - x_ * w_)],
+                           [2 * (x_ * z_ - y_ * w_), 2 * (y_ * z_ + x_ * w_), 1 - 2 * (x_ * x_ + y_ * y_)]])
+            tv = rs.normal(size=3)
+            rigid = _types.SimpleNamespace(rotation=_types.SimpleNamespace(matrix=lambda Rm=Rm: Rm), translation=tv)
+            for im in (_types.SimpleNamespace(cam_from_world=rigid), _types.SimpleNamespace(cam_from_world=lambda rigid=rigid: rigid),
+                       type("OldImage", (), {"qvec": _types.SimpleNamespace(to_rotation_matrix=lambda Rm=Rm: Rm.astype(np.float32)), "tvec": tv})()):
+                (R_u, t_u), (R_m, t_m) = G.pose_world2cam(im), dens_mine.pose_world2cam(im)
+                t.check("pose_world2cam R", R_u, R_m)
+                t.check("pose_world2cam t", t_u, t_m)
+                t.check("P_from_KRt / cam_center_world", np.concatenate([G.P_from_KRt(np.eye(3, dtype=np.float32), R_u, t_u).reshape(-1), G.cam_center_world(R_u, t_u)]),
+                        np.concatenate([(np.eye(3, dtype=np.float32) @ np.concatenate([R_m, t_m], axis=1)).reshape(-1), (-R_m.T @ t_m).reshape(3)]))
     total, bad = sum(t.cases.values()), sum(t.bad.values())
     for k in sorted(t.cases):
         print(f"{k:48s} {t.cases[k]:6d} cases  {t.bad.get(k, 0)} mismatches")

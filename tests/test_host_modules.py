@@ -248,3 +248,21 @@ def test_host_threads_fit_the_container_quota(monkeypatch, tmp_path):
         assert hostenv.fit_threads_to_quota() == max(before, 4)
     finally:
         torch.set_num_threads(before)
+
+
+def test_intrinsics_follow_upstreams_model_chain_in_its_order():
+    """K_from_camera (upstream core/geometry.py:10-30): SIMPLE_RADIAL_FISHEYE is a SIMPLE_RADIAL (f, cx, cy) before it is a FISHEYE (fx, fy, cx, cy) -
+    the order of upstream's tests matters (found by tests/golden/check_oracle_fuzz.py against upstream's own function)"""
+    import types
+    from lichtfeld_densification_plugin_amd import densify
+
+    def cam(name, params):
+        return types.SimpleNamespace(model=types.SimpleNamespace(name=name), params=np.asarray(params, np.float64), width=1000, height=800)
+    for name, params, want in [("PINHOLE", [900, 910, 500, 400], (900, 910, 500, 400)), ("SIMPLE_PINHOLE", [900, 500, 400], (900, 900, 500, 400)),
+                               ("SIMPLE_RADIAL", [900, 500, 400, 0.1], (900, 900, 500, 400)), ("RADIAL", [900, 500, 400, 0.1, 0.0], (900, 900, 500, 400)),
+                               ("OPENCV", [900, 910, 500, 400, 0, 0, 0, 0], (900, 910, 500, 400)), ("OPENCV_FISHEYE", [900, 910, 500, 400, 0, 0, 0, 0], (900, 910, 500, 400)),
+                               ("SIMPLE_RADIAL_FISHEYE", [900, 500, 400, 0.1], (900, 900, 500, 400)),
+                               ("RADIAL_FISHEYE", [900, 500, 400, 0.1, 0.0], (900, 500, 400, 0.1)),       # (upstream reads four parameters here: reproduced, not corrected)
+                               ("FOV", [900, 910, 500, 400, 0.9], (900, 900, 910, 500)), ("UNKNOWN", [900], (900, 900, 500, 400))]:
+        K = densify.K_from_camera(cam(name, params))
+        assert K.dtype == np.float32 and (float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])) == tuple(float(np.float32(v)) for v in want), name
