@@ -78,7 +78,8 @@ def main():
         refs_local = sorted(int(r) for r in rs.choice(n_cams, size=int(rs.randint(1, min(n_cams, 4) + 1)), replace=False))
         nn_table = ns.selection.nearest_neighbors(np.stack([c.flat_pose() for c in cams]), k)
         no_filter = bool(sc % 3 == 1)
-        cfg_kw = dict(nns_per_ref=k, seed=int(rs.randint(0, 1000)), viz_interval=int(rs.choice([0, 1, 2])), pack_workers=1, no_filter=no_filter,
+        cfg_kw = dict(nns_per_ref=k, seed=int(rs.randint(0, 1000)), viz_interval=int(rs.choice([0, 1, 2])), pack_workers=int(rs.choice([1, 4])),
+                      prefetch_packages=int(rs.choice([1, 2, 8])), no_filter=no_filter,
                       matches_per_ref=int(rs.choice([200, 900, 2500])), reproj_thresh=float(rs.choice([0.8, 1.5])), min_parallax_deg=float(rs.choice([0.5, 0.0])))
         fail_at = 1 if (sc % 5 == 4 and len(refs_local) > 1) else -1
         with tempfile.TemporaryDirectory() as d:
@@ -113,7 +114,10 @@ def main():
                         if who == "upstream":
                             P.RomaMatcher = lambda device="cpu", mode="outdoor", setting="fast", _fm=fm: _fm
                             P.has_cached_romav2_weights = lambda: True
-                            cfg = ns.config.DensePipelineConfig(output_path=os.path.join(sub, "dense.ply"), roma_setting="fast", **cfg_kw)
+                            # (upstream's loader hands packages over in COMPLETION order when it has several workers - its run then depends on thread
+                            # timing, and a matcher that replays a table cannot follow it: one worker there; this package's prefetcher is ordered, so
+                            # its side runs with whatever the case drew and must still give the one-worker result)
+                            cfg = ns.config.DensePipelineConfig(output_path=os.path.join(sub, "dense.ply"), roma_setting="fast", **dict(cfg_kw, pack_workers=1))
                             res = P.run_dense_pipeline(cams, refs_local, nn_table, cfg, progress_callback=lambda p, m: progress.append((p, m)),
                                                        on_sequential_viz=lambda path: viz.append(path))
                         else:
