@@ -81,3 +81,34 @@ def test_copy_segments_places_byte_ranges_in_one_launch():
     assert torch.equal(big[500:550], rows[100:150]) and torch.equal(big[550:650], rows[0:100]) and float(big[:500].abs().sum()) == 0.0 and float(big[650:].abs().sum()) == 0.0
     with pytest.raises(ValueError):
         hb.copy_segments(rows, big[500:1500], [(0, 999 * 28, 2 * 28)])            # leaves the destination view
+
+
+@pytest.mark.gpu
+def test_device_packers_equal_upstreams_writers_on_adversarial_values():
+    """lfd_pack_ply / lfd_pack_points3d / lfd_quantise_rgb against the oracle's writers (themselves equal to upstream's, byte for byte:
+    tests/golden/g9_oracle_fuzz.json) on seeded arrays with every value where the colour quantisation can go wrong - exact halves k + 0.5 (round half to
+    even), values just below and above them, negatives, values above 1, NaN / Inf colours and positions - and on the sizes 0, 1, 255, 256, 257, 100 003"""
+    dev = torch.device("cuda:0")
+    dens = hb.HipDensifier(dev)
+    rs = np.random.RandomState(8)
+    for n in (0, 1, 255, 256, 257, 100_003):
+        xyz = rs.normal(0, 50, (n, 3)).astype(np.float32)
+        rgb = rs.uniform(-0.1, 1.1, (n, 3)).astype(np.float32)
+        err = rs.uniform(0, 3, (n,)).astype(np.float32)
+        if n >= 255:
+            halves = ((np.arange(0, 255) + 0.5) / 255.0).astype(np.float32)
+            rgb[:255, 0] = halves
+            rgb[:255, 1] = np.nextafter(halves, np.float32(2))
+            rgb[:255, 2] = np.nextafter(halves, np.float32(-1))
+            rgb[3] = [np.nan, np.inf, -np.inf]
+            xyz[5] = [np.nan, -np.inf, 1e38]
+            err[7] = np.inf
+        tx, tc, te = (torch.from_numpy(a).to(dev) for a in (xyz, rgb, err))
+        with np.errstate(all="ignore"):
+            u8 = orc.to_uint8_rgb(rgb)
+            want_ply = orc.ply_bytes(xyz, u8).split(b"end_header\n", 1)[1]
+            want_p3d = orc.points3d_bin_bytes(xyz, u8, err)[8:]                     # behind the u64 count
+        assert dens.quantise_rgb(tc).cpu().numpy().tobytes() == u8.tobytes()
+        assert dens.pack_ply(tx, tc).cpu().numpy().tobytes() == want_ply
+        assert dens.pack_points3d(tx, tc, te, id_base=0).cpu().numpy().tobytes() == want_p3d
+    dens.close()
