@@ -691,7 +691,13 @@ class SharedFilePlyStream(OverlappedExchange):
                     fh.write(streamed_ply_header(0))
             except BaseException as exc:               # noqa: BLE001 - kept: the collectives below must still match on every rank
                 self.error = exc
-        dist.barrier(group=group)                      # the file exists before anybody opens it
+        # the file exists before anybody opens it - or the root could not create it, and then NOBODY opens whatever stale file may sit at that
+        # path: the root's status travels in the collective that doubles as the barrier
+        made = torch.tensor([0 if self.error is None else 1], dtype=torch.int32, device=self.dev)
+        dist.all_reduce(made, op=dist.ReduceOp.MAX, group=group)
+        if int(made.item()):
+            self.error = self.error or RuntimeError(f"the writer rank could not create {path}")
+            return
         try:
             self._fd = os.open(path, os.O_RDWR)
         except BaseException as exc:                   # noqa: BLE001
@@ -729,7 +735,8 @@ class SharedFilePlyStream(OverlappedExchange):
 
     def finish(self):
         import os
-        recs, counts = super().finish()
+        # (concat=False: this rank's records have been written where they belong; nothing concatenates them into a second copy of the shard)
+        recs, counts = super().finish(concat=False)
         if self._fd is not None:
             try:
                 os.fsync(self._fd)

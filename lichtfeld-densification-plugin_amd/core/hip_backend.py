@@ -160,7 +160,7 @@ def make_params(config: DensePipelineConfig, sample_cap: float = 0.9, exact_colo
     """``exact_colour``: dense mode blends colours in f64 like upstream (bit-identical rgb) instead of f32 (within 2.5e-7);
     default: the configuration's ``exact_colour`` field (False)."""
     if exact_colour is None:
-        exact_colour = bool(getattr(config, "exact_colour", False))
+        exact_colour = bool(config.exact_colour)
     return lfd_params(sampson_thresh=float(config.sampson_thresh), certainty_thresh=float(config.certainty_thresh),
                       sample_cap=float(sample_cap), reproj_thresh=float(config.reproj_thresh),
                       min_parallax_deg=float(config.min_parallax_deg), no_filter=1 if config.no_filter else 0,

@@ -13,6 +13,8 @@ from typing import Tuple
 
 import numpy as np
 
+from . import stages
+
 # Budget of the two caches of DECODED (full-resolution) files below.  Upstream only ever caches match-size arrays (~0.8 MB each); a
 # decoded 12-24 MP photograph is 36-72 MB, so these caches are bounded by BYTES, not by entries: at the default a camera's decode
 # survives until the neighbouring references that list it again have been packed (a few dozen images), never tens of GB.
@@ -84,10 +86,13 @@ def to_uint8_rgb(rgb01: np.ndarray) -> np.ndarray:
 def load_rgb_u8(path: str, size: Tuple[int, int]) -> np.ndarray:
     """(h, w, 3) u8 array of ``path`` resized to ``size=(w, h)``."""
     from PIL import Image
-    im = Image.open(path).convert("RGB")
-    if im.size != tuple(size):
-        im = im.resize(tuple(size), Image.BILINEAR)
-    arr = np.asarray(im, dtype=np.uint8)
+    clock = stages.current()
+    with clock.stage("decode", sync=False):
+        im = Image.open(path).convert("RGB")
+    with clock.stage("prepare", sync=False):
+        if im.size != tuple(size):
+            im = im.resize(tuple(size), Image.BILINEAR)
+        arr = np.asarray(im, dtype=np.uint8)
     arr.setflags(write=False)
     return arr
 
@@ -98,13 +103,16 @@ def load_mask01(path: str, size: Tuple[int, int], invert: bool = False, threshol
     from PIL import Image
     if not os.path.isfile(path):
         raise FileNotFoundError(path)
-    im = Image.open(path).convert("L")
-    if im.size != tuple(size):
-        im = im.resize(tuple(size), Image.NEAREST)
-    keep = (np.asarray(im, dtype=np.uint8).astype(np.float32) / 255.0) > float(threshold)
-    if invert:
-        keep = ~keep
-    out = keep.astype(np.uint8)
+    clock = stages.current()
+    with clock.stage("decode", sync=False):
+        im = Image.open(path).convert("L")
+    with clock.stage("prepare", sync=False):
+        if im.size != tuple(size):
+            im = im.resize(tuple(size), Image.NEAREST)
+        keep = (np.asarray(im, dtype=np.uint8).astype(np.float32) / 255.0) > float(threshold)
+        if invert:
+            keep = ~keep
+        out = keep.astype(np.uint8)
     out.setflags(write=False)
     return out
 
@@ -113,7 +121,8 @@ def load_mask01(path: str, size: Tuple[int, int], invert: bool = False, threshol
 def decode_rgb_u8(path: str) -> np.ndarray:
     """(h, w, 3) u8 array of ``path`` as decoded (no resize): input of the device image preparation (lfd_prepare_image)."""
     from PIL import Image
-    arr = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
+    with stages.current().stage("decode", sync=False):
+        arr = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
     arr.setflags(write=False)
     return arr
 
@@ -124,7 +133,8 @@ def decode_mask_l(path: str) -> np.ndarray:
     from PIL import Image
     if not os.path.isfile(path):
         raise FileNotFoundError(path)
-    arr = np.asarray(Image.open(path).convert("L"), dtype=np.uint8)
+    with stages.current().stage("decode", sync=False):
+        arr = np.asarray(Image.open(path).convert("L"), dtype=np.uint8)
     arr.setflags(write=False)
     return arr
 

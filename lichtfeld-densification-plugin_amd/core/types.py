@@ -2,18 +2,46 @@
 
 ``DensePipelineConfig`` keeps the 18 fields of the upstream dataclass with the same names, order and
 defaults (upstream core/config.py:7-26) so that the GUI panel / CLI can construct it unchanged, and
-adds MI355X-specific knobs *after* them (all defaulted, so positional construction still works).
+adds twelve settings of this implementation *after* them (all defaulted, so positional construction still
+works) plus one ``experimental`` dict for the knobs that exist only because an experiment was run.
+``problem()`` names every combination that cannot run: nothing is silently ignored.
 ``CameraRecord`` keeps upstream's per-camera record (core/camera_models.py:10-28): f32 intrinsics and
 world-to-camera pose, the projection ``P = K [R|t]`` and the centre ``C = -R^T t``.
 """
 from __future__ import annotations
 
 import dataclasses
-from typing import Optional
+from typing import Dict, Optional
 
 import numpy as np
 
 TRIANGULATION_MODES = ("sampled", "dense")
+
+# Knobs that exist because an experiment was run (DESIGN.md 4.3, 5): they stay reachable for the profiles and the tests that pin them, but they are not
+# part of the configuration surface a caller is expected to touch.  ``DensePipelineConfig(experimental={...})``; an unknown key is an error.
+EXPERIMENTAL_DEFAULTS = {
+    # sharded runs (torch.distributed, world > 1): the exchange happens in ROUNDS beside the compute (core/distributed.py::OverlappedExchange)
+    # instead of ONE exchange after the last reference; same sequence either way.  Not used together with stream_output (one communicator at a time).
+    "exchange_overlap": True,
+    # references per round of the overlapped exchange (0: refs_per_launch, at least 4)
+    "exchange_round": 0,
+    # what the overlapped exchange moves: "f32" the 28-byte rows of the result; "ply" the 15-byte PLY vertex records packed on the device
+    # (positions exact, colours as the writer quantises them, no reprojection error: the result's rgb is then u8 / 255 and err zero);
+    # "auto": "ply" when the output is a .ply and no voxel filter has to see f32 colours
+    "exchange_records": "f32",
+    # fraction of the reference list (its LAST references) computed by every rank that receives the cloud instead of exchanged
+    # (core/distributed.py::plan_replication says when that pays: never with a real matcher in the loop)
+    "exchange_replicate": 0.0,
+    # sharded run + stream_output on ONE node: every rank writes its own byte ranges of the output file, only counts travel
+    "stream_shared_file": False,
+    # dense mode: the kernel with UNORDERED retirement + lfd_order_segments (bit-identical result, ~6 % less kernel time)
+    "dense_tile_segments": False,
+    # hand upstream's own fundamental matrices (np.linalg.inv products, computed on the host exactly as upstream computes them) to the
+    # kernels instead of the closed-form F the library derives from the camera table (agrees to ~2e-6 relative, not bit for bit)
+    "upstream_fundamental": True,
+    # backend="host": threads of the CPU twin (0: all hardware threads)
+    "host_threads": 0,
+}
 
 
 @dataclasses.dataclass
@@ -36,38 +64,33 @@ class DensePipelineConfig:
     viz_interval: int = 3
     prefetch_packages: int = 8
     pack_workers: int = 4
-    # ---- extensions of this implementation (not present upstream) --------------------------
+    # ---- extensions of this implementation (not present upstream; 12 + the experimental dict) -------------------------------------------
     # "sampled": upstream behaviour - coverage sampling picks ~0.85*M+tiles cells per reference and
     #            only those are triangulated.  "dense": every grid cell upstream's sampler COULD draw (best certainty after
     #            floor and masks not <= 0: a masked-out cell never is) goes through the fused kernel.
     triangulation_mode: str = "sampled"
-    # references whose RoMa outputs are kept resident and triangulated by ONE kernel launch
+    # references whose RoMa outputs are kept resident and triangulated by ONE kernel launch (dense mode; sampled mode: references per fused
+    # call, which needs one RNG stream per reference)
     refs_per_launch: int = 1
     # per-reference RNG stream (seed ^ uid) instead of upstream's single process-global stream;
     # forced on when references are sharded over several GPUs (results then do not depend on
     # the shard count).
     per_reference_rng: bool = False
     # where the coverage-sampling stage of the "sampled" mode runs: "device" (lfd_select_samples: the
-    # whole per-reference path stays on the GPU) or "host" (core/sampling.py: the library calls
+    # whole per-reference path stays where the backend runs) or "host" (core/sampling.py: the library calls
     # upstream makes, including torch's own f32 sum as the normaliser).
     selection_backend: str = "device"
-    # selection_backend="device", one RNG stream (upstream's mode): normalise the sampling weights with upstream's OWN normaliser - torch's
-    # CPU f32 `sum` of the weight map, computed on this host exactly as core/sampling.py:27-31 computes it - instead of the device's
-    # correctly rounded exact sum.  torch's sum rounds differently from the exact one on most maps (by 1-2 ulp, depending on the
-    # host's thread count and vector ISA), which moves a cumulative-sum boundary under a draw on up to a quarter of the maps; with
-    # this on, the cells drawn are the ones upstream draws ON THE SAME MACHINE, bit for bit, at the price of one 1 MB read-back and a
-    # host reduction per reference (~0.2 ms; the fused asynchronous call and the launch-ahead are then not used).  Off: everything
-    # stays on the device (0.2 ms per reference, pipelined).  Sharded / per-reference-stream runs always use the exact sum: they do not
-    # reproduce upstream's single stream anyway.
+    # selection on the device, one RNG stream (upstream's mode), filter mode: normalise the sampling weights with upstream's OWN normaliser -
+    # torch's CPU f32 `sum` of the weight map, computed on this host exactly as core/sampling.py:27-31 computes it - instead of the device's
+    # correctly rounded exact sum (the cells drawn are then the ones upstream draws ON THE SAME MACHINE, bit for bit).  Per-reference
+    # streams / sharded runs / no_filter / dense mode have no such normaliser and are not affected.
     upstream_normaliser: bool = True
-    # dense mode only: blend colours with upstream's f64 arithmetic (bit-identical rgb) instead of f32 (within 2.5e-7)
+    # dense mode: blend colours with upstream's f64 arithmetic (bit-identical rgb) instead of f32 (within 2.5e-7); sampled mode always does
     exact_colour: bool = False
-    # hand upstream's own fundamental matrices (np.linalg.inv products, computed on the host exactly as upstream computes
-    # them) to the kernels instead of the closed-form F the library derives from the camera table
-    upstream_fundamental: bool = True
-    # write the output PLY while the run proceeds: every completed reference's survivors are packed on the device
-    # (lfd_pack_ply, 15 B per point across PCIe) and appended to ``output_path``; the vertex count in the header is patched at
-    # the end.  Honoured when the output is a .ply and neither a point cap nor a voxel filter has to see the whole cloud first.
+    # write the output PLY while the run proceeds: every completed reference's survivors leave as 15-byte records packed on the device
+    # (dense mode: written by the kernel itself, copied out on a side stream while the next launch computes) and are appended to
+    # ``output_path``; the vertex count in the header is patched at the end.  Needs a .ply output and neither a point cap nor a voxel
+    # filter (both have to see the whole cloud first).
     stream_output: bool = False
     # resize / mask / black-out the decoded images on the GPU (lfd_prepare_image / lfd_prepare_mask: Pillow's BILINEAR and
     # NEAREST arithmetic, bit for bit) instead of with PIL on the host pack threads; decoding stays on the host
@@ -75,58 +98,97 @@ class DensePipelineConfig:
     # compute every camera's backbone (DINOv3) features once per run and share them between the references that list the camera
     # (core/scheduler.py); upstream recomputes a neighbour's features for every reference
     share_features: bool = True
-    # neighbours of a reference matched per RoMa-v2 forward (one batched pass through the model instead of one pass per pair, which is
-    # what upstream's loop does, core/matcher.py:175-188).  1 = upstream's behaviour; batched GEMMs may round differently from single ones
+    # neighbours of a reference matched per RoMa-v2 forward (1 = upstream's loop, core/matcher.py:175-188)
     pairs_per_forward: int = 1
     # where the per-reference hot path runs.  "device": the HIP kernels (needs a GPU; raises HipBackendError without one - there is
-    # no fallback).  "host": the CPU twin of the C-ABI (lfd_create_host: the host build of the kernels' per-cell source on the host
-    # cores) with the host sampling stage - upstream's CPU-only configuration (densify.py:148-212 run without a GPU, BASELINE
-    # config 1); chosen by the caller, never automatically.
+    # no fallback).  "host": the CPU twin of the C-ABI (lfd_create_host) with the host sampling stage - upstream's CPU-only configuration
+    # (densify.py:148-212 run without a GPU, BASELINE config 1); chosen by the caller, never automatically.
     backend: str = "device"
     # how the survivors of a sharded run (torch.distributed, world > 1) reach the writer: "all_gather" leaves the whole cloud on
     # every rank (what BASELINE's north star names), "gather_to_root" sends every rank's records straight to their place in rank
     # 0's buffer (the other ranks return their own shard only)
     exchange: str = "all_gather"
-    # sharded runs: the exchange happens in ROUNDS beside the compute (core/distributed.py::OverlappedExchange) - every
-    # ``exchange_round`` local references (0: ``refs_per_launch``, at least 4) the finished references' records go into an asynchronous
-    # collective while the next batch computes - instead of ONE exchange after the last reference.  The result is the same sequence.
-    exchange_overlap: bool = True
-    exchange_round: int = 0
-    # what travels: "f32" the 28-byte rows the result holds (xyz, rgb, err as f32); "ply" the 15-byte PLY vertex records packed on the
-    # device (positions exact, colours as the writer quantises them, no reprojection error: ``PipelineResult.rgb`` is then u8 / 255 and
-    # ``err`` zero - the written file is the same bytes); "auto": "ply" when the output is a .ply and no voxel filter has to see f32
-    # colours, else "f32".  Only used by the overlapped exchange of a sharded run.
-    exchange_records: str = "f32"
-    # sharded runs: the fraction of the reference list (its LAST references) computed by EVERY rank that receives the cloud instead of being
-    # exchanged - recompute instead of communicate.  core/distributed.py::plan_replication says when it pays: for the bare hot path (one GPU
-    # triangulates a reference faster than its survivors cross an xGMI link), never with a real matcher in the loop (default 0).  Needs the
-    # overlapped exchange; ignored with stream_output.  The result is the same sequence.
-    exchange_replicate: float = 0.0
-    # sharded run + stream_output on ONE node: every rank writes its own byte ranges of the output file (core/distributed.py::SharedFilePlyStream) -
-    # only the per-reference counts cross a link - instead of sending its records to rank 0 (ShardedPlyStream).  Needs a file system all ranks see.
-    stream_shared_file: bool = False
-    # dense mode: the kernel with UNORDERED retirement (lfd_triangulate_dense_segments: no look-back, ~6 % less kernel time); raster order is
-    # restored from the tile table by lfd_order_segments (bit-identical result).  Opt-in.
-    dense_tile_segments: bool = False
+    experimental: Dict[str, object] = dataclasses.field(default_factory=dict)
 
     def __post_init__(self) -> None:
+        self.validate()
+
+    def exp(self, key: str):
+        """The value of an experimental knob (EXPERIMENTAL_DEFAULTS lists them)."""
+        return self.experimental.get(key, EXPERIMENTAL_DEFAULTS[key])
+
+    def exchange_record_format(self) -> str:
+        rec = str(self.exp("exchange_records"))
+        if rec == "auto":
+            return "ply" if (str(self.output_path).lower().endswith(".ply") and float(self.voxel_size) <= 0.0) else "f32"
+        return rec
+
+    def problem(self) -> Optional[str]:
+        """Why this combination of settings cannot run, or None.  Every pair of settings either works together or is named here: nothing
+        is silently ignored (tests/test_config_matrix.py generates the pairs)."""
         if self.triangulation_mode not in TRIANGULATION_MODES:
-            raise ValueError(f"triangulation_mode must be one of {TRIANGULATION_MODES}, "
-                             f"got {self.triangulation_mode!r}")
+            return f"triangulation_mode must be one of {TRIANGULATION_MODES}, got {self.triangulation_mode!r}"
         if int(self.refs_per_launch) < 1:
-            raise ValueError("refs_per_launch must be >= 1")
+            return "refs_per_launch must be >= 1"
+        if int(self.pairs_per_forward) < 1:
+            return "pairs_per_forward must be >= 1"
         if self.selection_backend not in ("device", "host"):
-            raise ValueError("selection_backend must be 'device' or 'host'")
+            return "selection_backend must be 'device' or 'host'"
         if self.backend not in ("device", "host"):
-            raise ValueError("backend must be 'device' or 'host'")
+            return "backend must be 'device' or 'host'"
         if self.exchange not in ("all_gather", "gather_to_root"):
-            raise ValueError("exchange must be 'all_gather' or 'gather_to_root'")
-        if self.exchange_records not in ("f32", "ply", "auto"):
-            raise ValueError("exchange_records must be 'f32', 'ply' or 'auto'")
-        if int(self.exchange_round) < 0:
-            raise ValueError("exchange_round must be >= 0")
-        if not (0.0 <= float(self.exchange_replicate) <= 1.0):
-            raise ValueError("exchange_replicate must be a fraction in [0, 1]")
+            return "exchange must be 'all_gather' or 'gather_to_root'"
+        if not isinstance(self.experimental, dict):
+            return "experimental must be a dict"
+        unknown = sorted(set(self.experimental) - set(EXPERIMENTAL_DEFAULTS))
+        if unknown:
+            return f"unknown experimental setting(s) {unknown}; known: {sorted(EXPERIMENTAL_DEFAULTS)}"
+        if self.exp("exchange_records") not in ("f32", "ply", "auto"):
+            return "experimental['exchange_records'] must be 'f32', 'ply' or 'auto'"
+        if int(self.exp("exchange_round")) < 0:
+            return "experimental['exchange_round'] must be >= 0"
+        if not (0.0 <= float(self.exp("exchange_replicate")) <= 1.0):
+            return "experimental['exchange_replicate'] must be a fraction in [0, 1]"
+        dense = self.triangulation_mode == "dense"
+        if self.stream_output:
+            if not str(self.output_path).lower().endswith(".ply"):
+                return "stream_output writes a PLY while the run proceeds: output_path must end in .ply"
+            if int(self.max_points) > 0:
+                return "stream_output cannot be combined with max_points: the point cap has to see the whole cloud before anything is written"
+            if float(self.voxel_size) > 0.0:
+                return "stream_output cannot be combined with voxel_size: the voxel filter has to see the whole cloud before anything is written"
+        if self.device_image_prep and self.backend != "device":
+            return "device_image_prep resizes the images with the HIP kernels: it needs backend='device'"
+        if dense and self.selection_backend == "host":
+            return "selection_backend='host' names where the coverage sampling of the sampled mode runs; dense mode has no sampling stage"
+        if not dense and int(self.refs_per_launch) > 1:
+            if self.backend != "device" or self.selection_backend != "device":
+                return ("refs_per_launch > 1 in sampled mode puts several references into one fused device call: it needs backend='device' and "
+                        "selection_backend='device'")
+        if self.exp("dense_tile_segments"):
+            if not dense:
+                return "experimental['dense_tile_segments'] is a form of the dense kernel: it needs triangulation_mode='dense'"
+            if self.backend != "device":
+                return "experimental['dense_tile_segments'] is a form of the HIP kernel: it needs backend='device'"
+        if float(self.exp("exchange_replicate")) > 0.0:
+            if not self.exp("exchange_overlap"):
+                return "experimental['exchange_replicate'] needs the overlapped exchange (experimental['exchange_overlap'])"
+            if self.stream_output:
+                return "experimental['exchange_replicate'] cannot be combined with stream_output: a streamed sharded run sends every reference to the writer"
+        if self.exp("stream_shared_file") and not self.stream_output:
+            return "experimental['stream_shared_file'] is a form of the streamed output: it needs stream_output"
+        if self.exp("exchange_records") == "ply":
+            if not self.exp("exchange_overlap"):
+                return "experimental['exchange_records']='ply' is a format of the overlapped exchange (experimental['exchange_overlap'])"
+            if self.stream_output:
+                return ("experimental['exchange_records']='ply' cannot be combined with stream_output: a streamed sharded run exchanges its result "
+                        "once, at the end, as f32 rows")
+        return None
+
+    def validate(self) -> None:
+        msg = self.problem()
+        if msg:
+            raise ValueError(msg)
 
 
 @dataclasses.dataclass

@@ -252,8 +252,8 @@ def _shared_file_worker(rank, world, port, n_refs, per_round, path, q):
         for i, g in enumerate(mine):
             if counts[g]:
                 st.push(i, torch.from_numpy(np.ascontiguousarray(pts[g].view(np.uint8).reshape(-1, 28)[:, :15]).reshape(-1)))
-        recs, gcounts = st.finish()
-        q.put((rank, int(recs.numel()), gcounts))
+        recs, gcounts = st.finish()               # this rank's own records, round by round, where they are (nothing concatenated)
+        q.put((rank, sum(int(r.numel()) for r in recs), gcounts))
     finally:
         dist.destroy_process_group()
 

@@ -57,13 +57,15 @@ def _rank(rank, world, port, tmp, cfg_kw, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,exchange,overlap,shared", [("sampled", "all_gather", True, False), ("sampled", "gather_to_root", True, False),
-                                                          ("dense", "gather_to_root", True, False), ("dense", "all_gather", True, True),
-                                                          ("sampled", "all_gather", False, False), ("dense", "gather_to_root", False, True)])
-def test_two_host_ranks_equal_one_and_stream_the_same_file(g4, tmp_path, mode, exchange, overlap, shared):
-    """``overlap``: the exchange in rounds beside the compute (OverlappedExchange, rounds of ONE reference here so that several rounds run)
-    or the one exchange after the last reference; ``shared``: the streamed file written by both ranks into their own byte ranges (only counts travel)
-    instead of sent to rank 0"""
+@pytest.mark.parametrize("mode,exchange,form", [("sampled", "all_gather", "stream"), ("sampled", "gather_to_root", "stream"),
+                                                ("dense", "gather_to_root", "stream"), ("dense", "all_gather", "shared_file"),
+                                                ("dense", "gather_to_root", "shared_file"), ("sampled", "all_gather", "rounds"),
+                                                ("dense", "gather_to_root", "rounds"), ("sampled", "gather_to_root", "end"), ("dense", "all_gather", "end")])
+def test_two_host_ranks_equal_one_and_stream_the_same_file(g4, tmp_path, mode, exchange, form):
+    """``form``: what the sharded run exchanges (core/sinks.py::ShardLink) - "stream": the streamed file, records sent to rank 0, then one exchange of
+    the result; "shared_file": the streamed file written by both ranks into their own byte ranges (only counts travel); "rounds": the exchange in
+    rounds beside the compute (OverlappedExchange, rounds of ONE reference here so that several rounds run); "end": the one exchange after the last
+    reference"""
     import torch.multiprocessing as mp
     from lichtfeld_densification_plugin_amd.core import writers
     from lichtfeld_densification_plugin_amd.core.image_io import to_uint8_rgb
@@ -77,7 +79,9 @@ def test_two_host_ranks_equal_one_and_stream_the_same_file(g4, tmp_path, mode, e
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     out = os.path.join(tmp, "sharded.ply")
-    cfg_kw = dict(output_path=out, exchange=exchange, stream_output=True, exchange_overlap=overlap, exchange_round=1, stream_shared_file=shared, **kw)
+    streams = form in ("stream", "shared_file")
+    cfg_kw = dict(output_path=out, exchange=exchange, stream_output=streams,
+                  experimental={"exchange_overlap": form != "end", "exchange_round": 1, "stream_shared_file": form == "shared_file"}, **kw)
     procs = [ctx.Process(target=_rank, args=(r, 2, port, tmp, cfg_kw, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -88,7 +92,7 @@ def test_two_host_ranks_equal_one_and_stream_the_same_file(g4, tmp_path, mode, e
     world = 2
     for rank, xyz, rgb, err, counts, n_refs, n_pairs, streamed in results:
         np.testing.assert_array_equal(counts, single.points_per_reference)
-        assert n_refs == single.pairs_processed and n_pairs == single.pairs_matched and streamed == out
+        assert n_refs == single.pairs_processed and n_pairs == single.pairs_matched and streamed == (out if streams else None)
         if exchange == "all_gather" or rank == 0:
             np.testing.assert_array_equal(xyz, single.xyz)
             np.testing.assert_array_equal(rgb, single.rgb)
@@ -97,6 +101,8 @@ def test_two_host_ranks_equal_one_and_stream_the_same_file(g4, tmp_path, mode, e
             offs = np.concatenate([[0], np.cumsum(single.points_per_reference)])
             own = np.concatenate([single.xyz[offs[g]:offs[g + 1]] for g in range(rank, len(refs), world)])
             np.testing.assert_array_equal(xyz, own)
+    if not streams:
+        return
     # the streamed file of the sharded run: the single run's cloud through upstream's writer, byte for byte behind the header
     head, body = open(out, "rb").read().split(b"end_header\n", 1)
     ref_head, ref_body = open(os.path.join(tmp, "single.ply"), "rb").read().split(b"end_header\n", 1)
@@ -132,15 +138,15 @@ def _failing_rank(rank, world, port, tmp, cfg_kw, q):
 @pytest.mark.parametrize("overlap", [True, False])
 def test_a_rank_that_fails_before_the_loop_does_not_hang_the_others(g4, tmp_path, overlap):
     """with a streamed sharded output, a rank whose matcher cannot even be constructed used to reach `finally` without a stream
-    object and went straight to the status agreement while rank 0 waited for its records.  The stream (and the overlapped exchange) now
-    exist before anything can fail: the failing rank sends empty references / closes empty rounds, everybody raises."""
+    object and went straight to the status agreement while rank 0 waited for its records.  The stream (``overlap`` False) or the overlapped
+    exchange (True) now exists before anything can fail: the failing rank sends empty references / closes empty rounds, everybody raises."""
     import torch.multiprocessing as mp
     tmp = str(tmp_path)
     _scene(g4, tmp)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    cfg_kw = dict(output_path=os.path.join(tmp, "sharded.ply"), stream_output=True, exchange_overlap=overlap, exchange_round=1, nns_per_ref=2, seed=5,
+    cfg_kw = dict(output_path=os.path.join(tmp, "sharded.ply"), stream_output=not overlap, experimental={"exchange_round": 1}, nns_per_ref=2, seed=5,
                   viz_interval=0, matches_per_ref=1200, triangulation_mode="sampled", per_reference_rng=True, backend="host", pack_workers=1)
     procs = [ctx.Process(target=_failing_rank, args=(r, 2, port, tmp, cfg_kw, q)) for r in range(2)]
     for p in procs:
@@ -163,7 +169,7 @@ def _rank_replicating(rank, world, port, tmp, cfg_kw, q):
     try:
         cams, refs, nn, table = _scene(load_golden("g4_pipeline.npz"), tmp)
         cfg = lfd.DensePipelineConfig(**cfg_kw)
-        n_rep = int(round(cfg.exchange_replicate * len(refs)))
+        n_rep = int(round(cfg.exp("exchange_replicate") * len(refs)))
         positions, _n_sh = lfd_dist.split_replicated(len(refs), n_rep, rank, world, replicas_here=(cfg.exchange == "all_gather" or rank == 0))
         res = pl.run_dense_pipeline(cams, refs, nn, cfg, matcher=_Replay([table[g] for g in positions]))       # the matcher sees exactly these references
         q.put((rank, res.xyz, res.rgb, res.err, res.points_per_reference, res.pairs_processed, res.pairs_matched, len(positions)))
@@ -174,7 +180,7 @@ def _rank_replicating(rank, world, port, tmp, cfg_kw, q):
 @pytest.mark.parametrize("mode,exchange,records,frac", [("dense", "all_gather", "f32", 0.5), ("sampled", "gather_to_root", "f32", 0.34), ("dense", "all_gather", "ply", 1.0),
                                                         ("sampled", "all_gather", "f32", 0.5)])
 def test_replicated_references_give_the_single_process_result(g4, tmp_path, mode, exchange, records, frac):
-    """config.exchange_replicate: the last references of the list are computed by every rank that receives the cloud and never sent; the others are
+    """experimental['exchange_replicate']: the last references of the list are computed by every rank that receives the cloud and never sent; the others are
     sharded and exchanged in rounds.  Same sequence, same counts, every reference and pair counted once."""
     import torch.multiprocessing as mp
     from lichtfeld_densification_plugin_amd.core.image_io import to_uint8_rgb
@@ -185,7 +191,8 @@ def test_replicated_references_give_the_single_process_result(g4, tmp_path, mode
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    cfg_kw = dict(output_path=os.path.join(tmp, "sharded.ply"), exchange=exchange, exchange_round=1, exchange_records=records, exchange_replicate=frac, **kw)
+    cfg_kw = dict(output_path=os.path.join(tmp, "sharded.ply"), exchange=exchange,
+                  experimental={"exchange_round": 1, "exchange_records": records, "exchange_replicate": frac}, **kw)
     procs = [ctx.Process(target=_rank_replicating, args=(r, 2, port, tmp, cfg_kw, q)) for r in range(2)]
     for p in procs:
         p.start()
