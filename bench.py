@@ -94,6 +94,10 @@ def parse_args():
     ap.add_argument("--scene-root", default=os.environ.get("LFD_SCENE_ROOT"),
                     help="a COLMAP scene (images*/ + sparse/0/) for the END-TO-END leg: dense_init through the real RoMa-v2 matcher; needs the `romav2` package "
                          "and its weights (torch hub cache, or LFD_ROMA_WEIGHTS=path/to/romav2.pt); without them `end_to_end` stays null with the reason")
+    ap.add_argument("--pipeline-cams", type=int, default=185,
+                    help="cameras of the generated on-disk scene of the `pipeline` leg (densify.dense_init end to end, bench_pipeline.py); 0 = skip the leg")
+    ap.add_argument("--pipeline-latency-ms", type=float, default=20.0, help="stand-in matcher latency per pair of the leg's second pass (0 = skip that pass)")
+    ap.add_argument("--pipeline-size", default="1297x840", help="image size of the generated scene (garden's images_4)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc run of this same command (profiles/)")
     args = ap.parse_args()
@@ -233,9 +237,9 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16, cams_for_hot=None)
     res["pipelined_ms_per_reference"] = dt2 / len(todo) * 1e3
     # the pipeline's DEFAULT configuration (upstream_normaliser: the weights normalised with torch's own CPU f32 sum, upstream's library call):
     # reference i's aggregated map travels to the host on a side stream while the host sums reference i - 1's and launches its fused call
-    # (core/pipeline.py::_HotPath.begin_normaliser / finish_normaliser) - the launch stream never waits for the host
-    from lichtfeld_densification_plugin_amd.core.pipeline import _HotPath
-    hot = _HotPath(cams_for_hot, cfg, 0.9, wm, hm, dens.device, dens)
+    # (core/hotpath.py::HotPath.begin_normaliser / finish_normaliser) - the launch stream never waits for the host
+    from lichtfeld_densification_plugin_amd.core.hotpath import HotPath
+    hot = HotPath(cams_for_hot, cfg, 0.9, wm, hm, dens.device, dens)
     passes_ms = []
     for warm in (True, False, False, False, False, False):      # one warm pass, five timed ones: the host side of this path (torch's CPU reduction on
         dens.seed_rng(cfg.seed)                                  # the host's thread pool) depends on what else runs on the host - the pool's four GPU slots share it
@@ -259,6 +263,7 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16, cams_for_hot=None)
         if not warm:
             passes_ms.append(dt3 / len(todo) * 1e3)
     res["default_config_ms_per_reference"] = min(passes_ms)
+    res["default_config_points_per_reference"] = pts3 / len(todo)
     res["default_config_passes_ms_per_reference"] = passes_ms
     res["default_config_note"] = ("upstream_normaliser=True (the pipeline's default): upstream's torch f32 sum of every aggregated map on the host, the map copied on a "
                                   "side stream while the neighbouring references are launched / collected")
@@ -305,7 +310,7 @@ def unordered_rate(args, dens, batch, params, out, H, W, algo_bytes, launches=10
     k_ms = float(np.mean(ms))
     return {"kernel": "lfd_dense_segments_kernel", "kernel_ms": k_ms, "achieved": algo_bytes / (k_ms * 1e-3) / 1e9, "frac": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "survivors": int(counts.sum().item()),
-            "note": "opt-in (DensePipelineConfig.dense_tile_segments): tiles claim output room with one atomic instead of the ordered look-back; lfd_order_segments / "
+            "note": "opt-in (DensePipelineConfig.experimental['dense_tile_segments']): tiles claim output room with one atomic instead of the ordered look-back; lfd_order_segments / "
                     "lfd_pack_*_segments restore raster order from the tile table (bit-identical result, tests/test_gpu_segments.py; their cost: profiles/r4/ab_segments_v3_chunk_index.txt)"}
 
 
@@ -602,6 +607,10 @@ def run_sharded(args, world, rank, dev, dist, backend):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(v) for v in t.tolist()]
 
+    # ranks the communicator actually reports: an all-reduce of ones ON THE DEVICE through it (0 when the backend is not RCCL)
+    ones = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(ones)
+    rccl = int(ones.item()) if backend == "nccl" else 0
     cfg = lfd.DensePipelineConfig(output_path="", roma_setting=args.preset, nns_per_ref=args.k)
     refs_at(lfd_dist.shard_references(total_refs, rank, world))          # (also fixes args.k and the camera ring)
     cams = cams_box[0]
@@ -852,7 +861,10 @@ def run_sharded(args, world, rank, dev, dist, backend):
     if args.replicate == "auto" and world > 1:
         probe_steps = max(4, min(args.steps, 15))
         cands = [(0, 1)] if pure.n_rounds != 1 else []
-        cands += [(c_, 1) for c_ in sorted({int(plan["n_replicated"]), total_refs // 4, total_refs // 2, (3 * total_refs) // 4, total_refs} - {0})]
+        # (never "everything replicated": every rank would compute the whole scene, nothing would cross a link, and the headline would be the 1-GPU
+        # number - not a measurement of strong scaling; at least one reference per rank stays sharded)
+        most = max(0, total_refs - world)
+        cands += [(c_, 1) for c_ in sorted({min(int(plan["n_replicated"]), most), total_refs // 4, total_refs // 2, min((3 * total_refs) // 4, most)} - {0})]
         for cand, rnd in cands:
             trial = Schedule(cand, rnd)
             trial.scene()
@@ -946,7 +958,6 @@ def run_sharded(args, world, rank, dev, dist, backend):
         s_frac = (n_pts_pure / cells_rank) if cells_rank else 0.0
         bytes_per_cell = 4 * args.k + 11 + (15 if ply else 28) * s_frac        # what this launch moves at least: k certainties, the winner's warp, a texel; 15 / 28 B per survivor
         kname = "lfd_dense_ply_kernel" if ply else "lfd_dense_kernel"
-        rccl = world if backend == "nccl" else 0
         step_ms = el_value / args.steps * 1e3
         n_sh = int(plan["n_sharded"])
         line = {
@@ -972,6 +983,7 @@ def run_sharded(args, world, rank, dev, dist, backend):
                             "redundant_cells_per_step": n_rep * H * W * (world - 1 if args.exchange == "all_gather" else 0),
                             "note": "core/distributed.py::plan_replication: the references whose recomputation on every rank is cheaper than their "
                                     "survivors' trip over a link; with a matcher in the loop (tens of ms per pair) the plan is 0"},
+            "nothing_sharded": n_sh == 0,     # a forced --replicate of the whole scene: `value` is then one GPU's work N times over, not strong scaling
             "value_pure_sharding": total_pts * args.steps / el_pure, "pure_sharding_ms": el_pure / args.steps * 1e3,
             "value_compute_only": total_pts * args.steps / el_compute, "compute_ms": el_compute / args.steps * 1e3,
             "kernel_ms": kernel_ms_max, "exchange_ms_exposed": (el_pure - el_compute) / args.steps * 1e3,
@@ -1058,17 +1070,46 @@ def launch_ranks(args):
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
-    procs = []
+    import tempfile
+    procs, logs = [], []
     for rank in range(args.gpus):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0 or "")
+        # every rank's output goes to files of its own (a pipe nobody drains would block a chatty rank); only fresh children are started, this
+        # process never becomes one of them
+        logs.append((tempfile.TemporaryFile(mode="w+"), tempfile.TemporaryFile(mode="w+")))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=logs[-1][0], stderr=logs[-1][1], text=True))
+    # ALL children are watched: when one exits non-zero the others - who would sit in a collective until the backend's timeout - are terminated
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[i] = p.wait()
+            break
+        time.sleep(0.05)
+
+    def tail(fh, n=2000):
+        fh.seek(0)
+        return fh.read()[-n:]
+    logs[0][0].seek(0)
+    sys.stdout.write(logs[0][0].read())
     sys.stdout.flush()
     if any(codes):
+        for r, (_o, e) in enumerate(logs):
+            t = tail(e).strip()
+            if t:
+                sys.stderr.write(f"---- rank {r} (exit {codes[r]}) stderr tail ----\n{t}\n")
         raise SystemExit(f"rank exit codes {codes}")
 
 
@@ -1202,7 +1243,7 @@ def main():
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         value = total_pts * args.steps / elapsed
         traffic, traffic_source = traffic_bytes(args)
-        rccl = 1
+        rccl = 0                                   # ranks the collective backend reports: no communicator exists on the N = 1 line
         line = {
             "metric": "triangulated points/sec + pairs/sec, MipNeRF360 garden @fast, 1/2/4/8 GPU",     # BASELINE.json's metric; value = points/s, pairs_per_s beside it
             "value": value, "unit": "points/s", "n_gpus": world, "rccl_ranks": rccl, "collective_backend": backend, "steps": args.steps, "warmup": args.warmup,
@@ -1258,6 +1299,19 @@ def main():
             base = cpu_baseline(args, cams, srefs, dims, cfg)
             if base is not None:
                 line["cpu_baseline"] = base
+            # the user-visible default (triangulation_mode="sampled", one reference per call, upstream's normaliser) beside the dense headline
+            sm = line["sampled_mode"]
+            dflt_ms = sm.get("default_config_ms_per_reference")
+            if dflt_ms:
+                line["default_mode"] = {"mode": "sampled (upstream-equivalent), refs_per_launch=1, upstream_normaliser", "ms_per_reference": dflt_ms,
+                                        "refs_per_s": 1e3 / dflt_ms, "pairs_per_s": 1e3 / dflt_ms * args.k,
+                                        "points_per_s": sm["default_config_points_per_reference"] * 1e3 / dflt_ms}
+            if args.pipeline_cams > 0:
+                import bench_pipeline
+                dens.close()                        # the leg builds its own contexts
+                pw, ph = (int(v) for v in args.pipeline_size.split("x"))
+                line["pipeline"] = bench_pipeline.pipeline_leg(dev, n_cams=args.pipeline_cams, latency_ms=args.pipeline_latency_ms, roma_setting=args.preset,
+                                                               width=pw, height=ph)
         print(json.dumps(line), flush=True)
     dens.close()
 

@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py's `pipeline` leg: SURVEY 8d's points/s definition (ii) - the hot path INCLUDING image loading, preparation, selection, compaction,
+the survivors' way to the host and the written PLY - measured through ``densify.dense_init`` end to end on a generated on-disk scene.
+
+What it replaces upstream: the driver loop core/pipeline.py:783-928 with core/threaded_dataloader.py:42-241 (loading), core/image_utils.py:85-91
+(resize / mask), core/pipeline.py:602-780 (per reference), core/writers.py:29-46 (the PLY).  The matcher is a stand-in (RoMa-v2's weights are not
+on the box): ``synthetic.SyntheticMatcher`` hands out the analytic warp + certainty fields of the scene, resident on the GPU, from a table made
+before the run - zero latency - or after a stated sleep per pair.
+
+    python bench_pipeline.py [--cams 185] [--latency-ms 20]          # prints the leg's JSON object alone
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PCIE_GEN5_X16_GBPS = 64.0        # nominal, one direction (32 GT/s x 16 lanes, 128b/130b)
+
+
+def _clear_image_caches() -> None:
+    """Every run of the leg decodes its images again: the loaders' caches live in the process, a second run would find them warm."""
+    from lichtfeld_densification_plugin_amd.core import image_io
+    for fn in (image_io.load_rgb_u8, image_io.load_mask01, image_io.decode_rgb_u8, image_io.decode_mask_l):
+        fn.cache_clear()
+
+
+def pinned_d2h_GBps(dev, n_bytes: int = 1 << 28, reps: int = 5) -> float:
+    """What a plain device -> pinned host copy reaches on this box: the ceiling the streamed records are priced against."""
+    src = torch.empty((n_bytes,), dtype=torch.uint8, device=dev)
+    dst = torch.empty((n_bytes,), dtype=torch.uint8).pin_memory()
+    dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src, non_blocking=True)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return n_bytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def _ply_vertices(path: str) -> int:
+    with open(path, "rb") as fh:
+        head = fh.read(512).split(b"end_header\n", 1)[0].decode("ascii", "replace")
+    return int([ln for ln in head.split("\n") if ln.startswith("element vertex")][0].split()[-1])
+
+
+def run_once(scene_root: str, matcher, *, mode: str, device_prep: bool, backend: str = "device", refs_per_launch: int = 16, sync_stages: bool = False,
+             roma_setting: str = "fast", num_refs: float = 0.8, nns: int = 3, matches: int = 10000, pack_workers: int = 4) -> dict:
+    """One ``dense_init`` on the scene, down to the written PLY.  GUI defaults (reprojection 0.8 px, 3 neighbours, 0.8 of the cameras as references).
+    dense mode streams its output (``stream_output``: 15-byte records written by the kernel, copied out beside the next launch); sampled mode takes
+    upstream's own flow - result arrays, then the writer (records packed on the device)."""
+    from lichtfeld_densification_plugin_amd import densify
+    from lichtfeld_densification_plugin_amd.core.stages import StageClock
+    tag = f"{mode}_{'dev' if device_prep else 'host'}prep"
+    argv = ["--scene_root", scene_root, "--images_subdir", "images_4", "--roma_setting", roma_setting, "--num_refs", str(num_refs), "--nns_per_ref", str(nns),
+            "--matches_per_ref", str(matches), "--reproj_thresh", "0.8", "--out_name", f"bench_{tag}.ply", "--triangulation_mode", mode,
+            "--pack_workers", str(pack_workers), "--backend", backend]
+    if mode == "dense":
+        argv += ["--refs_per_launch", str(refs_per_launch), "--stream_output"]
+    if device_prep:
+        argv += ["--device_image_prep"]
+    args = densify.build_argparser().parse_args(argv)
+    out_path = os.path.join(scene_root, "sparse", "0", f"bench_{tag}.ply")
+    if os.path.exists(out_path):
+        os.remove(out_path)
+    _clear_image_caches()
+    on_gpu = backend == "device"
+    clock = StageClock(sync=(torch.cuda.synchronize if (sync_stages and on_gpu) else None))
+    matcher.calls = matcher.pairs = 0
+    matcher.seconds = 0.0
+    if on_gpu:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rc = densify.dense_init(args, matcher=matcher, stage_clock=clock)
+    if on_gpu:
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rc != 0:
+        raise RuntimeError(f"dense_init returned {rc}")
+    n = _ply_vertices(out_path)
+    rep = clock.report()
+    stages = {k: v["seconds"] for k, v in rep.items() if isinstance(v, dict)}
+    res = {"seconds": dt, "references": matcher.calls, "pairs": matcher.pairs, "points": n, "refs_per_s": matcher.calls / dt, "pairs_per_s": matcher.pairs / dt,
+           "points_per_s": n / dt, "matcher_seconds": matcher.seconds, "file_bytes": os.path.getsize(out_path), "stage_seconds": stages}
+    if "d2h_bytes" in rep and stages.get("d2h"):
+        res["d2h_bytes"] = rep["d2h_bytes"]
+        res["d2h_GBps"] = rep["d2h_bytes"] / stages["d2h"] / 1e9
+    os.remove(out_path)
+    return res
+
+
+def pipeline_leg(dev, *, n_cams: int = 185, latency_ms: float = 20.0, scene_root: str = None, backend: str = "device", roma_setting: str = "fast",
+                 width: int = 1297, height: int = 840, refs_per_launch: int = 16, runs=("zero", "latency", "stages")) -> dict:
+    """The `pipeline` object of the bench line: {"scene", "sampled": {...}, "dense": {...}, "pcie"}."""
+    from lichtfeld_densification_plugin_amd import densify, synthetic
+    t_setup = time.perf_counter()
+    own_tmp = None
+    if scene_root is None:
+        own_tmp = tempfile.TemporaryDirectory(prefix="lfd_bench_scene_")
+        scene_root = own_tmp.name
+    synthetic.write_colmap_scene(scene_root, n_cams=n_cams, width=width, height=height, images_subdir="images_4", fmt="jpg", seed=0)
+    plan_args = densify.build_argparser().parse_args(["--scene_root", scene_root, "--images_subdir", "images_4", "--num_refs", "0.8", "--nns_per_ref", "3"])
+    records, refs_local, nn_table, _sparse = densify.plan_scene(plan_args)
+    on_gpu = backend == "device"
+    matcher = synthetic.SyntheticMatcher(records, setting=roma_setting, device=dev if on_gpu else "cpu", noise_px=0.5, outlier_frac=0.05, channels=2, seed=0)
+    matcher.precompute(refs_local, nn_table, 3)
+    setup_s = time.perf_counter() - t_setup
+    kw = dict(backend=backend, roma_setting=roma_setting, refs_per_launch=refs_per_launch)
+    leg = {"scene": {"cameras": n_cams, "image_size": [width, height], "image_format": "jpeg q90", "references": len(refs_local), "neighbours": 3,
+                     "pairs": sum(len(k[1]) for k in matcher.table), "grid": [matcher.H, matcher.W], "setup_seconds": round(setup_s, 2),
+                     "what": "synthetic garden-like COLMAP scene on disk (sparse/0 + images_4), densify.dense_init with GUI defaults "
+                             "(0.8 of the cameras as references x 3 neighbours, M = 10000, reprojection 0.8 px), matcher = analytic fields from a table on the GPU"},
+           "note": "seconds = wall time of densify.dense_init (COLMAP read, reference / neighbour selection, image decode + preparation, matcher stand-in, "
+                   "hot path, survivors to the host, PLY written and closed); image caches cleared before every run; `stage_seconds` of the plain runs are "
+                   "host wall time per stage (launches are asynchronous: device time shows where the host next waits), `stages` is a separate run that "
+                   "drains the device after every stage (a split, not a throughput); decode / prepare on the pack threads and write on the writer thread "
+                   "overlap the loop, so the stages do not add up to the wall time"}
+    if on_gpu:
+        run_once(scene_root, matcher, mode="sampled", device_prep=True, **kw)      # untimed: module load, pinned pools, page cache of the scene's files
+    for mode in ("sampled", "dense"):
+        m = {}
+        if "zero" in runs:
+            m["host_prep"] = run_once(scene_root, matcher, mode=mode, device_prep=False, **kw)
+            if on_gpu:
+                m["device_prep"] = run_once(scene_root, matcher, mode=mode, device_prep=True, **kw)
+        if "latency" in runs and latency_ms > 0:
+            matcher.latency = latency_ms * 1e-3
+            m[f"device_prep_matcher_{latency_ms:g}ms_per_pair" if on_gpu else f"host_prep_matcher_{latency_ms:g}ms_per_pair"] = \
+                run_once(scene_root, matcher, mode=mode, device_prep=on_gpu, **kw)
+            matcher.latency = 0.0
+        if "stages" in runs and on_gpu:
+            st = run_once(scene_root, matcher, mode=mode, device_prep=True, sync_stages=True, **kw)
+            m["stages"] = {"seconds_per_stage": st["stage_seconds"], "run_seconds": st["seconds"],
+                           "ms_per_reference": {k: round(v / max(1, st["references"]) * 1e3, 4) for k, v in st["stage_seconds"].items()}}
+        leg[mode] = m
+    if on_gpu:
+        ceiling = pinned_d2h_GBps(dev)
+        best = max((r.get("d2h_GBps", 0.0) for r in leg["dense"].values() if isinstance(r, dict)), default=0.0)
+        leg["pcie"] = {"d2h_pinned_copy_GBps": ceiling, "nominal_gen5_x16_GBps": PCIE_GEN5_X16_GBPS, "dense_records_d2h_GBps": best or None,
+                       "frac_of_measured_copy": (best / ceiling) if best else None, "frac_of_nominal": (best / PCIE_GEN5_X16_GBPS) if best else None,
+                       "what": "dense mode's 15-byte records, device -> pinned host on a side stream while the next launch computes (HIP events around each copy)"}
+    if own_tmp is not None:
+        own_tmp.cleanup()
+    return leg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cams", type=int, default=185)
+    ap.add_argument("--latency-ms", type=float, default=20.0)
+    ap.add_argument("--scene-root", default=None)
+    ap.add_argument("--backend", default="device", choices=["device", "host"])
+    ap.add_argument("--setting", default="fast")
+    ap.add_argument("--size", default="1297x840")
+    a = ap.parse_args()
+    from lichtfeld_densification_plugin_amd.core import hostenv
+    hostenv.fit_threads_to_quota()
+    w, h = (int(v) for v in a.size.split("x"))
+    dev = torch.device("cuda", 0) if a.backend == "device" else torch.device("cpu")
+    print(json.dumps({"pipeline": pipeline_leg(dev, n_cams=a.cams, latency_ms=a.latency_ms, scene_root=a.scene_root, backend=a.backend,
+                                               roma_setting=a.setting, width=w, height=h)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -43,7 +43,7 @@ from . import distributed as lfd_dist
 from . import hip_backend as hb
 from .debug_viz import MatchDebugState
 from .hostlog import log
-from .hotpath import HotPath, PREPARED_CACHE_BYTES  # noqa: F401
+from .hotpath import HotPath
 from .matcher import RomaMatcher, has_cached_romav2_weights, romav2_cached_weights_paths
 from .packing import OrderedPrefetcher, PackedReference, PipelineCancelled, cancelled, pack_reference, raise_if_cancelled
 from .scheduler import FeatureCache, PairSchedule

@@ -292,7 +292,7 @@ class DensePlyStreamer:
         slot, items, _batch = self.launched.pop(0)
         with self.hot.clock.stage("kernel", sync=False):     # the host waits here for the launch's offsets, i.e. for its kernel
             slot.offsets_here.synchronize()
-        offs = slot.h_offsets.numpy().copy()
+        offs = slot.h_offsets.numpy()[:len(items) + 1].copy()       # (a pair sized for refs_per_launch serves a last, smaller batch too)
         n = int(offs[-1])
         with torch.cuda.stream(self.side):
             slot.copy_start.record(self.side)

@@ -165,6 +165,9 @@ class DensePipelineConfig:
             if self.backend != "device" or self.selection_backend != "device":
                 return ("refs_per_launch > 1 in sampled mode puts several references into one fused device call: it needs backend='device' and "
                         "selection_backend='device'")
+        if not self.upstream_normaliser and not dense and (self.selection_backend == "host" or self.backend == "host"):
+            return ("upstream_normaliser=False asks for the device selection's exact weight sum; the host selection stage "
+                    "(selection_backend='host' or backend='host') always normalises with torch's own sum, as upstream does")
         if self.exp("dense_tile_segments"):
             if not dense:
                 return "experimental['dense_tile_segments'] is a form of the dense kernel: it needs triangulation_mode='dense'"

@@ -208,9 +208,10 @@ def _was_cancelled(cb) -> bool:
 
 
 # ---- entry points ------------------------------------------------------------------------------------
-def dense_init(args, progress_callback: Optional[Callable[[float, str], None]] = None, debug_state=None,
-               cancel_requested: Optional[Callable[[], bool]] = None) -> int:
-    """CLI / COLMAP entry point.  Returns 0 on success, 2 when cancelled; raises on error."""
+def plan_scene(args):
+    """What upstream's CLI derives from the scene before the pipeline starts (densify.py:154-165 there): the camera records, the reference
+    views (greedy visibility cover of the sparse points, k-centres on the poses if that fails) and the neighbour table.
+    Returns ``(records, refs_local, nn_table, sparse_dir)``."""
     scene_root = os.path.abspath(args.scene_root)
     sparse_dir = os.path.join(scene_root, "sparse", "0")
     images_dir = image_dir(scene_root, args.images_subdir)
@@ -225,7 +226,14 @@ def dense_init(args, progress_callback: Optional[Callable[[float, str], None]] =
         log.warn(f"Visibility-based selection failed: {exc}")
         refs_local = select_cameras_kcenters(flat, want)
     nn_table = nearest_neighbors(flat, max(1, args.nns_per_ref))
+    return records, refs_local, nn_table, sparse_dir
 
+
+def dense_init(args, progress_callback: Optional[Callable[[float, str], None]] = None, debug_state=None,
+               cancel_requested: Optional[Callable[[], bool]] = None, **pipeline_kwargs) -> int:
+    """CLI / COLMAP entry point.  Returns 0 on success, 2 when cancelled; raises on error.  ``pipeline_kwargs``: the injection points of
+    ``run_dense_pipeline`` (a warm matcher, a stage clock), as ``dense_init_from_lfs`` takes them."""
+    records, refs_local, nn_table, sparse_dir = plan_scene(args)
     config = DensePipelineConfig(
         output_path=os.path.join(sparse_dir, args.out_name), roma_setting=args.roma_setting, num_refs=args.num_refs,
         nns_per_ref=args.nns_per_ref, matches_per_ref=args.matches_per_ref, certainty_thresh=args.certainty_thresh,
@@ -233,10 +241,11 @@ def dense_init(args, progress_callback: Optional[Callable[[float, str], None]] =
         max_points=args.max_points, no_filter=args.no_filter, seed=args.seed, viz_interval=0,
         prefetch_packages=args.prefetch_packages, pack_workers=args.pack_workers,
         triangulation_mode=getattr(args, "triangulation_mode", "sampled"),
-        refs_per_launch=getattr(args, "refs_per_launch", 1), backend=getattr(args, "backend", "device"))
+        refs_per_launch=getattr(args, "refs_per_launch", 1), backend=getattr(args, "backend", "device"),
+        stream_output=bool(getattr(args, "stream_output", False)), device_image_prep=bool(getattr(args, "device_image_prep", False)))
     try:
         result = run_dense_pipeline(records, refs_local, nn_table, config, progress_callback=progress_callback,
-                                    on_sequential_viz=None, debug_state=debug_state, cancel_requested=cancel_requested)
+                                    on_sequential_viz=None, debug_state=debug_state, cancel_requested=cancel_requested, **pipeline_kwargs)
     except PipelineCancelled:
         if progress_callback:
             progress_callback(0.0, "Cancelled")
@@ -245,15 +254,18 @@ def dense_init(args, progress_callback: Optional[Callable[[float, str], None]] =
         if progress_callback:
             progress_callback(0.0, "Cancelled")
         return 2
-    xyz, rgb, err = _apply_point_cap(result.xyz, result.rgb, result.err, args.max_points, args.seed)
-    dev_pts = _cap_device_points(result.device_points, result.xyz.shape[0], args.max_points, args.seed)
     if progress_callback:
         progress_callback(95.0, "Writing output...")
-    if getattr(result, "streamed_path", None) != config.output_path:      # config.stream_output: the file is already complete
+    if result.streamed_path == config.output_path:      # config.stream_output: the file is already complete (and no cap applies to it)
+        n_points = result.n_points
+    else:
+        xyz, rgb, err = _apply_point_cap(result.xyz, result.rgb, result.err, args.max_points, args.seed)
+        dev_pts = _cap_device_points(result.device_points, result.xyz.shape[0], args.max_points, args.seed)
         _write_output(config.output_path, xyz, rgb, err, dev_pts)
-    log.info(f"Dense reconstruction finished: {xyz.shape[0]:,} points -> {config.output_path}")
+        n_points = int(xyz.shape[0])
+    log.info(f"Dense reconstruction finished: {n_points:,} points -> {config.output_path}")
     if progress_callback:
-        progress_callback(100.0, f"Done! {xyz.shape[0]:,} points")
+        progress_callback(100.0, f"Done! {n_points:,} points")
     return 0
 
 
@@ -290,6 +302,13 @@ def dense_init_from_lfs(camera_nodes, config: DensePipelineConfig,
         return 1, str(exc)
     if _was_cancelled(cancel_requested):
         return 2, "Cancelled"
+    if result.streamed_path == config.output_path:      # config.stream_output: the PLY is complete; neither a cap nor a voxel filter applies to it
+        if progress_callback:
+            progress_callback(95.0, "Writing output PLY...")
+        log.info(f"Dense point cloud saved to {config.output_path} ({result.n_points:,} points)")
+        if progress_callback:
+            progress_callback(100.0, f"Done! {result.n_points:,} points")
+        return 0, config.output_path
     xyz, rgb, err = _apply_point_cap(result.xyz, result.rgb, result.err, config.max_points, config.seed)
     dev_pts = _cap_device_points(result.device_points, result.xyz.shape[0], config.max_points, config.seed)
     if config.voxel_size > 0.0:
@@ -307,7 +326,7 @@ def dense_init_from_lfs(camera_nodes, config: DensePipelineConfig,
             os.makedirs(d, exist_ok=True)
         if _is_writer_rank():
             write_ply(config.output_path, xyz, to_uint8_rgb(rgb))
-    elif getattr(result, "streamed_path", None) != config.output_path:    # config.stream_output: the file is already complete
+    else:
         _write_output(config.output_path, xyz, rgb, err, dev_pts)
     log.info(f"Dense point cloud saved to {config.output_path} ({xyz.shape[0]:,} points)")
     if progress_callback:
@@ -343,6 +362,12 @@ def build_argparser() -> argparse.ArgumentParser:
     ap.add_argument("--backend", type=str, default="device", choices=["device", "host"],
                     help="device = the HIP kernels (needs a GPU); host = the CPU twin of the C-ABI + the host sampling stage "
                          "(upstream's CPU-only configuration); never chosen automatically")
+    ap.add_argument("--stream_output", action="store_true",
+                    help="write the PLY while the run proceeds (15-byte records packed on the device; needs a .ply --out_name and no --max_points)")
+    ap.add_argument("--device_image_prep", action="store_true", help="resize / mask the decoded images on the GPU (Pillow's arithmetic, bit for bit)")
+    ap.add_argument("--keep_threads", action="store_true",
+                    help="leave torch's intra-op thread count alone (by default it is lowered to the container's CPU quota; the count decides the last "
+                         "bits of upstream's sampling normaliser, so a run compared bit for bit with upstream keeps upstream's setting)")
     return ap
 
 
@@ -351,8 +376,15 @@ def main(argv=None) -> int:
     (core/hostenv.py: a pool sized by the CPUs the container SEES gets the whole process throttled); inside LichtFeld Studio - ``dense_init`` /
     ``dense_init_from_lfs`` called by the plugin - process-wide settings are the host application's and nothing is touched."""
     from .core import hostenv
-    hostenv.fit_threads_to_quota(log=log.info)
-    return dense_init(build_argparser().parse_args(argv))
+    args = build_argparser().parse_args(argv)
+    if not args.keep_threads:
+        import torch
+        before = int(torch.get_num_threads())
+        after = hostenv.fit_threads_to_quota(log=log.info)
+        if after != before:
+            log.info("note: upstream's sampling normaliser is a torch f32 sum whose last bits depend on the thread count - for draws bit-identical "
+                     "to an upstream run on this machine pass --keep_threads or set OMP_NUM_THREADS to upstream's count")
+    return dense_init(args)
 
 
 if __name__ == "__main__":

@@ -198,3 +198,128 @@ def ring_neighbours(n_cams: int, ref_index: int, k: int) -> List[int]:
         if step > n_cams:
             break
     return out
+
+
+# ---- a whole scene on disk + a matcher that knows it (bench.py's pipeline leg, tests/golden/time_reference.py) -------------------------------
+def write_colmap_scene(root: str, n_cams: int = 185, width: int = 1297, height: int = 840, images_subdir: str = "images_4", fmt: str = "jpg",
+                       seed: int = 0, n_points: int = 600, workers: int = 8) -> List[CameraRecord]:
+    """A garden-like scene as upstream's CLI reads it (densify.py:54-88): ``root/sparse/0/{cameras,images,points3D}.bin`` (one PINHOLE camera per
+    view, principal point off the centre; ``n_points`` ground points with their tracks, which the visibility-based reference selection needs) and
+    ``root/<images_subdir>/view_NNNN.<fmt>`` - ``n_cams`` images of ``width`` x ``height`` (MipNeRF360 garden: 185 views, ``images_4`` 1297 x 840).
+    Returns the cameras with their image paths.  Files that exist already are kept (the images take ~10 s to make)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    from PIL import Image
+
+    from .core import colmap_io as cio
+    sparse, img_dir = os.path.join(root, "sparse", "0"), os.path.join(root, images_subdir)
+    os.makedirs(sparse, exist_ok=True)
+    os.makedirs(img_dir, exist_ok=True)
+    cams = ring_cameras(n_cams, width=width, height=height, seed=seed)
+    rs = np.random.RandomState(seed + 7)
+    pts = {pid: (rs.uniform(-1.0, 1.0, 3) * np.array([1.8, 1.8, 0.15]), rs.randint(0, 255, 3).astype(np.uint8), float(rs.uniform(0.1, 1.0)))
+           for pid in range(1, n_points + 1)}
+    tracks = {pid: [] for pid in pts}
+    cameras, images = [], []
+    xyz = np.stack([pts[p][0] for p in sorted(pts)])
+    for i, c in enumerate(cams):
+        name = f"view_{i:04d}.{fmt}"
+        c.image_path = os.path.join(img_dir, name)
+        K = np.asarray(c.K, np.float64)
+        cameras.append(cio.Camera(i + 1, "PINHOLE", c.width, c.height, [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]))
+        proj = (np.asarray(c.P, np.float64) @ np.concatenate([xyz, np.ones((xyz.shape[0], 1))], 1).T).T
+        uv = proj[:, :2] / proj[:, 2:3]
+        seen = (proj[:, 2] > 0) & (uv[:, 0] >= 0) & (uv[:, 0] < c.width) & (uv[:, 1] >= 0) & (uv[:, 1] < c.height) & (rs.rand(xyz.shape[0]) < 0.7)
+        ids = (np.flatnonzero(seen) + 1).astype(np.int64)
+        for j, pid in enumerate(ids):
+            tracks[int(pid)].append((i + 1, j))
+        images.append(cio.Image(i + 1, cio.quaternion_from_rotation(np.asarray(c.R, np.float64)), np.asarray(c.t, np.float64).reshape(3), i + 1, name,
+                                uv[seen], ids))
+    cio.write_cameras_bin(os.path.join(sparse, "cameras.bin"), cameras)
+    cio.write_images_bin(os.path.join(sparse, "images.bin"), images)
+    cio.write_colmap_points3D_bin(os.path.join(sparse, "points3D.bin"), pts, tracks)
+
+    def one(i):
+        if not os.path.exists(cams[i].image_path):
+            im = Image.fromarray(synth_image(height, width, seed * 1000 + i).numpy())
+            im.save(cams[i].image_path, **({"quality": 90} if fmt.lower() in ("jpg", "jpeg") else {}))
+    with ThreadPoolExecutor(max_workers=max(1, int(workers))) as pool:
+        list(pool.map(one, range(n_cams)))
+    return cams
+
+
+class SyntheticMatcher:
+    """Stand-in for upstream's ``RomaMatcher`` (core/matcher.py:74-211: ``w_resized / h_resized / sample_thresh / match_grids_batch / close``) on a
+    scene whose cameras it knows: ``match_grids_batch`` returns the analytic warp + certainty of ``synth_reference`` for the reference and the
+    neighbours it is handed, resident on ``device``.  The fields of the references named to ``precompute`` are made ahead of the run (a table, so the
+    matcher costs a dictionary lookup); ``latency_s_per_pair`` then stands in for the model's forward (a host sleep: RoMa-v2 itself takes tens of
+    ms per pair).  Which cameras a call is about comes from ``keys`` (this package's driver names them: ``supports_feature_keys``) or, for a driver
+    that hands over nothing but images (upstream's), from a fingerprint of the match-size image registered with ``register_image``."""
+    sample_thresh = 0.9
+    accepts_device_images = True
+    supports_feature_keys = True
+
+    def __init__(self, cams: Sequence[CameraRecord], setting: str = "fast", device="cpu", *, noise_px: float = 0.5, outlier_frac: float = 0.05,
+                 channels: int = 2, seed: int = 0, latency_s_per_pair: float = 0.0, cert_mode: str = "smooth"):
+        self.cams, self.device = list(cams), torch.device(device)
+        h_lr, w_lr, self.H, self.W = ROMA_PRESETS[setting]
+        self.w_resized, self.h_resized = int(w_lr), int(h_lr)
+        self.kw = dict(noise_px=noise_px, outlier_frac=outlier_frac, channels=int(channels), seed=int(seed), cert_mode=cert_mode)
+        self.latency = float(latency_s_per_pair)
+        self.table: dict = {}
+        self.fingerprints: dict = {}
+        self.calls = self.pairs = 0
+        self.seconds = 0.0                 # wall time spent inside match_grids_batch (the stand-in latency included)
+
+    def set_feature_cache(self, cache) -> None:
+        pass
+
+    def reference_axes(self, H: int, W: int):
+        return identity_axis_torch(W, self.device), identity_axis_torch(H, self.device)
+
+    @staticmethod
+    def _fingerprint(img) -> bytes:
+        a = np.asarray(img) if not isinstance(img, torch.Tensor) else img.cpu().numpy()
+        h, w = a.shape[:2]
+        ys, xs = np.linspace(1, h - 2, 6).astype(int), np.linspace(1, w - 2, 6).astype(int)
+        return a[np.ix_(ys, xs)].tobytes()
+
+    def register_image(self, cam_index: int, image) -> None:
+        """``image``: the camera's match-size image exactly as the driver's loader prepares it"""
+        self.fingerprints[self._fingerprint(image)] = int(cam_index)
+
+    def fields(self, ref: int, nbrs: Sequence[int]):
+        key = (int(ref), tuple(int(n) for n in nbrs))
+        hit = self.table.get(key)
+        if hit is None:
+            s = synth_reference(self.cams, key[0], list(key[1]), self.H, self.W, self.w_resized, self.h_resized, device=self.device, **self.kw)
+            hit = [(s.warp[j].contiguous(), s.cert[j].contiguous()) for j in range(len(key[1]))]
+        return key, hit
+
+    def precompute(self, refs: Sequence[int], nn_table, nns_per_ref: int) -> int:
+        """The fields of these references with the neighbours the driver will load (``nn_table[r][:nns_per_ref]`` without r itself)."""
+        for r in refs:
+            nbrs = [int(n) for n in nn_table[int(r)][:int(nns_per_ref)] if self.cams[int(n)].uid != self.cams[int(r)].uid]
+            if nbrs:
+                key, val = self.fields(int(r), nbrs)
+                self.table[key] = val
+        return len(self.table)
+
+    def match_grids_batch(self, imA, imB_list, keys=None):
+        import time
+        t0 = time.perf_counter()
+        if keys is not None:
+            ref, nbrs = int(keys[0]), [int(k) for k in keys[1]]
+        else:
+            ref, nbrs = self.fingerprints[self._fingerprint(imA)], [self.fingerprints[self._fingerprint(b)] for b in imB_list]
+        _key, out = self.fields(ref, nbrs)
+        self.calls += 1
+        self.pairs += len(out)
+        if self.latency > 0.0:
+            time.sleep(max(0.0, t0 + self.latency * len(out) - time.perf_counter()))
+        self.seconds += time.perf_counter() - t0
+        return list(out)
+
+    def close(self) -> None:
+        pass

@@ -253,7 +253,10 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert ra["inputs_measured_in_this_run"]["link_gbps"] > 0 and ra["planned_step_ms"] <= ra["planned_pure_sharding_ms"] + 1e-9
     cm = ra["candidates_measured_ms"]                     # "n replicated, r round(s)" -> ms per step
     reps = {int(k_.split()[0]) for k_ in cm}
-    assert {0, 6} <= reps and ra["n_replicated"] in reps and "0 replicated, 1 round(s)" in cm and "0 replicated, 2 round(s)" in cm
+    # pure sharding both ways is always measured; "everything replicated" never is (every rank would compute the whole scene and nothing would cross
+    # a link: the headline would be the 1-GPU number, not strong scaling) - at least one reference per rank stays sharded
+    assert 0 in reps and 6 not in reps and max(reps) <= 6 - 2 and ra["n_replicated"] in reps and "0 replicated, 1 round(s)" in cm and "0 replicated, 2 round(s)" in cm
+    assert da["nothing_sharded"] is False
     assert min(v_ for k_, v_ in cm.items() if int(k_.split()[0]) == ra["n_replicated"]) == min(cm.values())      # measured, and the fastest one taken
     # the other forms: gather to the writer rank, 28-byte rows, weak scaling
     cmd_s = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--refs", "3", "--preset", "turbo",
@@ -441,7 +444,8 @@ def test_prepared_images_stay_on_the_device_once_per_camera(g4, tmp_path, monkey
     used = {int(r) for r in refs} | {int(n) for r in refs for n in list(g4["nn_table"][r])[:2]}
     assert calls == {"image": len(used), "mask": len(used)} and len(used) < n_places
     calls.update(image=0, mask=0)
-    monkeypatch.setattr(pl, "PREPARED_CACHE_BYTES", 0)
+    from lichtfeld_densification_plugin_amd.core import hotpath
+    monkeypatch.setattr(hotpath, "PREPARED_CACHE_BYTES", 0)
     plain = pl.run_dense_pipeline(cams, refs, g4["nn_table"], lfd.DensePipelineConfig(**kw), matcher=FakeMatcher(64, 64, table))
     assert calls == {"image": n_places, "mask": n_places}
     assert cached.xyz.shape[0] > 300
@@ -640,3 +644,55 @@ def test_device_selection_with_upstreams_normaliser_is_the_host_stage_on_this_ma
     assert abs(int(exact.xyz.shape[0]) - int(host.xyz.shape[0])) < 200
     print(f"[normaliser] torch's f32 sum differs from the exact sum on {differ} of {len(refs)} maps; "
           f"points: upstream's normaliser {dev_up.xyz.shape[0]}, exact sum {exact.xyz.shape[0]}")
+
+
+@pytest.mark.parametrize("per_launch", [1, 2, 5])
+def test_dense_streamer_writes_upstreams_file_from_kernel_made_records(g4, tmp_path, per_launch):
+    """dense mode + stream_output with nobody else looking at the points (core/strategies.py::DensePlyStreamer): lfd_triangulate_dense_ply writes the
+    15-byte records, they cross PCIe on a side stream into pinned double buffers, a writer thread appends them.  The file is upstream's write_ply of the
+    plain dense run's result (core/writers.py:29-46 there), no f32 cloud is assembled, and the result's arrays - read back from the file when somebody
+    asks - are that run's positions and quantised colours."""
+    from lichtfeld_densification_plugin_amd.core import writers
+    from lichtfeld_densification_plugin_amd.core.image_io import to_uint8_rgb
+    from lichtfeld_densification_plugin_amd.core.stages import StageClock
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+    kw = dict(nns_per_ref=2, seed=5, viz_interval=0, triangulation_mode="dense", refs_per_launch=per_launch)
+    plain = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(output_path=os.path.join(str(tmp_path), "plain.ply"), **kw),
+                                  matcher=FakeMatcher(64, 64, table))
+    out_path = os.path.join(str(tmp_path), "s", "streamed.ply")
+    clock = StageClock()
+    res = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(output_path=out_path, stream_output=True, **kw),
+                                matcher=FakeMatcher(64, 64, table), stage_clock=clock)
+    assert res.streamed_path == out_path and res.device_points is None and res._arrays is None      # nothing but records so far
+    assert res.n_points == plain.xyz.shape[0] and res.pairs_processed == plain.pairs_processed and res.pairs_matched == plain.pairs_matched
+    np.testing.assert_array_equal(res.points_per_reference, plain.points_per_reference)
+    ref_path = os.path.join(str(tmp_path), "ref.ply")
+    writers.write_ply(ref_path, plain.xyz, to_uint8_rgb(plain.rgb))
+    head, body = open(out_path, "rb").read().split(b"end_header\n", 1)
+    ref_head, ref_body = open(ref_path, "rb").read().split(b"end_header\n", 1)
+    assert body == ref_body
+    assert [l for l in head.decode().split("\n") if l and not l.startswith("comment")] == [l for l in ref_head.decode().split("\n") if l]
+    np.testing.assert_array_equal(res.xyz, plain.xyz)                          # (read back from the file)
+    np.testing.assert_array_equal(to_uint8_rgb(res.rgb), to_uint8_rgb(plain.rgb))
+    assert not res.err.any()
+    st = res.stages
+    assert st["d2h_bytes"] == 15 * res.n_points and st["kernel"]["calls"] >= 1 and st["write"]["seconds"] > 0 and st["match"]["calls"] == len(refs)
+
+
+def test_stage_clock_attributes_a_sampled_run_without_changing_it(g4, tmp_path):
+    """run_dense_pipeline(stage_clock=StageClock(sync=...)): the attribution run drains the device after every stage and takes the unfused calls so
+    that `select` and `kernel` are separate stages - the points are the plain run's."""
+    from lichtfeld_densification_plugin_amd.core.stages import StageClock
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+    kw = dict(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=2, seed=5, viz_interval=0, matches_per_ref=1200)
+    plain = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**kw), matcher=FakeMatcher(64, 64, table))
+    assert plain.stages is None
+    from lichtfeld_densification_plugin_amd.core import image_io
+    image_io.load_rgb_u8.cache_clear()              # (the loaders' caches live in the process: the plain run has warmed them)
+    clock = StageClock(sync=torch.cuda.synchronize)
+    timed = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**kw), matcher=FakeMatcher(64, 64, table), stage_clock=clock)
+    np.testing.assert_array_equal(timed.xyz, plain.xyz)
+    np.testing.assert_array_equal(timed.rgb, plain.rgb)
+    for stage in ("decode", "prepare", "match", "select", "kernel", "d2h"):
+        assert timed.stages[stage]["seconds"] > 0 and timed.stages[stage]["calls"] >= 1, stage
+    assert timed.stages["select"]["calls"] == len(refs) == timed.stages["kernel"]["calls"]
