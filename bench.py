@@ -516,9 +516,31 @@ def cpu_baseline(args, cams, srefs, dims, cfg):
             "sampled_mode": out["sampled"],
             "oracle_numpy": {"value": opts / dto, "cores": 1, "pairs_per_s": n_o * args.k / dto,
                              "sample": f"{n_o} references dense, {dto:.1f} s, BLAS threads limited to 1 (upstream's arithmetic: batched LAPACK f32 SVD)"},
-            "reference_python": {"ms_per_reference": [300, 700], "points_per_s": [15000, 30000], "cores": 8,
-                                 "note": "upstream core/pipeline.py::_triangulate_ref (sampled mode, 512^2, k=3, M=10000) probed in the development "
-                                         "container, BASELINE.md section 2; not runnable on the GPU box"}}
+            "reference_python": reference_python_record()}
+
+
+def reference_python_record():
+    """Upstream's OWN Python on this benchmark's workloads, timed in the development container by tests/golden/time_reference.py (which imports
+    /root/reference; its files cannot travel to the GPU box) and committed as tests/golden/g11_reference_timing.json: `_triangulate_ref` on references
+    of the headline workload, `run_dense_pipeline` + `write_ply` on the `pipeline` leg's on-disk scene."""
+    path = os.path.join(ROOT, "tests", "golden", "g11_reference_timing.json")
+    try:
+        with open(path) as fh:
+            g = json.load(fh)
+    except Exception as exc:
+        return {"note": f"tests/golden/g11_reference_timing.json not readable ({exc})"}
+    tri = g["triangulate_ref"]["gui_k3"]
+    pipe = g["run_dense_pipeline"]
+    return {"source": "tests/golden/g11_reference_timing.json (tests/golden/time_reference.py, development container; not runnable on the GPU box)",
+            "cores": g["host"]["cores_usable"], "torch_threads": g["host"]["torch_threads"], "versions": g["versions"],
+            "triangulate_ref": {name: {"ms_per_reference": r["seconds_per_reference"]["mean"] * 1e3, "points_per_s": r["points_per_s"], "pairs_per_s": r["pairs_per_s"],
+                                       "points_per_reference": r["points_per_reference"], "references": r["references"], "neighbours": r["neighbours"],
+                                       "matches_per_ref": r["matches_per_ref"]} for name, r in g["triangulate_ref"].items()},
+            "ms_per_reference": tri["seconds_per_reference"]["mean"] * 1e3, "points_per_s": tri["points_per_s"],
+            "run_dense_pipeline": {name: {k_: r[k_] for k_ in ("pack_workers", "cameras", "references", "pairs", "points", "seconds", "matcher_seconds", "refs_per_s",
+                                                              "pairs_per_s", "points_per_s", "write_ply_seconds")} for name, r in pipe.items()},
+            "note": "upstream core/pipeline.py::_triangulate_ref (sampled mode, 512^2, GUI k = 3 / M = 10000 and CLI k = 4 / M = 12000) on references of this "
+                    "workload, and upstream's run_dense_pipeline + write_ply on the pipeline leg's scene (same images, plan and matcher fields)"}
 
 
 def parity_report(args, dens, cams, refs, srefs, dims, cfg):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LFD_ABI_VERSION 6
+#define LFD_ABI_VERSION 7
 #define LFD_MAX_SLOTS 16 /* neighbours per reference handled by one launch */
 
 enum lfd_status {
@@ -117,6 +117,15 @@ int lfd_reload_env(lfd_context* ctx);
 int lfd_kernel_timing(lfd_context* ctx, int32_t n_launches);
 int lfd_kernel_timing_read(lfd_context* ctx, float* ms, int32_t capacity, int32_t* n_out);
 const char* lfd_last_error(const lfd_context* ctx); /* ctx may be NULL: last creation error */
+/* How THIS build of the library lays out the structures of this header, so that a binding that mirrors them by hand (ctypes, cffi ABI mode,
+ * JNA ...) can check itself at load time instead of trusting a transcription: for lfd_params, lfd_batch, lfd_points, lfd_tile_segment and
+ * lfd_copy_segment, in that order, {sizeof, number of fields, then offsetof(field), sizeof(field) for every field in declaration order}.  Writes at most `capacity`
+ * values to `out` (host int32; may be NULL with capacity 0) and returns how many values the table has.  The Python mirror compares its
+ * ctypes `_fields_` with it when it loads the library (core/hip_backend.py::check_struct_layout). */
+int lfd_struct_layout(int32_t* out, int32_t capacity);
+/* ... and the names behind those numbers: "lfd_params:sampson_thresh,certainty_thresh,...;lfd_batch:n_refs,...;..." - the same structures and
+ * fields in the same order (two neighbouring fields of one type swapped in a mirror keep every offset; their names tell). */
+const char* lfd_struct_fields(void);
 
 /* Camera table, all host f32 row-major as upstream's CameraRecord holds them
  * (core/camera_models.py:10-28): K[n][9] R[n][9] t[n][3] P[n][12] C[n][3], wh[n][2] = width,height. */

@@ -18,7 +18,7 @@ import torch
 from .types import CameraRecord, DensePipelineConfig
 
 LFD_MAX_SLOTS = 16
-LFD_ABI_VERSION = 6
+LFD_ABI_VERSION = 7
 LFD_FLAG_EXACT_COLOUR = 1     # lfd_params.flags: dense mode blends colours with upstream's f64 arithmetic (bit-identical rgb)
 LFD_FLAG_TILE_SEGMENTS = 2    # informational: the caller takes the unordered-retirement route (lfd_triangulate_dense_segments)
 _LIB_NAME = "liblfd_densify.so"
@@ -55,6 +55,49 @@ class lfd_points(C.Structure):
                 ("slot", C.c_void_p), ("capacity", C.c_int64)]
 
 
+class lfd_tile_segment(C.Structure):
+    """one row of the tile table of lfd_triangulate_dense_segments (handled as an (n, 2) int32 tensor on this side)"""
+    _fields_ = [("offset", C.c_int32), ("count", C.c_int32)]
+
+
+class lfd_copy_segment(C.Structure):
+    """one copy of lfd_copy_segments (handled as an (n, 3) int64 array on this side)"""
+    _fields_ = [("src_offset", C.c_int64), ("dst_offset", C.c_int64), ("nbytes", C.c_int64)]
+
+
+ABI_STRUCTS = (lfd_params, lfd_batch, lfd_points, lfd_tile_segment, lfd_copy_segment)     # the order lfd_struct_layout reports them in
+
+
+def check_struct_layout(lib, structs=ABI_STRUCTS) -> None:
+    """The ctypes mirrors above against what the COMPILER made of include/lfd_densify.h (lfd_struct_layout: sizeof, field count and every
+    field's offset and size per structure; lfd_struct_fields: their names): a field added, dropped, reordered or retyped on one side only is an import error here, not a corrupted
+    launch later."""
+    lib.lfd_struct_layout.argtypes = [C.POINTER(C.c_int32), C.c_int32]
+    lib.lfd_struct_layout.restype = C.c_int
+    n = int(lib.lfd_struct_layout(None, 0))
+    table = (C.c_int32 * n)()
+    lib.lfd_struct_layout(table, n)
+    lib.lfd_struct_fields.restype = C.c_char_p
+    names = dict(part.split(":") for part in lib.lfd_struct_fields().decode().split(";"))
+    vals, at = list(table), 0
+    for cls in structs:
+        theirs = names.get(cls.__name__, "").split(",")
+        if [name for name, *_ in cls._fields_] != theirs:
+            raise HipBackendError(f"ctypes mirror of {cls.__name__} lists the fields {[name for name, *_ in cls._fields_]}, the library's header has "
+                                  f"{theirs} (include/lfd_densify.h and core/hip_backend.py disagree)")
+        if at + 2 > len(vals):
+            raise HipBackendError(f"lfd_struct_layout ends before {cls.__name__}: the library is older than this binding")
+        size, n_fields = vals[at], vals[at + 1]
+        offsets = list(zip(vals[at + 2:at + 2 + 2 * n_fields:2], vals[at + 3:at + 2 + 2 * n_fields:2]))       # (offset, size) per field
+        at += 2 + 2 * n_fields
+        mine = [(name, getattr(cls, name).offset, getattr(cls, name).size) for name, *_ in cls._fields_]
+        if C.sizeof(cls) != size or [(o, z) for _n, o, z in mine] != offsets:
+            raise HipBackendError(f"ctypes mirror of {cls.__name__} does not match the library's layout: here sizeof {C.sizeof(cls)} with offsets "
+                                  f"(name, offset, size) {mine}, the library has sizeof {size} with (offset, size) {offsets} (include/lfd_densify.h and core/hip_backend.py disagree)")
+    if at != len(vals):
+        raise HipBackendError("lfd_struct_layout reports structures this binding does not mirror")
+
+
 _lib = None
 
 
@@ -77,6 +120,10 @@ def load_library() -> C.CDLL:
     lib = C.CDLL(path)
     ctxp = C.c_void_p
     lib.lfd_abi_version.restype = C.c_int
+    if int(lib.lfd_abi_version()) != LFD_ABI_VERSION:
+        raise HipBackendError(f"{path} implements ABI {int(lib.lfd_abi_version())}, this binding ABI {LFD_ABI_VERSION}: rebuild the library "
+                              f"(python {os.path.join(_PKG_DIR, 'csrc', 'build.py')})")
+    check_struct_layout(lib)
     lib.lfd_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(ctxp)]
     lib.lfd_destroy.argtypes = [ctxp]
     lib.lfd_destroy.restype = None

@@ -1,5 +1,6 @@
 // Host side of the C-ABI declared in include/lfd_densify.h: context, tables, launches.
 // No compute happens on the host here except the tiny helpers the header lists as host-side.
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -434,6 +435,35 @@ int lfd_fail(lfd_context* ctx, int code, const std::string& msg) {
 extern "C" {
 
 int lfd_abi_version(void) { return LFD_ABI_VERSION; }
+
+int lfd_struct_layout(int32_t* out, int32_t capacity) {
+#define LFD_OFF(T, f) (int32_t)offsetof(T, f), (int32_t)sizeof(((T*)nullptr)->f)
+    const int32_t table[] = {
+        (int32_t)sizeof(lfd_params), 7, LFD_OFF(lfd_params, sampson_thresh), LFD_OFF(lfd_params, certainty_thresh), LFD_OFF(lfd_params, sample_cap),
+        LFD_OFF(lfd_params, reproj_thresh), LFD_OFF(lfd_params, min_parallax_deg), LFD_OFF(lfd_params, no_filter), LFD_OFF(lfd_params, flags),
+        (int32_t)sizeof(lfd_batch), 19, LFD_OFF(lfd_batch, n_refs), LFD_OFF(lfd_batch, k), LFD_OFF(lfd_batch, H), LFD_OFF(lfd_batch, W),
+        LFD_OFF(lfd_batch, w_match), LFD_OFF(lfd_batch, h_match), LFD_OFF(lfd_batch, warp_channels), LFD_OFF(lfd_batch, reserved),
+        LFD_OFF(lfd_batch, ref_cam), LFD_OFF(lfd_batch, n_slots), LFD_OFF(lfd_batch, nbr_cam), LFD_OFF(lfd_batch, cert), LFD_OFF(lfd_batch, warp),
+        LFD_OFF(lfd_batch, image), LFD_OFF(lfd_batch, mask_a), LFD_OFF(lfd_batch, mask_b), LFD_OFF(lfd_batch, axis_x), LFD_OFF(lfd_batch, axis_y),
+        LFD_OFF(lfd_batch, fundamental),
+        (int32_t)sizeof(lfd_points), 6, LFD_OFF(lfd_points, xyz), LFD_OFF(lfd_points, rgb), LFD_OFF(lfd_points, err), LFD_OFF(lfd_points, cell),
+        LFD_OFF(lfd_points, slot), LFD_OFF(lfd_points, capacity),
+        (int32_t)sizeof(lfd_tile_segment), 2, LFD_OFF(lfd_tile_segment, offset), LFD_OFF(lfd_tile_segment, count),
+        (int32_t)sizeof(lfd_copy_segment), 3, LFD_OFF(lfd_copy_segment, src_offset), LFD_OFF(lfd_copy_segment, dst_offset), LFD_OFF(lfd_copy_segment, nbytes),
+    };
+#undef LFD_OFF
+    const int32_t n = (int32_t)(sizeof(table) / sizeof(table[0]));
+    for (int32_t i = 0; out != nullptr && i < n && i < capacity; ++i) out[i] = table[i];
+    return n;
+}
+
+const char* lfd_struct_fields(void) {
+    return "lfd_params:sampson_thresh,certainty_thresh,sample_cap,reproj_thresh,min_parallax_deg,no_filter,flags;"
+           "lfd_batch:n_refs,k,H,W,w_match,h_match,warp_channels,reserved,ref_cam,n_slots,nbr_cam,cert,warp,image,mask_a,mask_b,axis_x,axis_y,fundamental;"
+           "lfd_points:xyz,rgb,err,cell,slot,capacity;"
+           "lfd_tile_segment:offset,count;"
+           "lfd_copy_segment:src_offset,dst_offset,nbytes";
+}
 
 const char* lfd_last_error(const lfd_context* ctx) {
     if (ctx) return ctx->err.c_str();
