@@ -92,7 +92,8 @@ def synth_reference(cams: Sequence[CameraRecord], ref_index: int, nbr_indices: S
                     outlier_frac: float = 0.0, channels: int = 2, seed: int = 0,
                     cert_mode: str = "smooth", device="cpu", far_depth: float = 25.0,
                     low_parallax_patch: Optional[Sequence[float]] = None,
-                    patch_depths: Sequence[float] = (6.0, 60.0)) -> SyntheticReference:
+                    patch_depths: Sequence[float] = (6.0, 60.0), out_of_range: float = 0.0,
+                    occlusion_steps: bool = False) -> SyntheticReference:
     """Dense warp + certainty of ``ref_index`` into each neighbour.
 
     low_parallax_patch: (y0, y1, x0, x1) as fractions of the grid.  Inside it the surface is replaced by a ramp of
@@ -103,6 +104,13 @@ def synth_reference(cams: Sequence[CameraRecord], ref_index: int, nbr_indices: S
     cert_mode: "smooth"  - low-frequency overlap-like field + 2 % jitter (coherent best-neighbour regions)
                "tiefree" - distinct uniform values in (0.2, 0.9) (no ties under floor/cap clamps)
                "beta"    - iid Beta(2,2) (floor and cap clamps produce massive ties, like real data edges)
+               "bimodal" - what ``sigmoid(confidence logits)`` gives (RoMaV2's overlap head): most cells near 0.02 or near 0.98, coherent regions
+                           of each, a thin transition - after the 0.2 floor and the 0.9 cap nearly EVERY cell sits on a clamp
+
+    out_of_range: that fraction of the grid's columns (on its right) and, at half that width, of its rows (at the top) is warped past the edge
+               of the neighbour - x (y) beyond [-1, 1], through the border and on to 2.5 image half-widths outside - as the real matcher does for
+               content the neighbour does not see; upstream does not reject such coordinates (core/pipeline.py:697-703), the reprojection test does.
+    occlusion_steps: the surface gets depth discontinuities (a checker of foreground slabs at 0.65 of the depth): the warp jumps at their edges.
     """
     dev = torch.device(device)
     gen = torch.Generator(device="cpu").manual_seed(int(seed) * 7919 + int(ref_index) * 104729 + 13)
@@ -125,6 +133,11 @@ def synth_reference(cams: Sequence[CameraRecord], ref_index: int, nbr_indices: S
     Xw = CA.view(1, 1, 3) + s.unsqueeze(-1) * dirs_w
     relief = 0.08 * torch.sin(2.1 * Xw[..., 0] + 0.3) * torch.cos(1.7 * Xw[..., 1] - 0.2)
     s = s * (1.0 - relief / CA[2].clamp(min=0.5))
+    if occlusion_steps:
+        gy_ = torch.linspace(0, 1, H, dtype=torch.float64, device=dev).view(H, 1)
+        gx_ = torch.linspace(0, 1, W, dtype=torch.float64, device=dev).view(1, W)
+        slab = (torch.floor(5.0 * gx_ + 0.8 * gy_) + torch.floor(3.0 * gy_ - 0.4 * gx_)).to(torch.int64) % 2 == 1
+        s = torch.where(slab, s * 0.65, s)
     if low_parallax_patch is not None:
         fy0, fy1, fx0, fx1 = [float(v) for v in low_parallax_patch]
         iy0, iy1, ix0, ix1 = int(fy0 * H), max(int(fy1 * H), int(fy0 * H) + 1), int(fx0 * W), max(int(fx1 * W), int(fx0 * W) + 1)
@@ -149,6 +162,12 @@ def synth_reference(cams: Sequence[CameraRecord], ref_index: int, nbr_indices: S
         yB = vB / (camB.height / float(h_match))
         xBn = xB / (0.5 * (w_match - 1)) - 1.0
         yBn = yB / (0.5 * (h_match - 1)) - 1.0
+        if out_of_range > 0:
+            gxo = torch.linspace(0, 1, W, dtype=torch.float64, device=dev).view(1, W)
+            gyo = torch.linspace(0, 1, H, dtype=torch.float64, device=dev).view(H, 1)
+            fx_, fy_ = float(out_of_range), 0.5 * float(out_of_range)
+            xBn = xBn + 3.5 * ((gxo - (1.0 - fx_)) / fx_).clamp(min=0.0)           # from where it was, across the border, to well outside
+            yBn = yBn - 3.5 * (((fy_ - gyo)) / fy_).clamp(min=0.0)
         if outlier_frac > 0:
             pick = (torch.rand((H, W), generator=gen) < outlier_frac).to(dev)
             rnd = (torch.rand((2, H, W), generator=gen, dtype=torch.float64) * 2.0 - 1.0).to(dev)
@@ -169,6 +188,10 @@ def synth_reference(cams: Sequence[CameraRecord], ref_index: int, nbr_indices: S
             a = torch.distributions.Beta(2.0, 2.0)
             torch.manual_seed(int(seed) * 31 + slot + 1000 * int(ref_index))
             c = a.sample((H, W)).to(torch.float64).to(dev)
+        elif cert_mode == "bimodal":
+            ph = 2.399963 * (slot + 1) + 0.37 * ref_index
+            logit = 18.0 * torch.sin(3.0 * gx + ph) * torch.sin(2.0 * gy + 1.3 * ph) + 1.5 * torch.randn((H, W), generator=gen, dtype=torch.float64).to(dev)
+            c = torch.sigmoid(logit - 6.0 * (1.0 - inside))
         else:
             raise ValueError(cert_mode)
         wp = torch.stack([xBn, yBn], dim=-1)
