@@ -179,6 +179,13 @@ typedef struct lfd_tile_segment { int32_t offset; int32_t count; } lfd_tile_segm
 int lfd_dense_tiles_per_ref(int32_t H, int32_t W); /* host helper: rows of the tile table per reference */
 int lfd_triangulate_dense_segments(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, const lfd_points* out,
                                    int64_t* ref_counts, int32_t* seg_counts, lfd_tile_segment* table);
+/* Both at once: the 15-byte PLY vertex records of lfd_triangulate_dense_ply with the unordered retirement of lfd_triangulate_dense_segments, for a
+ * consumer that wants every reference's point SET as file payload and does not care about its raster order (a point cloud has none; the streamed
+ * output of a run that does not have to reproduce upstream's byte sequence).  records: device u8 [capacity * 15], capacity >= n_refs*H*W;
+ * reference r's records fill [15*r*H*W, 15*(r*H*W + ref_counts[r])) tile after tile in retirement order, raster order inside a tile; table and
+ * ref_counts as above.  The same points, byte for byte per record, as lfd_triangulate_dense_ply emits (tests/test_gpu_segments.py). */
+int lfd_triangulate_dense_ply_segments(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, uint8_t* records, int64_t capacity,
+                                       int64_t* ref_counts, int32_t* seg_counts, lfd_tile_segment* table);
 /* src: the unordered buffers of lfd_triangulate_dense_segments (capacity ignored); dst: ordered result, at most dst->capacity records
  * (cell / slot copied when both sides give them); ref_offsets: device i64 [n_refs + 1] or NULL.  Asynchronous on the context's stream. */
 int lfd_order_segments(lfd_context* ctx, int32_t n_refs, int32_t H, int32_t W, const lfd_tile_segment* table, const lfd_points* src,

@@ -144,6 +144,7 @@ def load_library() -> C.CDLL:
     lib.lfd_dense_tiles_per_ref.argtypes = [C.c_int32, C.c_int32]
     lib.lfd_triangulate_dense_segments.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.POINTER(lfd_points),
                                                    C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.lfd_triangulate_dense_ply_segments.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.lfd_order_segments.argtypes = [ctxp, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(lfd_points), C.POINTER(lfd_points), C.c_void_p]
     lib.lfd_pack_ply_segments.argtypes = [ctxp, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.lfd_pack_points3d_segments.argtypes = [ctxp, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
@@ -191,7 +192,7 @@ def load_library() -> C.CDLL:
     lib.lfd_host_eval_correspondence.argtypes = [fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                                  C.c_int32, C.POINTER(lfd_params), fptr]
     for name in ("lfd_create", "lfd_set_stream", "lfd_reload_env", "lfd_kernel_timing", "lfd_kernel_timing_read", "lfd_upload_cameras", "lfd_prepare_batch", "lfd_aggregate", "lfd_triangulate_dense",
-                 "lfd_triangulate_dense_ply", "lfd_dense_tiles_per_ref", "lfd_triangulate_dense_segments", "lfd_order_segments", "lfd_pack_ply_segments", "lfd_pack_points3d_segments",
+                 "lfd_triangulate_dense_ply", "lfd_triangulate_dense_ply_segments", "lfd_dense_tiles_per_ref", "lfd_triangulate_dense_segments", "lfd_order_segments", "lfd_pack_ply_segments", "lfd_pack_points3d_segments",
                  "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_triangulate_sampled_multi", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
                  "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_copy_segments", "lfd_identity_axis",
                  "lfd_host_fundamental", "lfd_get_pair_fundamental", "lfd_create_host", "lfd_aggregate_host",
@@ -836,6 +837,21 @@ class HipDensifier:
         self.check_launches()
         h = offs.cpu().numpy()
         return rec[:int(h[-1]) * 15], h
+
+    def launch_dense_ply_segments(self, batch: PreparedBatch, params: lfd_params, records: torch.Tensor, ref_counts: torch.Tensor, table: torch.Tensor,
+                                  seg_counts: Optional[torch.Tensor] = None) -> None:
+        """lfd_triangulate_dense_ply_segments: the PLY records without a look-back - reference r's ``ref_counts[r]`` records start at byte
+        ``15 * r * H * W`` of ``records`` (uint8, n_refs * H * W * 15), tile after tile in retirement order; ``table`` (int32 (n_tiles, 2)) says where
+        each tile went.  Asynchronous."""
+        self._same_device(batch, None, records, ref_counts, table, seg_counts)
+        if records.dtype != torch.uint8 or ref_counts.dtype != torch.int64 or table.dtype != torch.int32 or not records.is_contiguous() or not table.is_contiguous():
+            raise ValueError("records must be a contiguous uint8 tensor, ref_counts int64, table a contiguous int32 (n_tiles, 2) tensor")
+        self._check(self._lib.lfd_triangulate_dense_ply_segments(self._ctx, C.byref(batch.c), C.byref(params), records.data_ptr(), int(records.numel()) // 15,
+                                                                 ref_counts.data_ptr(), seg_counts.data_ptr() if seg_counts is not None else None, table.data_ptr()),
+                    "lfd_triangulate_dense_ply_segments")
+
+    def tiles_per_ref(self, H: int, W: int) -> int:
+        return int(self._lib.lfd_dense_tiles_per_ref(int(H), int(W)))
 
     # -- unordered retirement (opt-in): tiles claim room with one atomic, the consumers restore raster order from the tile table ------------
     def launch_dense_segments(self, batch: PreparedBatch, params: lfd_params, out: OutputBuffers, table: torch.Tensor,

@@ -323,12 +323,18 @@ class HotPath:
                 return self.dens.order_segments(self.dens.triangulate_dense_segments(batch, self.params))
             return self.dens.triangulate_dense(batch, self.params)
 
-    def launch_dense_ply(self, refs: List[hb.ReferenceInputs], axes, records: torch.Tensor, ref_offsets: torch.Tensor) -> hb.PreparedBatch:
+    def launch_dense_ply(self, refs: List[hb.ReferenceInputs], axes, records: torch.Tensor, ref_offsets: torch.Tensor,
+                         table: Optional[torch.Tensor] = None) -> hb.PreparedBatch:
         """The dense kernel writing the 15-byte PLY records itself (lfd_triangulate_dense_ply), asynchronously, into the caller's buffers
-        (the streamed output of a dense run: core/sinks.py::DensePlyStreamer).  Returns the batch, which keeps the inputs alive."""
+        (the streamed output of a dense run: core/strategies.py::DensePlyStreamer).  ``table``: the form without the look-back
+        (lfd_triangulate_dense_ply_segments) - ``ref_offsets[:n]`` then receives the references' COUNTS and reference r's records start at
+        byte 15 * r * H * W.  Returns the batch, which keeps the inputs alive."""
         batch = hb.PreparedBatch(refs, self.w_match, self.h_match, axes=axes, cameras=self.cams)
         with self.clock.stage("kernel"):
-            self.dens.launch_dense_ply(batch, self.params, records, ref_offsets)
+            if table is not None:
+                self.dens.launch_dense_ply_segments(batch, self.params, records, ref_offsets, table)
+            else:
+                self.dens.launch_dense_ply(batch, self.params, records, ref_offsets)
         return batch
 
     def debug_matches(self, ref: hb.ReferenceInputs, out_cell: torch.Tensor, out_slot: torch.Tensor, axes,

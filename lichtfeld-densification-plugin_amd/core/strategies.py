@@ -205,9 +205,11 @@ class DenseBatcher:
 class _Slot:
     """One of the streamer's buffer pairs: the device records a launch writes, their pinned landing area, and the events between them."""
 
-    def __init__(self, n_refs: int, cells: int, dev):
+    def __init__(self, n_refs: int, cells: int, dev, tiles_per_ref: int = 0):
         self.n_refs, self.points = int(n_refs), int(n_refs) * int(cells)
         cap = self.points
+        # unordered retirement: where each tile went (not read by this side: a reference's records are contiguous anyway)
+        self.table = torch.zeros((max(1, int(n_refs) * int(tiles_per_ref)), 2), dtype=torch.int32, device=dev) if tiles_per_ref else None
         self.records = torch.empty((max(cap * 15, 4),), dtype=torch.uint8, device=dev)
         self.offsets = torch.zeros((n_refs + 1,), dtype=torch.int64, device=dev)
         self.h_records = torch.empty((max(cap * 15, 4),), dtype=torch.uint8).pin_memory()
@@ -226,10 +228,15 @@ class DensePlyStreamer:
     records of the launch before last have been written out.  15 instead of 28 bytes per survivor cross the bus, once, and no f32 cloud is
     ever assembled (``PipelineResult`` reads the file back if somebody asks for arrays).
 
+    experimental['dense_tile_segments']: the kernel form without the look-back (lfd_triangulate_dense_ply_segments).  Every reference's records
+    are then its point SET in tile-retirement order - the same points, not upstream's byte sequence, and not the same sequence from run to run -
+    and cross in one copy per reference.
+
     Replaces upstream core/pipeline.py:753-780,880-884,917-919 + core/writers.py:29-46 for that consumer."""
 
     def __init__(self, hot: HotPath, outputs: RunOutputs, config):
         self.hot, self.out, self.config = hot, outputs, config
+        self.unordered = bool(config.exp("dense_tile_segments"))
         self.pending: List[Matched] = []
         self.launched: List[tuple] = []
         self.slots: List[_Slot] = []
@@ -243,7 +250,7 @@ class DensePlyStreamer:
     @staticmethod
     def applies(config, plan, on_host: bool, outputs: RunOutputs, debug_enabled: bool) -> bool:
         return (config.triangulation_mode == "dense" and bool(config.stream_output) and plan.world == 1 and not on_host
-                and outputs.intermediate_base is None and not debug_enabled and not config.exp("dense_tile_segments"))
+                and outputs.intermediate_base is None and not debug_enabled)
 
     def submit(self, m: Matched) -> None:
         self.pending.append(m)
@@ -257,7 +264,8 @@ class DensePlyStreamer:
             if s.free.is_set():
                 return s
         if len(fits) < 2:
-            self.slots.append(_Slot(max(n_refs, int(self.config.refs_per_launch)), cells, self.hot.dev))
+            tpr = self.hot.dens.tiles_per_ref(cells, 1) if self.unordered else 0
+            self.slots.append(_Slot(max(n_refs, int(self.config.refs_per_launch)), cells, self.hot.dev, tpr))
             return self.slots[-1]
         with self.hot.clock.stage("write", sync=False):      # both pairs are busy: the file is what the run waits for
             fits[0].free.wait()
@@ -274,7 +282,10 @@ class DensePlyStreamer:
         slot = self._slot(len(items), items[0].H * items[0].W)
         slot.free.clear()
         try:
-            batch = self.hot.launch_dense_ply([m.ref for m in items], items[0].axes, slot.records, slot.offsets)
+            if self.unordered:       # (slot.offsets receives the per-reference COUNTS: reference r's records start at byte 15 * r * H * W)
+                batch = self.hot.launch_dense_ply([m.ref for m in items], items[0].axes, slot.records, slot.offsets, table=slot.table)
+            else:
+                batch = self.hot.launch_dense_ply([m.ref for m in items], items[0].axes, slot.records, slot.offsets)
         except Exception as ex:
             slot.free.set()
             log.error(f"Triangulation error for refs {[m.packed.ref_uid for m in items]}: {ex}")
@@ -293,11 +304,20 @@ class DensePlyStreamer:
         with self.hot.clock.stage("kernel", sync=False):     # the host waits here for the launch's offsets, i.e. for its kernel
             slot.offsets_here.synchronize()
         offs = slot.h_offsets.numpy()[:len(items) + 1].copy()       # (a pair sized for refs_per_launch serves a last, smaller batch too)
+        if self.unordered:
+            counts = offs[:len(items)]
+            offs = np.concatenate([[0], np.cumsum(counts)])
         n = int(offs[-1])
         with torch.cuda.stream(self.side):
             slot.copy_start.record(self.side)
-            if n:
+            if n and not self.unordered:
                 slot.h_records[:n * 15].copy_(slot.records[:n * 15], non_blocking=True)
+            elif n:                      # one copy per reference, out of its own region of the launch's buffer
+                cells = items[0].H * items[0].W
+                for bi in range(len(items)):
+                    lo, hi = int(offs[bi]), int(offs[bi + 1])
+                    if hi > lo:
+                        slot.h_records[lo * 15:hi * 15].copy_(slot.records[bi * cells * 15:(bi * cells + hi - lo) * 15], non_blocking=True)
             slot.copied.record(self.side)
         for bi, m in enumerate(items):
             if int(offs[bi + 1]) > int(offs[bi]):

@@ -22,6 +22,8 @@ extern "C" __global__ void lfd_dense_ply_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_dense_ply_exact_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_dense_segments_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_dense_segments_exact_kernel(LfdLaunch L);
+extern "C" __global__ void lfd_dense_ply_segments_kernel(LfdLaunch L);
+extern "C" __global__ void lfd_dense_ply_segments_exact_kernel(LfdLaunch L);
 extern "C" __global__ void lfd_segment_scan_kernel(const LfdTileSeg* table, int n_tiles, int tiles_per_ref, int n_refs, long long* tile_dst, long long* ref_offsets);
 extern "C" __global__ void lfd_order_segments_kernel(const long long* tile_dst, const LfdTileSeg* table, long long hw, int tiles_per_ref, int n_tiles,
                                                      const float* sxyz, const float* srgb, const float* serr, const int* scell, const unsigned char* sslot,
@@ -660,7 +662,8 @@ static int dense_launch(lfd_context* ctx, const lfd_batch* batch, const lfd_para
     int rc = prepare_launch(ctx, batch, params, nullptr, 0, L, nullptr);
     if (rc != LFD_OK) return rc;
     if (ply) {                         // file-payload output: the records go to `ply`; out carries the capacity (and optionally cell / slot)
-        if (!out || out->capacity < 0 || !ref_offsets) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_dense_ply: out (capacity) and ref_offsets are required");
+        if (!out || out->capacity < 0 || !(unordered ? (void*)ref_counts : (void*)ref_offsets))
+            return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_dense_ply[_segments]: the capacity and ref_offsets (ordered) / ref_counts (unordered) are required");
     } else {
         rc = check_points(ctx, out, reinterpret_cast<long long*>(unordered ? ref_counts : ref_offsets));
         if (rc != LFD_OK) return rc;
@@ -708,7 +711,8 @@ static int dense_launch(lfd_context* ctx, const lfd_batch* batch, const lfd_para
     if (rc != LFD_OK) return rc;
     hipEvent_t t_start = nullptr, t_stop = used_slot.idle;
     if (ctx->kt_used < ctx->kt_start.size()) { t_start = ctx->kt_start[ctx->kt_used]; t_stop = ctx->kt_stop[ctx->kt_used]; ++ctx->kt_used; }
-    auto kernel = ply ? (exact_colour ? lfd_dense_ply_exact_kernel : lfd_dense_ply_kernel)
+    auto kernel = (ply && unordered) ? (exact_colour ? lfd_dense_ply_segments_exact_kernel : lfd_dense_ply_segments_kernel)
+                : ply ? (exact_colour ? lfd_dense_ply_exact_kernel : lfd_dense_ply_kernel)
                 : unordered ? (exact_colour ? lfd_dense_segments_exact_kernel : lfd_dense_segments_kernel)
                             : (exact_colour ? lfd_dense_exact_kernel : lfd_dense_kernel);
     hipExtLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(LFD_DENSE_BLOCK), (unsigned)extra_lds, ctx->stream, t_start, t_stop, 0, L);
@@ -752,6 +756,15 @@ int lfd_triangulate_dense_segments(lfd_context* ctx, const lfd_batch* batch, con
                                    int64_t* ref_counts, int32_t* seg_counts, lfd_tile_segment* table) {
     if (ctx && !table) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_dense_segments: the tile table is required");
     return dense_launch(ctx, batch, params, out, nullptr, seg_counts, ref_counts, table);
+}
+
+int lfd_triangulate_dense_ply_segments(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, uint8_t* records, int64_t capacity,
+                                       int64_t* ref_counts, int32_t* seg_counts, lfd_tile_segment* table) {
+    if (ctx && (!records || !table)) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_dense_ply_segments: records and the tile table are required");
+    lfd_points out;
+    std::memset(&out, 0, sizeof(out));
+    out.capacity = capacity;
+    return dense_launch(ctx, batch, params, &out, nullptr, seg_counts, ref_counts, table, records);
 }
 
 // exclusive prefix of the table in tile order into the context's scratch (tile_dst[n_tiles + 1]); the launches that follow read it

@@ -1066,6 +1066,10 @@ extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) l
 extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_ply_exact_kernel(LfdLaunch L) { lfd_dense_body<true, false, true>(L); }
 extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_segments_kernel(LfdLaunch L) { lfd_dense_body<false, true>(L); }
 extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_segments_exact_kernel(LfdLaunch L) { lfd_dense_body<true, true>(L); }
+// ... and both at once (lfd_triangulate_dense_ply_segments): the file payload without a look-back, for a consumer that wants the point SET of every
+// reference, not its raster order
+extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_ply_segments_kernel(LfdLaunch L) { lfd_dense_body<false, true, true>(L); }
+extern "C" __global__ void __launch_bounds__(kBlock, LFD_DENSE_WAVES_PER_SIMD) lfd_dense_ply_segments_exact_kernel(LfdLaunch L) { lfd_dense_body<true, true, true>(L); }
 
 // =================================================================================================
 // indexed mode, pass A on the whole chip: every selected cell is evaluated by its own thread (256 cells per workgroup,

@@ -696,3 +696,23 @@ def test_stage_clock_attributes_a_sampled_run_without_changing_it(g4, tmp_path):
     for stage in ("decode", "prepare", "match", "select", "kernel", "d2h"):
         assert timed.stages[stage]["seconds"] > 0 and timed.stages[stage]["calls"] >= 1, stage
     assert timed.stages["select"]["calls"] == len(refs) == timed.stages["kernel"]["calls"]
+
+
+def test_dense_streamer_without_the_look_back_writes_every_references_point_set(g4, tmp_path):
+    """experimental['dense_tile_segments'] + stream_output: the records come from lfd_triangulate_dense_ply_segments (no ordered retirement) and cross
+    in one copy per reference: per reference the same 15-byte records as the ordered run's, in tile-retirement order; same counts, same header."""
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+    kw = dict(nns_per_ref=2, seed=5, viz_interval=0, triangulation_mode="dense", refs_per_launch=2, stream_output=True)
+    a_path, b_path = os.path.join(str(tmp_path), "a.ply"), os.path.join(str(tmp_path), "b.ply")
+    a = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(output_path=a_path, **kw), matcher=FakeMatcher(64, 64, table))
+    b = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(output_path=b_path, experimental={"dense_tile_segments": True}, **kw),
+                              matcher=FakeMatcher(64, 64, table))
+    np.testing.assert_array_equal(a.points_per_reference, b.points_per_reference)
+    ha, ba = open(a_path, "rb").read().split(b"end_header\n", 1)
+    hb_, bb = open(b_path, "rb").read().split(b"end_header\n", 1)
+    assert ha == hb_ and len(ba) == len(bb) == 15 * a.n_points
+    ra, rb = np.frombuffer(ba, np.uint8).reshape(-1, 15), np.frombuffer(bb, np.uint8).reshape(-1, 15)
+    offs = np.concatenate([[0], np.cumsum(a.points_per_reference)])
+    for i in range(len(offs) - 1):
+        sa, sb = ra[offs[i]:offs[i + 1]], rb[offs[i]:offs[i + 1]]
+        np.testing.assert_array_equal(sa[np.lexsort(sa.T[::-1])], sb[np.lexsort(sb.T[::-1])])

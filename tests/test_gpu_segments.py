@@ -176,3 +176,34 @@ def test_degenerate_inputs_through_the_unordered_and_ply_forms(dev, fill):
     assert body_s.numel() == body_k.numel() == ply_ref.numel() == 15 * ordered.count
     assert torch.equal(body_s, ply_ref) and torch.equal(body_k, ply_ref)
     dens.close()
+
+
+@pytest.mark.parametrize("name,exact", [("fast_k3_gui", False), ("fast_k8_multi", False), ("fast_k3_masks_c4", True)])
+def test_unordered_ply_records_are_the_ordered_ply_kernels_tile_by_tile(dev, name, exact):
+    """lfd_triangulate_dense_ply_segments (round 5: the file payload WITHOUT the look-back): every tile's records, put back in tile order with the
+    table, are lfd_triangulate_dense_ply's records byte for byte; a reference's region holds exactly its point set."""
+    spec = SHAPES[name]
+    H, W, wm, hm = spec["grid"]
+    cams, _srefs, refs = _scene(spec, dev)
+    dens = hb.HipDensifier(dev)
+    dens.upload_cameras(cams)
+    cfg = lfd.DensePipelineConfig(output_path="", reproj_thresh=spec["reproj"], nns_per_ref=spec["k"])
+    params = hb.make_params(cfg, exact_colour=exact)
+    batch = hb.PreparedBatch(refs, wm, hm, cameras=cams)
+    ordered, offs = dens.triangulate_dense_ply(batch, params)
+    n = len(refs)
+    tpr = dens.tiles_per_ref(H, W)
+    rec = torch.zeros((n * H * W * 15,), dtype=torch.uint8, device=dev)
+    counts = torch.zeros((n,), dtype=torch.int64, device=dev)
+    table = torch.zeros((n * tpr, 2), dtype=torch.int32, device=dev)
+    for _ in range(2):                   # twice on one context: the cursors are zeroed by the launch itself
+        dens.launch_dense_ply_segments(batch, params, rec, counts, table)
+        dens.check_launches()
+    np.testing.assert_array_equal(counts.cpu().numpy(), np.diff(offs))
+    t = table.cpu().numpy().reshape(n, tpr, 2)
+    host = rec.cpu().numpy().reshape(n, H * W, 15)
+    want = ordered.cpu().numpy().reshape(-1, 15)
+    for r in range(n):
+        mine = np.concatenate([host[r, o:o + c] for o, c in t[r]]) if int(t[r, :, 1].sum()) else np.zeros((0, 15), np.uint8)
+        np.testing.assert_array_equal(mine, want[offs[r]:offs[r + 1]])
+    dens.close()
