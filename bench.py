@@ -98,6 +98,9 @@ def parse_args():
                     help="cameras of the generated on-disk scene of the `pipeline` leg (densify.dense_init end to end, bench_pipeline.py); 0 = skip the leg")
     ap.add_argument("--pipeline-latency-ms", type=float, default=20.0, help="stand-in matcher latency per pair of the leg's second pass (0 = skip that pass)")
     ap.add_argument("--pipeline-size", default="1297x840", help="image size of the generated scene (garden's images_4)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="--gpus N: print what every rank WILL do - shard plan, launches and rounds per step, buffer sizes, the collectives in issue "
+                         "order - as one JSON object, without touching a GPU or creating a communicator, and exit")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc run of this same command (profiles/)")
     args = ap.parse_args()
@@ -1080,6 +1083,51 @@ def end_to_end(args):
             "note": "densify.dense_init (CLI defaults): COLMAP read, image loading, RoMa-v2 forward, sampled-mode hot path, PLY written"}, None
 
 
+def dry_run(args):
+    """`--gpus N --dry-run`: the sharded benchmark's plan, rank by rank, from the arguments alone (no GPU, no communicator).  The collective
+    sequence comes from core/distributed.py::exchange_schedule, which tests/test_distributed_cpu.py compares operation by operation with the
+    calls a gloo run of the same exchange really makes: the first run on real hardware either issues exactly this list on every rank or the
+    diff says where it departed.  Sizes use the workload's nominal survivor fraction (0.87 of the cells)."""
+    from lichtfeld_densification_plugin_amd.core import distributed as lfd_dist
+    world = int(args.gpus)
+    h_lr, w_lr, H, W = synthetic.ROMA_PRESETS[args.preset]
+    total_refs = args.refs * world if args.scaling == "weak" else args.refs
+    ply = args.exchange_records == "ply"
+    cols, rec_bytes = (15, 15) if ply else (7, 28)
+    n_rep = 0 if args.replicate == "auto" else max(0, min(int(args.replicate), total_refs))
+    s_nominal = 0.87
+    per_ref = int(H * W * s_nominal)
+    ranks = []
+    per_round = n_rounds = n_sh = 0
+    for rank in range(world):
+        consumes = args.exchange == "all_gather" or rank == 0
+        mine, n_sh = lfd_dist.split_replicated(total_refs, n_rep, rank, world, replicas_here=consumes)
+        sh = [g for g in mine if g < n_sh]
+        rp = [g for g in mine if g >= n_sh]
+        n_local_max = (n_sh + world - 1) // world
+        per_round = max(1, -(-n_local_max // max(1, int(args.exchange_rounds)))) if n_sh else 1
+        n_rounds = -(-n_local_max // per_round) if n_sh else 0
+        chunks = [sh[c * per_round:(c + 1) * per_round] for c in range(n_rounds)]
+        ranks.append({"rank": rank, "device": f"cuda:{rank}", "sharded_positions": sh, "replicated_positions": rp, "consumes_cloud": consumes,
+                      "launches_per_step": sum(1 for ch in chunks if ch) + (1 if rp else 0),
+                      "launches": [{"round": c, "references": ch, "record_buffer_bytes": len(ch) * H * W * rec_bytes,
+                                    "inputs_bytes": len(ch) * (args.k * H * W * 12 + h_lr * w_lr * 3)} for c, ch in enumerate(chunks)],
+                      "cloud_buffer_bytes": ((n_sh + len(rp)) * H * W * rec_bytes) if consumes else 0,
+                      "nominal_records_sent_per_step": len(sh) * per_ref * rec_bytes})
+    plan = lfd_dist.exchange_schedule(n_sh, world, per_round, args.exchange, "ply" if ply else "f32", counts=[per_ref] * n_sh, eager=True)
+    out = {"dry_run": True, "n_gpus": world, "workload": WORKLOADS[args.workload]["what"], "scaling": args.scaling, "refs_total": total_refs, "neighbours": args.k,
+           "grid": [H, W], "exchange": {"form": args.exchange, "record_bytes": rec_bytes, "rounds": plan["rounds"], "refs_per_round": plan["refs_per_round"],
+                                        "eager": True, "replicated": n_rep,
+                                        "replicated_note": "`--replicate auto` measures its candidates at run time: the plan shows pure sharding" if args.replicate == "auto" else None},
+           "ranks": ranks,
+           "per_step_collectives": plan["collectives"],
+           "around_the_timed_region": ["barrier (torch.cuda.synchronize + dist.barrier) before and after the K steps", "all_reduce(MAX) of the elapsed times",
+                                       "all_reduce(SUM) of the survivor counts"],
+           "backend": "nccl (RCCL over xGMI), one process per GPU, rendezvous 127.0.0.1",
+           "note": "every rank issues per_step_collectives in exactly this order, K + warm-up times; numel_* are per rank, in elements of the tensor handed over"}
+    print(json.dumps(out), flush=True)
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes - this parent has not touched
     the GPU and never will - wait for them, pass rank 0's JSON line through."""
@@ -1137,6 +1185,8 @@ def launch_ranks(args):
 
 def main():
     args = parse_args()
+    if args.dry_run:
+        return dry_run(args)                      # nothing below is reached: no GPU, no communicator
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)                 # before anything here touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -762,3 +762,86 @@ class SharedFilePlyStream(OverlappedExchange):
         if self.error is not None:
             raise self.error
         return recs, counts
+
+
+# ---- dry run: what a sharded run WILL do, without touching a GPU or a communicator -------------------------------------------------------------
+def exchange_schedule(n_refs: int, world: int, refs_per_round: int, form: str = "all_gather", record: str = RECORD_F32, counts: Optional[Sequence[int]] = None,
+                      eager: bool = False, root: int = 0) -> dict:
+    """The collectives an ``OverlappedExchange(n_refs, refs_per_round, form, record)`` issues, in issue order - the SAME list on every rank, which is
+    the point: RCCL matches (and executes) the operations of a communicator in issue order, so a rank that would issue another sequence hangs the
+    job.  ``counts``: survivors per GLOBAL reference position (None: sizes of the record collectives are left open).  Returns
+
+        {"rounds": n, "refs_per_round": B, "ranks": [{"rank", "positions", "rounds": [[positions of round c], ...]}, ...],
+         "collectives": [{"op", "what": "counts" | "records", "round", "numel_in", "numel_out" (per rank, in elements of the tensor handed over),
+                          "dtype", "rows" (records: the round's padded rows per rank)}, ...]}
+
+    Order (``_close_round`` / ``_send_round`` / ``finish``): the counts of round c leave when the round closes, its records one round LATER (when the
+    counts have long arrived) - C0 C1 R0 C2 R1 ... C(n-1) R(n-2) R(n-1); ``eager``: C0 R0 C1 R1 ...; a round without a single survivor on any
+    rank sends no records (every rank sees that in the gathered counts).  tests/test_distributed_cpu.py records a gloo run's calls and compares."""
+    if form not in ("all_gather", "gather_to_root", "counts_only"):
+        raise ValueError("form must be 'all_gather', 'gather_to_root' or 'counts_only'")
+    n_refs, world, B = int(n_refs), int(world), max(1, int(refs_per_round))
+    cols, dtype = (7, "float32") if record == RECORD_F32 else (15, "uint8")
+    n_local_max = (n_refs + world - 1) // world
+    n_rounds = (n_local_max + B - 1) // B
+    ranks = []
+    for r in range(world):
+        pos = shard_references(n_refs, r, world)
+        ranks.append({"rank": r, "positions": pos, "rounds": [pos[c * B:(c + 1) * B] for c in range(n_rounds)]})
+
+    def rows_of(c):
+        if counts is None:
+            return None
+        per_rank = [sum(int(counts[g]) for g in ranks[r]["rounds"][c]) for r in range(world)]
+        return max(per_rank) if per_rank else 0
+
+    def count_step(c):
+        return {"op": "all_gather_into_tensor", "what": "counts", "round": c, "numel_in": B, "numel_out": world * B, "dtype": "int64"}
+
+    def record_step(c):
+        rows = rows_of(c)
+        if form == "counts_only" or rows == 0:
+            return None
+        n = None if rows is None else rows * cols
+        if form == "all_gather":
+            return {"op": "all_gather_into_tensor", "what": "records", "round": c, "rows": rows, "numel_in": n, "numel_out": None if n is None else world * n, "dtype": dtype}
+        return {"op": "gather", "what": "records", "round": c, "rows": rows, "numel_in": n, "numel_out": None if n is None else world * n, "dtype": dtype, "dst": int(root)}
+
+    seq = []
+    for c in range(n_rounds):
+        seq.append(count_step(c))
+        send = c if eager else c - 1
+        if send >= 0:
+            seq.append(record_step(send))
+    if n_rounds and not eager:
+        seq.append(record_step(n_rounds - 1))
+    return {"rounds": n_rounds, "refs_per_round": B, "form": form, "record": record, "record_bytes": cols * (4 if record == RECORD_F32 else 1),
+            "ranks": ranks, "collectives": [s for s in seq if s is not None]}
+
+
+class RecordingDist:
+    """A stand-in for the ``torch.distributed`` module handed to the classes of this file that forwards every call and logs the collectives - op name,
+    elements in / out, dtype - so that a run's ACTUAL sequence can be compared with ``exchange_schedule`` (CPU tests, gloo)."""
+    _LOGGED = ("all_gather_into_tensor", "gather", "all_reduce", "all_gather", "barrier", "isend", "recv", "batch_isend_irecv")
+
+    def __init__(self, dist):
+        self._dist = dist
+        self.log: List[dict] = []
+
+    def __getattr__(self, name):
+        fn = getattr(self._dist, name)
+        if name not in self._LOGGED:
+            return fn
+
+        def logged(*a, **kw):
+            entry = {"op": name}
+            tens = [x for x in a if isinstance(x, torch.Tensor)]
+            if name == "all_gather_into_tensor" and len(tens) >= 2:
+                entry.update(numel_out=int(tens[0].numel()), numel_in=int(tens[1].numel()), dtype=str(tens[1].dtype).replace("torch.", ""))
+            elif name == "gather" and tens:
+                entry.update(numel_in=int(tens[0].numel()), dtype=str(tens[0].dtype).replace("torch.", ""), dst=kw.get("dst"))
+            elif tens:
+                entry.update(numel_in=int(tens[0].numel()), dtype=str(tens[0].dtype).replace("torch.", ""))
+            self.log.append(entry)
+            return fn(*a, **kw)
+        return logged

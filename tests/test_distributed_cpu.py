@@ -127,14 +127,15 @@ def _overlap_worker(rank, world, port, n_refs, per_round, form, record, q):
     try:
         counts, pts = _make_points(n_refs, seed=3)
         mine = lfd_dist.shard_references(n_refs, rank, world)
-        ex = lfd_dist.OverlappedExchange(dist, n_refs, per_round, torch.device("cpu"), form=form, record=record)
+        rec_dist = lfd_dist.RecordingDist(dist)        # forwards every call, logs the collectives (the dry run's plan is compared with this log)
+        ex = lfd_dist.OverlappedExchange(rec_dist, n_refs, per_round, torch.device("cpu"), form=form, record=record)
         for i, g in enumerate(mine):
             if not counts[g]:
                 continue                                  # a reference without survivors is never pushed
             t = torch.from_numpy(pts[g])
             ex.push(i, t if record == "f32" else torch.from_numpy(np.ascontiguousarray(pts[g].view(np.uint8).reshape(-1, 28)[:, :15]).reshape(-1)))
         recs, gcounts = ex.finish()
-        q.put((rank, recs.numpy(), gcounts, ex.n_rounds))
+        q.put((rank, recs.numpy(), gcounts, ex.n_rounds, rec_dist.log))
     finally:
         dist.destroy_process_group()
 
@@ -162,12 +163,24 @@ def test_overlapped_exchange_is_the_single_process_sequence(n_refs, world, per_r
             return np.zeros((0, 7), np.float32) if record == "f32" else np.zeros((0,), np.uint8)
         full = np.concatenate(parts, 0)
         return full if record == "f32" else np.ascontiguousarray(full.view(np.uint8).reshape(-1, 28)[:, :15]).reshape(-1)
-    for rank, recs, gcounts, n_rounds in results:
+    # the dry run (core/distributed.py::exchange_schedule: no communicator, no GPU) names the collectives this run really issued, on every rank, in
+    # order: op, elements handed over and received, dtype - what RCCL will match operation by operation on the first real multi-GPU run
+    plan = lfd_dist.exchange_schedule(n_refs, world, per_round, form, record, counts=counts)
+    for rank, recs, gcounts, n_rounds, log in results:
         np.testing.assert_array_equal(gcounts, counts)
-        assert n_rounds == -(-(-(-n_refs // world)) // per_round)
+        assert n_rounds == -(-(-(-n_refs // world)) // per_round) == plan["rounds"]
         mine = lfd_dist.shard_references(n_refs, rank, world)
+        assert plan["ranks"][rank]["positions"] == mine
         expect = as_sent(pts) if (form == "all_gather" or rank == 0) else as_sent([pts[g] for g in mine])
         np.testing.assert_array_equal(recs, expect)
+        issued = [e for e in log if e["op"] in ("all_gather_into_tensor", "gather")]
+        assert len(issued) == len(plan["collectives"]), (rank, issued, plan["collectives"])
+        for got, want in zip(issued, plan["collectives"]):
+            assert got["op"] == want["op"] and got["numel_in"] == want["numel_in"] and got["dtype"] == want["dtype"], (rank, got, want)
+            if want["op"] == "all_gather_into_tensor":
+                assert got["numel_out"] == want["numel_out"]
+            else:
+                assert got["dst"] == want["dst"]
 
 
 def test_ply_records_give_back_positions_and_quantised_colours():
