@@ -135,6 +135,13 @@ def pipeline_leg(dev, *, n_cams: int = 185, latency_ms: float = 20.0, scene_root
             m["host_prep"] = run_once(scene_root, matcher, mode=mode, device_prep=False, **kw)
             if on_gpu:
                 m["device_prep"] = run_once(scene_root, matcher, mode=mode, device_prep=True, **kw)
+        if "zero" in runs and on_gpu:
+            # the zero-latency runs are bound by the JPEG decode on upstream's default of 4 pack threads: the same run with one thread per core
+            # the container may use (the decode is the only stage that scales with it)
+            from lichtfeld_densification_plugin_amd.core import hostenv
+            cores = max(4, hostenv.usable_cores())
+            if cores > 4:
+                m[f"device_prep_{cores}_pack_workers"] = run_once(scene_root, matcher, mode=mode, device_prep=True, pack_workers=cores, **kw)
         if "latency" in runs and latency_ms > 0:
             matcher.latency = latency_ms * 1e-3
             m[f"device_prep_matcher_{latency_ms:g}ms_per_pair" if on_gpu else f"host_prep_matcher_{latency_ms:g}ms_per_pair"] = \

@@ -78,6 +78,12 @@ class Image:
     def points2D(self) -> List[Point2D]:
         return [Point2D(x, y, p) for (x, y), p in zip(self._xys, self._p3d)]
 
+    def observed_point3D_ids(self) -> np.ndarray:
+        """The ids ``[p.point3D_id for p in points2D if p.has_point3D() and p.point3D_id != -1]`` as one array (what the visibility-based
+        reference selection asks of every image, core/selection.py: millions of observations in a real scene - not one Python object each)."""
+        p = self._p3d
+        return p[(p != -1) & (p.astype(np.uint64) != np.uint64(0xFFFFFFFFFFFFFFFF))]
+
 
 class Reconstruction:
     """``cameras`` / ``images`` / ``points3D`` dictionaries of a sparse model directory (binary files preferred, text otherwise)."""

@@ -266,3 +266,51 @@ def test_intrinsics_follow_upstreams_model_chain_in_its_order():
                                ("FOV", [900, 910, 500, 400, 0.9], (900, 900, 910, 500)), ("UNKNOWN", [900], (900, 900, 500, 400))]:
         K = densify.K_from_camera(cam(name, params))
         assert K.dtype == np.float32 and (float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])) == tuple(float(np.float32(v)) for v in want), name
+
+
+def test_visibility_selection_is_upstreams_greedy_loop_at_scene_size():
+    """core/selection.py::select_cameras_by_visibility computes upstream's picks (core/selection.py:10-33 there: the first by observations incl.
+    duplicates, the others by distinct uncovered points, ties to the first image) incrementally; against the plain loop on a scene-sized model -
+    60 images, 20 000 points, 0.3 M observations with duplicates, unobserved entries and ties."""
+    from lichtfeld_densification_plugin_amd.core import colmap_io as cio, selection
+    rs = np.random.RandomState(3)
+    n_img, n_pts = 60, 20000
+
+    class Rec:
+        points3D = {1: 1}
+        images = {}
+    rec = Rec()
+    for i in range(n_img):
+        m = int(rs.randint(2000, 8000))
+        p = (int(rs.randint(0, n_pts)) + rs.randint(-4000, 4000, size=m)) % n_pts + 1
+        p[rs.rand(m) < 0.1] = -1
+        if i % 7 == 3:
+            p = rec.images[i].observed_point3D_ids().copy() if i in rec.images else p           # an exact duplicate of the previous image: a tie
+        rec.images[i + 1] = cio.Image(i + 1, [1, 0, 0, 0], [0, 0, 0], 1, f"{i}.jpg", np.zeros((p.size, 2)), p)
+
+    def upstream_loop(k):
+        lists = {im.image_id: [int(x) for x in im.observed_point3D_ids()] for im in rec.images.values()}
+        k = min(k, len(lists))
+        sel, cov, scores = [], set(), {i: len(p) for i, p in lists.items()}
+        for _ in range(k):
+            if not scores:
+                break
+            b = max(scores, key=scores.get)
+            sel.append(b)
+            cov.update(set(lists[b]) - cov)
+            del scores[b]
+            for c, pts in lists.items():
+                if c in scores:
+                    scores[c] = len(set(pts) - cov)
+        return sorted(sel)
+    for k in (1, 7, 48, 60, 200):
+        assert selection.select_cameras_by_visibility(rec, k) == upstream_loop(k), k
+    # objects that only offer pycolmap's interface (points2D / has_point3D) take the same path through the generic extraction
+    class Img:
+        def __init__(self, im):
+            self.image_id, self._im = im.image_id, im
+        points2D = property(lambda self: self._im.points2D)
+    rec2 = Rec()
+    rec2.images = {i: Img(im) for i, im in list(rec.images.items())[:12]}
+    rec.images = dict(list(rec.images.items())[:12])
+    assert selection.select_cameras_by_visibility(rec2, 9) == upstream_loop(9)
