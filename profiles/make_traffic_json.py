@@ -33,7 +33,7 @@ def main():
     f32 = sum(per_cell(n) for n in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32"))
     trans = per_cell("SQ_INSTS_VALU_TRANS_F64") + per_cell("SQ_INSTS_VALU_TRANS_F32")
     total = per_cell("SQ_INSTS_VALU")
-    # real cycles per wave-instruction under load and the clock it runs at: profiles/r3/clock_under_load.txt (profiles/microbench/clock_under_load.hip)
+    # real cycles per wave-instruction under load and the clock it runs at: profiles/microbench/clock_under_load.txt (profiles/microbench/clock_under_load.hip)
     cyc_f64, cyc_other, clock_ghz = 4.4, 2.3, 1.9
     cycles_per_cell = f64 * cyc_f64 + (total - f64) * cyc_other + trans * 8.0       # (reciprocals / roots are quarter rate: ~8 more cycles each)
     issue_ms = cells / 64.0 / 1024.0 * cycles_per_cell / (clock_ghz * 1e9) * 1e3
@@ -52,7 +52,7 @@ def main():
             "cycles_per_wave_instruction": {"f64": cyc_f64, "other": cyc_other}, "sustained_clock_GHz": clock_ghz,
             "issue_cycles_per_cell": cycles_per_cell, "issue_ms": issue_ms,
             "source": f"{where}/instruction_mix.txt (SQ_INSTS_VALU_* per launch x 64 lanes / cells); cycles per wave-instruction and the sustained clock from "
-                      "profiles/r3/clock_under_load.txt (profiles/microbench/clock_under_load.hip)",
+                      "profiles/microbench/clock_under_load.txt (profiles/microbench/clock_under_load.hip)",
             "note": "SQ_ACTIVE_INST_VALU counts 4-cycle units summed over the chip; SQ_BUSY_CYCLES is summed over the 32 shader engines (32 SIMDs each)"},
     }
     print(json.dumps(out, indent=2))
