@@ -15,7 +15,7 @@ OUT = os.path.join(os.path.dirname(HERE), "liblfd_densify.so")
 SOURCES = ["lfd_api.hip", "lfd_kernels.hip", "lfd_select.hip", "lfd_writer.hip", "lfd_host.hip", "lfd_image.hip"]
 HEADERS = ["lfd_device.hpp", "lfd_geometry.hpp", "lfd_context.hpp", os.path.join("..", "..", "include", "lfd_densify.h")]
 # -amdgpu-sched-strategy=max-ilp: the dense kernel is bound by its vector arithmetic (long dependent f64 chains); the
-# ILP-first machine scheduler is worth 3.5 % on it (profiles/r1/ablation.txt), instruction semantics are unchanged
+# ILP-first machine scheduler is worth 3.5 % on it (profiles/history.md (r1/ablation.txt)), instruction semantics are unchanged
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-pthread", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 

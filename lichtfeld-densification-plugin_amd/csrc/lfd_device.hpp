@@ -21,18 +21,18 @@
 #define LFD_DENSE_CPT 4         // consecutive grid cells per thread (one 16-byte certainty load per slot)
 #ifndef LFD_DENSE_WAVES_PER_SIMD
 #define LFD_DENSE_WAVES_PER_SIMD 8       // register budget of the fused kernel: 512/8 = 64 VGPRs.  Round 3: the geometry loop fits (63-64, no scratch) since
-                                         // nothing constant is kept in vector registers across it any more, and the tile's LDS block is 20.4 KB: eight workgroups per CU (7: 0.2819, 8: see profiles/r3/ablation.txt)
+                                         // nothing constant is kept in vector registers across it any more, and the tile's LDS block is 20.4 KB: eight workgroups per CU (7: 0.2819, 8: see profiles/history.md (r3/ablation.txt))
 #endif
 #ifndef LFD_DENSE_ALL_WARPS
 #define LFD_DENSE_ALL_WARPS 2   // dense kernel, references with at most this many neighbours (two-channel warps, no masks): the warps of ALL slots ride
                                 // along with the certainty planes - one dependent memory round trip less for 8 (k-1) B per cell more traffic.
-                                // Measured (profiles/r2/ablation.txt): k = 1 0.118 -> 0.116 ms, k = 2 0.307 -> 0.290, k = 3 0.317 -> 0.307 (but 1.44 x
+                                // Measured (profiles/history.md (r2/ablation.txt)): k = 1 0.118 -> 0.116 ms, k = 2 0.307 -> 0.290, k = 3 0.317 -> 0.307 (but 1.44 x
                                 // the algorithmic bytes instead of 1.10 x), k = 4 slower.  On up to two neighbours; 0 = never.
 #endif
 #ifndef LFD_FRONT_PRIO
 #define LFD_FRONT_PRIO 1        // s_setprio of a dense-kernel wave until its geometry loop starts (0 = off): the handful of instructions between the
                                 // front end's memory requests then go ahead of older waves' f64 streams instead of waiting for a free slot
-                                // (profiles/r2/ablation.txt: 0.331 -> 0.318 ms)
+                                // (profiles/history.md (r2/ablation.txt): 0.331 -> 0.318 ms)
 #endif
 #define LFD_INDEXED_BLOCK 1024  // one workgroup (16 waves) per reference in the indexed kernel
 #define LFD_INDEXED_EVAL_BLOCK 256   // cells per workgroup of the indexed-mode evaluation kernel

@@ -195,7 +195,7 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
 // Two solves are always made; more follow only while the growth factor has not settled (bad
 // conditioning: sigma4/sigma3 not small).
 #ifndef LFD_PACK_ROWS
-#define LFD_PACK_ROWS 0     /* bit 0: the reference view's DLT rows as packed f32 operations, bit 1: the neighbour's.  Measured: the packed forms need 2-6 registers more than the geometry loop has (scratch in the loop: 0.333-0.384 ms against 0.315), profiles/r2/ablation.txt */
+#define LFD_PACK_ROWS 0     /* bit 0: the reference view's DLT rows as packed f32 operations, bit 1: the neighbour's.  Measured: the packed forms need 2-6 registers more than the geometry loop has (scratch in the loop: 0.333-0.384 ms against 0.315), profiles/history.md (r2/ablation.txt) */
 #endif
 #ifndef LFD_PARALLAX_EXACT
 #define LFD_PARALLAX_EXACT 4      /* upstream's own parallax sequence (normalised rays).  1: IEEE sqrtf, one IEEE reciprocal + three Markstein quotients per ray
@@ -208,7 +208,7 @@ LFD_HD void lfd_make_pair_const(const LfdCam& a, const LfdCam& b, int cam_index,
 /* direction change (relative, on x_i/x_3) of the last solve that counts as settled.  The change measures the error of the
  * PREVIOUS iterate; the one returned is q = (sigma4/sigma3)^2 times closer: within 1e-8 of v4 for sigma4/sigma3 <= 0.1.
  * (1e-5 instead would save 0.35 solves per cell - a wave iterates until its slowest lane has settled - for 1 % of the dense
- * kernel's time and ten times the error: measured, not taken, profiles/r2/ablation.txt.) */
+ * kernel's time and ten times the error: measured, not taken, profiles/history.md (r2/ablation.txt.)) */
 #define LFD_NULLVEC_TOL 1e-6
 #endif
 #ifndef LFD_NULLVEC_MAXIT
@@ -230,7 +230,7 @@ LFD_HD double lfd_pow2_inv_scale(double t) {
 }
 
 #ifndef LFD_RCP_NEWTON_STEPS
-/* v_rcp_f64 is good to 2^-24.4; one Newton step brings it to 2^-48.7 (2.2e-15 relative, profiles/r1/valu_rate.txt), two to the last
+/* v_rcp_f64 is good to 2^-24.4; one Newton step brings it to 2^-48.7 (2.2e-15 relative, profiles/history.md (r1/valu_rate.txt)), two to the last
  * bit.  One is enough here: the factorisation then is that of a matrix 2e-15 (relative) away from M - M itself carries 1e-16 per
  * entry - which turns v4 by at most 2e-15 (sigma1/sigma3)^2.  Measured on three full-size shapes against two steps
  * (profiles/cmp_newton.py): the same survivors, 99.998 % of the f32 coordinates bit-identical, the others 1 ulp apart; -1.1 % of the

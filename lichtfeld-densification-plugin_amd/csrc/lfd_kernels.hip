@@ -554,7 +554,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
     // The workgroups that are resident when the launch starts all begin at once and would run through their phases in step -
     // every tile fetching, then every tile computing (the first generation of tiles lives 48 us, the later ones 33).  The k-th
     // workgroup a CU receives waits k x ~1.5 us before it draws its ticket (a heuristic on the dispatch order: harmless where it
-    // does not hold).  Measured 0.2966 -> 0.292 ms (profiles/r2/ablation.txt).
+    // does not hold).  Measured 0.2966 -> 0.292 ms (profiles/history.md (r2/ablation.txt)).
     if (blockIdx.x < (unsigned)LFD_DENSE_WAVES_PER_SIMD * 256u) {      // (one resident workgroup per wave slot of a SIMD, 256 CUs)
         const unsigned slot = blockIdx.x >> 8;
         for (unsigned i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(LFD_STAGGER_UNITS);
@@ -629,7 +629,7 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
         // Up to four neighbours, two-channel warps, no masks: the warps of ALL slots are requested together with the certainty
         // planes (dense 16-byte loads) and the winner's is picked in registers, instead of a second, dependent round trip for the
         // winner's warp alone (8-byte loads at a 32-byte stride).  Costs 8 (k - 1) more bytes per cell of HBM traffic - the
-        // kernel is bound by its chain of memory round trips, not by bandwidth (profiles/r2/phases_*.txt).
+        // kernel is bound by its chain of memory round trips, not by bandwidth (profiles/history.md (r2/phases_*.txt)).
         float spec_xb[4] = {0.0f, 0.0f, 0.0f, 0.0f}, spec_yb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         bool have_warps = false;
         if (!any_mask && (HW & 3) == 0 && kCpt == 4 && cell0 + 3 < HW && ns <= LFD_DENSE_ALL_WARPS && L.warp_channels == 2) {
