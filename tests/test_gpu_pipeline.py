@@ -716,3 +716,40 @@ def test_dense_streamer_without_the_look_back_writes_every_references_point_set(
     for i in range(len(offs) - 1):
         sa, sb = ra[offs[i]:offs[i + 1]], rb[offs[i]:offs[i + 1]]
         np.testing.assert_array_equal(sa[np.lexsort(sa.T[::-1])], sb[np.lexsort(sb.T[::-1])])
+
+
+def test_dense_streamer_failure_paths_raise_and_never_hang(g4, tmp_path, monkeypatch):
+    """The writer thread of DensePlyStreamer: a failing append (disk full) is kept, the queued records are still drained, the run raises that error and the
+    thread is gone; a cancellation between references raises PipelineCancelled with the thread stopped and the file closed (a valid PLY of what was written)."""
+    import threading
+    from lichtfeld_densification_plugin_amd.core import writers
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+    kw = dict(nns_per_ref=2, seed=5, viz_interval=0, triangulation_mode="dense", refs_per_launch=1, stream_output=True)
+    real = writers.StreamedPlyWriter.append_packed
+    calls = {"n": 0}
+
+    def failing(self, body):
+        calls["n"] += 1
+        if calls["n"] == 2:
+            raise OSError(28, "No space left on device")
+        return real(self, body)
+    monkeypatch.setattr(writers.StreamedPlyWriter, "append_packed", failing)
+    with pytest.raises(OSError, match="No space left"):
+        pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(output_path=os.path.join(str(tmp_path), "full.ply"), **kw), matcher=FakeMatcher(64, 64, table))
+    assert calls["n"] >= 2 and not [t for t in threading.enumerate() if t.name == "lfd-ply-writer"]
+    monkeypatch.setattr(writers.StreamedPlyWriter, "append_packed", real)
+    seen = {"n": 0}
+
+    def cancel():
+        seen["n"] += 1
+        return seen["n"] > 5
+    out = os.path.join(str(tmp_path), "cancelled.ply")
+    with pytest.raises(pl.PipelineCancelled):
+        pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(output_path=out, **kw), matcher=FakeMatcher(64, 64, table), cancel_requested=cancel)
+    assert not [t for t in threading.enumerate() if t.name == "lfd-ply-writer"]
+    head, body = open(out, "rb").read().split(b"end_header\n", 1)
+    n = int([ln for ln in head.decode().split("\n") if ln.startswith("element vertex")][0].split()[-1])
+    assert len(body) == 15 * n                                   # closed properly: the header counts what the body holds
+    # ... and the next run on the same process is unaffected
+    ok = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(output_path=os.path.join(str(tmp_path), "ok.ply"), **kw), matcher=FakeMatcher(64, 64, table))
+    assert ok.n_points > 3000
