@@ -25,6 +25,17 @@ from .writers import ply_records
 PREPARED_CACHE_BYTES = int(os.environ.get("LFD_PREPARED_CACHE_MB", "4096")) << 20
 
 
+def _upload_u8(a, dev) -> torch.Tensor:
+    """A u8 array to where the kernels run, without a host copy in between.  The loaders' caches hand out READ-ONLY arrays (a cached image must not be
+    written to); torch warns when it wraps one - the wrapper here is only ever read (uploaded, or handed to the CPU twin, which takes const pointers)."""
+    import warnings
+    arr = np.ascontiguousarray(a, dtype=np.uint8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        t = torch.from_numpy(arr)
+    return t if torch.device(dev).type == "cpu" else t.to(dev)
+
+
 class HotPath:
     """Per-run state of the hot path: context, camera table, and the ways of triangulating a reference."""
 
@@ -59,6 +70,15 @@ class HotPath:
         if self._own:
             self.dens.close()
 
+    def stage_decoded(self, cam_index: int, size_wh: Tuple[int, int], img, mask_l):
+        """Called on a PACK thread with a freshly decoded view (device_image_prep): unless the camera's prepared tensors are already on the device,
+        the decoded bytes start their way there now - a 3-4 MB pageable copy per image that would otherwise sit on the driver's thread between
+        two matcher calls.  (Two packages that need the same new camera at the same moment both upload it: harmless.)"""
+        if (int(cam_index), int(size_wh[0]), int(size_wh[1]), mask_l is not None) in self._prepared:
+            return img, mask_l
+        with self.clock.stage("prepare", sync=False):
+            return _upload_u8(img, self.dev), (_upload_u8(mask_l, self.dev) if mask_l is not None else None)
+
     def prepare_on_device(self, packed: PackedReference, size_wh: Tuple[int, int], need_host: bool) -> PackedReference:
         """device_image_prep: the decoded arrays of ``packed`` are uploaded and resized / thresholded / blacked out by
         lfd_prepare_mask + lfd_prepare_image (Pillow's arithmetic, bit for bit); the result replaces the host-prepared arrays
@@ -66,7 +86,7 @@ class HotPath:
         dev = self.dev
 
         def up(a):
-            return torch.from_numpy(np.array(a, dtype=np.uint8, copy=True)).to(dev)      # the decode cache hands out read-only arrays
+            return a if isinstance(a, torch.Tensor) else _upload_u8(a, dev)          # (a pack thread may have uploaded it already: stage_decoded)
 
         def one(cam_index, img, mask_l):
             # A camera is prepared the same way whether it is the reference or a neighbour, and it appears in ~k + 1 packages of a
@@ -115,10 +135,9 @@ class HotPath:
         mask_b = None
         with self.clock.stage("prepare"):        # the host-prepared image and masks cross to where the kernels run
             if use_masks:
-                mask_b = [torch.from_numpy(np.array(m, dtype=np.uint8, copy=True)).to(dev) if m is not None else None
-                          for m in packed.nbr_masks]
-            image = torch.from_numpy(np.array(packed.image, dtype=np.uint8, copy=True)).to(dev)
-            mask_a = torch.from_numpy(np.array(packed.mask_a, dtype=np.uint8, copy=True)).to(dev) if packed.mask_a is not None else None
+                mask_b = [_upload_u8(m, dev) if m is not None else None for m in packed.nbr_masks]
+            image = _upload_u8(packed.image, dev)
+            mask_a = _upload_u8(packed.mask_a, dev) if packed.mask_a is not None else None
         return hb.ReferenceInputs(ref_cam=packed.ref_index, nbr_cams=list(packed.nbr_indices), cert=certs, warp=warps, image=image,
                                   mask_a=mask_a, mask_b=mask_b)
 

@@ -72,14 +72,18 @@ def _load_view(cam: CameraRecord, size_wh: Tuple[int, int], raw: bool, who: str)
 
 
 def pack_reference(position: int, ref_index: int, cams: Sequence[CameraRecord], nn_table, nns_per_ref: int,
-                   size_wh: Tuple[int, int], cancel, raw: bool = False) -> Optional[PackedReference]:
+                   size_wh: Tuple[int, int], cancel, raw: bool = False, stage=None) -> Optional[PackedReference]:
     """Load and pre-process one reference and its neighbours (upstream core/pipeline.py:132-227): same skip / warn rules.  ``raw``: decode
-    only; the resize / mask / black-out steps then run on the GPU (``HotPath.prepare_on_device``)."""
+    only; the resize / mask / black-out steps then run on the GPU (``HotPath.prepare_on_device``).  ``stage(cam_index, image, mask)``: what a
+    pack thread does with a freshly decoded view before it hands the package over (``HotPath.stage_decoded``: the upload, here instead of on the
+    driver's thread)."""
     if cancelled(cancel):
         return None
     cam = cams[ref_index]
     try:
         img_a, mask_a = _load_view(cam, size_wh, raw, "reference")
+        if stage is not None:
+            img_a, mask_a = stage(ref_index, img_a, mask_a)
     except Exception as exc:
         log.warn(f"Failed to load reference {cam.image_path}: {exc}")
         return None
@@ -96,6 +100,8 @@ def pack_reference(position: int, ref_index: int, cams: Sequence[CameraRecord], 
             continue
         try:
             img_b, mask_b = _load_view(nb, size_wh, raw, "neighbor")
+            if stage is not None:
+                img_b, mask_b = stage(n, img_b, mask_b)
         except Exception as exc:
             log.warn(f"Failed to load neighbor {nb.uid}: {exc}")
             continue

@@ -118,8 +118,8 @@ def _match_reference(local_i: int, packed: PackedReference, matcher, hot: HotPat
         if not results:
             return None
         first_pair = outputs.note_pairs(local_i, len(results))
-        warps = [torch.as_tensor(w).detach().to(dev, torch.float32).contiguous() for w, _c in results]
-        certs = [torch.as_tensor(c).detach().to(dev, torch.float32).contiguous() for _w, c in results]
+        warps = [_as_device_map(w, dev) for w, _c in results]
+        certs = [_as_device_map(c, dev) for _w, c in results]
     H, W = certs[0].shape
     axes = None
     ax = getattr(matcher, "reference_axes", None)
@@ -127,6 +127,13 @@ def _match_reference(local_i: int, packed: PackedReference, matcher, hot: HotPat
         a0, a1 = ax(H, W)
         axes = (torch.as_tensor(a0).to(dev, torch.float32).contiguous(), torch.as_tensor(a1).to(dev, torch.float32).contiguous())
     return Matched(local_i, packed, hot.inputs(packed, warps, certs), axes, int(H), int(W), first_pair, want_debug)
+
+
+def _as_device_map(t, dev) -> torch.Tensor:
+    """A matcher output as the contiguous f32 tensor on ``dev`` the kernels read in place - which it normally already is (no call, no copy then)."""
+    if isinstance(t, torch.Tensor) and t.device == dev and t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad:
+        return t
+    return torch.as_tensor(t).detach().to(dev, torch.float32).contiguous()
 
 
 def _make_strategy(config, plan: ShardPlan, hot: HotPath, outputs: RunOutputs, per_ref_rng: bool, debug_state):
@@ -198,9 +205,12 @@ def run_dense_pipeline(
         if bool(getattr(matcher, "supports_feature_keys", False)):
             feat_cache = FeatureCache(schedule.last_use) if config.share_features else None
             matcher.set_feature_cache(feat_cache)    # always (re)set: an injected, warm matcher may still hold the cache of an earlier run
+        stage = (lambda ci, im, mk: hot.stage_decoded(ci, size_wh, im, mk)) if config.device_image_prep else None
         jobs = [(lambda p=p: pack_reference(p, refs_local[p], camera_records, nn_table, config.nns_per_ref, size_wh, cancel_requested,
-                                            raw=bool(config.device_image_prep))) for p in plan.my_positions]
-        prefetch = OrderedPrefetcher(jobs, workers=int(config.pack_workers), window=int(config.prefetch_packages), clock=clock)
+                                            raw=bool(config.device_image_prep), stage=stage)) for p in plan.my_positions]
+        # (upstream's `prefetch_packages` bounds the queue of FINISHED packages while all of its workers keep loading: the look-ahead here is at
+        # least one package per worker, so that none of them idles)
+        prefetch = OrderedPrefetcher(jobs, workers=int(config.pack_workers), window=max(int(config.prefetch_packages), int(config.pack_workers)), clock=clock)
         outputs.open()
         strategy = _make_strategy(config, plan, hot, outputs, per_ref_rng, debug_state)
         total_refs = len(plan.my_positions)
@@ -267,7 +277,10 @@ def _release(prefetch, strategy, feat_cache, own_matcher, matcher, outputs: RunO
         hot.close()
     if debug_state:
         debug_state.release_waiters()
-    gc.collect()
+    # upstream's `gc.collect(); torch.cuda.empty_cache()` (core/pipeline.py:904-907) exists to give the model's memory back: the collection runs where a
+    # model was torn down (this run built it; RomaMatcher.close collects too), the run's own buffers - no reference cycles - go back to the driver either way
+    if own_matcher is not None:
+        gc.collect()
     if torch.cuda.is_available():
         torch.cuda.empty_cache()
     return failed

@@ -291,6 +291,7 @@ class SyntheticMatcher:
         self.kw = dict(noise_px=noise_px, outlier_frac=outlier_frac, channels=int(channels), seed=int(seed), cert_mode=cert_mode)
         self.latency = float(latency_s_per_pair)
         self.table: dict = {}
+        self._axes: dict = {}
         self.fingerprints: dict = {}
         self.calls = self.pairs = 0
         self.seconds = 0.0                 # wall time spent inside match_grids_batch (the stand-in latency included)
@@ -299,7 +300,10 @@ class SyntheticMatcher:
         pass
 
     def reference_axes(self, H: int, W: int):
-        return identity_axis_torch(W, self.device), identity_axis_torch(H, self.device)
+        key = (int(H), int(W))
+        if key not in self._axes:
+            self._axes[key] = (identity_axis_torch(W, self.device), identity_axis_torch(H, self.device))
+        return self._axes[key]
 
     @staticmethod
     def _fingerprint(img) -> bytes:
