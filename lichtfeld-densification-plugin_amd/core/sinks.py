@@ -28,13 +28,13 @@ _PREVIEW_MAX_MATCHES = 10000     # upstream core/pipeline.py:50
 
 class PipelineResult:
     """upstream core/pipeline.py:37-43 (``xyz``, ``rgb``, ``err``, ``elapsed_seconds``, ``pairs_processed``) plus what this implementation
-    knows beyond it.  When the run streamed its output as file records (dense mode + ``stream_output``) the three arrays are read back from
-    the written file on first access - positions exact, colours as quantised (u8 / 255), no reprojection error (a PLY vertex has none) -
-    so a caller that only wants the file never pays for them."""
+    knows beyond it.  The three arrays are made on FIRST ACCESS: from the device tensors (``device_points``: one copy across PCIe), or - when the run
+    streamed its output as file records (dense mode + ``stream_output``) - read back from the written file: positions exact, colours as quantised
+    (u8 / 255), no reprojection error (a PLY vertex has none).  A caller that only wants the file, or keeps working on the GPU, never pays for them."""
 
     def __init__(self, xyz=None, rgb=None, err=None, elapsed_seconds: float = 0.0, pairs_processed: int = 0, pairs_matched: int = 0,
                  points_per_reference: Optional[np.ndarray] = None, device_points=None, streamed_path: Optional[str] = None,
-                 stages: Optional[dict] = None, loader: Optional[Callable[[], Tuple[np.ndarray, np.ndarray, np.ndarray]]] = None):
+                 clock=None, loader: Optional[Callable[[], Tuple[np.ndarray, np.ndarray, np.ndarray]]] = None):
         self._arrays = (xyz, rgb, err) if loader is None else None
         self._loader = loader
         self.elapsed_seconds = float(elapsed_seconds)
@@ -43,12 +43,18 @@ class PipelineResult:
         self.points_per_reference = points_per_reference
         self.device_points = device_points                    # the same points, still on the GPU (None when only records were made)
         self.streamed_path = streamed_path                    # config.stream_output: the PLY already written while the run proceeded
-        self.stages = stages                                  # run_dense_pipeline(stage_clock=...): StageClock.report()
+        self._clock = clock
 
     def _get(self, i: int) -> np.ndarray:
         if self._arrays is None:
             self._arrays = tuple(self._loader())
         return self._arrays[i]
+
+    @property
+    def stages(self) -> Optional[dict]:
+        """run_dense_pipeline(stage_clock=...): StageClock.report() as it stands NOW (what the caller does with the result afterwards - bringing
+        the arrays to the host, writing the file - is charged to the same clock); None without a clock"""
+        return self._clock.report() if hasattr(self._clock, "report") else None
 
     xyz = property(lambda self: self._get(0))      # (N,3) f32
     rgb = property(lambda self: self._get(1))      # (N,3) f32 in [0,1]
@@ -56,9 +62,12 @@ class PipelineResult:
 
     @property
     def n_points(self) -> int:
-        if self.points_per_reference is not None:
-            return int(np.sum(self.points_per_reference))
-        return int(self.xyz.shape[0])
+        """points this result holds (a rank of a gather_to_root run that is not the root holds its own shard), without materialising the arrays"""
+        if self.device_points is not None:
+            return int(self.device_points[0].shape[0])
+        if self._arrays is not None:
+            return int(self._arrays[0].shape[0])
+        return int(np.sum(self.points_per_reference)) if self.points_per_reference is not None else int(self.xyz.shape[0])
 
 
 def arrays_from_ply(path: str):
@@ -380,15 +389,20 @@ class RunOutputs:
             raise RuntimeError("No points triangulated. Try adjusting parameters.")
         if self.records_only:
             loader = lambda path=self.config.output_path: arrays_from_ply(path)       # noqa: E731
+        elif device_points is not None and device_points[0].is_cuda:
+            # the f32 cloud crosses PCIe when - and only if - somebody asks for the arrays: a caller that writes the file (densify.py packs the
+            # records on the device) or keeps working on the GPU never pays for it
+            def loader(pts=device_points, clk=clock):
+                with clk.stage("d2h"):
+                    return tuple(t.cpu().numpy() for t in pts)
         elif device_points is not None:
-            with clock.stage("d2h"):           # the survivors cross PCIe once, here
-                arrays = tuple(t.cpu().numpy() for t in device_points)
+            arrays = tuple(t.numpy() for t in device_points)
         else:
             arrays = (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0,), np.float32))
         xyz, rgb, err = arrays if arrays is not None else (None, None, None)
         return PipelineResult(xyz=xyz, rgb=rgb, err=err, elapsed_seconds=time.time() - t0, pairs_processed=refs_with_points,
                               pairs_matched=pairs, points_per_reference=counts, device_points=device_points, streamed_path=streamed_path,
-                              stages=clock.report() if hasattr(clock, "report") else None, loader=loader)
+                              clock=clock, loader=loader)
 
 
 __all__ = ["PipelineResult", "ShardPlan", "Emission", "ShardLink", "RunOutputs", "arrays_from_ply", "build_preview", "cancelled"]

@@ -123,6 +123,19 @@ def _apply_point_cap(xyz, rgb, err, max_points: int, seed: int):
     return xyz, rgb, err
 
 
+def _finish_on_device(result, path: str, max_points: int, seed: int, clock=None) -> Optional[int]:
+    """Point cap + output file for a result whose points are still on the GPU, without ever bringing the f32 cloud to the host: the same subset
+    ``_apply_point_cap`` picks (the same generator, the same call), applied to the device tensors, then the file payload packed on the device
+    (``_write_output``).  Returns the number of points written, or None when the result is not on a GPU (the host path applies)."""
+    pts = result.device_points
+    if pts is None or not pts[0].is_cuda:
+        return None
+    pts = _cap_device_points(pts, int(pts[0].shape[0]), max_points, seed)
+    n = int(pts[0].shape[0])
+    _write_output(path, np.empty((n, 0), np.float32), None, None, pts, clock=clock)
+    return n
+
+
 def _voxel_downsample(xyz: np.ndarray, rgb: np.ndarray, voxel_size: float) -> Tuple[np.ndarray, np.ndarray]:
     """One averaged point (and colour) per occupied voxel.  Uses Open3D when installed (upstream
     densify.py:29-50); otherwise an equivalent NumPy voxel-grid average (voxel order then follows the
@@ -157,7 +170,7 @@ def _is_writer_rank() -> bool:
         return True
 
 
-def _write_output(path: str, xyz, rgb, err, device_points=None) -> None:
+def _write_output(path: str, xyz, rgb, err, device_points=None, clock=None) -> None:
     """``.ply`` -> upstream's PLY, anything else -> upstream's points3D.bin (densify.py:129-135).  When
     the points are still on the GPU the records are quantised and packed there (lfd_pack_*) and only
     the final bytes are copied to the host; the files are byte-identical either way."""
@@ -170,13 +183,16 @@ def _write_output(path: str, xyz, rgb, err, device_points=None) -> None:
     if device_points is not None and device_points[0].is_cuda and int(device_points[0].shape[0]) == int(xyz.shape[0]):
         from .core import hip_backend as hb
         from .core.writers import write_ply_packed, write_points3D_bin_packed
+        from .core.stages import NULL_CLOCK
+        clock = clock if clock is not None else NULL_CLOCK
         dens = hb.HipDensifier(device_points[0].device)
         try:
             n = int(xyz.shape[0])
-            if as_ply:
-                write_ply_packed(path, n, dens.pack_ply(device_points[0], device_points[1]).cpu().numpy().tobytes())
-            else:
-                write_points3D_bin_packed(path, n, dens.pack_points3d(*device_points).cpu().numpy().tobytes())
+            with clock.stage("d2h"):            # the file payload - 15 / 43 bytes per point - is what crosses PCIe
+                packed = dens.pack_ply(device_points[0], device_points[1]) if as_ply else dens.pack_points3d(*device_points)
+                body = packed.cpu().numpy().tobytes()
+            with clock.stage("write", sync=False):
+                (write_ply_packed if as_ply else write_points3D_bin_packed)(path, n, body)
         finally:
             dens.close()
         return
@@ -259,10 +275,11 @@ def dense_init(args, progress_callback: Optional[Callable[[float, str], None]] =
     if result.streamed_path == config.output_path:      # config.stream_output: the file is already complete (and no cap applies to it)
         n_points = result.n_points
     else:
-        xyz, rgb, err = _apply_point_cap(result.xyz, result.rgb, result.err, args.max_points, args.seed)
-        dev_pts = _cap_device_points(result.device_points, result.xyz.shape[0], args.max_points, args.seed)
-        _write_output(config.output_path, xyz, rgb, err, dev_pts)
-        n_points = int(xyz.shape[0])
+        n_points = _finish_on_device(result, config.output_path, args.max_points, args.seed, clock=pipeline_kwargs.get("stage_clock"))
+        if n_points is None:
+            xyz, rgb, err = _apply_point_cap(result.xyz, result.rgb, result.err, args.max_points, args.seed)
+            _write_output(config.output_path, xyz, rgb, err, None)
+            n_points = int(xyz.shape[0])
     log.info(f"Dense reconstruction finished: {n_points:,} points -> {config.output_path}")
     if progress_callback:
         progress_callback(100.0, f"Done! {n_points:,} points")
@@ -308,6 +325,15 @@ def dense_init_from_lfs(camera_nodes, config: DensePipelineConfig,
         log.info(f"Dense point cloud saved to {config.output_path} ({result.n_points:,} points)")
         if progress_callback:
             progress_callback(100.0, f"Done! {result.n_points:,} points")
+        return 0, config.output_path
+    if config.voxel_size <= 0.0 and config.output_path.lower().endswith(".ply") and result.device_points is not None and result.device_points[0].is_cuda:
+        # nothing has to see the cloud on the host: the cap is applied and the file payload packed where the points are
+        if progress_callback:
+            progress_callback(95.0, "Writing output PLY...")
+        n_written = _finish_on_device(result, config.output_path, config.max_points, config.seed, clock=pipeline_kwargs.get("stage_clock"))
+        log.info(f"Dense point cloud saved to {config.output_path} ({n_written:,} points)")
+        if progress_callback:
+            progress_callback(100.0, f"Done! {n_written:,} points")
         return 0, config.output_path
     xyz, rgb, err = _apply_point_cap(result.xyz, result.rgb, result.err, config.max_points, config.seed)
     dev_pts = _cap_device_points(result.device_points, result.xyz.shape[0], config.max_points, config.seed)
