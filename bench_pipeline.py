@@ -102,7 +102,8 @@ def run_once(scene_root: str, matcher, *, mode: str, device_prep: bool, backend:
 
 
 def pipeline_leg(dev, *, n_cams: int = 185, latency_ms: float = 20.0, scene_root: str = None, backend: str = "device", roma_setting: str = "fast",
-                 width: int = 1297, height: int = 840, refs_per_launch: int = 16, runs=("zero", "latency", "stages")) -> dict:
+                 width: int = 1297, height: int = 840, refs_per_launch: int = 16, runs=("zero", "latency", "stages"), num_refs: float = 0.8,
+                 nns: int = 3) -> dict:
     """The `pipeline` object of the bench line: {"scene", "sampled": {...}, "dense": {...}, "pcie"}."""
     from lichtfeld_densification_plugin_amd import densify, synthetic
     t_setup = time.perf_counter()
@@ -111,17 +112,17 @@ def pipeline_leg(dev, *, n_cams: int = 185, latency_ms: float = 20.0, scene_root
         own_tmp = tempfile.TemporaryDirectory(prefix="lfd_bench_scene_")
         scene_root = own_tmp.name
     synthetic.write_colmap_scene(scene_root, n_cams=n_cams, width=width, height=height, images_subdir="images_4", fmt="jpg", seed=0)
-    plan_args = densify.build_argparser().parse_args(["--scene_root", scene_root, "--images_subdir", "images_4", "--num_refs", "0.8", "--nns_per_ref", "3"])
+    plan_args = densify.build_argparser().parse_args(["--scene_root", scene_root, "--images_subdir", "images_4", "--num_refs", str(num_refs), "--nns_per_ref", str(nns)])
     records, refs_local, nn_table, _sparse = densify.plan_scene(plan_args)
     on_gpu = backend == "device"
     matcher = synthetic.SyntheticMatcher(records, setting=roma_setting, device=dev if on_gpu else "cpu", noise_px=0.5, outlier_frac=0.05, channels=2, seed=0)
-    matcher.precompute(refs_local, nn_table, 3)
+    matcher.precompute(refs_local, nn_table, nns)
     setup_s = time.perf_counter() - t_setup
-    kw = dict(backend=backend, roma_setting=roma_setting, refs_per_launch=refs_per_launch)
-    leg = {"scene": {"cameras": n_cams, "image_size": [width, height], "image_format": "jpeg q90", "references": len(refs_local), "neighbours": 3,
+    kw = dict(backend=backend, roma_setting=roma_setting, refs_per_launch=refs_per_launch, num_refs=num_refs, nns=nns)
+    leg = {"scene": {"cameras": n_cams, "image_size": [width, height], "image_format": "jpeg q90", "references": len(refs_local), "neighbours": nns,
                      "pairs": sum(len(k[1]) for k in matcher.table), "grid": [matcher.H, matcher.W], "setup_seconds": round(setup_s, 2),
                      "what": "synthetic garden-like COLMAP scene on disk (sparse/0 + images_4), densify.dense_init with GUI defaults "
-                             "(0.8 of the cameras as references x 3 neighbours, M = 10000, reprojection 0.8 px), matcher = analytic fields from a table on the GPU"},
+                             f"({num_refs:g} of the cameras as references x {nns} neighbours, M = 10000, reprojection 0.8 px), matcher = analytic fields from a table on the GPU"},
            "note": "seconds = wall time of densify.dense_init (COLMAP read, reference / neighbour selection, image decode + preparation, matcher stand-in, "
                    "hot path, survivors to the host, PLY written and closed); image caches cleared before every run; `stage_seconds` of the plain runs are "
                    "host wall time per stage (launches are asynchronous: device time shows where the host next waits), `stages` is a separate run that "
@@ -171,13 +172,17 @@ def main():
     ap.add_argument("--backend", default="device", choices=["device", "host"])
     ap.add_argument("--setting", default="fast")
     ap.add_argument("--size", default="1297x840")
+    ap.add_argument("--num-refs", type=float, default=0.8, help="fraction (<= 1) or count of reference views (GUI default 0.8)")
+    ap.add_argument("--nns", type=int, default=3, help="neighbours per reference (GUI default 3)")
+    ap.add_argument("--refs-per-launch", type=int, default=16)
     a = ap.parse_args()
     from lichtfeld_densification_plugin_amd.core import hostenv
     hostenv.fit_threads_to_quota()
     w, h = (int(v) for v in a.size.split("x"))
     dev = torch.device("cuda", 0) if a.backend == "device" else torch.device("cpu")
     print(json.dumps({"pipeline": pipeline_leg(dev, n_cams=a.cams, latency_ms=a.latency_ms, scene_root=a.scene_root, backend=a.backend,
-                                               roma_setting=a.setting, width=w, height=h)}), flush=True)
+                                               roma_setting=a.setting, width=w, height=h, num_refs=a.num_refs, nns=a.nns, refs_per_launch=a.refs_per_launch)}),
+          flush=True)
 
 
 if __name__ == "__main__":

@@ -267,11 +267,18 @@ class DensePlyStreamer:
             tpr = self.hot.dens.tiles_per_ref(cells, 1) if self.unordered else 0
             self.slots.append(_Slot(max(n_refs, int(self.config.refs_per_launch)), cells, self.hot.dev, tpr))
             return self.slots[-1]
-        with self.hot.clock.stage("write", sync=False):      # both pairs are busy: the file is what the run waits for
-            fits[0].free.wait()
-        self.slots.remove(fits[0])
-        self.slots.append(fits[0])                            # (the pair written longest ago is asked first next time)
-        return fits[0]
+        # Both pairs are busy.  One of them may belong to a launch that is still in flight: its records reach the writer - and the pair comes back -
+        # only after that launch has been COLLECTED, so everything in flight is collected first (waiting for such a pair without doing so would
+        # wait forever); from then on every busy pair is in the writer's queue and the file is what the run waits for.
+        while self.launched:
+            self._collect()
+        with self.hot.clock.stage("write", sync=False):
+            while True:
+                for s in fits:
+                    if s.free.wait(timeout=0.002):
+                        return s
+                if not self.thread.is_alive():
+                    raise RuntimeError("the PLY writer thread has stopped")
 
     def _launch(self) -> None:
         if not self.pending:

@@ -753,3 +753,31 @@ def test_dense_streamer_failure_paths_raise_and_never_hang(g4, tmp_path, monkeyp
     # ... and the next run on the same process is unaffected
     ok = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(output_path=os.path.join(str(tmp_path), "ok.ply"), **kw), matcher=FakeMatcher(64, 64, table))
     assert ok.n_points > 3000
+
+
+def test_dense_streamer_with_a_writer_that_falls_behind(g4, tmp_path, monkeypatch):
+    """Six launches of one reference each, a file that is fast at first and then slower than the kernels: both buffer pairs are busy when a launch
+    needs one - one of them still with a launch in flight.  (Round 5 found the first version waiting for exactly that pair without collecting its
+    launch: a deadlock that only showed at `high` on a 2 GB file.)  The run completes and the file is the plain run's."""
+    import time as _time
+    from lichtfeld_densification_plugin_amd.core import writers
+    from lichtfeld_densification_plugin_amd.core.image_io import to_uint8_rgb
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+    refs6, table6 = refs + refs, table + table
+    kw = dict(nns_per_ref=2, seed=5, viz_interval=0, triangulation_mode="dense", refs_per_launch=1)
+    plain = pl.run_dense_pipeline(cams, refs6, nn, lfd.DensePipelineConfig(output_path=os.path.join(str(tmp_path), "p.ply"), **kw), matcher=FakeMatcher(64, 64, table6))
+    real = writers.StreamedPlyWriter.append_packed
+    calls = {"n": 0}
+
+    def slow(self, body):
+        calls["n"] += 1
+        if calls["n"] > 2:
+            _time.sleep(0.25)
+        return real(self, body)
+    monkeypatch.setattr(writers.StreamedPlyWriter, "append_packed", slow)
+    out = os.path.join(str(tmp_path), "slow.ply")
+    res = pl.run_dense_pipeline(cams, refs6, nn, lfd.DensePipelineConfig(output_path=out, stream_output=True, **kw), matcher=FakeMatcher(64, 64, table6))
+    assert calls["n"] == 6 and res.n_points == plain.xyz.shape[0]
+    ref = os.path.join(str(tmp_path), "ref.ply")
+    writers.write_ply(ref, plain.xyz, to_uint8_rgb(plain.rgb))
+    assert open(out, "rb").read().split(b"end_header\n", 1)[1] == open(ref, "rb").read().split(b"end_header\n", 1)[1]
