@@ -4,7 +4,7 @@
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 run() {   # name, args...
   name=$1; shift
-  python3 $REPO/bench_pipeline.py --latency-ms 0 "$@" 2>/dev/null | python3 -c "
+  timeout 400 python3 $REPO/bench_pipeline.py --latency-ms 0 "$@" 2>>$REPO/gpurun_out/pipeline_other_configs.err | python3 -c "
 import json, sys
 p = json.load(sys.stdin)['pipeline']
 sc = p['scene']
