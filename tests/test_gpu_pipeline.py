@@ -781,3 +781,33 @@ def test_dense_streamer_with_a_writer_that_falls_behind(g4, tmp_path, monkeypatc
     ref = os.path.join(str(tmp_path), "ref.ply")
     writers.write_ply(ref, plain.xyz, to_uint8_rgb(plain.rgb))
     assert open(out, "rb").read().split(b"end_header\n", 1)[1] == open(ref, "rb").read().split(b"end_header\n", 1)[1]
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_dense_streamer_under_random_writer_delays(g4, tmp_path, monkeypatch, seed):
+    """nine launches' worth of references, 1-4 per launch, an appending file whose latency jumps around between 0 and 30 ms (seeded): whatever the
+    interleaving of launches, copies and appends, the file is the plain run's"""
+    import time as _time
+    from lichtfeld_densification_plugin_amd.core import writers
+    from lichtfeld_densification_plugin_amd.core.image_io import to_uint8_rgb
+    rs = np.random.RandomState(seed)
+    cams, refs, nn, table = _scene(g4, str(tmp_path))
+    refs9, table9 = refs * 3, table * 3
+    per_launch = int(rs.randint(1, 5))
+    kw = dict(nns_per_ref=2, seed=5, viz_interval=0, triangulation_mode="dense", refs_per_launch=per_launch)
+    plain = pl.run_dense_pipeline(cams, refs9, nn, lfd.DensePipelineConfig(output_path=os.path.join(str(tmp_path), "p.ply"), **kw), matcher=FakeMatcher(64, 64, table9))
+    real = writers.StreamedPlyWriter.append_packed
+    delays = rs.choice([0.0, 0.0, 0.002, 0.03], size=32)
+    calls = {"n": 0}
+
+    def jittery(self, body):
+        _time.sleep(float(delays[calls["n"] % len(delays)]))
+        calls["n"] += 1
+        return real(self, body)
+    monkeypatch.setattr(writers.StreamedPlyWriter, "append_packed", jittery)
+    out = os.path.join(str(tmp_path), "j.ply")
+    res = pl.run_dense_pipeline(cams, refs9, nn, lfd.DensePipelineConfig(output_path=out, stream_output=True, **kw), matcher=FakeMatcher(64, 64, table9))
+    assert res.n_points == plain.xyz.shape[0] and calls["n"] == -(-9 // per_launch)
+    ref = os.path.join(str(tmp_path), "ref.ply")
+    writers.write_ply(ref, plain.xyz, to_uint8_rgb(plain.rgb))
+    assert open(out, "rb").read().split(b"end_header\n", 1)[1] == open(ref, "rb").read().split(b"end_header\n", 1)[1]
