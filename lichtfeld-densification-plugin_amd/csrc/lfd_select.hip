@@ -719,8 +719,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         return;
     }
 
-    // ---- p = (weights / s) as f32; exactness precondition; non-zero count; span sums; marks and first-occurrence words
-    //      initialised; coverage bins (best cell of every tile bin, by weight, ties: lower index) -----------------------------
+    // ---- p = (weights / s) as f32; exactness precondition; non-zero count; span sums; marks initialised; coverage bins (best cell of every tile bin, by weight, ties: lower index) -----------------------------
     {
         int nz = 0, inexact = 0, neg = 0;
         double part = 0.0;
@@ -732,9 +731,8 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
                 pf[0] = w4.x / s32; pf[1] = w4.y / s32; pf[2] = w4.z / s32; pf[3] = w4.w / s32;
                 *reinterpret_cast<float4*>(wbuf + i) = make_float4(pf[0], pf[1], pf[2], pf[3]);
                 *reinterpret_cast<unsigned*>(mark + i) = 0u;
-                *reinterpret_cast<int4*>(A.first + i) = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
             } else {
-                for (int e = 0; e < 4 && i + e < w_hi; ++e) { pf[e] = wbuf[i + e] / s32; wbuf[i + e] = pf[e]; mark[i + e] = 0; A.first[i + e] = 0x7fffffff; }
+                for (int e = 0; e < 4 && i + e < w_hi; ++e) { pf[e] = wbuf[i + e] / s32; wbuf[i + e] = pf[e]; mark[i + e] = 0; }
             }
             int cur_bin = -1;
             unsigned long long cur_key = 0ull;
@@ -858,9 +856,16 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             __syncthreads();
             if (!ok) { if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
         }
-        // new = searchsorted(cdf, x, side="right"); the first occurrence of a value is found with an atomicMin of the draw index
+        // new = searchsorted(cdf, x, side="right"), and what numpy does with it - keep the first occurrence of every distinct value, append, p[found] = 0 -
+        // in the SAME phase: the selection's result is np.unique(...) of the cells found, so the ORDER they are appended in is never observed; a cell is
+        // new exactly when its "drawn" bit was clear (a cell found in an earlier round has p = 0 and a zero-width interval of the cumulative sum: the
+        // search cannot return it again), which one atomic OR on the mark's word tells - no first-occurrence words, no ordered compaction, and two grid
+        // barriers per round instead of four.  (The marks live in bytes; the coverage picks below set bit 1 with the same atomic, so that neither
+        // update can lose the other's bit.)
         s_chunk[tid] = cdf[min((tid + 1) * per, N) - 1];
         __syncthreads();
+        unsigned* mark32 = reinterpret_cast<unsigned*>(mark);
+        int cnt = 0;
         for (int j = gt; j < need; j += T) {
             const double x = A.draws[j];
             int lo = 0, len = kSelBlock;
@@ -869,8 +874,12 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             lo = b;
             int hi = min(b + per, N);
             while (hi - lo > 0) { const int half = (hi - lo) >> 1, mid = lo + half; if (cdf[mid] <= x) lo = mid + 1; else hi = mid; }
-            A.cand[j] = lo;
-            atomicMin(&A.first[lo], (int)(tag | (unsigned)j));
+            const unsigned bit = 1u << (8 * (lo & 3));
+            const unsigned old = atomicOr(mark32 + (lo >> 2), bit);
+            if (!(old & bit)) {
+                ++cnt;
+                atomicAdd(&g_span[lo / span], -(double)wbuf[lo]);                                // p[found] = 0 from now on: exact, hence order-independent
+            }
         }
         if (guard == 1) {
             // the coverage picks (the `budget` heaviest bins) are flagged now - bit 1 of the mark, which the cumulative sum ignores
@@ -888,46 +897,29 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
                 if (mine != 0ull) for (int o = sub; o < nbins; o += 32) rank += (s_bin[o] > mine);
 #pragma unroll
                 for (int off = 16; off > 0; off >>= 1) rank += __shfl_xor(rank, off, 32);
-                if (mine != 0ull && sub == 0 && rank < budget) mark[0xffffffffu - (unsigned)(mine & 0xffffffffull)] = 2;
-            }
-        }
-        LFD_MW_STAMP();
-        LFD_GRID_SYNC();
-        LFD_MW_STAMP();
-    LFD_MW_STAMP();
-        // first occurrence of every distinct value, in draw order: thread g owns the draws [g*c, (g+1)*c)
-        {
-            const int c = (need + T - 1) / T;
-            const long long jl = (long long)gt * c;
-            const int j_lo = (int)(jl < need ? jl : need), j_hi = min(j_lo + c, need);
-            int cnt = 0;
-            for (int j = j_lo; j < j_hi; ++j)
-                cnt += __hip_atomic_load(&A.first[A.cand[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)(tag | (unsigned)j);
-            int total;
-            int pos = block_excl_scan_i32(cnt, s_i, tid, total);
-            if (tid == 0) g_cnt[wg] = total;
-            LFD_MW_STAMP();
-            LFD_GRID_SYNC();
-            LFD_MW_STAMP();
-        LFD_MW_STAMP();
-    LFD_MW_STAMP();
-            int base = 0, appended = 0;
-            for (int g = 0; g < G; ++g) { const int v = g_cnt[g]; if (g < wg) base += v; appended += v; }
-            if (n_uniq + appended < size) LFD_TELL_RNG(guard + 1, size - n_uniq - appended);      // next round's draws can start now
-            for (int j = j_lo; j < j_hi; ++j) {
-                const int cell = A.cand[j];
-                if (__hip_atomic_load(&A.first[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)(tag | (unsigned)j)) {
-                    A.found[n_uniq + base + pos++] = cell;
-                    mark[cell] = (unsigned char)(mark[cell] | 1);                                // p[found] = 0 from now on ...
-                    atomicAdd(&g_span[cell / span], -(double)wbuf[cell]);                      // ... exact, hence order-independent
+                if (mine != 0ull && sub == 0 && rank < budget) {
+                    const unsigned cell = 0xffffffffu - (unsigned)(mine & 0xffffffffull);
+                    atomicOr(mark32 + (cell >> 2), 2u << (8 * (cell & 3u)));
                 }
             }
-            n_uniq += appended;
+        }
+        // per-workgroup counts of this round, in a slot of their own per round parity (the `found` scratch, which nothing else uses any more): a
+        // workgroup that is through the barrier below and already counting for the NEXT barrier - the next round's, or the final unique pass's, which
+        // uses g_cnt - must not overwrite what a slower one is still summing
+        int* round_cnt = A.found + (guard & 1) * G;
+        {
+            const int total = block_sum_i32(cnt, s_i, tid);
+            if (tid == 0) round_cnt[wg] = total;
         }
         LFD_MW_STAMP();
         LFD_GRID_SYNC();
         LFD_MW_STAMP();
-    LFD_MW_STAMP();
+        {
+            int appended = 0;
+            for (int g = 0; g < G; ++g) appended += round_cnt[g];
+            if (n_uniq + appended < size) LFD_TELL_RNG(guard + 1, size - n_uniq - appended);      // next round's draws can start now
+            n_uniq += appended;
+        }
     }
     LFD_TELL_RNG(0xffffffffu, 0);                                  // the stream is final: the other workgroup commits it
 
