@@ -50,6 +50,26 @@ SCRIPT = textwrap.dedent("""
             if b.numel(): stream.push(i, b)
         stream.finish()
         assert b"".join(sink.parts) == b"".join(b.cpu().numpy().tobytes() for b in bodies)
+        # round 5 (core/sinks.py::ShardLink): the streamed file travels on a process group OF ITS OWN, which is destroyed at the end of the run, and the
+        # result is exchanged on the default group only AFTER that stream has been drained - never two communicators in flight at once
+        grp = dist.new_group()
+        sink2 = Sink()
+        stream2 = D.ShardedPlyStream(dist, 3, sink2, dev, group=grp)
+        for i, b in enumerate(bodies):
+            if b.numel(): stream2.push(i, b)
+        stream2.finish()
+        assert b"".join(sink2.parts) == b"".join(sink.parts)
+        dist.destroy_process_group(grp)
+        x, c, e, gc = D.all_gather_by_reference(xyz, rgb, err, counts, len(counts), dist)          # the default communicator is untouched by that
+        assert torch.equal(x, xyz) and gc.tolist() == counts
+        plan = D.exchange_schedule(len(counts), 1, 2, "all_gather", "f32", counts=counts)
+        rec_dist = D.RecordingDist(dist)
+        ex = D.OverlappedExchange(rec_dist, len(counts), 2, dev, form="all_gather", record="f32")
+        for i, c_ in enumerate(counts):
+            if c_: ex.push(i, torch.zeros(c_, 7, device=dev))
+        ex.finish()
+        issued = [e_ for e_ in rec_dist.log if e_["op"] in ("all_gather_into_tensor", "gather")]
+        assert [(e_["op"], e_["numel_in"]) for e_ in issued] == [(p_["op"], p_["numel_in"]) for p_ in plan["collectives"]], (issued, plan["collectives"])
         # the exchange in rounds (asynchronous collectives on the communicator's stream), both forms and both record kinds
         parts = [torch.randn(c, 7, generator=g).to(dev) for c in counts]
         for form in ("all_gather", "gather_to_root"):
@@ -102,7 +122,7 @@ def test_bench_exchange_legs_through_rccl_on_one_rank():
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
         assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
         d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
-        assert d["n_gpus"] == 1 and d["collective_backend"] == "nccl"
+        assert d["n_gpus"] == 1 and d["collective_backend"] == "nccl" and d["rccl_ranks"] == 1       # (what the communicator itself reports through an all-reduce)
         ex = d["exchange"]
         assert ex["points"] > 0 and ex["overlapped"] and ex["end_of_run_28B"]["allgather_ms"] > 0 and ex["end_of_run_28B"]["gather_to_root_ms"] > 0
         assert ex["rounds"] == (3 if "gather_to_root" in extra else 2) and ex["record_bytes"] == (28 if "f32" in extra else 15)
