@@ -333,7 +333,22 @@ def ply_output_rate(args, dens, batch, params, H, W, cells, s_frac, launches=100
     dens.check_launches()
     k_ms = float(np.mean(ms))
     bytes_ply = cells * (4 * args.k + 11 + 15 * s_frac)
-    return {"kernel": "lfd_dense_ply_kernel", "kernel_ms": k_ms, "bytes_per_cell": 4 * args.k + 11 + 15 * s_frac, "achieved": bytes_ply / (k_ms * 1e-3) / 1e9,
+    # ... and without the ordered retirement (round 5: lfd_triangulate_dense_ply_segments, every reference's point set in its own region)
+    tpr = dens.tiles_per_ref(H, W)
+    table = torch.zeros((n * tpr, 2), dtype=torch.int32, device=dens.device)
+    counts = torch.zeros((n,), dtype=torch.int64, device=dens.device)
+    for _ in range(16):
+        dens.launch_dense_ply_segments(batch, params, rec, counts, table)
+    dens.time_dense_kernels(launches)
+    for _ in range(launches):
+        dens.launch_dense_ply_segments(batch, params, rec, counts, table)
+    ms_u = dens.dense_kernel_times_ms()
+    dens.time_dense_kernels(0)
+    dens.check_launches()
+    u_ms = float(np.mean(ms_u))
+    unordered = {"kernel": "lfd_dense_ply_segments_kernel", "kernel_ms": u_ms, "achieved": bytes_ply / (u_ms * 1e-3) / 1e9, "frac": bytes_ply / (u_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "survivors": int(counts.sum().item())}
+    return {"kernel": "lfd_dense_ply_kernel", "kernel_ms": k_ms, "unordered": unordered, "bytes_per_cell": 4 * args.k + 11 + 15 * s_frac, "achieved": bytes_ply / (k_ms * 1e-3) / 1e9,
             "frac": bytes_ply / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "survivors": int(offs[-1].item()),
             "note": "15-byte records from the kernel itself: replaces lfd_triangulate_dense + lfd_pack_ply (secondary_kernels.lfd_pack_ply_kernel.ms) where the consumer "
                     "is the PLY writer / the exchange; bytes equal the packer's (tests/test_gpu_segments.py)"}

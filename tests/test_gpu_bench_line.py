@@ -16,7 +16,7 @@ def test_single_gpu_bench_line_contract():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LFD_BENCH_FORCE_DIST"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "5", "--warmup", "2", "--refs", "6", "--preset", "turbo", "--cpu-sample-refs", "2",
-           "--parity-refs", "1", "--spinup-s", "0.05"]
+           "--parity-refs", "1", "--spinup-s", "0.05", "--pipeline-cams", "8", "--pipeline-size", "320x208", "--pipeline-latency-ms", "1"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -34,6 +34,15 @@ def test_single_gpu_bench_line_contract():
     assert d["parity"]["flipped_out_of_band"] == 0 and d["parity"]["cells"] == 320 * 320
     u = d["unordered_retirement"]
     assert u["kernel"] == "lfd_dense_segments_kernel" and u["kernel_ms"] > 0 and u["survivors"] > 0
+    po = d["ply_output"]
+    assert po["kernel"] == "lfd_dense_ply_kernel" and po["unordered"]["kernel"] == "lfd_dense_ply_segments_kernel" and po["unordered"]["survivors"] == po["survivors"] == u["survivors"]
+    dm = d["default_mode"]                                   # the user-visible default beside the dense headline
+    assert dm["ms_per_reference"] > 0 and abs(dm["refs_per_s"] - 1e3 / dm["ms_per_reference"]) < 1e-6 * dm["refs_per_s"] and dm["pairs_per_s"] > dm["refs_per_s"]
+    assert d["rccl_ranks"] == 0 and d["collective_backend"] is None
+    rp = d["cpu_baseline"]["reference_python"]               # upstream's own code, timed in the development container (tests/golden/g11_reference_timing.json)
+    assert rp["cores"] >= 1 and rp["ms_per_reference"] > 10 and rp["run_dense_pipeline"]["pack_workers_1"]["references"] > 100
+    pl = d["pipeline"]                                       # the end-to-end leg on a small scene (--pipeline-cams 8)
+    assert pl["scene"]["cameras"] == 8 and pl["sampled"]["device_prep"]["points"] > 0 and pl["dense"]["device_prep"]["d2h_bytes"] == 15 * pl["dense"]["device_prep"]["points"]
     s = d["sampled_mode"]
     assert s["ms_per_reference"] > 0 and s["pipelined_ms_per_reference"] > 0 and s["default_config_ms_per_reference"] > 0 and s["grouped"]["ms_per_reference"] > 0
     assert d["end_to_end"] is None and "unmeasured" in d["end_to_end_note"]
