@@ -216,3 +216,46 @@ def test_replicated_references_give_the_single_process_result(g4, tmp_path, mode
         else:
             assert n_mine == len(range(rank, len(refs) - n_rep, 2))                            # not a consumer of the cloud: its share of the sharded part only
             np.testing.assert_array_equal(counts[:len(refs) - n_rep], single.points_per_reference[:len(refs) - n_rep])
+
+
+def _rank_repeating(rank, world, port, tmp, cfg_kw, q):
+    import torch.distributed as dist
+    from torch.distributed import distributed_c10d as c10d
+    from conftest import load_golden
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cams, refs, nn, table = _scene(load_golden("g4_pipeline.npz"), tmp)
+        mine = [table[i] for i in range(len(refs)) if i % world == rank]
+        groups, counts = [], []
+        for _ in range(3):
+            res = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**cfg_kw), matcher=_Replay(mine))
+            groups.append(len(c10d._world.pg_map))
+            counts.append(int(res.points_per_reference.sum()))
+        q.put((rank, groups, counts))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_repeated_streamed_sharded_runs_leave_no_process_group_behind(g4, tmp_path):
+    """a streamed sharded run creates a process group of its own (dist.new_group()); it is destroyed at the end of the run - three runs in one
+    process (the plugin lives in LichtFeld Studio for hours) leave exactly the default group, and each gives the same cloud"""
+    import torch.multiprocessing as mp
+    tmp = str(tmp_path)
+    _scene(g4, tmp)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    cfg_kw = dict(output_path=os.path.join(tmp, "sharded.ply"), stream_output=True, nns_per_ref=2, seed=5, viz_interval=0, matches_per_ref=1200,
+                  triangulation_mode="dense", per_reference_rng=True, backend="host", pack_workers=1)
+    procs = [ctx.Process(target=_rank_repeating, args=(r, 2, port, tmp, cfg_kw, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, groups, counts in results:
+        assert groups == [groups[0]] * 3 and groups[0] == 1, (rank, groups)         # only the default group is left after every run
+        assert counts == [counts[0]] * 3 and counts[0] > 3000
