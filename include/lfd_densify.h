@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LFD_ABI_VERSION 7
+#define LFD_ABI_VERSION 8
 #define LFD_MAX_SLOTS 16 /* neighbours per reference handled by one launch */
 
 enum lfd_status {
@@ -226,6 +226,19 @@ int lfd_triangulate_sampled(lfd_context* ctx, const lfd_batch* batch, const lfd_
  * reference's seed. */
 int lfd_triangulate_sampled_multi(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, int32_t M, float cap,
                                   int32_t border, int32_t tiles, const uint32_t* seeds, const lfd_points* out,
+                                  int64_t* ref_offsets, int32_t* seg_counts, int32_t* seg_order, int32_t* sel_info,
+                                  int64_t* sel_cells);
+
+/* SEVERAL reference views per call on the CONTEXT's one MT19937 stream - upstream's single global stream (np.random.seed(config.seed) once,
+ * core/pipeline.py:793; every reference's np.random.choice continues where the one before it stopped, core/sampling.py:32) - consumed in
+ * batch order: the points, the cells selected and the position the stream is left at are those of n_refs successive
+ * lfd_triangulate_sampled calls, bit for bit.  What does not depend on the stream (weights, probabilities, the first cumulative sum of every
+ * reference) runs side by side; a reference starts drawing where the one before it stopped.  A reference whose selection refuses its input
+ * (selection status != 0: upstream raises before it draws) consumes nothing and emits nothing, the others are not affected.
+ * s_overrides: host f32 [n_refs] or NULL - the normaliser of reference r (> 0: upstream's own torch sum, handed in; else the exact device sum).
+ * out->capacity, sel_info, sel_cells: as lfd_triangulate_sampled_multi.  lfd_rng_seed / lfd_rng_set_state first. */
+int lfd_triangulate_sampled_chain(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, int32_t M, float cap,
+                                  int32_t border, int32_t tiles, const float* s_overrides, const lfd_points* out,
                                   int64_t* ref_offsets, int32_t* seg_counts, int32_t* seg_order, int32_t* sel_info,
                                   int64_t* sel_cells);
 

@@ -18,7 +18,7 @@ import torch
 from .types import CameraRecord, DensePipelineConfig
 
 LFD_MAX_SLOTS = 16
-LFD_ABI_VERSION = 7
+LFD_ABI_VERSION = 8
 LFD_FLAG_EXACT_COLOUR = 1     # lfd_params.flags: dense mode blends colours with upstream's f64 arithmetic (bit-identical rgb)
 LFD_FLAG_TILE_SEGMENTS = 2    # informational: the caller takes the unordered-retirement route (lfd_triangulate_dense_segments)
 _LIB_NAME = "liblfd_densify.so"
@@ -158,6 +158,9 @@ def load_library() -> C.CDLL:
     lib.lfd_triangulate_sampled_multi.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_int32, C.c_float, C.c_int32,
                                                   C.c_int32, C.POINTER(C.c_uint32), C.POINTER(lfd_points), C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_void_p]
+    lib.lfd_triangulate_sampled_chain.argtypes = [ctxp, C.POINTER(lfd_batch), C.POINTER(lfd_params), C.c_int32, C.c_float, C.c_int32,
+                                                  C.c_int32, C.POINTER(C.c_float), C.POINTER(lfd_points), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p]
     lib.lfd_select_top_m.argtypes = [ctxp, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int64,
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.lfd_pack_ply.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -193,7 +196,7 @@ def load_library() -> C.CDLL:
                                                  C.c_int32, C.POINTER(lfd_params), fptr]
     for name in ("lfd_create", "lfd_set_stream", "lfd_reload_env", "lfd_kernel_timing", "lfd_kernel_timing_read", "lfd_upload_cameras", "lfd_prepare_batch", "lfd_aggregate", "lfd_triangulate_dense",
                  "lfd_triangulate_dense_ply", "lfd_triangulate_dense_ply_segments", "lfd_dense_tiles_per_ref", "lfd_triangulate_dense_segments", "lfd_order_segments", "lfd_pack_ply_segments", "lfd_pack_points3d_segments",
-                 "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_triangulate_sampled_multi", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
+                 "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_triangulate_sampled_multi", "lfd_triangulate_sampled_chain", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
                  "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_copy_segments", "lfd_identity_axis",
                  "lfd_host_fundamental", "lfd_get_pair_fundamental", "lfd_create_host", "lfd_aggregate_host",
                  "lfd_triangulate_dense_host", "lfd_triangulate_indexed_host", "lfd_prepare_image", "lfd_prepare_mask",
@@ -371,6 +374,7 @@ class TriangulationOutput:
     seg_order: Optional[np.ndarray] = None   # indexed mode: slot of the g-th emitted group, -1 = none
     n_selected: Optional[int] = None         # sampled call: cells the selection stage picked
     launch_status: int = 0                   # sampled call: look-back status of the launch (0 = ok)
+    sel_status: Optional[np.ndarray] = None  # sampled calls: selection status per reference (0 = ok, else what upstream would have raised for)
     _packed: Optional[torch.Tensor] = None   # the one float buffer xyz / rgb / err are views of
     _cap: int = 0
 
@@ -492,6 +496,11 @@ _tls = threading.local()
 _SELECT_ERRORS = {1: "probabilities contain NaN", 2: "probabilities are not non-negative", 3: "Fewer non-zero entries in p than size"}
 
 
+def selection_error(status: int) -> str:
+    """What upstream's sampling stage says (np.random.choice's ValueError texts) for a selection status of the fused calls."""
+    return _SELECT_ERRORS.get(int(status), f"selection failed with status {int(status)}")
+
+
 def _read_back_i32(t: torch.Tensor) -> np.ndarray:
     """Small int32 device tensor -> NumPy copy, staged through a per-thread pinned buffer (a pageable ``.cpu()`` costs
     ~2x as much and pinning a fresh buffer per call far more)."""
@@ -563,7 +572,8 @@ class OutputBuffers:
 
     def collect(self, indexed: bool = False, check_selection: bool = False) -> TriangulationOutput:
         """Synchronise and trim to the number of survivors.  ``check_selection``: raise what upstream's sampling stage
-        would have raised if the fused call's selection refused its input."""
+        would have raised if the fused call's selection refused its input (any reference's; without it the caller reads
+        ``sel_status`` reference by reference)."""
         if getattr(self, "_meta_pending", False):             # begin_collect() was called: wait for that copy alone
             self._meta_event.synchronize()
             self._meta_pending = False
@@ -589,6 +599,7 @@ class OutputBuffers:
             ref_offsets=offs, seg_counts=meta[n_off:n_off + n_seg].reshape(self._n_refs, self._k).copy(),
             seg_order=meta[n_off + n_seg:n_off + 2 * n_seg].reshape(self._n_refs, self._k).copy() if indexed else None,
             n_selected=int(meta[n_off + 2 * n_seg:n_off + 2 * n_seg + 2 * self._n_refs:2].sum()),
+            sel_status=meta[n_off + 2 * n_seg + 1:n_off + 2 * n_seg + 2 * self._n_refs:2].copy(),
             launch_status=int(meta[n_off + 2 * n_seg + 2 * self._n_refs]), _packed=self._f,
             _cap=max(self.capacity, 1))
 
@@ -935,6 +946,22 @@ class HipDensifier:
                                                             int(tiles), arr, C.byref(out.c), out.ref_offsets.data_ptr(),
                                                             out.seg_counts.data_ptr(), out.seg_order.data_ptr(), out.sel_info.data_ptr(), None),
                     "lfd_triangulate_sampled_multi")
+
+    def launch_sampled_chain(self, batch: PreparedBatch, params: lfd_params, M: int, out: OutputBuffers,
+                             s_overrides: Optional[Sequence[float]] = None, cap: float = 0.9, border: int = 2, tiles: int = 24,
+                             sel_cells: Optional[torch.Tensor] = None) -> None:
+        """Several reference views through the fused call at once on the context's ONE MT19937 stream, consumed in batch order
+        (lfd_triangulate_sampled_chain): the results and the stream afterwards are those of ``n_refs`` successive ``launch_sampled`` calls.
+        ``s_overrides[r]`` > 0: upstream's own normaliser of reference r.  ``out`` needs capacity n_refs * (M + tiles*tiles + 64)."""
+        if s_overrides is not None and len(s_overrides) != batch.n_refs:
+            raise ValueError("one normaliser per reference")
+        self._same_device(batch, out, sel_cells)
+        arr = (C.c_float * batch.n_refs)(*[float(v) for v in s_overrides]) if s_overrides is not None else None
+        self._check(self._lib.lfd_triangulate_sampled_chain(self._ctx, C.byref(batch.c), C.byref(params), int(M), C.c_float(cap), int(border),
+                                                            int(tiles), arr, C.byref(out.c), out.ref_offsets.data_ptr(),
+                                                            out.seg_counts.data_ptr(), out.seg_order.data_ptr(), out.sel_info.data_ptr(),
+                                                            sel_cells.data_ptr() if sel_cells is not None else None),
+                    "lfd_triangulate_sampled_chain")
 
     def triangulate_sampled(self, batch: PreparedBatch, params: lfd_params, M: int, cap: float = 0.9, border: int = 2,
                             tiles: int = 24, s_override: float = 0.0, with_cell: bool = True) -> TriangulationOutput:

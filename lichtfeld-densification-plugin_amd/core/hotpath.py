@@ -305,15 +305,44 @@ class HotPath:
             out.begin_collect(self.dens.stream)
         return batch, out
 
-    def finish_sampled(self, handle) -> Optional[hb.TriangulationOutput]:
-        """Wait for the reference's counts, copy its survivors out of the (recycled) buffers: the result owns trimmed tensors."""
+    # -- several references per fused call on upstream's ONE stream ------------------------------------------------------------------
+    def can_chain(self, need_best: bool, H: int, W: int) -> bool:
+        """``refs_per_launch`` references of the single-stream sampled mode may share one fused call (lfd_triangulate_sampled_chain: they draw one
+        after the other from the context's MT19937 stream, everything else runs side by side) under the launch-ahead's preconditions: device
+        selection that cannot refuse its input for inexactness, no debug preview that wants the aggregated map."""
+        cfg = self.config
+        if self.on_host or cfg.selection_backend != "device" or need_best:
+            return False
+        if cfg.no_filter:
+            return cfg.matches_per_ref <= self.dens.TOP_M_MAX
+        return float(cfg.certainty_thresh) >= 2.0 ** -29 * H * W * max(self.sample_cap, 1e-6)
+
+    def chain_uses_upstream_normaliser(self) -> bool:
+        return bool(self.config.upstream_normaliser) and not self.config.no_filter
+
+    def prepare_chain(self, refs: List[hb.ReferenceInputs], axes) -> hb.PreparedBatch:
+        """(separate from the launch: a reference that cannot be batched fails HERE, before anything has drawn from the stream)"""
+        return hb.PreparedBatch(refs, self.w_match, self.h_match, axes=axes, cameras=self.cams)
+
+    def launch_sampled_chain(self, batch: hb.PreparedBatch, s_overrides: Optional[List[float]]):
+        M = self.config.matches_per_ref
+        with self.clock.stage("kernel"):
+            out = self._take_buffers(batch.n_refs * (int(M) + 24 * 24 + 64), batch.n_refs, batch.k)
+            self.dens.launch_sampled_chain(batch, self.params, M, out, s_overrides=s_overrides, cap=self.sample_cap, border=2, tiles=24)
+            out.begin_collect(self.dens.stream)
+        return batch, out
+
+    def finish_sampled(self, handle, check_selection: bool = True) -> Optional[hb.TriangulationOutput]:
+        """Wait for the reference's counts, copy its survivors out of the (recycled) buffers: the result owns trimmed tensors.
+        ``check_selection=False``: the caller reads ``sel_status`` reference by reference (a chained group: a refused reference is that
+        reference's error, not the group's)."""
         _batch, out = handle
         try:
             with self.clock.stage("d2h"):          # the counts: whatever the device still had to do for this reference shows here
-                res = out.collect(indexed=True, check_selection=True)
+                res = out.collect(indexed=True, check_selection=check_selection)
             if res.launch_status != 0:
                 self.dens.check_launches()
-            if not res.count:
+            if not res.count and check_selection:
                 return None
             return dataclasses.replace(res, xyz=res.xyz.clone(), rgb=res.rgb.clone(), err=res.err.clone(),
                                        cell=res.cell.clone() if res.cell is not None else None,

@@ -173,9 +173,6 @@ def run_dense_pipeline(
     config.validate()
     config, dev = _resolve_backend(config, backend, device)
     per_ref_rng = bool(config.per_reference_rng) or world > 1
-    if config.triangulation_mode == "sampled" and int(config.refs_per_launch) > 1 and not per_ref_rng:
-        raise ValueError("refs_per_launch > 1 in sampled mode needs one RNG stream per reference (per_reference_rng=True, or a sharded run): "
-                         "upstream's single MT19937 stream is consumed reference after reference")
     clock = stage_clock if stage_clock is not None else NULL_CLOCK
     uids = [c.uid for c in camera_records]
     total_pairs_est = _estimate_total_pairs(refs_local, nn_table, uids, config.nns_per_ref)

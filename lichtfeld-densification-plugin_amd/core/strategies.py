@@ -3,7 +3,8 @@ closed with ``drain()``.
 
   * ``SampledLoop``      - upstream's mode (core/pipeline.py:602-780 per reference): coverage sampling, then the selected cells.  Four
                            schedules, picked per reference from what the configuration allows: several references per fused call (one RNG
-                           stream each), upstream's normaliser pipelined over a side stream, launch-ahead, or one synchronous reference.
+                           stream each - or, round 5, chained on upstream's one stream), upstream's normaliser pipelined over a side stream,
+                           launch-ahead, or one synchronous reference.
   * ``DenseBatcher``     - every candidate cell of ``refs_per_launch`` references through one launch of the fused kernel.
   * ``DensePlyStreamer`` - dense mode whose only consumer is the streamed output file: the kernel writes the 15-byte PLY records itself,
                            the records cross PCIe on a side stream into pinned double buffers while the next launch computes, and a
@@ -56,6 +57,8 @@ class SampledLoop:
         self.group: List[tuple] = []          # several references per fused call: (Matched, seed)
         self.pend_norm: List[tuple] = []      # default mode: aggregated map on its way to the host: (Matched, handle)
         self.inflight: List[tuple] = []       # launched, not yet read back: (Matched, handle)
+        self.chain: List[tuple] = []          # single stream, several references per fused call: (Matched, normaliser handle or None)
+        self.chain_fly: List[tuple] = []      # ... launched groups: (items, handle)
 
     # -- the four schedules ---------------------------------------------------------------------------------------------------------
     def submit(self, m: Matched) -> None:
@@ -70,6 +73,25 @@ class SampledLoop:
                 self._flush_group()
             return
         self._flush_group()
+        if not self.per_ref_rng and int(cfg.refs_per_launch) > 1 and hot.can_chain(need_best, m.H, m.W):
+            # upstream's ONE stream, refs_per_launch references per fused call (lfd_triangulate_sampled_chain): they draw one after the other, in
+            # this order, everything else of their selections runs side by side.  With upstream's normaliser every reference's weight map starts
+            # its way to the host now; the sums are taken when the group is launched.
+            while self.pend_norm:
+                self._promote_one()
+            while self.inflight:
+                self._finish_one()
+            if self.chain and (self.chain[0][0].H, self.chain[0][0].W) != (m.H, m.W):
+                self._launch_chain()
+            try:
+                self.chain.append((m, hot.begin_normaliser(m.ref, m.axes) if hot.chain_uses_upstream_normaliser() else None))
+            except Exception as ex:
+                log.error(f"Triangulation error for ref {m.packed.ref_uid}: {ex}")
+                return
+            if len(self.chain) >= int(cfg.refs_per_launch):
+                self._launch_chain()
+            return
+        self._drain_chain()
         if hot.can_pipeline_normaliser(need_best, self.per_ref_rng, m.H, m.W):
             # upstream's normaliser (the default) without a host wait in the launch stream: this reference's aggregated map starts its way to
             # the host; the reference before it - whose map has arrived meanwhile - gets its sum and its fused launch; the one before that is
@@ -101,6 +123,7 @@ class SampledLoop:
 
     def drain(self) -> None:
         self._flush_group()
+        self._drain_chain()
         while self.pend_norm:
             self._promote_one()
         while self.inflight:
@@ -145,6 +168,55 @@ class SampledLoop:
             return
         if res is not None:
             self.out.emit(Emission(m.local_i, m.packed, (res.xyz, res.rgb, res.err)), self.hot)
+
+    def _launch_chain(self) -> None:
+        """The pending group's fused call; the group before it is collected only afterwards (its read-back hides under this one's kernels)."""
+        if not self.chain:
+            return
+        items, self.chain = list(self.chain), []
+        sums: List[float] = []
+        try:
+            for _m, h in items:
+                sums.append(self.hot.finish_normaliser(h) if h is not None else 0.0)
+            batch = self.hot.prepare_chain([m.ref for m, _ in items], items[0][0].axes)
+        except Exception as ex:
+            # nothing of the group has drawn from the stream yet: upstream isolates failures per reference (core/pipeline.py:874-879), so the
+            # group is redone one reference at a time, in order, behind the groups already launched
+            log.warn(f"Grouped triangulation of refs {[m.packed.ref_uid for m, _ in items]} failed ({ex}); retrying one by one")
+            while self.chain_fly:
+                self._finish_chain()
+            for m, _h in items:
+                self._one_synchronously(m, None, False)
+            return
+        try:
+            self.chain_fly.append((items, self.hot.launch_sampled_chain(batch, sums if any(h is not None for _, h in items) else None)))
+        except Exception as ex:
+            for m, _h in items:
+                log.error(f"Triangulation error for ref {m.packed.ref_uid}: {ex}")
+        while len(self.chain_fly) > 1:
+            self._finish_chain()
+
+    def _finish_chain(self) -> None:
+        items, handle = self.chain_fly.pop(0)
+        try:
+            res = self.hot.finish_sampled(handle, check_selection=False)
+        except Exception as ex:
+            for m, _h in items:
+                log.error(f"Triangulation error for ref {m.packed.ref_uid}: {ex}")
+            return
+        for bi, (m, _h) in enumerate(items):
+            st = int(res.sel_status[bi])
+            if st != 0:     # what upstream's sampling stage raises for this reference (it has drawn nothing); the others are not affected
+                log.error(f"Triangulation error for ref {m.packed.ref_uid}: {hb.selection_error(st)}")
+                continue
+            lo, hi = int(res.ref_offsets[bi]), int(res.ref_offsets[bi + 1])
+            if hi > lo:
+                self.out.emit(Emission(m.local_i, m.packed, _trimmed(res, lo, hi)), self.hot)
+
+    def _drain_chain(self) -> None:
+        self._launch_chain()
+        while self.chain_fly:
+            self._finish_chain()
 
     def _flush_group(self) -> None:
         if not self.group:

@@ -513,7 +513,7 @@ void lfd_destroy(lfd_context* ctx) {
     }
     for (hipEvent_t ev : ctx->kt_start) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->kt_stop) (void)hipEventDestroy(ev);
-    for (DeviceBuffer* b : {&ctx->cams, &ctx->ws, &ctx->axes, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->colour_tab, &ctx->mt, &ctx->mt_batch, &ctx->sel_scratch, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab, &ctx->seg_scan})
+    for (DeviceBuffer* b : {&ctx->cams, &ctx->ws, &ctx->axes, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->colour_tab, &ctx->mt, &ctx->mt_batch, &ctx->sel_scratch, &ctx->sel_chain, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab, &ctx->seg_scan})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
     delete ctx;
@@ -926,6 +926,14 @@ int lfd_rng_set_state(lfd_context* ctx, const uint32_t* key624, int32_t pos) {
     return LFD_OK;
 }
 
+// whether a filtered selection of an N-cell map runs on the multi-workgroup kernel (the only one that can chain references on one stream)
+static bool select_runs_on_several_workgroups(lfd_context* ctx, long long N) {
+    int n_wg = LFD_SELECT_DEFAULT_WG;
+    if (ctx->env.select_workgroups >= 0) n_wg = ctx->env.select_workgroups;
+    n_wg = std::min(std::min(n_wg, (int)LFD_SELECT_MAX_WG), (int)(N / 8192));
+    return n_wg >= 2 && ctx->env.select_timing == 0;
+}
+
 // launches the selection of one reference; *d_info = device {n_out, status}; nothing is read back here.
 // n_batch > 1 (or info_batch set): n_batch references in ONE launch (blockIdx.y = reference) - maps best_cert + r*H*W, cells
 // sel_out + r*capacity, {begin, end} pairs sel_offsets_dev + 2r, MT19937 states mt_batch + r*LFD_MT_STATE_STRIDE, results at
@@ -934,7 +942,7 @@ int lfd_rng_set_state(lfd_context* ctx, const uint32_t* key624, int32_t pos) {
 static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
                          int32_t border, int32_t tiles, float s_override, int64_t* sel_out, int64_t capacity,
                          long long* sel_offsets_dev, int** d_info, unsigned char** d_time, int n_batch = 1,
-                         unsigned* mt_batch = nullptr, int* info_batch = nullptr) {
+                         unsigned* mt_batch = nullptr, int* info_batch = nullptr, bool chain = false, const float* s_batch = nullptr) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
     if (!best_cert || !sel_out) return fail(ctx, LFD_ERR_INVALID, "null argument");
     if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
@@ -975,6 +983,10 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
     A.capacity = capacity;
     A.H = H; A.W = W; A.M = M; A.border = border; A.tiles = tiles; A.cap = cap; A.s_override = s_override;
     A.sel_offsets_out = sel_offsets_dev;
+    if (s_batch) {
+        A.use_s_batch = 1;
+        for (int i = 0; i < n_batch; ++i) A.s_batch[i] = s_batch[i];
+    }
     *d_info = reinterpret_cast<int*>(base + o_out);
     *d_time = nullptr;
     const bool timing = !topm && n_batch == 1 && ctx->env.select_timing != 0;
@@ -1007,6 +1019,26 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
                             "stage (selection_backend=\"host\" in the Python mirror: upstream's own library calls) has no such limit");
         }
         const bool timing_mw = timing && ctx->env.select_timing == 2;     // 2: stamps of workgroup 0 of the multi-workgroup kernel
+        if (chain && !select_runs_on_several_workgroups(ctx, (long long)N))
+            return fail(ctx, LFD_ERR_STATE, "selection: a chained launch needs the multi-workgroup kernel");
+        if (chain) {
+            // the stream as an array: a ring of doubles four first rounds long (later rounds are shorter than the first, the producer stays one
+            // first round ahead), and the key of every twist the producer can be ahead by
+            const long long first_round = std::max<long long>(std::min<long long>((long long)((double)M * 0.85), (long long)N), 1);
+            long long ring_cap = 4096;
+            while (ring_cap < 4 * first_round) ring_cap *= 2;
+            const int snap_slots = (int)(2 * ring_cap / 624) + 8;
+            const size_t o_ring = LFD_CHAIN_BYTES, o_snaps = o_ring + (size_t)ring_cap * 8, chain_total = o_snaps + (size_t)snap_slots * 624 * 4;
+            rc = ensure(ctx, ctx->sel_chain, chain_total);
+            if (rc != LFD_OK) return rc;
+            unsigned char* cb = static_cast<unsigned char*>(ctx->sel_chain.ptr);
+            LFD_HIP(ctx, hipMemsetAsync(cb, 0, LFD_CHAIN_BYTES, ctx->stream));
+            A.chain = cb;
+            A.ring = reinterpret_cast<double*>(cb + o_ring);
+            A.snaps = reinterpret_cast<unsigned*>(cb + o_snaps);
+            A.ring_cap = ring_cap;
+            A.snap_slots = snap_slots;
+        }
         if (n_wg >= 2 && (!timing || timing_mw)) {
             A.coop = base + o_coop;
             A.n_wg = n_wg;
@@ -1055,14 +1087,17 @@ static int select_impl(lfd_context* ctx, bool topm, const float* best_cert, int3
     return LFD_OK;
 }
 
+// seeds: one MT19937 stream per reference (lfd_triangulate_sampled_multi).  chain: all references on the CONTEXT's stream, consumed in batch order
+// (lfd_triangulate_sampled_chain; s_chain: their normalisers, or null).  Neither: one reference on the context's stream.
 static int sampled_impl(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, int32_t M, float cap, int32_t border, int32_t tiles,
                         float s_override, const uint32_t* seeds, const lfd_points* out, int64_t* ref_offsets, int32_t* seg_counts,
-                        int32_t* seg_order, int32_t* sel_info, int64_t* sel_cells) {
+                        int32_t* seg_order, int32_t* sel_info, int64_t* sel_cells, bool chain = false, const float* s_chain = nullptr) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
     if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
     if (!batch || !params || !sel_info) return fail(ctx, LFD_ERR_INVALID, "null argument");
     const int R = batch->n_refs;
-    if (R != 1 && !seeds) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_sampled takes one reference view per call (several need per-reference seeds: lfd_triangulate_sampled_multi)");
+    if (R != 1 && !seeds && !chain) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_sampled takes one reference view per call (several: lfd_triangulate_sampled_chain on the context's stream, lfd_triangulate_sampled_multi on per-reference streams)");
+    if (R < 1) return fail(ctx, LFD_ERR_INVALID, "no reference view");
     if (M < 0 || tiles <= 0 || border < 0) return fail(ctx, LFD_ERR_INVALID, "bad selection arguments");
     const bool topm = params->no_filter != 0;
     if (topm && M > LFD_SELECT_TOPM_MAX) return fail(ctx, LFD_ERR_INVALID, "no_filter selection is limited to 16384 matches per reference");
@@ -1098,13 +1133,29 @@ static int sampled_impl(lfd_context* ctx, const lfd_batch* batch, const lfd_para
         LFD_HIP(ctx, hipMemcpyAsync(sel_pairs, begins.data(), begins.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
         LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));       // the host vector goes out of scope
     }
-    if (!seeds) {            // one reference on the context's MT19937 stream (upstream's single global stream)
-        int* d_info = nullptr;
-        unsigned char* d_time = nullptr;
-        rc = select_launch(ctx, topm, best, batch->H, batch->W, M, cap, topm ? 0 : border, topm ? 1 : tiles, topm ? 0.0f : s_override,
-                           reinterpret_cast<int64_t*>(cells), cap_sel, sel_pairs, &d_info, &d_time);
-        if (rc != LFD_OK) return rc;
-        LFD_HIP(ctx, hipMemcpyAsync(sel_info, d_info, 2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    if (!seeds && (topm || select_runs_on_several_workgroups(ctx, HW)) && R > 1) {
+        // the context's stream, R references in ONE launch per LFD_SELECT_BATCH_MAX of them: everything that does not depend on the stream runs
+        // side by side, a reference starts drawing where the one before it stopped (no_filter draws nothing: plain side by side)
+        if (!topm && !ctx->mt_seeded) return fail(ctx, LFD_ERR_STATE, "lfd_rng_seed must be called before lfd_triangulate_sampled_chain");
+        for (int r0 = 0; r0 < R; r0 += LFD_SELECT_BATCH_MAX) {
+            const int nb = std::min(R - r0, (int)LFD_SELECT_BATCH_MAX);
+            int* d_info = nullptr;
+            unsigned char* d_time = nullptr;
+            rc = select_launch(ctx, topm, best + (size_t)r0 * HW, batch->H, batch->W, M, cap, topm ? 0 : border, topm ? 1 : tiles, 0.0f,
+                               reinterpret_cast<int64_t*>(cells + (size_t)r0 * cap_sel), cap_sel, sel_pairs + 2 * (size_t)r0, &d_info, &d_time,
+                               nb, nullptr, sel_info + 2 * (size_t)r0, !topm, (s_chain && !topm) ? s_chain + r0 : nullptr);
+            if (rc != LFD_OK) return rc;
+        }
+    } else if (!seeds) {     // the context's MT19937 stream (upstream's single global stream), reference after reference
+        for (int r = 0; r < R; ++r) {
+            int* d_info = nullptr;
+            unsigned char* d_time = nullptr;
+            const float s_r = topm ? 0.0f : (s_chain ? s_chain[r] : s_override);
+            rc = select_launch(ctx, topm, best + (size_t)r * HW, batch->H, batch->W, M, cap, topm ? 0 : border, topm ? 1 : tiles, s_r,
+                               reinterpret_cast<int64_t*>(cells + (size_t)r * cap_sel), cap_sel, sel_pairs + 2 * (size_t)r, &d_info, &d_time);
+            if (rc != LFD_OK) return rc;
+            LFD_HIP(ctx, hipMemcpyAsync(sel_info + 2 * (size_t)r, d_info, 2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        }
     } else {                 // every reference on its own stream: up to LFD_SELECT_BATCH_MAX selections side by side per launch
         rc = ensure(ctx, ctx->mt_batch, (size_t)LFD_SELECT_BATCH_MAX * LFD_MT_STATE_STRIDE * sizeof(unsigned));
         if (rc != LFD_OK) return rc;
@@ -1161,6 +1212,12 @@ int lfd_triangulate_sampled(lfd_context* ctx, const lfd_batch* batch, const lfd_
                             int32_t* seg_counts, int32_t* seg_order, int32_t* sel_info, int64_t* sel_cells) {
     if (ctx && batch && batch->n_refs != 1) return fail(ctx, LFD_ERR_INVALID, "lfd_triangulate_sampled takes one reference view per call");
     return sampled_impl(ctx, batch, params, M, cap, border, tiles, s_override, nullptr, out, ref_offsets, seg_counts, seg_order, sel_info, sel_cells);
+}
+
+int lfd_triangulate_sampled_chain(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, int32_t M, float cap,
+                                  int32_t border, int32_t tiles, const float* s_overrides, const lfd_points* out, int64_t* ref_offsets,
+                                  int32_t* seg_counts, int32_t* seg_order, int32_t* sel_info, int64_t* sel_cells) {
+    return sampled_impl(ctx, batch, params, M, cap, border, tiles, 0.0f, nullptr, out, ref_offsets, seg_counts, seg_order, sel_info, sel_cells, true, s_overrides);
 }
 
 int lfd_triangulate_sampled_multi(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, int32_t M, float cap,

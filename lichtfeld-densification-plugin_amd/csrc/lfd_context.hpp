@@ -86,6 +86,7 @@ struct lfd_context {
     DeviceBuffer scratch, codes, idx_tab, agg, sel_buf;
     // selection stage: legacy MT19937 stream (625 words) + scratch
     DeviceBuffer mt, sel_scratch, mt_batch;      // mt_batch: per-reference MT19937 states of lfd_triangulate_sampled_multi
+    DeviceBuffer sel_chain;                      // lfd_triangulate_sampled_chain: chain block, the stream's ring of doubles, the keys of its twists
     DeviceBuffer stamps;           // profiling builds: phase stamps of the dense kernel
     DeviceBuffer seg_scan;         // tile segments: exclusive prefix of the last table handed to lfd_order_segments / lfd_pack_*_segments
     // N3 image preparation: coefficient / index tables of the last size pair

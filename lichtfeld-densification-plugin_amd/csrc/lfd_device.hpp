@@ -169,6 +169,7 @@ struct LfdLaunch {              // kernel argument, passed by value
 #define LFD_SELECT_TOO_MANY_BINS 6
 #define LFD_SELECT_CAPACITY 7
 
+#define LFD_SELECT_BATCH_MAX 32       // references per selection launch (17 workgroups each: co-resident with room to spare)
 struct LfdSelectArgs {
     const float* best_cert;   // [H*W] aggregated certainty of ONE reference (output of lfd_aggregate)
     float* weights;           // [H*W] scratch: capped, border-masked, normalised f32 weights
@@ -198,7 +199,25 @@ struct LfdSelectArgs {
     long long batch_out_stride;       // elements between their sel_out areas
     long long batch_mt_stride;        // words between their MT19937 states (one stream per reference)
     int* batch_info;                  // device i32 [2 * n] or null: reference y reports {n_out, status} at [2y], [2y + 1] instead of n_out / status
+    // Several references in one launch ON ONE MT19937 STREAM, consumed in batch order (lfd_triangulate_sampled_chain; multi-workgroup kernel
+    // only): the stream is an ARRAY - one producer workgroup (the extra workgroup of reference 0) writes its doubles, by absolute index, into
+    // `ring`; reference y uses the doubles from where reference y - 1 stopped, an offset it learns from the chain block when y - 1 is through
+    // with its last round.  Everything that does not depend on the stream (weights, p, the first cumulative sum) runs side by side.
+    unsigned char* chain;             // null, or the launch's chain block (LFD_CHAIN_* byte offsets, zeroed before the launch)
+    double* ring;                     // [ring_cap] double i of the stream at i & (ring_cap - 1)
+    unsigned* snaps;                  // [snap_slots * 624] the key after the t-th twist at slot t % snap_slots (what the producer commits from)
+    long long ring_cap;               // a power of two >= 4 * int(M * 0.85)
+    int snap_slots;
+    int use_s_batch;                  // the normaliser of reference y is s_batch[y] (> 0: overrides the exact device sum) instead of s_override
+    float s_batch[LFD_SELECT_BATCH_MAX];
 };
-#define LFD_SELECT_BATCH_MAX 32       // references per selection launch (17 workgroups each: co-resident with room to spare)
 #define LFD_MT_STATE_STRIDE 640       // words per MT19937 state of a batch (624 key + position, padded)
+// chain block (byte offsets; u64 words unless noted)
+#define LFD_CHAIN_PRODUCED 0          // doubles of the stream written so far
+#define LFD_CHAIN_WANT 8              // end (absolute index) of the draws the reference at work has asked for
+#define LFD_CHAIN_RELEASED 16         // doubles below this index are not read any more
+#define LFD_CHAIN_STATE 24            // u32: 0 producer at work, 1 stream committed, 2 producer gave up / chain broken (stream left where it was)
+#define LFD_CHAIN_OFF 64              // [LFD_SELECT_BATCH_MAX + 1]: 1 + the absolute index of reference y's first draw; 0 = not known yet
+#define LFD_CHAIN_BROKEN (~0ull)      //   ... or this: a predecessor failed, nobody knows where the stream stands
+#define LFD_CHAIN_BYTES 512
 struct LfdSeedBatch { unsigned seed[LFD_SELECT_BATCH_MAX]; };

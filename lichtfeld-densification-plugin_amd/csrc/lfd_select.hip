@@ -99,6 +99,119 @@ __device__ void mt_fill_doubles(unsigned* mt, double* draws, int n, int tid) {
     __syncthreads();
 }
 
+// The whole stream as an array: doubles `from` .. `to` (absolute indices) of the legacy stream go to ring[i & mask]; the key lives in LDS across
+// calls (`cur`, `pos`, `twists`: the caller's), and every key a twist produces is also kept in `snaps` (slot = number of the twist % slots): the
+// producer runs AHEAD of what is consumed, so the key it ends with is not the one to commit - that one is looked up by the position the
+// consumers stopped at.
+struct MtCursor { int cur, pos; unsigned twists; };
+
+__device__ void mt_twist_and_keep(unsigned (*s_mt)[624], MtCursor& c, unsigned* snaps, int snap_slots, int tid) {
+    mt_twist_lds(s_mt[c.cur], s_mt[c.cur ^ 1], tid);
+    c.cur ^= 1;
+    ++c.twists;
+    unsigned* dst = snaps + (size_t)(c.twists % (unsigned)snap_slots) * 624u;
+    for (int i = tid; i < 624; i += kSelBlock) dst[i] = s_mt[c.cur][i];
+}
+
+__device__ void mt_stream_fill(unsigned (*s_mt)[624], MtCursor& c, double* ring, unsigned long long mask, unsigned long long from,
+                               unsigned long long to, unsigned* snaps, int snap_slots, int tid) {
+    unsigned long long produced = from;
+    while (produced < to) {
+        if (c.pos >= 624) { mt_twist_and_keep(s_mt, c, snaps, snap_slots, tid); c.pos = 0; }
+        const int avail = 624 - c.pos;
+        const unsigned long long left = to - produced;
+        const int want_words = left > 312ull ? 624 : 2 * (int)left;
+        const int take = avail < want_words ? avail : want_words;
+        const int pairs = take >> 1;
+        for (int i = tid; i < pairs; i += kSelBlock) {
+            const unsigned a = mt_temper(s_mt[c.cur][c.pos + 2 * i]), b = mt_temper(s_mt[c.cur][c.pos + 2 * i + 1]);
+            ring[(produced + (unsigned long long)i) & mask] = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+        }
+        if (take & 1) {       // the last word of this key pairs with the first word of the next one
+            const unsigned a = mt_temper(s_mt[c.cur][c.pos + take - 1]);
+            __syncthreads();
+            mt_twist_and_keep(s_mt, c, snaps, snap_slots, tid);
+            if (tid == 0) {
+                const unsigned b = mt_temper(s_mt[c.cur][0]);
+                ring[(produced + (unsigned long long)pairs) & mask] = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+            }
+            c.pos = 1;
+            produced += (unsigned long long)pairs + 1ull;
+        } else {
+            c.pos += take;
+            produced += (unsigned long long)pairs;
+        }
+        __syncthreads();
+    }
+}
+
+// The producer workgroup of a chained launch.  It stays `look` doubles ahead of the highest index anybody has asked for (the first round of the
+// next reference needs exactly that many), never more than the ring holds beyond what has been released, until the last reference of the launch
+// has said where it stopped; then it commits the stream AT THAT POSITION: the key of the twist the position lies in, from `snaps`.
+__device__ void mt_stream_producer(const LfdSelectArgs& A, int n_refs, int look, int tid) {
+    __shared__ unsigned s_key[2][624];
+    __shared__ unsigned long long s_tgt;
+    __shared__ int s_cmd, s_pos0;
+    unsigned long long* produced_w = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_PRODUCED);
+    unsigned long long* want_w = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_WANT);
+    unsigned long long* released_w = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_RELEASED);
+    unsigned* state_w = reinterpret_cast<unsigned*>(A.chain + LFD_CHAIN_STATE);
+    unsigned long long* off_w = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_OFF);
+    for (int i = tid; i < 624; i += kSelBlock) s_key[0][i] = A.mt[i];
+    if (tid == 0) s_pos0 = (int)A.mt[624];
+    __syncthreads();
+    const int pos0 = s_pos0;
+    MtCursor c = {0, pos0, 0u};
+    const unsigned long long mask = (unsigned long long)A.ring_cap - 1ull;
+    unsigned long long produced = 0ull, last = 0ull;
+    while (true) {
+        if (tid == 0) {
+            int cmd = 3;
+            unsigned spins = 0;
+            while (++spins < (1u << 23)) {
+                last = __hip_atomic_load(off_w + n_refs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (last != 0ull) { cmd = 2; break; }
+                const unsigned long long want = __hip_atomic_load(want_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long rel = __hip_atomic_load(released_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long tgt = want + (unsigned long long)look;
+                if (tgt > rel + (unsigned long long)A.ring_cap) tgt = rel + (unsigned long long)A.ring_cap;
+                if (tgt > produced) { cmd = 1; s_tgt = tgt; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            s_cmd = cmd;
+            if (cmd == 2) s_tgt = last;
+        }
+        __syncthreads();
+        const int cmd = s_cmd;
+        const unsigned long long tgt = s_tgt;
+        __syncthreads();
+        if (cmd == 1) {
+            mt_stream_fill(s_key, c, A.ring, mask, produced, tgt, A.snaps, A.snap_slots, tid);
+            produced = tgt;
+            if (tid == 0) { __threadfence(); __hip_atomic_store(produced_w, produced, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            continue;
+        }
+        if (cmd == 2 && tgt != LFD_CHAIN_BROKEN) {
+            // tgt = 1 + doubles consumed by the whole launch; the word after them is word W of the stream counted from word 0 of the key the
+            // launch started with.  numpy twists lazily: W <= 624 stays in that key; otherwise the key after k = (W - 1) / 624 twists, position W - 624 k
+            // (1 ... 624)
+            const unsigned long long Wd = (unsigned long long)pos0 + 2ull * (tgt - 1ull);
+            if (Wd <= 624ull) {
+                if (tid == 0) A.mt[624] = (unsigned)Wd;
+            } else {
+                const unsigned long long k = (Wd - 1ull) / 624ull;
+                const unsigned* src = A.snaps + (size_t)(k % (unsigned long long)A.snap_slots) * 624u;
+                for (int i = tid; i < 624; i += kSelBlock) A.mt[i] = src[i];
+                if (tid == 0) A.mt[624] = (unsigned)(Wd - 624ull * k);
+            }
+            if (tid == 0) __hip_atomic_store(state_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) __hip_atomic_store(state_w, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // broken chain, or nobody spoke: nothing is committed
+        return;
+    }
+}
+
 // ---- workgroup-wide helpers --------------------------------------------------------------------------
 __device__ double block_sum_f64(double v, double* s_tmp, int tid) {
 #pragma unroll
@@ -150,6 +263,7 @@ __device__ int block_excl_scan_i32(int v, int* s_tmp, int tid, int& total) {
 __device__ __forceinline__ LfdSelectArgs lfd_select_args_of(LfdSelectArgs A) {
     const long long y = (long long)blockIdx.y;
     if (A.batch_info) { A.n_out = A.batch_info + 2 * y; A.status = A.n_out + 1; }
+    if (A.use_s_batch) A.s_override = A.s_batch[y];
     if (y == 0) return A;
     const long long sb = A.batch_scratch_stride * y;
     A.best_cert += A.batch_cert_stride * y;
@@ -612,6 +726,12 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     // ================= the workgroup on the MT19937 stream =================
     // It never meets the others at a barrier: the first round's draws are generated on a copy of the state while the others
     // stream the map; whether they count (upstream's argument checks) and what later rounds need arrives as messages.
+    const bool chained = A.chain != nullptr;
+    if (rng_wg && chained) {
+        // one stream for the whole launch: the extra workgroup of reference 0 produces it, the others have nothing to do
+        if (blockIdx.y == 0) mt_stream_producer(A, (int)gridDim.y, size, tid);
+        return;
+    }
     if (rng_wg) {
         if (A.timing && tid == 0) A.timing[30] = wall_clock64();
         for (int i = tid; i < 625; i += kSelBlock) mt_spec[i] = A.mt[i];
@@ -652,8 +772,39 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     }
 
     // ================= the compute workgroups =================
-#define LFD_GRID_SYNC() do { if (!grid_barrier(bar, (unsigned)G)) { if (tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; } } while (0)
+#define LFD_GRID_SYNC() do { if (!grid_barrier(bar, (unsigned)G)) { if (tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (chained) chain_hand_on(LFD_CHAIN_BROKEN); } return; } } while (0)
 #define LFD_TELL_RNG(round, need) do { if (wg == 0 && tid == 0) { __threadfence(); __hip_atomic_store(msg_req, ((unsigned long long)(unsigned)(round) << 32) | (unsigned long long)(unsigned)(need), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } } while (0)
+    // chained launches: where this reference's draws begin in the stream (absolute index of the doubles), learnt from the reference before it
+    // (LFD_CHAIN_OFF: 1 + index; the launch's first reference starts at 0), and handed on - by EVERY way out of this kernel, refusals included: a
+    // refused reference consumes nothing (upstream raises before it draws), a failed one breaks the chain for those behind it
+    const int yref = (int)blockIdx.y;
+    unsigned long long* ch_off = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_OFF);
+    unsigned long long* ch_want = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_WANT);
+    unsigned long long* ch_released = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_RELEASED);
+    unsigned long long* ch_produced = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_PRODUCED);
+    const unsigned long long ring_mask = (unsigned long long)A.ring_cap - 1ull;
+    auto chain_begin = [&]() -> unsigned long long {            // every thread of the workgroup; LFD_CHAIN_BROKEN: the predecessor failed or never spoke
+        if (yref == 0) return 0ull;
+        if (tid == 0) {
+            unsigned long long v = 0ull;
+            unsigned spins = 0;
+            while ((v = __hip_atomic_load(ch_off + yref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
+                if (++spins > (1u << 23)) { v = LFD_CHAIN_BROKEN; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            s_msg = v;
+        }
+        __syncthreads();
+        const unsigned long long v = s_msg;
+        __syncthreads();
+        return v == LFD_CHAIN_BROKEN ? v : v - 1ull;
+    };
+    auto chain_hand_on = [&](unsigned long long next_begin) {    // one thread
+        __hip_atomic_store(ch_off + yref + 1, next_begin == LFD_CHAIN_BROKEN ? next_begin : next_begin + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // a reference that leaves before it has drawn: the stream passes through it untouched
+#define LFD_CHAIN_PASS() do { if (chained && wg == 0) { const unsigned long long b_ = chain_begin(); if (tid == 0) chain_hand_on(b_); } } while (0)
+#define LFD_CHAIN_BREAK() do { if (chained && tid == 0) chain_hand_on(LFD_CHAIN_BROKEN); } while (0)
     if (wg == 0 && tid == 0) { *A.n_out = 0; *A.status = LFD_SELECT_OK; }
     int t_slot = 0;
 #define LFD_MW_STAMP() do { if (A.timing && wg == 0 && tid == 0 && t_slot < 30) A.timing[t_slot] = wall_clock64(); ++t_slot; } while (0)
@@ -712,10 +863,12 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     const float s32 = (A.s_override > 0.0f) ? A.s_override : (float)s64;
     if (__hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_NAN; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        LFD_CHAIN_PASS();
         return;
     }
     if (!(s32 > 0.0f)) {                                           // upstream: `if s <= 0: return empty` (the stream is not touched)
         if (wg == 0 && tid == 0) __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        LFD_CHAIN_PASS();
         return;
     }
 
@@ -773,10 +926,11 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         if (neg) st = LFD_SELECT_NEGATIVE; else if (nz < size) st = LFD_SELECT_FEWER_NONZERO; else if (inexact) st = LFD_SELECT_INEXACT;
         if (st != LFD_SELECT_OK) {
             if (wg == 0 && tid == 0) { *A.status = st; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            LFD_CHAIN_PASS();
             return;
         }
     }
-    if (wg == 0 && tid == 0) {      // the checks passed: the draws count
+    if (!chained && wg == 0 && tid == 0) {      // the checks passed: the draws count
         __hip_atomic_store(msg_req, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(msg_go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -784,8 +938,13 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     // ---- legacy choice(replace=False, p) -----------------------------------------------------------------------
     const int per = (N + kSelBlock - 1) / kSelBlock;              // run length of the coarse search table
     int n_uniq = 0, guard = 0;
+    unsigned long long my_begin = 0ull, consumed = 0ull;           // chained: this reference's first double in the stream, doubles it has used
     while (n_uniq < size) {
-        if (++guard > 60) { if (wg == 0 && tid == 0) *A.status = LFD_SELECT_NO_PROGRESS; LFD_TELL_RNG(0xffffffffu, 0); return; }
+        if (++guard > 60) {
+            if (wg == 0 && tid == 0) *A.status = LFD_SELECT_NO_PROGRESS;
+            if (chained) { if (wg == 0) LFD_CHAIN_BREAK(); } else LFD_TELL_RNG(0xffffffffu, 0);
+            return;
+        }
         const int need = size - n_uniq;
         const unsigned tag = (unsigned)(64 - guard) << 24;        // later rounds win the atomicMin below over stale words
         // cdf = cumsum(p) / cdf[-1] over this wave's span; the carry comes from the table of span sums
@@ -840,7 +999,32 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         LFD_MW_STAMP();
     LFD_MW_STAMP();
         // the draws of this round must be in place
-        {
+        if (chained) {
+            if (guard == 1) {
+                // only now does anything here depend on the references before this one: where they left the stream
+                my_begin = chain_begin();
+                if (my_begin == LFD_CHAIN_BROKEN) { if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; chain_hand_on(LFD_CHAIN_BROKEN); } return; }
+                if (wg == 0 && tid == 0) {
+                    __hip_atomic_store(ch_released, my_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ch_want, my_begin + (unsigned long long)need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (tid == 0) {
+                const unsigned long long end = my_begin + consumed + (unsigned long long)need;
+                unsigned spins = 0;
+                int ok = 1;
+                while (__hip_atomic_load(ch_produced, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < end) {
+                    if (++spins > (1u << 22)) { ok = 0; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                __threadfence();
+                s_i[0] = ok;
+            }
+            __syncthreads();
+            const int ok = s_i[0];
+            __syncthreads();
+            if (!ok) { if (tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; chain_hand_on(LFD_CHAIN_BROKEN); } return; }
+        } else {
             if (tid == 0) {
                 unsigned spins = 0;
                 int ok = 1;
@@ -866,8 +1050,9 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         __syncthreads();
         unsigned* mark32 = reinterpret_cast<unsigned*>(mark);
         int cnt = 0;
+        const unsigned long long round_begin = my_begin + consumed;
         for (int j = gt; j < need; j += T) {
-            const double x = A.draws[j];
+            const double x = chained ? A.ring[(round_begin + (unsigned long long)j) & ring_mask] : A.draws[j];
             int lo = 0, len = kSelBlock;
             while (len > 0) { const int half = len >> 1, mid = lo + half; if (s_chunk[mid] <= x) { lo = mid + 1; len -= half + 1; } else len = half; }
             const int b = min(lo * per, N);
@@ -917,11 +1102,23 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         {
             int appended = 0;
             for (int g = 0; g < G; ++g) appended += round_cnt[g];
-            if (n_uniq + appended < size) LFD_TELL_RNG(guard + 1, size - n_uniq - appended);      // next round's draws can start now
+            consumed += (unsigned long long)need;
+            if (n_uniq + appended < size) {
+                if (!chained) LFD_TELL_RNG(guard + 1, size - n_uniq - appended);      // next round's draws can start now
+                else if (wg == 0 && tid == 0) {
+                    // (everybody is through with this round's draws: they are behind the barrier above)
+                    __hip_atomic_store(ch_released, my_begin + consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ch_want, my_begin + consumed + (unsigned long long)(size - n_uniq - appended), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             n_uniq += appended;
         }
     }
-    LFD_TELL_RNG(0xffffffffu, 0);                                  // the stream is final: the other workgroup commits it
+    if (!chained) LFD_TELL_RNG(0xffffffffu, 0);                    // the stream is final: the other workgroup commits it
+    else if (wg == 0 && tid == 0) {                                // ... or the next reference starts where this one stopped (the producer commits behind the last)
+        __hip_atomic_store(ch_released, my_begin + consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        chain_hand_on(my_begin + consumed);
+    }
 
     // ---- np.unique(concat): marked cells in ascending order; thread (wg, wave, lane) owns span/64 consecutive cells ------------
     {
@@ -950,6 +1147,8 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
 #undef LFD_MW_STAMP
 #undef LFD_TELL_RNG
 #undef LFD_GRID_SYNC
+#undef LFD_CHAIN_PASS
+#undef LFD_CHAIN_BREAK
 }
 
 // =================================================================================================

@@ -811,3 +811,89 @@ def test_dense_streamer_under_random_writer_delays(g4, tmp_path, monkeypatch, se
     ref = os.path.join(str(tmp_path), "ref.ply")
     writers.write_ply(ref, plain.xyz, to_uint8_rgb(plain.rgb))
     assert open(out, "rb").read().split(b"end_header\n", 1)[1] == open(ref, "rb").read().split(b"end_header\n", 1)[1]
+
+
+# ---- several references per fused call on upstream's ONE stream (lfd_triangulate_sampled_chain) --------------------------------
+def _chain_scene(d, n_cams=9, H=256, W=256, k=2):
+    """nine cameras, 256 x 256 match grids (large enough for the multi-workgroup selection kernel, the only one that chains), one camera whose
+    mask leaves fewer non-zero weights than draws: upstream's np.random.choice raises for that reference - before it draws"""
+    from PIL import Image
+    from lichtfeld_densification_plugin_amd import synthetic
+    from lichtfeld_densification_plugin_amd.core import selection
+    cams = synthetic.ring_cameras(n_cams, seed=77, arc=0.9)
+    nn = selection.nearest_neighbors(np.stack([c.flat_pose() for c in cams]), k)
+    for i, c in enumerate(cams):
+        c.image_path = os.path.join(d, f"im{i:02d}.png")
+        Image.fromarray(synthetic.synth_image(H, W, 40 + i).numpy()).save(c.image_path)
+        c.mask_path = None
+    blob = np.zeros((H, W), np.uint8)
+    blob[H // 2, 10:60] = 255
+    cams[4].mask_path = os.path.join(d, "mask04.png")
+    Image.fromarray(blob, mode="L").save(cams[4].mask_path)
+    refs = [0, 2, 3, 4, 5, 7, 8]
+    table = []
+    for r in refs:
+        nbrs = [int(n) for n in nn[r][:k]]
+        s = synthetic.synth_reference(cams, r, nbrs, H, W, W, H, noise_px=0.4, outlier_frac=0.05, channels=4, seed=500 + r, cert_mode="tiefree")
+        table.append([(s.warp[j], s.cert[j]) for j in range(len(nbrs))])
+    return cams, refs, nn, table, (W, H)
+
+
+@pytest.mark.parametrize("upstream_normaliser", [True, False])
+def test_chained_groups_on_one_stream_equal_the_plain_run(tmp_path, upstream_normaliser):
+    """The default single-stream sampled mode with refs_per_launch = 2 / 4 / 16 (groups of 2+2+2+1, 4+3, 7): the same cloud, counts and order
+    as one reference per call - which is upstream's sequence (fixtures g4 / g12) - including a reference whose selection is refused in the
+    middle of a group (it logs upstream's error, draws nothing, and the references behind it are not affected)."""
+    from fuzz_scenes import Table
+    d = str(tmp_path)
+    cams, refs, nn, table, size = _chain_scene(d)
+    kw = dict(output_path=os.path.join(d, "o.ply"), nns_per_ref=2, seed=11, viz_interval=0, matches_per_ref=3000, use_masks=True,
+              upstream_normaliser=upstream_normaliser)
+    plain = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(refs_per_launch=1, **kw), matcher=Table(size[0], size[1], table))
+    assert plain.xyz.shape[0] > 8000 and int(plain.points_per_reference[3]) == 0 and int((plain.points_per_reference > 0).sum()) == 6
+    for n in (2, 4, 16):
+        got = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(refs_per_launch=n, **kw), matcher=Table(size[0], size[1], table))
+        np.testing.assert_array_equal(got.points_per_reference, plain.points_per_reference)
+        np.testing.assert_array_equal(got.xyz, plain.xyz)
+        np.testing.assert_array_equal(got.rgb, plain.rgb)
+        np.testing.assert_array_equal(got.err, plain.err)
+        assert (got.pairs_processed, got.pairs_matched) == (plain.pairs_processed, plain.pairs_matched)
+
+
+def test_chained_groups_with_previews_and_a_debug_reference_in_between(tmp_path):
+    """previews every second reference + a match-debug state that is switched on for the third reference only: that reference wants its
+    aggregated map on the host and leaves the chained schedule (it runs alone, between two groups); the stream and the emission order stay
+    upstream's"""
+    from fuzz_scenes import Table
+    d = str(tmp_path)
+    cams, refs, nn, table, size = _chain_scene(d)
+    kw = dict(nns_per_ref=2, seed=3, viz_interval=2, matches_per_ref=2000, use_masks=True)
+
+    class Toggling(Table):
+        def __init__(self, st, *a):
+            super().__init__(*a)
+            self.st = st
+
+        def match_grids_batch(self, imA, imB_list, **k):
+            res = super().match_grids_batch(imA, imB_list, **k)
+            self.st.set_enabled(self.calls == 2)          # (the driver asks is_enabled() before it matches the NEXT reference)
+            return res
+
+    def run(n, sub):
+        viz, seen = [], []
+        st = MatchDebugState()
+        submit = st.submit_preview
+        st.submit_preview = lambda pv: (seen.append(int(pv.matches.shape[0])), submit(pv))
+        os.makedirs(os.path.join(d, sub), exist_ok=True)
+        cfg = lfd.DensePipelineConfig(refs_per_launch=n, output_path=os.path.join(d, sub, "o.ply"), **kw)
+        res = pl.run_dense_pipeline(cams, refs, nn, cfg, matcher=Toggling(st, size[0], size[1], table), debug_state=st,
+                                    on_sequential_viz=lambda p: viz.append((os.path.basename(p), open(p, "rb").read())))
+        return res, viz, seen
+    plain, pv, ps = run(1, "a")
+    got, gv, gs = run(3, "b")
+    np.testing.assert_array_equal(got.xyz, plain.xyz)
+    np.testing.assert_array_equal(got.points_per_reference, plain.points_per_reference)
+    assert [n for n, _ in gv] == [n for n, _ in pv] and len(pv) >= 2
+    for (_, a), (_, b) in zip(gv, pv):
+        assert a == b
+    assert gs == ps

@@ -32,6 +32,14 @@ def test_device_pipeline_equals_the_cpu_twin_pipeline(sc, tmp_path):
     # ... and against UPSTREAM'S OWN run on this scene (fixture g12, made in the development container from the imported reference): the chain
     # upstream -> device closes on the GPU box without the CPU twin in between
     assert_is_upstreams_run(dev, dp, dv, load_golden("g12_pipeline_upstream.npz"), sc, rgb_atol=2e-6 if sc % 4 == 2 else 0.0)
+    # several references per fused call on upstream's ONE stream (lfd_triangulate_sampled_chain; these grids are below the multi-workgroup kernel's
+    # size, so the references follow each other inside the call - tests/test_gpu_selection.py and test_gpu_pipeline.py chain them on large grids)
+    ch, cp, cv = _run(cams, refs, nn, table, size, os.path.join(d, "c", "dense.ply"), two=bool(sc % 4 == 2), device_image_prep=bool(sc % 2),
+                      refs_per_launch=3, **kw)
+    assert_is_upstreams_run(ch, cp, cv, load_golden("g12_pipeline_upstream.npz"), sc, rgb_atol=2e-6 if sc % 4 == 2 else 0.0)
+    if not isinstance(dev, str):
+        np.testing.assert_array_equal(ch.xyz, dev.xyz)
+        np.testing.assert_array_equal(ch.points_per_reference, dev.points_per_reference)
     if isinstance(host, str) or isinstance(dev, str):
         assert host == dev and "No points triangulated" in host and dp == hp
     else:

@@ -362,3 +362,104 @@ def test_batched_selection_equals_one_reference_at_a_time(dens, no_filter):
         np.testing.assert_array_equal(got.cell[lo:hi].cpu().numpy(), one.cell.cpu().numpy())
         total += one.count
     assert total > 1000 * (R - 1)
+
+
+def _chain_scene(dens, R, H, W, refuse=(), empty=()):
+    from lichtfeld_densification_plugin_amd import synthetic
+    dev = dens.device
+    n_cams = 48
+    cams = synthetic.ring_cameras(n_cams, seed=0)
+    dens.upload_cameras(cams)
+    refs, keep = [], []
+    for r in range(R):
+        ref = r % n_cams
+        nbrs = synthetic.ring_neighbours(n_cams, ref, 3)
+        s = synthetic.synth_reference(cams, ref, nbrs, H, W, H, W, noise_px=0.4, outlier_frac=0.05, channels=2, seed=300 + r,
+                                      cert_mode="tiefree", device=dev)
+        mask = None
+        if r in refuse:          # fewer non-zero weights than draws: np.random.choice raises before it draws (status 3)
+            mask = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+            mask[H // 2, :30] = 1
+        if r in empty:           # nothing but masked cells: s = 0, upstream returns an empty selection without drawing
+            mask = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+        keep.append(s)
+        refs.append(hb.ReferenceInputs(ref_cam=ref, nbr_cams=nbrs, cert=[s.cert[j] for j in range(3)], warp=[s.warp[j] for j in range(3)],
+                                       image=s.image, mask_a=mask))
+    return refs, keep
+
+
+@pytest.mark.parametrize("H,M,R,pos0,with_s", [(256, 2500, 40, None, False), (256, 2500, 7, 311, True), (512, 10000, 6, 623, True),
+                                               (512, 12000, 3, 624, False), (64, 900, 5, 17, True), (128, 3000, 33, 0, False)])
+def test_chained_references_equal_successive_calls_on_one_stream(dens, H, M, R, pos0, with_s):
+    """lfd_triangulate_sampled_chain: R references in one call on the context's single MT19937 stream give, bit for bit, the cells, the
+    points and the final stream of R successive lfd_triangulate_sampled calls - with a refused reference (it consumes nothing) and an empty one
+    in the middle, from even and odd stream positions (a double that straddles two keys), with handed-in normalisers, across the 32-reference
+    launch boundary, and on a map too small for the multi-workgroup kernel (64 x 64: reference after reference inside the call)."""
+    import lichtfeld_densification_plugin_amd as lfd
+    dev = dens.device
+    W = H
+    refuse, empty = ({2, R - 1} if R > 4 else {1}), ({4} if R > 5 else set())
+    refs, _keep = _chain_scene(dens, R, H, W, refuse=refuse, empty=empty)
+    cfg = lfd.DensePipelineConfig(output_path="", matches_per_ref=M)
+    params = hb.make_params(cfg)
+    cap = M + 24 * 24 + 64
+
+    def start():
+        dens.seed_rng(4242)
+        if pos0 is not None:
+            key, _ = dens.rng_state()
+            dens.set_rng_state(key, pos0)
+
+    # the normalisers: the exact sum for most, one ulp off for every third reference (upstream's torch sum may round either way)
+    s_list = None
+    if with_s:
+        best, _ = dens.aggregate(hb.PreparedBatch(refs, W, H), params)
+        s_list = []
+        for r in range(R):
+            s = float(_exact_s(best[r].cpu().numpy()))
+            if r % 3 == 1 and s > 0:
+                s = float(np.nextafter(np.float32(s), np.float32(np.inf)))
+            s_list.append(s)
+    # reference after reference
+    start()
+    singles = []
+    for r in range(R):
+        out1 = hb.OutputBuffers(cap, 1, 3, dev, True)
+        cells1 = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+        dens.launch_sampled(hb.PreparedBatch([refs[r]], W, H), params, M, out1, cap=0.9, border=2, tiles=24,
+                            s_override=s_list[r] if s_list else 0.0, sel_cells=cells1)
+        with torch.cuda.stream(dens.stream):
+            one = out1.collect(indexed=True, check_selection=False)
+        singles.append((one, cells1.cpu().numpy(), out1.sel_info.cpu().numpy().copy()))
+    key_a, pos_a = dens.rng_state()
+    # the same in one call
+    start()
+    out = hb.OutputBuffers(cap * R, R, 3, dev, True)
+    cells = torch.full((cap * R,), -1, dtype=torch.int64, device=dev)
+    dens.launch_sampled_chain(hb.PreparedBatch(refs, W, H), params, M, out, s_overrides=s_list, cap=0.9, border=2, tiles=24, sel_cells=cells)
+    with torch.cuda.stream(dens.stream):
+        got = out.collect(indexed=True, check_selection=False)
+    key_b, pos_b = dens.rng_state()
+    assert got.launch_status == 0
+    assert pos_a == pos_b and np.array_equal(key_a, key_b)
+    cells = cells.cpu().numpy()
+    offs = got.ref_offsets
+    drew = 0
+    for r, (one, cells1, info1) in enumerate(singles):
+        assert int(got.sel_status[r]) == int(info1[1]), r
+        if r in refuse:
+            assert int(got.sel_status[r]) == 3
+        n_sel = int(info1[0])
+        assert int(out.sel_info[2 * r]) == n_sel
+        np.testing.assert_array_equal(cells[r * cap:r * cap + n_sel], cells1[:n_sel])
+        lo, hi = int(offs[r]), int(offs[r + 1])
+        assert hi - lo == one.count
+        if r in refuse or r in empty:
+            assert hi == lo
+            continue
+        drew += 1
+        np.testing.assert_array_equal(got.xyz[lo:hi].cpu().numpy(), one.xyz.cpu().numpy())
+        np.testing.assert_array_equal(got.rgb[lo:hi].cpu().numpy(), one.rgb.cpu().numpy())
+        np.testing.assert_array_equal(got.err[lo:hi].cpu().numpy(), one.err.cpu().numpy())
+        np.testing.assert_array_equal(got.cell[lo:hi].cpu().numpy(), one.cell.cpu().numpy())
+    assert drew == R - len(refuse) - len(empty) and got.count > 0.5 * M * drew
