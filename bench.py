@@ -277,7 +277,7 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16, cams_for_hot=None)
     outg = hb.OutputBuffers(cap * G, G, args.k, dens.device)
     bg = hb.PreparedBatch(todo, wm, hm)
     seeds = [(cfg.seed * 2654435761 + i) & 0xFFFFFFFF for i in range(G)]
-    reps = 4
+    reps = 6
     for warm in (True, False):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -290,6 +290,51 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16, cams_for_hot=None)
     res["grouped"] = {"references_per_call": G, "ms_per_reference": dtg / (reps * G) * 1e3, "refs_per_s": reps * G / dtg,
                       "pairs_per_s": reps * G * args.k / dtg, "points_per_s": ptsg / dtg,
                       "note": "per-reference MT19937 streams (sharded runs): the group's selections run side by side"}
+    # round 5: the SAME single stream (upstream's semantics, bit for bit), several references per fused call: lfd_triangulate_sampled_chain - the
+    # references draw one after the other from the context's stream, everything else of their selections runs side by side.  First the call alone
+    # (the device's exact sums), then as the driver runs it by default (upstream's normaliser: every reference's weight map to the host, torch's sum)
+    outc = [hb.OutputBuffers(cap * G, G, args.k, dens.device) for _ in range(2)]
+    for warm in (True, False):
+        dens.seed_rng(cfg.seed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ptsc = 0
+        dens.launch_sampled_chain(bg, params, cfg.matches_per_ref, outc[0], cap=0.9, border=2, tiles=24)
+        for i in range(reps):
+            if i + 1 < reps:
+                dens.launch_sampled_chain(bg, params, cfg.matches_per_ref, outc[(i + 1) & 1], cap=0.9, border=2, tiles=24)
+            ptsc += outc[i & 1].collect(indexed=True, check_selection=True).count
+        torch.cuda.synchronize()
+        dtc = time.perf_counter() - t0
+    res["chained"] = {"references_per_call": G, "ms_per_reference": dtc / (reps * G) * 1e3, "refs_per_s": reps * G / dtc,
+                      "pairs_per_s": reps * G * args.k / dtc, "points_per_s": ptsc / dtc,
+                      "note": "ONE MT19937 stream (upstream's): the group's references draw in order, the rest of their selections side by side; device sums"}
+    passes_c = []
+    for warm in (True, False, False, False):
+        dens.seed_rng(cfg.seed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ptsd, ready, fly = 0, [], []
+        for _ in range(reps):          # (core/strategies.py::SampledLoop._launch_chain: a group's weight maps travel while the group before it computes)
+            b = hot.prepare_chain(todo, None)
+            ready.append((b, hot.begin_chain_normalisers(b)))
+            while len(ready) > 1:
+                b0, s0 = ready.pop(0)
+                fly.append(hot.launch_sampled_chain(b0, hot.finish_chain_normalisers(s0)))
+            while len(fly) > 1:
+                ptsd += getattr(hot.finish_sampled(fly.pop(0), check_selection=False), 'count', 0)
+        while ready:
+            b0, s0 = ready.pop(0)
+            fly.append(hot.launch_sampled_chain(b0, hot.finish_chain_normalisers(s0)))
+        while fly:
+            ptsd += getattr(hot.finish_sampled(fly.pop(0), check_selection=False), 'count', 0)
+        torch.cuda.synchronize()
+        dtd = time.perf_counter() - t0
+        if not warm:
+            passes_c.append(dtd / (reps * G) * 1e3)
+    res["chained"]["default_config_ms_per_reference"] = min(passes_c)
+    res["chained"]["default_config_passes_ms_per_reference"] = passes_c
+    res["chained"]["default_config_points_per_reference"] = ptsd / (reps * G)
     return res
 
 
@@ -1393,6 +1438,14 @@ def main():
                 line["default_mode"] = {"mode": "sampled (upstream-equivalent), refs_per_launch=1, upstream_normaliser", "ms_per_reference": dflt_ms,
                                         "refs_per_s": 1e3 / dflt_ms, "pairs_per_s": 1e3 / dflt_ms * args.k,
                                         "points_per_s": sm["default_config_points_per_reference"] * 1e3 / dflt_ms}
+                ch = sm.get("chained") or {}
+                if ch.get("default_config_ms_per_reference"):
+                    # the same stream, the same results (bit for bit): refs_per_launch references per fused call (lfd_triangulate_sampled_chain)
+                    cms = ch["default_config_ms_per_reference"]
+                    line["default_mode"]["chained"] = {"mode": f"the same single stream, refs_per_launch={ch['references_per_call']} (lfd_triangulate_sampled_chain)",
+                                                       "ms_per_reference": cms, "refs_per_s": 1e3 / cms, "pairs_per_s": 1e3 / cms * args.k,
+                                                       "points_per_s": ch["default_config_points_per_reference"] * 1e3 / cms,
+                                                       "ms_per_reference_device_sums": ch["ms_per_reference"]}
             if args.pipeline_cams > 0:
                 import bench_pipeline
                 dens.close()                        # the leg builds its own contexts

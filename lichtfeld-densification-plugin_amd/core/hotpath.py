@@ -265,7 +265,7 @@ class HotPath:
             self._norm_masks[(H, W)] = mask
         slot = None
         for i, cand in enumerate(self._norm_free):
-            if tuple(cand["best"].shape) == (1, H, W):
+            if tuple(cand["best"].shape) == (1, H, W) and cand["w"].dim() == 2:
                 slot = self._norm_free.pop(i)
                 break
         if slot is None:
@@ -323,6 +323,47 @@ class HotPath:
     def prepare_chain(self, refs: List[hb.ReferenceInputs], axes) -> hb.PreparedBatch:
         """(separate from the launch: a reference that cannot be batched fails HERE, before anything has drawn from the stream)"""
         return hb.PreparedBatch(refs, self.w_match, self.h_match, axes=axes, cameras=self.cams)
+
+    def begin_chain_normalisers(self, batch: hb.PreparedBatch):
+        """``begin_normaliser`` for a whole group: ONE aggregate launch, the capped, border-masked weights of all its references in one pass, one
+        copy to pinned host memory on the side stream.  The caller launches the group BEFORE this one next (its sums have long arrived), so that
+        the copy and torch's sums of this group hide under that group's kernels."""
+        if self._norm_side is None:
+            self._norm_side = torch.cuda.Stream(device=self.dev)
+        R, H, W = batch.n_refs, batch.H, batch.W
+        mask = self._norm_masks.get((H, W))
+        if mask is None:
+            ys = torch.arange(H, device=self.dev).view(H, 1)
+            xs = torch.arange(W, device=self.dev).view(1, W)
+            mask = ((xs >= 2) & (xs <= W - 1 - 2) & (ys >= 2) & (ys <= H - 1 - 2)).to(torch.float32)          # border = 2 (core/pipeline.py:642-649 upstream)
+            self._norm_masks[(H, W)] = mask
+        slot = None
+        for i, cand in enumerate(self._norm_free):
+            if tuple(cand["best"].shape) == (R, H, W) and cand["w"].dim() == 3:
+                slot = self._norm_free.pop(i)
+                break
+        if slot is None:
+            slot = {"best": torch.empty((R, H, W), dtype=torch.float32, device=self.dev), "w": torch.empty((R, H, W), dtype=torch.float32, device=self.dev),
+                    "host": torch.empty((R, H, W), dtype=torch.float32).pin_memory(), "agg_done": torch.cuda.Event(), "copied": torch.cuda.Event()}
+        with self.clock.stage("select", sync=False):
+            self.dens.launch_aggregate(batch, self.params, slot["best"], None)
+            with torch.cuda.stream(self.dens.stream):
+                torch.clamp(slot["best"], max=self.sample_cap, out=slot["w"])
+                slot["w"].mul_(mask)
+                slot["agg_done"].record(self.dens.stream)
+            with torch.cuda.stream(self._norm_side):
+                self._norm_side.wait_event(slot["agg_done"])
+                slot["host"].copy_(slot["w"], non_blocking=True)
+                slot["copied"].record(self._norm_side)
+        return slot
+
+    def finish_chain_normalisers(self, slot) -> List[float]:
+        """upstream's torch f32 sum (core/sampling.py:27 there) of every reference's weight map, each over its own contiguous (H, W) block"""
+        with self.clock.stage("select", sync=False):
+            slot["copied"].synchronize()
+            sums = [float(slot["host"][r].reshape(-1).sum()) for r in range(int(slot["host"].shape[0]))]
+        self._norm_free.append(slot)
+        return [v if v > 0.0 else 0.0 for v in sums]
 
     def launch_sampled_chain(self, batch: hb.PreparedBatch, s_overrides: Optional[List[float]]):
         M = self.config.matches_per_ref

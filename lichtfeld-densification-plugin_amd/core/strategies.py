@@ -57,7 +57,8 @@ class SampledLoop:
         self.group: List[tuple] = []          # several references per fused call: (Matched, seed)
         self.pend_norm: List[tuple] = []      # default mode: aggregated map on its way to the host: (Matched, handle)
         self.inflight: List[tuple] = []       # launched, not yet read back: (Matched, handle)
-        self.chain: List[tuple] = []          # single stream, several references per fused call: (Matched, normaliser handle or None)
+        self.chain: List[Matched] = []        # single stream, several references per fused call: the group that is filling up
+        self.chain_ready: List[tuple] = []    # ... groups whose weight maps are on their way to the host: (items, batch, normaliser slot or None)
         self.chain_fly: List[tuple] = []      # ... launched groups: (items, handle)
 
     # -- the four schedules ---------------------------------------------------------------------------------------------------------
@@ -75,19 +76,14 @@ class SampledLoop:
         self._flush_group()
         if not self.per_ref_rng and int(cfg.refs_per_launch) > 1 and hot.can_chain(need_best, m.H, m.W):
             # upstream's ONE stream, refs_per_launch references per fused call (lfd_triangulate_sampled_chain): they draw one after the other, in
-            # this order, everything else of their selections runs side by side.  With upstream's normaliser every reference's weight map starts
-            # its way to the host now; the sums are taken when the group is launched.
+            # this order, everything else of their selections runs side by side
             while self.pend_norm:
                 self._promote_one()
             while self.inflight:
                 self._finish_one()
-            if self.chain and (self.chain[0][0].H, self.chain[0][0].W) != (m.H, m.W):
+            if self.chain and (self.chain[0].H, self.chain[0].W) != (m.H, m.W):
                 self._launch_chain()
-            try:
-                self.chain.append((m, hot.begin_normaliser(m.ref, m.axes) if hot.chain_uses_upstream_normaliser() else None))
-            except Exception as ex:
-                log.error(f"Triangulation error for ref {m.packed.ref_uid}: {ex}")
-                return
+            self.chain.append(m)
             if len(self.chain) >= int(cfg.refs_per_launch):
                 self._launch_chain()
             return
@@ -170,30 +166,42 @@ class SampledLoop:
             self.out.emit(Emission(m.local_i, m.packed, (res.xyz, res.rgb, res.err)), self.hot)
 
     def _launch_chain(self) -> None:
-        """The pending group's fused call; the group before it is collected only afterwards (its read-back hides under this one's kernels)."""
+        """The group that has filled up.  With upstream's normaliser its weight maps start their way to the host now (one aggregate launch, one
+        copy on the side stream) and the group BEFORE it - whose maps have arrived meanwhile - gets its sums and its fused call: copy and sums of
+        a group hide under the kernels of the other.  With the device's own sums the group is launched at once."""
         if not self.chain:
             return
         items, self.chain = list(self.chain), []
-        sums: List[float] = []
         try:
-            for _m, h in items:
-                sums.append(self.hot.finish_normaliser(h) if h is not None else 0.0)
-            batch = self.hot.prepare_chain([m.ref for m, _ in items], items[0][0].axes)
+            batch = self.hot.prepare_chain([m.ref for m in items], items[0].axes)
+            slot = self.hot.begin_chain_normalisers(batch) if self.hot.chain_uses_upstream_normaliser() else None
         except Exception as ex:
-            # nothing of the group has drawn from the stream yet: upstream isolates failures per reference (core/pipeline.py:874-879), so the
-            # group is redone one reference at a time, in order, behind the groups already launched
-            log.warn(f"Grouped triangulation of refs {[m.packed.ref_uid for m, _ in items]} failed ({ex}); retrying one by one")
-            while self.chain_fly:
-                self._finish_chain()
-            for m, _h in items:
+            # nothing of the group has drawn from the stream: upstream isolates failures per reference (core/pipeline.py:874-879), so the group is
+            # redone one reference at a time, in order, behind the groups before it
+            log.warn(f"Grouped triangulation of refs {[m.packed.ref_uid for m in items]} failed ({ex}); retrying one by one")
+            self._drain_ready()
+            for m in items:
                 self._one_synchronously(m, None, False)
             return
+        self.chain_ready.append((items, batch, slot))
+        while len(self.chain_ready) > (1 if slot is not None else 0):
+            self._promote_chain()
+
+    def _promote_chain(self) -> None:
+        items, batch, slot = self.chain_ready.pop(0)
         try:
-            self.chain_fly.append((items, self.hot.launch_sampled_chain(batch, sums if any(h is not None for _, h in items) else None)))
+            sums = self.hot.finish_chain_normalisers(slot) if slot is not None else None
+            self.chain_fly.append((items, self.hot.launch_sampled_chain(batch, sums)))
         except Exception as ex:
-            for m, _h in items:
+            for m in items:
                 log.error(f"Triangulation error for ref {m.packed.ref_uid}: {ex}")
         while len(self.chain_fly) > 1:
+            self._finish_chain()
+
+    def _drain_ready(self) -> None:
+        while self.chain_ready:
+            self._promote_chain()
+        while self.chain_fly:
             self._finish_chain()
 
     def _finish_chain(self) -> None:
@@ -201,10 +209,10 @@ class SampledLoop:
         try:
             res = self.hot.finish_sampled(handle, check_selection=False)
         except Exception as ex:
-            for m, _h in items:
+            for m in items:
                 log.error(f"Triangulation error for ref {m.packed.ref_uid}: {ex}")
             return
-        for bi, (m, _h) in enumerate(items):
+        for bi, m in enumerate(items):
             st = int(res.sel_status[bi])
             if st != 0:     # what upstream's sampling stage raises for this reference (it has drawn nothing); the others are not affected
                 log.error(f"Triangulation error for ref {m.packed.ref_uid}: {hb.selection_error(st)}")
@@ -215,8 +223,7 @@ class SampledLoop:
 
     def _drain_chain(self) -> None:
         self._launch_chain()
-        while self.chain_fly:
-            self._finish_chain()
+        self._drain_ready()
 
     def _flush_group(self) -> None:
         if not self.group:

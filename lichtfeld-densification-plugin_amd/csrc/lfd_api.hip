@@ -41,7 +41,7 @@ extern "C" __global__ void lfd_pack_points3d_kernel(const float* xyz, const floa
 extern "C" __global__ void lfd_copy_segments_kernel(LfdCopyArgs A, const unsigned char* src, unsigned char* dst);
 extern "C" __global__ void lfd_quantise_rgb_kernel(const float* rgb, long long n3, unsigned char* out);
 extern "C" __global__ void lfd_select_topm_kernel(LfdSelectArgs A);
-extern "C" __global__ void lfd_select_filter_mw_kernel(LfdSelectArgs A);
+extern "C" __global__ void lfd_select_filter_mw_kernel(LfdSelectArgs A, LfdSelectNorms norms);
 extern "C" __global__ void lfd_mt_seed_kernel(unsigned* mt, unsigned seed);
 extern "C" __global__ void lfd_mt_seed_batch_kernel(unsigned* mt_base, LfdSeedBatch seeds);
 extern "C" __global__ void lfd_indexed_eval_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets, float* scratch,
@@ -983,9 +983,11 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
     A.capacity = capacity;
     A.H = H; A.W = W; A.M = M; A.border = border; A.tiles = tiles; A.cap = cap; A.s_override = s_override;
     A.sel_offsets_out = sel_offsets_dev;
+    LfdSelectNorms norms;
+    std::memset(&norms, 0, sizeof(norms));
     if (s_batch) {
-        A.use_s_batch = 1;
-        for (int i = 0; i < n_batch; ++i) A.s_batch[i] = s_batch[i];
+        norms.use = 1;
+        for (int i = 0; i < n_batch; ++i) norms.s[i] = s_batch[i];
     }
     *d_info = reinterpret_cast<int*>(base + o_out);
     *d_time = nullptr;
@@ -1044,7 +1046,7 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
             A.n_wg = n_wg;
             if (n_batch == 1) LFD_HIP(ctx, hipMemsetAsync(base + o_coop, 0, 64, ctx->stream));       // barrier words and flags
             else LFD_HIP(ctx, hipMemset2DAsync(base + o_coop, total, 0, 64, (size_t)n_batch, ctx->stream));
-            hipLaunchKernelGGL(lfd_select_filter_mw_kernel, dim3((unsigned)n_wg + 1u, (unsigned)n_batch), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A);
+            hipLaunchKernelGGL(lfd_select_filter_mw_kernel, dim3((unsigned)n_wg + 1u, (unsigned)n_batch), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A, norms);
         } else {
             hipLaunchKernelGGL(lfd_select_filter_kernel, dim3(1, (unsigned)n_batch), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A);
         }

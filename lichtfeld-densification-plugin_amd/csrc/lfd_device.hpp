@@ -208,8 +208,12 @@ struct LfdSelectArgs {
     unsigned* snaps;                  // [snap_slots * 624] the key after the t-th twist at slot t % snap_slots (what the producer commits from)
     long long ring_cap;               // a power of two >= 4 * int(M * 0.85)
     int snap_slots;
-    int use_s_batch;                  // the normaliser of reference y is s_batch[y] (> 0: overrides the exact device sum) instead of s_override
-    float s_batch[LFD_SELECT_BATCH_MAX];
+};
+// per-reference normalisers of a batched launch, a kernel argument of its own: read with a run-time index straight from the argument segment (inside
+// LfdSelectArgs - which every kernel copies and edits for its reference - the array would drag the whole structure into scratch memory)
+struct LfdSelectNorms {
+    int use;                              // the normaliser of reference y is s[y] (> 0: overrides the exact device sum) instead of s_override
+    float s[LFD_SELECT_BATCH_MAX];
 };
 #define LFD_MT_STATE_STRIDE 640       // words per MT19937 state of a batch (624 key + position, padded)
 // chain block (byte offsets; u64 words unless noted)

@@ -29,6 +29,14 @@
 namespace {
 
 constexpr int kSelBlock = LFD_SELECT_BLOCK;
+#ifndef LFD_MW_COARSE
+#define LFD_MW_COARSE 1024
+#endif
+#ifndef LFD_MW_FINE
+#define LFD_MW_FINE 2
+#endif
+constexpr int kMwCoarse = LFD_MW_COARSE;      // multi-workgroup kernel: entries of the coarse search table (32 KiB of LDS)
+constexpr int kMwFine = LFD_MW_FINE;          // ... arity of the search inside a run (pivots / entries read in one round trip)
 
 // ---- MT19937 --------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned mt_temper(unsigned y) {
@@ -263,7 +271,6 @@ __device__ int block_excl_scan_i32(int v, int* s_tmp, int tid, int& total) {
 __device__ __forceinline__ LfdSelectArgs lfd_select_args_of(LfdSelectArgs A) {
     const long long y = (long long)blockIdx.y;
     if (A.batch_info) { A.n_out = A.batch_info + 2 * y; A.status = A.n_out + 1; }
-    if (A.use_s_batch) A.s_override = A.s_batch[y];
     if (y == 0) return A;
     const long long sb = A.batch_scratch_stride * y;
     A.best_cert += A.batch_cert_stride * y;
@@ -694,11 +701,12 @@ __device__ bool grid_barrier(unsigned* bar, unsigned n_wg_total) {
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter_mw_kernel(LfdSelectArgs A_launch) {
+extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter_mw_kernel(LfdSelectArgs A_launch, LfdSelectNorms norms) {
     const LfdSelectArgs A = lfd_select_args_of(A_launch);
+    const float s_handed_in = norms.use ? norms.s[blockIdx.y] : A.s_override;
     __shared__ double s_d[kSelBlock / 64];
     __shared__ int s_i[kSelBlock / 64];
-    __shared__ double s_chunk[kSelBlock];
+    __shared__ double s_chunk[kMwCoarse];                  // coarse search table: the cumulative sum at the end of every run of `per` cells
     __shared__ unsigned long long s_bin[LFD_SELECT_MAX_BINS];
     __shared__ double s_tab[16 * LFD_SELECT_MAX_WG];       // span sums, fetched once per round
     __shared__ unsigned long long s_msg;
@@ -860,7 +868,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
 
     double s64 = 0.0;
     for (int g = 0; g < G; ++g) s64 += g_part[g];                  // same order in every workgroup
-    const float s32 = (A.s_override > 0.0f) ? A.s_override : (float)s64;
+    const float s32 = (s_handed_in > 0.0f) ? s_handed_in : (float)s64;
     if (__hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_NAN; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         LFD_CHAIN_PASS();
@@ -936,7 +944,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     }
 
     // ---- legacy choice(replace=False, p) -----------------------------------------------------------------------
-    const int per = (N + kSelBlock - 1) / kSelBlock;              // run length of the coarse search table
+    const int per = (N + kMwCoarse - 1) / kMwCoarse;              // run length of the coarse search table
     int n_uniq = 0, guard = 0;
     unsigned long long my_begin = 0ull, consumed = 0ull;           // chained: this reference's first double in the stream, doubles it has used
     while (n_uniq < size) {
@@ -1046,19 +1054,44 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         // search cannot return it again), which one atomic OR on the mark's word tells - no first-occurrence words, no ordered compaction, and two grid
         // barriers per round instead of four.  (The marks live in bytes; the coverage picks below set bit 1 with the same atomic, so that neither
         // update can lose the other's bit.)
-        s_chunk[tid] = cdf[min((tid + 1) * per, N) - 1];
+        for (int t = tid; t < kMwCoarse; t += kSelBlock) s_chunk[t] = cdf[min((t + 1) * per, N) - 1];
         __syncthreads();
         unsigned* mark32 = reinterpret_cast<unsigned*>(mark);
         int cnt = 0;
         const unsigned long long round_begin = my_begin + consumed;
         for (int j = gt; j < need; j += T) {
             const double x = chained ? A.ring[(round_begin + (unsigned long long)j) & ring_mask] : A.draws[j];
-            int lo = 0, len = kSelBlock;
+            // searchsorted(cdf, x, side="right") = how many entries are <= x (the cumulative sum never decreases).  The table in LDS names the run;
+            // inside it the search is EIGHT-ary: seven pivots per step, read in one round trip (independent loads), cut the range to an eighth - the
+            // cumulative sum was written by other workgroups on other XCDs a moment ago, every dependent read of it is a trip to memory (~2 us), and
+            // a bisection's eight of them per draw were a quarter of this kernel's time.  A run of 64 cells: two trips.
+            int lo = 0, len = kMwCoarse;
             while (len > 0) { const int half = len >> 1, mid = lo + half; if (s_chunk[mid] <= x) { lo = mid + 1; len -= half + 1; } else len = half; }
             const int b = min(lo * per, N);
             lo = b;
             int hi = min(b + per, N);
-            while (hi - lo > 0) { const int half = (hi - lo) >> 1, mid = lo + half; if (cdf[mid] <= x) lo = mid + 1; else hi = mid; }
+            while (hi - lo > kMwFine) {
+                const int step = (hi - lo + kMwFine - 1) / kMwFine;
+                double piv[kMwFine - 1];
+#pragma unroll
+                for (int j = 1; j < kMwFine; ++j) piv[j - 1] = cdf[min(lo + j * step, hi) - 1];
+                int c = 0;
+#pragma unroll
+                for (int j = 1; j < kMwFine; ++j) c += (lo + j * step - 1 < hi && piv[j - 1] <= x) ? 1 : 0;
+                // pivots 1 .. c are <= x (everything up to pivot c is), pivot c + 1 - if it lies inside the range - is not
+                const int nlo = lo + c * step;
+                if (c + 1 < kMwFine && lo + (c + 1) * step - 1 < hi) hi = lo + (c + 1) * step - 1;
+                lo = nlo;
+            }
+            {
+                double v[kMwFine];
+#pragma unroll
+                for (int e = 0; e < kMwFine; ++e) v[e] = cdf[min(lo + e, N - 1)];
+                int below = 0;
+#pragma unroll
+                for (int e = 0; e < kMwFine; ++e) below += (lo + e < hi && v[e] <= x) ? 1 : 0;
+                lo += below;
+            }
             const unsigned bit = 1u << (8 * (lo & 3));
             const unsigned old = atomicOr(mark32 + (lo >> 2), bit);
             if (!(old & bit)) {
