@@ -29,14 +29,6 @@
 namespace {
 
 constexpr int kSelBlock = LFD_SELECT_BLOCK;
-#ifndef LFD_MW_COARSE
-#define LFD_MW_COARSE 1024
-#endif
-#ifndef LFD_MW_FINE
-#define LFD_MW_FINE 2
-#endif
-constexpr int kMwCoarse = LFD_MW_COARSE;      // multi-workgroup kernel: entries of the coarse search table (32 KiB of LDS)
-constexpr int kMwFine = LFD_MW_FINE;          // ... arity of the search inside a run (pivots / entries read in one round trip)
 
 // ---- MT19937 --------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned mt_temper(unsigned y) {
@@ -706,7 +698,6 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     const float s_handed_in = norms.use ? norms.s[blockIdx.y] : A.s_override;
     __shared__ double s_d[kSelBlock / 64];
     __shared__ int s_i[kSelBlock / 64];
-    __shared__ double s_chunk[kMwCoarse];                  // coarse search table: the cumulative sum at the end of every run of `per` cells
     __shared__ unsigned long long s_bin[LFD_SELECT_MAX_BINS];
     __shared__ double s_tab[16 * LFD_SELECT_MAX_WG];       // span sums, fetched once per round
     __shared__ unsigned long long s_msg;
@@ -944,7 +935,15 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     }
 
     // ---- legacy choice(replace=False, p) -----------------------------------------------------------------------
-    const int per = (N + kMwCoarse - 1) / kMwCoarse;              // run length of the coarse search table
+    // Guide table of the searches: guide[k] = searchsorted(cdf, k / K, side="right") for K a power of two of about a quarter of the cells.  The
+    // cumulative-sum pass writes it as it goes (the cell whose interval a k / K falls into knows so), a draw x then starts from
+    // [guide[k], guide[k + 1]], k = floor(x K): two dependent reads and - with weights within an order of magnitude of each other - about four
+    // cells, instead of a bisection's eight dependent reads of a cumulative sum that other XCDs wrote a moment ago.  (The searches of a round are
+    // bound by the cache misses a CU can have in flight: eight per draw were 13 of the phase's 19 us.)
+    int guide_K = 1024;
+    while (guide_K * 2 <= N / 4) guide_K *= 2;
+    const double guide_Kd = (double)guide_K;
+    int* guide = A.first;                                         // [N] scratch, K + 1 <= N entries used
     int n_uniq = 0, guard = 0;
     unsigned long long my_begin = 0ull, consumed = 0ull;           // chained: this reference's first double in the stream, doubles it has used
     while (n_uniq < size) {
@@ -991,13 +990,36 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
                     if (lane >= off) v += n;
                 }
                 const double before = carry + (v - v3);
+                const double c0 = div_total(before + v0), c1 = div_total(before + v1), c2 = div_total(before + v2), c3 = div_total(before + v3);
                 if (full) {
-                    *reinterpret_cast<double2*>(cdf + i) = make_double2(div_total(before + v0), div_total(before + v1));
-                    *reinterpret_cast<double2*>(cdf + i + 2) = make_double2(div_total(before + v2), div_total(before + v3));
+                    *reinterpret_cast<double2*>(cdf + i) = make_double2(c0, c1);
+                    *reinterpret_cast<double2*>(cdf + i + 2) = make_double2(c2, c3);
                 } else {
-                    if (i < w_hi) cdf[i] = div_total(before + v0);
-                    if (i + 1 < w_hi) cdf[i + 1] = div_total(before + v1);
-                    if (i + 2 < w_hi) cdf[i + 2] = div_total(before + v2);
+                    if (i < w_hi) cdf[i] = c0;
+                    if (i + 1 < w_hi) cdf[i + 1] = c1;
+                    if (i + 2 < w_hi) cdf[i + 2] = c2;
+                }
+                // guide table: cell j is the first one whose cumulative sum exceeds k / K for every k in [ceil(cdf[j - 1] K), ceil(cdf[j] K)) (all of it
+                // exact: K is a power of two); usually none or one k per cell.  A cell that owns many (a weight far above the others) shares them
+                // out over the wave.
+                {
+                    int kl = (int)ceil(div_total(before) * guide_Kd);
+                    const double cs[4] = {c0, c1, c2, c3};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool valid = i + e < w_hi;
+                        const int kh = valid ? min((int)ceil(cs[e] * guide_Kd), guide_K) : kl;
+                        if (kl < kh) guide[kl] = i + e;
+                        if (kl + 1 < kh) guide[kl + 1] = i + e;
+                        unsigned long long many = __ballot(kh - kl > 2);
+                        while (many) {
+                            const int src = __ffsll((long long)many) - 1;
+                            many &= many - 1ull;
+                            const int from = __shfl(kl, src, 64) + 2, to = __shfl(kh, src, 64), cell = __shfl(i, src, 64) + e;
+                            for (int k = from + lane; k < to; k += 64) guide[k] = cell;
+                        }
+                        kl = kh;
+                    }
                 }
                 carry += __shfl(v, 63, 64);
             }
@@ -1054,42 +1076,20 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         // search cannot return it again), which one atomic OR on the mark's word tells - no first-occurrence words, no ordered compaction, and two grid
         // barriers per round instead of four.  (The marks live in bytes; the coverage picks below set bit 1 with the same atomic, so that neither
         // update can lose the other's bit.)
-        for (int t = tid; t < kMwCoarse; t += kSelBlock) s_chunk[t] = cdf[min((t + 1) * per, N) - 1];
-        __syncthreads();
         unsigned* mark32 = reinterpret_cast<unsigned*>(mark);
         int cnt = 0;
         const unsigned long long round_begin = my_begin + consumed;
         for (int j = gt; j < need; j += T) {
             const double x = chained ? A.ring[(round_begin + (unsigned long long)j) & ring_mask] : A.draws[j];
-            // searchsorted(cdf, x, side="right") = how many entries are <= x (the cumulative sum never decreases).  The table in LDS names the run;
-            // inside it the search is EIGHT-ary: seven pivots per step, read in one round trip (independent loads), cut the range to an eighth - the
-            // cumulative sum was written by other workgroups on other XCDs a moment ago, every dependent read of it is a trip to memory (~2 us), and
-            // a bisection's eight of them per draw were a quarter of this kernel's time.  A run of 64 cells: two trips.
-            int lo = 0, len = kMwCoarse;
-            while (len > 0) { const int half = len >> 1, mid = lo + half; if (s_chunk[mid] <= x) { lo = mid + 1; len -= half + 1; } else len = half; }
-            const int b = min(lo * per, N);
-            lo = b;
-            int hi = min(b + per, N);
-            while (hi - lo > kMwFine) {
-                const int step = (hi - lo + kMwFine - 1) / kMwFine;
-                double piv[kMwFine - 1];
-#pragma unroll
-                for (int j = 1; j < kMwFine; ++j) piv[j - 1] = cdf[min(lo + j * step, hi) - 1];
-                int c = 0;
-#pragma unroll
-                for (int j = 1; j < kMwFine; ++j) c += (lo + j * step - 1 < hi && piv[j - 1] <= x) ? 1 : 0;
-                // pivots 1 .. c are <= x (everything up to pivot c is), pivot c + 1 - if it lies inside the range - is not
-                const int nlo = lo + c * step;
-                if (c + 1 < kMwFine && lo + (c + 1) * step - 1 < hi) hi = lo + (c + 1) * step - 1;
-                lo = nlo;
-            }
+            // searchsorted(cdf, x, side="right") = how many entries are <= x (the cumulative sum never decreases): from the guide table's bracket
+            const int k = (int)(x * guide_Kd);                  // x < 1: k <= K - 1
+            int lo = guide[k];
+            int hi = (k + 1 < guide_K) ? guide[k + 1] : N;
+            while (hi - lo > 8) { const int half = (hi - lo) >> 1, mid = lo + half; if (cdf[mid] <= x) lo = mid + 1; else hi = mid; }
             {
-                double v[kMwFine];
-#pragma unroll
-                for (int e = 0; e < kMwFine; ++e) v[e] = cdf[min(lo + e, N - 1)];
                 int below = 0;
 #pragma unroll
-                for (int e = 0; e < kMwFine; ++e) below += (lo + e < hi && v[e] <= x) ? 1 : 0;
+                for (int e = 0; e < 8; ++e) if (lo + e < hi) below += (cdf[lo + e] <= x) ? 1 : 0;
                 lo += below;
             }
             const unsigned bit = 1u << (8 * (lo & 3));

@@ -384,7 +384,7 @@ def build_argparser() -> argparse.ArgumentParser:
     ap.add_argument("--seed", type=int, default=0, help="Random seed")
     ap.add_argument("--triangulation_mode", type=str, default="sampled", choices=list(TRIANGULATION_MODES),
                     help="sampled = upstream behaviour; dense = every grid cell through the fused kernel")
-    ap.add_argument("--refs_per_launch", type=int, default=1, help="dense mode: references triangulated per kernel launch")
+    ap.add_argument("--refs_per_launch", type=int, default=1, help="references per kernel launch (dense mode) or per fused call (sampled mode, device backend: same results, same RNG stream)")
     ap.add_argument("--backend", type=str, default="device", choices=["device", "host"],
                     help="device = the HIP kernels (needs a GPU); host = the CPU twin of the C-ABI + the host sampling stage "
                          "(upstream's CPU-only configuration); never chosen automatically")
