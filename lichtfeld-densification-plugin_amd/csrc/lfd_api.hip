@@ -942,7 +942,7 @@ static bool select_runs_on_several_workgroups(lfd_context* ctx, long long N) {
 static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
                          int32_t border, int32_t tiles, float s_override, int64_t* sel_out, int64_t capacity,
                          long long* sel_offsets_dev, int** d_info, unsigned char** d_time, int n_batch = 1,
-                         unsigned* mt_batch = nullptr, int* info_batch = nullptr, bool chain = false, const float* s_batch = nullptr) {
+                         unsigned* mt_batch = nullptr, int* info_batch = nullptr, const float* s_batch = nullptr) {
     if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
     if (!best_cert || !sel_out) return fail(ctx, LFD_ERR_INVALID, "null argument");
     if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
@@ -1021,27 +1021,35 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
                             "stage (selection_backend=\"host\" in the Python mirror: upstream's own library calls) has no such limit");
         }
         const bool timing_mw = timing && ctx->env.select_timing == 2;     // 2: stamps of workgroup 0 of the multi-workgroup kernel
-        if (chain && !select_runs_on_several_workgroups(ctx, (long long)N))
-            return fail(ctx, LFD_ERR_STATE, "selection: a chained launch needs the multi-workgroup kernel");
-        if (chain) {
-            // the stream as an array: a ring of doubles four first rounds long (later rounds are shorter than the first, the producer stays one
-            // first round ahead), and the key of every twist the producer can be ahead by
+        const bool several_wg = n_wg >= 2 && (!timing || timing_mw);
+        const bool one_stream = mt_batch == nullptr;              // the references of the launch share the context's stream, in batch order
+        if (one_stream && n_batch > 1 && !several_wg)
+            return fail(ctx, LFD_ERR_STATE, "selection: several references on one stream need the multi-workgroup kernel");
+        if (several_wg) {
+            // the stream as an array (lfd_select.hip, mt_stream_producer): a ring of doubles four first rounds long (later rounds are shorter than
+            // the first, the producer stays at most one first round ahead) and the key of every twist the producer can be ahead by - one set for
+            // the launch when its references share a stream, one per reference when every reference has its own
             const long long first_round = std::max<long long>(std::min<long long>((long long)((double)M * 0.85), (long long)N), 1);
             long long ring_cap = 4096;
             while (ring_cap < 4 * first_round) ring_cap *= 2;
             const int snap_slots = (int)(2 * ring_cap / 624) + 8;
-            const size_t o_ring = LFD_CHAIN_BYTES, o_snaps = o_ring + (size_t)ring_cap * 8, chain_total = o_snaps + (size_t)snap_slots * 624 * 4;
-            rc = ensure(ctx, ctx->sel_chain, chain_total);
+            const size_t o_ring = LFD_CHAIN_BYTES, o_snaps = o_ring + (size_t)ring_cap * 8,
+                         chain_total = (o_snaps + (size_t)snap_slots * 624 * 4 + 255) & ~size_t(255);
+            const int n_chains = one_stream ? 1 : n_batch;
+            rc = ensure(ctx, ctx->sel_chain, chain_total * (size_t)n_chains);
             if (rc != LFD_OK) return rc;
             unsigned char* cb = static_cast<unsigned char*>(ctx->sel_chain.ptr);
-            LFD_HIP(ctx, hipMemsetAsync(cb, 0, LFD_CHAIN_BYTES, ctx->stream));
+            if (n_chains == 1) LFD_HIP(ctx, hipMemsetAsync(cb, 0, LFD_CHAIN_BYTES, ctx->stream));
+            else LFD_HIP(ctx, hipMemset2DAsync(cb, chain_total, 0, LFD_CHAIN_BYTES, (size_t)n_chains, ctx->stream));
             A.chain = cb;
             A.ring = reinterpret_cast<double*>(cb + o_ring);
             A.snaps = reinterpret_cast<unsigned*>(cb + o_snaps);
             A.ring_cap = ring_cap;
             A.snap_slots = snap_slots;
+            A.chain_refs = one_stream ? n_batch : 1;
+            A.batch_chain_stride = one_stream ? 0 : (long long)chain_total;
         }
-        if (n_wg >= 2 && (!timing || timing_mw)) {
+        if (several_wg) {
             A.coop = base + o_coop;
             A.n_wg = n_wg;
             if (n_batch == 1) LFD_HIP(ctx, hipMemsetAsync(base + o_coop, 0, 64, ctx->stream));       // barrier words and flags
@@ -1145,7 +1153,7 @@ static int sampled_impl(lfd_context* ctx, const lfd_batch* batch, const lfd_para
             unsigned char* d_time = nullptr;
             rc = select_launch(ctx, topm, best + (size_t)r0 * HW, batch->H, batch->W, M, cap, topm ? 0 : border, topm ? 1 : tiles, 0.0f,
                                reinterpret_cast<int64_t*>(cells + (size_t)r0 * cap_sel), cap_sel, sel_pairs + 2 * (size_t)r0, &d_info, &d_time,
-                               nb, nullptr, sel_info + 2 * (size_t)r0, !topm, (s_chain && !topm) ? s_chain + r0 : nullptr);
+                               nb, nullptr, sel_info + 2 * (size_t)r0, (s_chain && !topm) ? s_chain + r0 : nullptr);
             if (rc != LFD_OK) return rc;
         }
     } else if (!seeds) {     // the context's MT19937 stream (upstream's single global stream), reference after reference

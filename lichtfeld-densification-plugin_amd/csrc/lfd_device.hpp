@@ -199,15 +199,18 @@ struct LfdSelectArgs {
     long long batch_out_stride;       // elements between their sel_out areas
     long long batch_mt_stride;        // words between their MT19937 states (one stream per reference)
     int* batch_info;                  // device i32 [2 * n] or null: reference y reports {n_out, status} at [2y], [2y + 1] instead of n_out / status
-    // Several references in one launch ON ONE MT19937 STREAM, consumed in batch order (lfd_triangulate_sampled_chain; multi-workgroup kernel
-    // only): the stream is an ARRAY - one producer workgroup (the extra workgroup of reference 0) writes its doubles, by absolute index, into
-    // `ring`; reference y uses the doubles from where reference y - 1 stopped, an offset it learns from the chain block when y - 1 is through
-    // with its last round.  Everything that does not depend on the stream (weights, p, the first cumulative sum) runs side by side.
-    unsigned char* chain;             // null, or the launch's chain block (LFD_CHAIN_* byte offsets, zeroed before the launch)
+    // The multi-workgroup kernel's view of the MT19937 stream - an ARRAY: one producer workgroup (the extra workgroup of reference 0) writes its
+    // doubles, by absolute index, into `ring`.  With several references in one launch on ONE stream (lfd_triangulate_sampled_chain, batch_mt_stride
+    // = 0) reference y uses the doubles from where reference y - 1 stopped, an offset it learns from the chain block when y - 1 is through with
+    // its last round; everything that does not depend on the stream (weights, p, the first cumulative sum) runs side by side.  With one stream PER
+    // reference (lfd_triangulate_sampled_multi) every reference is a launch of its own as far as this goes: chain / ring / snaps at a stride.
+    unsigned char* chain;             // the launch's chain block (LFD_CHAIN_* byte offsets, zeroed before the launch)
     double* ring;                     // [ring_cap] double i of the stream at i & (ring_cap - 1)
     unsigned* snaps;                  // [snap_slots * 624] the key after the t-th twist at slot t % snap_slots (what the producer commits from)
     long long ring_cap;               // a power of two >= 4 * int(M * 0.85)
     int snap_slots;
+    int chain_refs;                   // references that share this chain: the whole launch (one stream), or 1 (a stream per reference)
+    long long batch_chain_stride;     // bytes between the chain / ring / snaps sets of consecutive references (0: one set for the launch)
 };
 // per-reference normalisers of a batched launch, a kernel argument of its own: read with a run-time index straight from the argument segment (inside
 // LfdSelectArgs - which every kernel copies and edits for its reference - the array would drag the whole structure into scratch memory)
@@ -221,6 +224,7 @@ struct LfdSelectNorms {
 #define LFD_CHAIN_WANT 8              // end (absolute index) of the draws the reference at work has asked for
 #define LFD_CHAIN_RELEASED 16         // doubles below this index are not read any more
 #define LFD_CHAIN_STATE 24            // u32: 0 producer at work, 1 stream committed, 2 producer gave up / chain broken (stream left where it was)
+#define LFD_CHAIN_CURRENT 28          // u32: the reference of the launch that is drawing (the producer looks a whole first round ahead only while another follows)
 #define LFD_CHAIN_OFF 64              // [LFD_SELECT_BATCH_MAX + 1]: 1 + the absolute index of reference y's first draw; 0 = not known yet
 #define LFD_CHAIN_BROKEN (~0ull)      //   ... or this: a predecessor failed, nobody knows where the stream stands
 #define LFD_CHAIN_BYTES 512

@@ -29,6 +29,7 @@
 namespace {
 
 constexpr int kSelBlock = LFD_SELECT_BLOCK;
+constexpr int kScanRoundDraws = 1024;     // multi-workgroup kernel: a later round with at most this many draws left searches the weights themselves
 
 // ---- MT19937 --------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned mt_temper(unsigned y) {
@@ -145,9 +146,10 @@ __device__ void mt_stream_fill(unsigned (*s_mt)[624], MtCursor& c, double* ring,
     }
 }
 
-// The producer workgroup of a chained launch.  It stays `look` doubles ahead of the highest index anybody has asked for (the first round of the
-// next reference needs exactly that many), never more than the ring holds beyond what has been released, until the last reference of the launch
-// has said where it stopped; then it commits the stream AT THAT POSITION: the key of the twist the position lies in, from `snaps`.
+// The producer workgroup of a launch.  It stays ahead of the highest index anybody has asked for - by `look` doubles while another reference is
+// still to come (its first round needs exactly that many), by a later round's worth behind the launch's last reference - never more than the
+// ring holds beyond what has been released, in pieces short enough to notice soon that the last reference has said where it stopped; then it
+// commits the stream AT THAT POSITION: the key of the twist the position lies in, from `snaps`.
 __device__ void mt_stream_producer(const LfdSelectArgs& A, int n_refs, int look, int tid) {
     __shared__ unsigned s_key[2][624];
     __shared__ unsigned long long s_tgt;
@@ -156,6 +158,7 @@ __device__ void mt_stream_producer(const LfdSelectArgs& A, int n_refs, int look,
     unsigned long long* want_w = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_WANT);
     unsigned long long* released_w = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_RELEASED);
     unsigned* state_w = reinterpret_cast<unsigned*>(A.chain + LFD_CHAIN_STATE);
+    unsigned* current_w = reinterpret_cast<unsigned*>(A.chain + LFD_CHAIN_CURRENT);
     unsigned long long* off_w = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_OFF);
     for (int i = tid; i < 624; i += kSelBlock) s_key[0][i] = A.mt[i];
     if (tid == 0) s_pos0 = (int)A.mt[624];
@@ -173,8 +176,12 @@ __device__ void mt_stream_producer(const LfdSelectArgs& A, int n_refs, int look,
                 if (last != 0ull) { cmd = 2; break; }
                 const unsigned long long want = __hip_atomic_load(want_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long rel = __hip_atomic_load(released_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned long long tgt = want + (unsigned long long)look;
+                const unsigned current = __hip_atomic_load(current_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (nothing asked for yet: the launch's first reference will want a whole first round)
+                const int ahead = (want == 0ull || (int)current + 1 < n_refs) ? look : (look < kScanRoundDraws ? look : kScanRoundDraws);
+                unsigned long long tgt = want + (unsigned long long)ahead;
                 if (tgt > rel + (unsigned long long)A.ring_cap) tgt = rel + (unsigned long long)A.ring_cap;
+                if (tgt > produced + 2048ull) tgt = produced + 2048ull;
                 if (tgt > produced) { cmd = 1; s_tgt = tgt; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
@@ -280,6 +287,11 @@ __device__ __forceinline__ LfdSelectArgs lfd_select_args_of(LfdSelectArgs A) {
         A.status = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(A.status) + sb);
     }
     A.mt += A.batch_mt_stride * y;
+    if (A.batch_chain_stride) {
+        A.chain += A.batch_chain_stride * y;
+        A.ring = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(A.ring) + A.batch_chain_stride * y);
+        A.snaps = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(A.snaps) + A.batch_chain_stride * y);
+    }
     A.sel_out += A.batch_out_stride * y;
     if (A.sel_offsets_out) A.sel_offsets_out += 2 * y;
     return A;
@@ -700,6 +712,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     __shared__ int s_i[kSelBlock / 64];
     __shared__ unsigned long long s_bin[LFD_SELECT_MAX_BINS];
     __shared__ double s_tab[16 * LFD_SELECT_MAX_WG];       // span sums, fetched once per round
+    __shared__ double s_pref[16 * LFD_SELECT_MAX_WG];      // ... their inclusive prefix (scan rounds)
     __shared__ unsigned long long s_msg;
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -712,71 +725,27 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     unsigned char* mark = A.mark;          // bit 0: drawn (p = 0 from now on), bit 1: coverage pick
     unsigned* bar = reinterpret_cast<unsigned*>(A.coop + LFD_COOP_BAR);
     int* flags = reinterpret_cast<int*>(A.coop + LFD_COOP_FLAGS);
-    unsigned* msg_ready = reinterpret_cast<unsigned*>(A.coop + LFD_COOP_MSG);
-    unsigned* msg_go = msg_ready + 1;
-    unsigned long long* msg_req = reinterpret_cast<unsigned long long*>(A.coop + LFD_COOP_MSG + 8);
     double* g_part = reinterpret_cast<double*>(A.coop + LFD_COOP_PART);
     double* g_span = reinterpret_cast<double*>(A.coop + LFD_COOP_SPAN);
     int* g_cnt = reinterpret_cast<int*>(A.coop + LFD_COOP_WGCNT);
     unsigned long long* g_bins = reinterpret_cast<unsigned long long*>(A.coop + LFD_COOP_BINS);
-    unsigned* mt_spec = reinterpret_cast<unsigned*>(A.coop + LFD_COOP_MT);
     const int size = min((int)((double)A.M * 0.85), N);           // int(M * 0.85), f64 product like Python
 
     // ================= the workgroup on the MT19937 stream =================
-    // It never meets the others at a barrier: the first round's draws are generated on a copy of the state while the others
-    // stream the map; whether they count (upstream's argument checks) and what later rounds need arrives as messages.
-    const bool chained = A.chain != nullptr;
-    if (rng_wg && chained) {
-        // one stream for the whole launch: the extra workgroup of reference 0 produces it, the others have nothing to do
-        if (blockIdx.y == 0) mt_stream_producer(A, (int)gridDim.y, size, tid);
-        return;
-    }
+    // The stream of a launch is an ARRAY (mt_stream_producer): the extra workgroup of the launch's first reference writes its doubles into a ring,
+    // ahead of what is asked for, and never meets the others at a barrier; a reference draws from where the one before it stopped (the chain block),
+    // and where the last one stops is where the producer commits the stream.  A launch of one reference is a chain of one.
     if (rng_wg) {
-        if (A.timing && tid == 0) A.timing[30] = wall_clock64();
-        for (int i = tid; i < 625; i += kSelBlock) mt_spec[i] = A.mt[i];
-        __syncthreads();
-        mt_fill_doubles(mt_spec, A.draws, size, tid);
-        if (tid == 0) { __threadfence(); __hip_atomic_store(msg_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        if (A.timing && tid == 0) A.timing[31] = wall_clock64();
-        unsigned round_done = 1;
-        while (true) {
-            if (tid == 0) {
-                unsigned long long m = 0ull;
-                unsigned spins = 0;
-                while (true) {
-                    const unsigned go = __hip_atomic_load(msg_go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (go == 2u) { m = ~0ull; break; }                         // refused input: the stream stays where it was
-                    if (go == 1u) {
-                        m = __hip_atomic_load(msg_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((unsigned)(m >> 32) > round_done) break;          // a new round, or 0xffffffff = finished
-                    }
-                    if (++spins > (1u << 22)) { m = ~0ull - 1ull; break; }      // the others never spoke: give up without committing
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                __threadfence();
-                s_msg = m;
-            }
-            __syncthreads();
-            const unsigned long long m = s_msg;
-            __syncthreads();
-            if (m == ~0ull || m == ~0ull - 1ull) return;
-            const unsigned round = (unsigned)(m >> 32);
-            if (round == 0xffffffffu) break;
-            mt_fill_doubles(mt_spec, A.draws, (int)(unsigned)m, tid);
-            round_done = round;
-            if (tid == 0) { __threadfence(); __hip_atomic_store(msg_ready, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        }
-        for (int i = tid; i < 625; i += kSelBlock) A.mt[i] = mt_spec[i];       // the draws were consumed: commit the stream
+        if (A.chain_refs == 1 || blockIdx.y == 0) mt_stream_producer(A, A.chain_refs, size, tid);
         return;
     }
 
     // ================= the compute workgroups =================
-#define LFD_GRID_SYNC() do { if (!grid_barrier(bar, (unsigned)G)) { if (tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (chained) chain_hand_on(LFD_CHAIN_BROKEN); } return; } } while (0)
-#define LFD_TELL_RNG(round, need) do { if (wg == 0 && tid == 0) { __threadfence(); __hip_atomic_store(msg_req, ((unsigned long long)(unsigned)(round) << 32) | (unsigned long long)(unsigned)(need), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } } while (0)
-    // chained launches: where this reference's draws begin in the stream (absolute index of the doubles), learnt from the reference before it
+#define LFD_GRID_SYNC() do { if (!grid_barrier(bar, (unsigned)G)) { if (tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; chain_hand_on(LFD_CHAIN_BROKEN); } return; } } while (0)
+    // where this reference's draws begin in the stream (absolute index of the doubles), learnt from the reference before it
     // (LFD_CHAIN_OFF: 1 + index; the launch's first reference starts at 0), and handed on - by EVERY way out of this kernel, refusals included: a
     // refused reference consumes nothing (upstream raises before it draws), a failed one breaks the chain for those behind it
-    const int yref = (int)blockIdx.y;
+    const int yref = A.chain_refs == 1 ? 0 : (int)blockIdx.y;            // this reference's place in its chain
     unsigned long long* ch_off = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_OFF);
     unsigned long long* ch_want = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_WANT);
     unsigned long long* ch_released = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_RELEASED);
@@ -802,8 +771,8 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         __hip_atomic_store(ch_off + yref + 1, next_begin == LFD_CHAIN_BROKEN ? next_begin : next_begin + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // a reference that leaves before it has drawn: the stream passes through it untouched
-#define LFD_CHAIN_PASS() do { if (chained && wg == 0) { const unsigned long long b_ = chain_begin(); if (tid == 0) chain_hand_on(b_); } } while (0)
-#define LFD_CHAIN_BREAK() do { if (chained && tid == 0) chain_hand_on(LFD_CHAIN_BROKEN); } while (0)
+#define LFD_CHAIN_PASS() do { if (wg == 0) { const unsigned long long b_ = chain_begin(); if (tid == 0) chain_hand_on(b_); } } while (0)
+#define LFD_CHAIN_BREAK() do { if (tid == 0) chain_hand_on(LFD_CHAIN_BROKEN); } while (0)
     if (wg == 0 && tid == 0) { *A.n_out = 0; *A.status = LFD_SELECT_OK; }
     int t_slot = 0;
 #define LFD_MW_STAMP() do { if (A.timing && wg == 0 && tid == 0 && t_slot < 30) A.timing[t_slot] = wall_clock64(); ++t_slot; } while (0)
@@ -832,10 +801,13 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             if (full && cert16) { const float4 c4 = *reinterpret_cast<const float4*>(cert + i); cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w; }
             else { for (int e = 0; e < 4 && i + e < w_hi; ++e) cs[e] = cert[i + e]; }
             float ws[4];
+            // (row and column of the first of the four cells by ONE division, the others by stepping: an integer division per cell - this pass
+            // has nothing else to do - was most of its time)
+            int y = i / W, x = i - y * W;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; ++e, ++x) {
                 const int ii = i + e;
-                const int y = ii / W, x = ii - y * W;
+                if (x == W) { x = 0; ++y; }
                 float c = cs[e];
                 c = (c > A.cap) ? A.cap : c;                       // torch.clamp(max=cap); NaN stays
                 const bool inside = x >= A.border && x <= W - 1 - A.border && y >= A.border && y <= H - 1 - A.border;
@@ -861,12 +833,11 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     for (int g = 0; g < G; ++g) s64 += g_part[g];                  // same order in every workgroup
     const float s32 = (s_handed_in > 0.0f) ? s_handed_in : (float)s64;
     if (__hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_NAN; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (wg == 0 && tid == 0) *A.status = LFD_SELECT_NAN;
         LFD_CHAIN_PASS();
         return;
     }
     if (!(s32 > 0.0f)) {                                           // upstream: `if s <= 0: return empty` (the stream is not touched)
-        if (wg == 0 && tid == 0) __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         LFD_CHAIN_PASS();
         return;
     }
@@ -888,21 +859,25 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             }
             int cur_bin = -1;
             unsigned long long cur_key = 0ull;
+            // row, column and coverage tile of the first of the four cells by three divisions, the others by stepping (six divisions per cell were
+            // most of this pass)
+            int y = i / W, x = i - y * W, bx = x / tile, rx = x - bx * tile, by = y / tile;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; ++e, ++x, ++rx) {
+                if (x == W) { x = 0; ++y; bx = 0; rx = 0; by = y / tile; }
+                if (rx == tile) { rx = 0; ++bx; }
                 if (pf[e] > 0.0f) {
                     ++nz;
                     if (pf[e] < 1.862645149230957e-09f) inexact = 1;   // 2^-29
                     const int ii = i + e;
-                    const int y = ii / W, x = ii - y * W;
                     const unsigned long long key = ((unsigned long long)__float_as_uint(pf[e]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)ii);
-                    const int b = (x / tile) * nby + (y / tile);
+                    const int b = bx * nby + by;
                     if (b == cur_bin) { cur_key = key > cur_key ? key : cur_key; }     // positive floats order like their bit patterns
                     else { if (cur_bin >= 0) atomicMax(&s_bin[cur_bin], cur_key); cur_bin = b; cur_key = key; }
                 }
                 if (pf[e] < 0.0f) neg = 1;
             }
-            if (cur_bin >= 0) atomicMax(&s_bin[cur_bin], cur_key);
+            if (cur_bin >= 0) atomicMax(&s_bin[cur_bin], cur_key);       // (handing a run of lanes' keys to one lane first was measured: no gain)
             part += ((double)pf[0] + (double)pf[1]) + ((double)pf[2] + (double)pf[3]);
         }
 #pragma unroll
@@ -924,14 +899,10 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         int st = LFD_SELECT_OK;
         if (neg) st = LFD_SELECT_NEGATIVE; else if (nz < size) st = LFD_SELECT_FEWER_NONZERO; else if (inexact) st = LFD_SELECT_INEXACT;
         if (st != LFD_SELECT_OK) {
-            if (wg == 0 && tid == 0) { *A.status = st; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (wg == 0 && tid == 0) *A.status = st;
             LFD_CHAIN_PASS();
             return;
         }
-    }
-    if (!chained && wg == 0 && tid == 0) {      // the checks passed: the draws count
-        __hip_atomic_store(msg_req, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(msg_go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     // ---- legacy choice(replace=False, p) -----------------------------------------------------------------------
@@ -945,29 +916,56 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     const double guide_Kd = (double)guide_K;
     int* guide = A.first;                                         // [N] scratch, K + 1 <= N entries used
     int n_uniq = 0, guard = 0;
-    unsigned long long my_begin = 0ull, consumed = 0ull;           // chained: this reference's first double in the stream, doubles it has used
+    unsigned long long my_begin = 0ull, consumed = 0ull;           // this reference's first double in the stream, doubles it has used
     while (n_uniq < size) {
         if (++guard > 60) {
             if (wg == 0 && tid == 0) *A.status = LFD_SELECT_NO_PROGRESS;
-            if (chained) { if (wg == 0) LFD_CHAIN_BREAK(); } else LFD_TELL_RNG(0xffffffffu, 0);
+            if (wg == 0) LFD_CHAIN_BREAK();
             return;
         }
         const int need = size - n_uniq;
-        const unsigned tag = (unsigned)(64 - guard) << 24;        // later rounds win the atomicMin below over stale words
-        // cdf = cumsum(p) / cdf[-1] over this wave's span; the carry comes from the table of span sums
-        {
-            for (int i = tid; i < n_spans; i += kSelBlock) s_tab[i] = g_span[i];
-            __syncthreads();
-            double carry = 0.0, total = 0.0;
-            for (int i = lane; i < n_spans; i += 64) { const double v = s_tab[i]; total += v; if (i < sidx) carry += v; }
+        // A LATER round with few draws left (the duplicates of the round before: ~140 of 8 500) does not rebuild the cumulative sum - a streaming
+        // pass and a grid barrier for a hundred searches: a wave finds every draw's cell from the live span sums and ONE span's weights (below).
+        const bool scan_round = guard > 1 && need <= kScanRoundDraws;
+        // the live span sums (the p pass wrote them, the draws of the rounds so far took their cells out), their total, the division by it
+        for (int i = tid; i < n_spans; i += kSelBlock) s_tab[i] = g_span[i];
+        __syncthreads();
+        double carry = 0.0, total = 0.0;
+        for (int i = lane; i < n_spans; i += 64) { const double v = s_tab[i]; total += v; if (i < sidx) carry += v; }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { carry += __shfl_xor(carry, off, 64); total += __shfl_xor(total, off, 64); }
-            const double rtot = 1.0 / total;
-            const bool quick_div = (__double_as_longlong(total) & 0xfffffffffffffll) != 0xfffffffffffffll;
-            auto div_total = [&](double a) {       // correctly rounded a / total (see the single-workgroup kernel)
-                if (quick_div) { const double q = a * rtot; return fma(fma(-total, q, a), rtot, q); }
-                return a / total;
-            };
+        for (int off = 32; off > 0; off >>= 1) { carry += __shfl_xor(carry, off, 64); total += __shfl_xor(total, off, 64); }
+        const double rtot = 1.0 / total;
+        const bool quick_div = (__double_as_longlong(total) & 0xfffffffffffffll) != 0xfffffffffffffll;
+        auto div_total = [&](double a) {       // correctly rounded a / total (see the single-workgroup kernel)
+            if (quick_div) { const double q = a * rtot; return fma(fma(-total, q, a), rtot, q); }
+            return a / total;
+        };
+        if (guard == 1) {
+            // the coverage picks (the `budget` heaviest bins) are flagged here - before the first cumulative sum, which does not look at them: with several
+            // references on one stream this is the part of a selection that runs side by side with the others, not the part they wait for - - bit 1 of the mark, which the cumulative sum ignores
+            unsigned* mark32 = reinterpret_cast<unsigned*>(mark);
+            const int budget = max(A.M - size, 1);
+            for (int b = tid; b < nbins; b += kSelBlock) s_bin[b] = g_bins[b];
+            __syncthreads();
+            // rank of a bin = bins with a larger key (keys are distinct: they embed the cell index); 32 threads per bin share the
+            // comparisons (one thread per bin walked the whole table: ~30 us of dependent LDS reads)
+            const int bpw = (nbins + G - 1) / G, b0 = wg * bpw;
+            for (int bl0 = 0; bl0 < bpw; bl0 += kSelBlock / 32) {
+                const int bl = bl0 + (tid >> 5), b = b0 + bl, sub = tid & 31;
+                const bool valid = bl < bpw && b < nbins;
+                const unsigned long long mine = valid ? s_bin[b] : 0ull;
+                int rank = 0;
+                if (mine != 0ull) for (int o = sub; o < nbins; o += 32) rank += (s_bin[o] > mine);
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) rank += __shfl_xor(rank, off, 32);
+                if (mine != 0ull && sub == 0 && rank < budget) {
+                    const unsigned cell = 0xffffffffu - (unsigned)(mine & 0xffffffffull);
+                    atomicOr(mark32 + (cell >> 2), 2u << (8 * (cell & 3u)));
+                }
+            }
+        }
+        // cdf = cumsum(p) / cdf[-1] over this wave's span; the carry comes from the table of span sums
+        if (!scan_round) {
             for (int base = w_lo; base < w_hi; base += 256) {
                 const int i = base + 4 * lane;
                 double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
@@ -1023,18 +1021,33 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
                 }
                 carry += __shfl(v, 63, 64);
             }
+            LFD_MW_STAMP();
+            LFD_GRID_SYNC();
+            LFD_MW_STAMP();
+        } else {
+            // inclusive prefix of the live span sums (exact, like every sum here): wave 0, 64 spans at a time
+            if (wave == 0) {
+                double run = 0.0;
+                for (int base = 0; base < n_spans; base += 64) {
+                    const int q = base + lane;
+                    double v = q < n_spans ? s_tab[q] : 0.0;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { const double n = __shfl_up(v, off, 64); if (lane >= off) v += n; }
+                    if (q < n_spans) s_pref[q] = run + v;
+                    run += __shfl(v, 63, 64);
+                }
+            }
+            __syncthreads();
         }
-        LFD_MW_STAMP();
-        LFD_GRID_SYNC();
-        LFD_MW_STAMP();
     LFD_MW_STAMP();
         // the draws of this round must be in place
-        if (chained) {
+        {
             if (guard == 1) {
                 // only now does anything here depend on the references before this one: where they left the stream
                 my_begin = chain_begin();
                 if (my_begin == LFD_CHAIN_BROKEN) { if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; chain_hand_on(LFD_CHAIN_BROKEN); } return; }
                 if (wg == 0 && tid == 0) {
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(A.chain + LFD_CHAIN_CURRENT), (unsigned)yref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(ch_released, my_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(ch_want, my_begin + (unsigned long long)need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1054,21 +1067,6 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             const int ok = s_i[0];
             __syncthreads();
             if (!ok) { if (tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; chain_hand_on(LFD_CHAIN_BROKEN); } return; }
-        } else {
-            if (tid == 0) {
-                unsigned spins = 0;
-                int ok = 1;
-                while (__hip_atomic_load(msg_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)guard) {
-                    if (++spins > (1u << 22)) { ok = 0; break; }
-                    __builtin_amdgcn_s_sleep(4);
-                }
-                __threadfence();
-                s_i[0] = ok;
-            }
-            __syncthreads();
-            const int ok = s_i[0];
-            __syncthreads();
-            if (!ok) { if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; __hip_atomic_store(msg_go, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
         }
         // new = searchsorted(cdf, x, side="right"), and what numpy does with it - keep the first occurrence of every distinct value, append, p[found] = 0 -
         // in the SAME phase: the selection's result is np.unique(...) of the cells found, so the ORDER they are appended in is never observed; a cell is
@@ -1079,8 +1077,69 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         unsigned* mark32 = reinterpret_cast<unsigned*>(mark);
         int cnt = 0;
         const unsigned long long round_begin = my_begin + consumed;
+        // a cell found in round r gets bit 0 AND r in bits 2-7 of its mark (r <= 60): a scan round has no snapshot of the cumulative sum to search
+        // in - it reads the weights themselves, while other waves mark this round's finds - and must count exactly the cells of EARLIER rounds as gone
+        const unsigned found_byte = 1u | ((unsigned)guard << 2);
+        auto found_now = [&](int cell) {             // one lane per found cell; true: nobody had drawn it before
+            const unsigned sh = 8u * ((unsigned)cell & 3u);
+            const unsigned old = atomicOr(mark32 + (cell >> 2), found_byte << sh);
+            if (old & (1u << sh)) return false;
+            atomicAdd(&g_span[cell / span], -(double)wbuf[cell]);                                // p[found] = 0 from now on: exact, hence order-independent
+            return true;
+        };
+        if (scan_round) {
+            // searchsorted(cumsum(p) / total, x, "right") = #{i : fl(S_i / total) <= x} = #{i : S_i <= s*}, s* the largest multiple of 2^-52 whose
+            // correctly rounded quotient by the total is <= x (the quotient is monotone, every S_i is a multiple of 2^-52): no cell is divided, the
+            // draw's threshold is.  s* = floor(x total) up to the rounding of that product: settled with the division itself.
+            const double U = 2.220446049250313e-16, t_units = total * 4503599627370496.0;       // 2^-52, total in units (an integer below 2^53)
+            const int wave_global = wg * nwaves + wave, n_waves = G * nwaves;
+            for (int j = wave_global; j < need; j += n_waves) {
+                const double x = A.ring[(round_begin + (unsigned long long)j) & ring_mask];
+                double m = floor(x * t_units);
+                while (div_total((m + 1.0) * U) <= x) m += 1.0;
+                while (div_total(m * U) > x) m -= 1.0;                 // (fl(0 / total) = 0 <= x: m >= 0)
+                const double sstar = m * U;
+                int sp = 0;
+                for (int q = lane; q < n_spans; q += 64) sp += (s_pref[q] <= sstar) ? 1 : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) sp += __shfl_xor(sp, off, 64);
+                // (sp < n_spans: the last prefix is the total, whose quotient 1.0 is above every draw)
+                const double rem = sstar - (sp ? s_pref[sp - 1] : 0.0);
+                const int c_lo = min(sp * span, N), c_hi = min(c_lo + span, N);
+                int below = 0;
+                double run = 0.0;
+                // (256 cells at a time, stopping at the piece the threshold falls into: reading the whole span ahead was measured and is slower)
+                for (int base = c_lo; base < c_hi; base += 256) {
+                    const int i = base + 4 * lane;
+                    double v[4] = {0.0, 0.0, 0.0, 0.0};
+                    if (i + 3 < c_hi) {
+                        const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
+                        const unsigned m4 = *reinterpret_cast<const unsigned*>(mark + i);
+                        const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const unsigned b = (m4 >> (8 * e)) & 0xffu; v[e] = ((b & 1u) && (b >> 2) < (unsigned)guard) ? 0.0 : (double)ws[e]; }
+                    } else {
+                        for (int e = 0; e < 4 && i + e < c_hi; ++e) { const unsigned b = mark[i + e]; v[e] = ((b & 1u) && (b >> 2) < (unsigned)guard) ? 0.0 : (double)wbuf[i + e]; }
+                    }
+                    v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+                    double incl = v[3];
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { const double n = __shfl_up(incl, off, 64); if (lane >= off) incl += n; }
+                    const double before = run + (incl - v[3]);
+                    int c = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) c += (i + e < c_hi && before + v[e] <= rem) ? 1 : 0;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+                    below += c;
+                    run += __shfl(incl, 63, 64);
+                    if (run > rem) break;
+                }
+                if (lane == 0 && found_now(c_lo + below)) ++cnt;
+            }
+        } else
         for (int j = gt; j < need; j += T) {
-            const double x = chained ? A.ring[(round_begin + (unsigned long long)j) & ring_mask] : A.draws[j];
+            const double x = A.ring[(round_begin + (unsigned long long)j) & ring_mask];
             // searchsorted(cdf, x, side="right") = how many entries are <= x (the cumulative sum never decreases): from the guide table's bracket
             const int k = (int)(x * guide_Kd);                  // x < 1: k <= K - 1
             int lo = guide[k];
@@ -1092,34 +1151,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
                 for (int e = 0; e < 8; ++e) if (lo + e < hi) below += (cdf[lo + e] <= x) ? 1 : 0;
                 lo += below;
             }
-            const unsigned bit = 1u << (8 * (lo & 3));
-            const unsigned old = atomicOr(mark32 + (lo >> 2), bit);
-            if (!(old & bit)) {
-                ++cnt;
-                atomicAdd(&g_span[lo / span], -(double)wbuf[lo]);                                // p[found] = 0 from now on: exact, hence order-independent
-            }
-        }
-        if (guard == 1) {
-            // the coverage picks (the `budget` heaviest bins) are flagged now - bit 1 of the mark, which the cumulative sum ignores
-            const int budget = max(A.M - size, 1);
-            for (int b = tid; b < nbins; b += kSelBlock) s_bin[b] = g_bins[b];
-            __syncthreads();
-            // rank of a bin = bins with a larger key (keys are distinct: they embed the cell index); 32 threads per bin share the
-            // comparisons (one thread per bin walked the whole table: ~30 us of dependent LDS reads)
-            const int bpw = (nbins + G - 1) / G, b0 = wg * bpw;
-            for (int bl0 = 0; bl0 < bpw; bl0 += kSelBlock / 32) {
-                const int bl = bl0 + (tid >> 5), b = b0 + bl, sub = tid & 31;
-                const bool valid = bl < bpw && b < nbins;
-                const unsigned long long mine = valid ? s_bin[b] : 0ull;
-                int rank = 0;
-                if (mine != 0ull) for (int o = sub; o < nbins; o += 32) rank += (s_bin[o] > mine);
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) rank += __shfl_xor(rank, off, 32);
-                if (mine != 0ull && sub == 0 && rank < budget) {
-                    const unsigned cell = 0xffffffffu - (unsigned)(mine & 0xffffffffull);
-                    atomicOr(mark32 + (cell >> 2), 2u << (8 * (cell & 3u)));
-                }
-            }
+            if (found_now(lo)) ++cnt;
         }
         // per-workgroup counts of this round, in a slot of their own per round parity (the `found` scratch, which nothing else uses any more): a
         // workgroup that is through the barrier below and already counting for the NEXT barrier - the next round's, or the final unique pass's, which
@@ -1137,8 +1169,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             for (int g = 0; g < G; ++g) appended += round_cnt[g];
             consumed += (unsigned long long)need;
             if (n_uniq + appended < size) {
-                if (!chained) LFD_TELL_RNG(guard + 1, size - n_uniq - appended);      // next round's draws can start now
-                else if (wg == 0 && tid == 0) {
+                if (wg == 0 && tid == 0) {
                     // (everybody is through with this round's draws: they are behind the barrier above)
                     __hip_atomic_store(ch_released, my_begin + consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(ch_want, my_begin + consumed + (unsigned long long)(size - n_uniq - appended), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1147,8 +1178,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             n_uniq += appended;
         }
     }
-    if (!chained) LFD_TELL_RNG(0xffffffffu, 0);                    // the stream is final: the other workgroup commits it
-    else if (wg == 0 && tid == 0) {                                // ... or the next reference starts where this one stopped (the producer commits behind the last)
+    if (wg == 0 && tid == 0) {                                     // the next reference starts where this one stopped (the producer commits behind the last)
         __hip_atomic_store(ch_released, my_begin + consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         chain_hand_on(my_begin + consumed);
     }
@@ -1160,7 +1190,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         int cnt = 0;
         for (int i = lo; i < hi; i += 4) {
             if (i + 3 < hi) { const unsigned m = *reinterpret_cast<const unsigned*>(mark + i); cnt += __popc((m | (m >> 1)) & 0x01010101u); }
-            else for (int e = 0; i + e < hi; ++e) cnt += mark[i + e] != 0;
+            else for (int e = 0; i + e < hi; ++e) cnt += (mark[i + e] & 3) != 0;
         }
         int total;
         int pos = block_excl_scan_i32(cnt, s_i, tid, total);
@@ -1173,12 +1203,11 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         for (int g = 0; g < G; ++g) { const int v = g_cnt[g]; if (g < wg) base += v; all += v; }
         if ((long long)all > A.capacity) { if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_CAPACITY; *A.n_out = all; } return; }
         pos += base;
-        if (cnt) for (int i = lo; i < hi; ++i) if (mark[i]) A.sel_out[pos++] = (long long)i;
+        if (cnt) for (int i = lo; i < hi; ++i) if (mark[i] & 3) A.sel_out[pos++] = (long long)i;
         if (wg == 0 && tid == 0) { *A.n_out = all; if (A.sel_offsets_out) A.sel_offsets_out[1] = A.sel_offsets_out[0] + all; }
     }
     LFD_MW_STAMP();
 #undef LFD_MW_STAMP
-#undef LFD_TELL_RNG
 #undef LFD_GRID_SYNC
 #undef LFD_CHAIN_PASS
 #undef LFD_CHAIN_BREAK
