@@ -463,3 +463,69 @@ def test_chained_references_equal_successive_calls_on_one_stream(dens, H, M, R, 
         np.testing.assert_array_equal(got.err[lo:hi].cpu().numpy(), one.err.cpu().numpy())
         np.testing.assert_array_equal(got.cell[lo:hi].cpu().numpy(), one.cell.cpu().numpy())
     assert drew == R - len(refuse) - len(empty) and got.count > 0.5 * M * drew
+
+
+@pytest.mark.parametrize("h,w,M,seed,heavy,light", [(256, 256, 6000, 21, 40, 0.0004), (512, 512, 10000, 22, 200, 0.0005), (320, 256, 4000, 23, 8, 0.00005),
+                                                    (128, 128, 3000, 24, 30, 0.0008)])
+def test_peaked_weights_take_many_rounds_of_both_kinds(dens, h, w, M, seed, heavy, light):
+    """A few cells that carry most of the weight: the first round's draws pile up on them, the second round has THOUSANDS of draws left (the
+    multi-workgroup kernel rebuilds its cumulative sum for it), the rounds after that a handful (searched in the weights themselves, a threshold
+    per draw instead of a division per cell).  Cells, their number and the stream position against NumPy's own choice() (the oracle), and the
+    single-workgroup kernel - which rebuilds every round - the same."""
+    rs = np.random.RandomState(seed)
+    perm = rs.permutation(h * w).astype(np.float64)
+    cert = (light * (1.0 + (perm + 0.5) / (h * w))).astype(np.float32).reshape(h, w)          # tie-free, all within a factor of two
+    inner = [(y, x) for y in range(4, h - 4) for x in range(4, w - 4)]
+    for n, k in enumerate(rs.choice(len(inner), size=heavy, replace=False)):
+        cert[inner[k]] = np.float32(0.5 + 0.3 * n / heavy)                                   # distinct heavy cells
+    dev = dens.device
+    t = torch.from_numpy(cert).to(dev)
+    dens.seed_rng(seed)
+    sel = dens.select_samples(t, M).cpu().numpy()
+    pos = dens.rng_state()[1]
+    rng = np.random.RandomState(seed)
+    counting = _CountingRng(rng)
+    ref = orc.select_samples(cert, M, rng=counting, s_override=_exact_s(cert))
+    np.testing.assert_array_equal(sel, ref)
+    assert pos == int(rng.get_state()[2])
+    assert len(counting.rounds) >= 3 and counting.rounds[1] > 1024 and counting.rounds[-1] <= 1024, counting.rounds
+    import os
+    os.environ["LFD_SELECT_WORKGROUPS"] = "0"                  # the single-workgroup kernel
+    try:
+        dens.reload_env()
+        dens.seed_rng(seed)
+        np.testing.assert_array_equal(dens.select_samples(t, M).cpu().numpy(), ref)
+        assert dens.rng_state()[1] == pos
+    finally:
+        del os.environ["LFD_SELECT_WORKGROUPS"]
+        dens.reload_env()
+
+
+class _CountingRng:
+    """np.random.RandomState that notes how many doubles every random_sample() call of choice() asks for (= the draws of a round)"""
+
+    def __init__(self, rs):
+        self._rs, self.rounds = rs, []
+
+    def choice(self, a, size=None, replace=True, p=None):
+        # numpy's legacy algorithm (mtrand.pyx, RandomState.choice, replace=False with p), restated to see the rounds
+        n_uniq, pp = 0, np.array(p, dtype=np.float64, copy=True)
+        found = np.zeros(size, dtype=np.int64)
+        flat_found = found.ravel()
+        while n_uniq < size:
+            self.rounds.append(size - n_uniq)
+            x = self._rs.random_sample((size - n_uniq,))
+            if n_uniq > 0:
+                pp[flat_found[0:n_uniq]] = 0
+            cdf = np.cumsum(pp)
+            cdf /= cdf[-1]
+            new = cdf.searchsorted(x, side="right")
+            _, unique_indices = np.unique(new, return_index=True)
+            unique_indices.sort()
+            new = new.take(unique_indices)
+            flat_found[n_uniq:n_uniq + new.size] = new
+            n_uniq += new.size
+        return found
+
+    def __getattr__(self, name):
+        return getattr(self._rs, name)
