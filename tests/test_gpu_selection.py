@@ -529,3 +529,68 @@ class _CountingRng:
 
     def __getattr__(self, name):
         return getattr(self._rs, name)
+
+
+def test_chained_selections_stress_against_numpy(dens):
+    """Thirty chained calls of random shape - 1 to 12 references, grids from 128 x 128 to 512 x 384, M from hundreds to 12 000, tie-free maps and maps
+    whose weight sits on a few cells (a second round of thousands of draws in the middle of a chain), one call continuing the stream of the other -
+    against NumPy's own choice() on ONE RandomState: every reference's cells, and the stream position after every call."""
+    import lichtfeld_densification_plugin_amd as lfd
+    from lichtfeld_densification_plugin_amd import synthetic
+    dev = dens.device
+    n_cams = 24
+    cams = synthetic.ring_cameras(n_cams, seed=0)
+    dens.upload_cameras(cams)
+    rs = np.random.RandomState(2026)
+    host_rng = np.random.RandomState(777)
+    dens.seed_rng(777)
+    warps = {}
+    total_refs = peaked_refs = 0
+    for call in range(30):
+        H, W = [(128, 128), (192, 160), (256, 256), (320, 320), (512, 384)][int(rs.randint(0, 5))]
+        R = int(rs.randint(1, 13))
+        M = int(rs.choice([400, 1500, 3000, 6000, 12000]))
+        M = min(M, int(0.5 * H * W))
+        if (H, W) not in warps:
+            s = synthetic.synth_reference(cams, 0, [1, 2], H, W, W, H, noise_px=0.4, outlier_frac=0.05, channels=2, seed=1, cert_mode="tiefree", device=dev)
+            warps[(H, W)] = (s.warp, s.image)
+        warp, image = warps[(H, W)]
+        maps, refs = [], []
+        for r in range(R):
+            perm = rs.permutation(H * W).astype(np.float64)
+            if rs.rand() < 0.3:          # a few heavy cells over a light floor
+                light = float(rs.choice([0.0004, 0.001]))
+                cert = (light * (1.0 + (perm + 0.5) / (H * W))).astype(np.float32).reshape(H, W)
+                heavy = int(rs.randint(5, 60))
+                ys, xs = rs.randint(4, H - 4, size=heavy), rs.randint(4, W - 4, size=heavy)
+                cert[ys, xs] = (0.5 + 0.3 * np.arange(heavy) / heavy).astype(np.float32)
+                peaked_refs += 1
+            else:
+                cert = (0.2 + 0.7 * (perm + 0.5) / (H * W)).astype(np.float32).reshape(H, W)
+            maps.append(cert)
+            t = torch.from_numpy(cert).to(dev)
+            refs.append(hb.ReferenceInputs(ref_cam=0, nbr_cams=[1, 2], cert=[t, t], warp=[warp[0], warp[1]], image=image))
+        cfg = lfd.DensePipelineConfig(output_path="", matches_per_ref=M, certainty_thresh=1e-5, nns_per_ref=2)
+        params = hb.make_params(cfg)
+        cap = M + 24 * 24 + 64
+        out = hb.OutputBuffers(cap * R, R, 2, dev, True)
+        cells = torch.full((cap * R,), -1, dtype=torch.int64, device=dev)
+        batch = hb.PreparedBatch(refs, W, H)
+        best, _ = dens.aggregate(batch, params)
+        dens.launch_sampled_chain(batch, params, M, out, cap=0.9, border=2, tiles=24, sel_cells=cells)
+        with torch.cuda.stream(dens.stream):
+            got = out.collect(indexed=True, check_selection=False)
+        assert got.launch_status == 0
+        cells = cells.cpu().numpy()
+        info = out.sel_info.cpu().numpy()
+        for r in range(R):
+            b = best[r].cpu().numpy()
+            np.testing.assert_array_equal(b, maps[r])                 # (the aggregated map IS the map handed in: both neighbours carry it)
+            assert int(info[2 * r + 1]) == 0, (call, r, int(info[2 * r + 1]))
+            ref = orc.select_samples(b, M, rng=host_rng, s_override=_exact_s(b))
+            n = int(info[2 * r])
+            assert n == ref.size, (call, r, n, ref.size)
+            np.testing.assert_array_equal(cells[r * cap:r * cap + n], ref)
+        assert dens.rng_state()[1] == int(host_rng.get_state()[2]), call
+        total_refs += R
+    assert total_refs > 120 and peaked_refs > 20
