@@ -1431,21 +1431,23 @@ def main():
             base = cpu_baseline(args, cams, srefs, dims, cfg)
             if base is not None:
                 line["cpu_baseline"] = base
-            # the user-visible default (triangulation_mode="sampled", one reference per call, upstream's normaliser) beside the dense headline
+            # the user-visible default beside the dense headline: triangulation_mode="sampled", upstream's normaliser, refs_per_launch = 0 = automatic -
+            # sixteen references per fused call on upstream's ONE MT19937 stream (lfd_triangulate_sampled_chain: the cells, points and stream of
+            # successive single calls, bit for bit) when nobody waits for intermediate previews (the CLI), one reference per call when somebody
+            # does (the GUI's previews, debug states): both are reported
             sm = line["sampled_mode"]
             dflt_ms = sm.get("default_config_ms_per_reference")
-            if dflt_ms:
-                line["default_mode"] = {"mode": "sampled (upstream-equivalent), refs_per_launch=1, upstream_normaliser", "ms_per_reference": dflt_ms,
-                                        "refs_per_s": 1e3 / dflt_ms, "pairs_per_s": 1e3 / dflt_ms * args.k,
-                                        "points_per_s": sm["default_config_points_per_reference"] * 1e3 / dflt_ms}
-                ch = sm.get("chained") or {}
-                if ch.get("default_config_ms_per_reference"):
-                    # the same stream, the same results (bit for bit): refs_per_launch references per fused call (lfd_triangulate_sampled_chain)
-                    cms = ch["default_config_ms_per_reference"]
-                    line["default_mode"]["chained"] = {"mode": f"the same single stream, refs_per_launch={ch['references_per_call']} (lfd_triangulate_sampled_chain)",
-                                                       "ms_per_reference": cms, "refs_per_s": 1e3 / cms, "pairs_per_s": 1e3 / cms * args.k,
-                                                       "points_per_s": ch["default_config_points_per_reference"] * 1e3 / cms,
-                                                       "ms_per_reference_device_sums": ch["ms_per_reference"]}
+            ch = sm.get("chained") or {}
+            if dflt_ms and ch.get("default_config_ms_per_reference"):
+                cms = ch["default_config_ms_per_reference"]
+                line["default_mode"] = {"mode": f"sampled (upstream-equivalent), upstream_normaliser, refs_per_launch=0 (automatic: {ch['references_per_call']} references per fused call on "
+                                                "the one stream, lfd_triangulate_sampled_chain)",
+                                        "ms_per_reference": cms, "refs_per_s": 1e3 / cms, "pairs_per_s": 1e3 / cms * args.k,
+                                        "points_per_s": ch["default_config_points_per_reference"] * 1e3 / cms,
+                                        "ms_per_reference_device_sums": ch["ms_per_reference"],
+                                        "one_reference_per_call": {"mode": "the same with refs_per_launch=1 (what a run with intermediate previews uses)", "ms_per_reference": dflt_ms,
+                                                                   "refs_per_s": 1e3 / dflt_ms, "pairs_per_s": 1e3 / dflt_ms * args.k,
+                                                                   "points_per_s": sm["default_config_points_per_reference"] * 1e3 / dflt_ms}}
             if args.pipeline_cams > 0:
                 import bench_pipeline
                 dens.close()                        # the leg builds its own contexts

@@ -57,7 +57,7 @@ def _ply_vertices(path: str) -> int:
 
 
 def run_once(scene_root: str, matcher, *, mode: str, device_prep: bool, backend: str = "device", refs_per_launch: int = 16, sync_stages: bool = False,
-             roma_setting: str = "fast", num_refs: float = 0.8, nns: int = 3, matches: int = 10000, pack_workers: int = 4, sampled_group: int = 1) -> dict:
+             roma_setting: str = "fast", num_refs: float = 0.8, nns: int = 3, matches: int = 10000, pack_workers: int = 4, sampled_group: int = 0) -> dict:
     """One ``dense_init`` on the scene, down to the written PLY.  GUI defaults (reprojection 0.8 px, 3 neighbours, 0.8 of the cameras as references).
     dense mode streams its output (``stream_output``: 15-byte records written by the kernel, copied out beside the next launch); sampled mode takes
     upstream's own flow - result arrays, then the writer (records packed on the device)."""
@@ -69,7 +69,7 @@ def run_once(scene_root: str, matcher, *, mode: str, device_prep: bool, backend:
             "--pack_workers", str(pack_workers), "--backend", backend]
     if mode == "dense":
         argv += ["--refs_per_launch", str(refs_per_launch), "--stream_output"]
-    elif sampled_group > 1:      # several references per fused call on upstream's one RNG stream (lfd_triangulate_sampled_chain): the same cloud
+    elif sampled_group > 0:      # (0: the CLI's default - automatic: 16 references per fused call on upstream's one RNG stream, lfd_triangulate_sampled_chain)
         argv += ["--refs_per_launch", str(sampled_group)]
     if device_prep:
         argv += ["--device_image_prep"]
@@ -146,11 +146,12 @@ def pipeline_leg(dev, *, n_cams: int = 185, latency_ms: float = 20.0, scene_root
             if cores > 4:
                 m[f"device_prep_{cores}_pack_workers"] = run_once(scene_root, matcher, mode=mode, device_prep=True, pack_workers=cores, **kw)
             if mode == "sampled":
-                r = run_once(scene_root, matcher, mode=mode, device_prep=True, pack_workers=cores, sampled_group=refs_per_launch, **kw)
-                m[f"device_prep_{cores}_pack_workers_{refs_per_launch}_refs_per_call"] = r
+                # the same run one reference per fused call (what a run with intermediate previews uses): the same cloud
+                r = run_once(scene_root, matcher, mode=mode, device_prep=True, pack_workers=cores, sampled_group=1, **kw)
+                m[f"device_prep_{cores}_pack_workers_1_ref_per_call"] = r
                 same = m.get(f"device_prep_{cores}_pack_workers", m["device_prep"])
                 if r["points"] != same["points"]:
-                    raise RuntimeError(f"grouped sampled run wrote {r['points']} points, the plain run {same['points']}")
+                    raise RuntimeError(f"the one-reference-per-call run wrote {r['points']} points, the grouped (default) run {same['points']}")
         if "latency" in runs and latency_ms > 0:
             matcher.latency = latency_ms * 1e-3
             m[f"device_prep_matcher_{latency_ms:g}ms_per_pair" if on_gpu else f"host_prep_matcher_{latency_ms:g}ms_per_pair"] = \

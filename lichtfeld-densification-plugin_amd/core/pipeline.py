@@ -173,6 +173,10 @@ def run_dense_pipeline(
     config.validate()
     config, dev = _resolve_backend(config, backend, device)
     per_ref_rng = bool(config.per_reference_rng) or world > 1
+    # refs_per_launch = 0 (the default): several references per launch where the results do not depend on it and nobody watches the run proceed
+    previews = (on_sequential_viz is not None and int(config.viz_interval) > 0) or debug_state is not None
+    if int(config.refs_per_launch) != config.launch_group(world, previews):
+        config = dataclasses.replace(config, refs_per_launch=config.launch_group(world, previews))
     clock = stage_clock if stage_clock is not None else NULL_CLOCK
     uids = [c.uid for c in camera_records]
     total_pairs_est = _estimate_total_pairs(refs_local, nn_table, uids, config.nns_per_ref)

@@ -16,6 +16,7 @@ from typing import Dict, Optional
 import numpy as np
 
 TRIANGULATION_MODES = ("sampled", "dense")
+AUTO_REFS_PER_LAUNCH = 16         # refs_per_launch = 0 (the default) where several references per launch are possible and nobody waits for previews
 
 # Knobs that exist because an experiment was run: they stay reachable for the profiles and the tests that pin them, but they are not
 # part of the configuration surface a caller is expected to touch.  ``DensePipelineConfig(experimental={...})``; an unknown key is an error.
@@ -69,9 +70,10 @@ class DensePipelineConfig:
     #            only those are triangulated.  "dense": every grid cell upstream's sampler COULD draw (best certainty after
     #            floor and masks not <= 0: a masked-out cell never is) goes through the fused kernel.
     triangulation_mode: str = "sampled"
-    # references whose RoMa outputs are kept resident and triangulated by ONE kernel launch (dense mode; sampled mode: references per fused
-    # call, which needs one RNG stream per reference)
-    refs_per_launch: int = 1
+    # references whose RoMa outputs are kept resident and triangulated by ONE kernel launch (dense mode) or ONE fused call (sampled mode: on
+    # upstream's single RNG stream - lfd_triangulate_sampled_chain - or on per-reference streams; same results either way).  0 = automatic
+    # (``launch_group``): AUTO_REFS_PER_LAUNCH where that is possible and nobody waits for intermediate results, else 1.
+    refs_per_launch: int = 0
     # per-reference RNG stream (seed ^ uid) instead of upstream's single process-global stream;
     # forced on when references are sharded over several GPUs (results then do not depend on
     # the shard count).
@@ -123,13 +125,27 @@ class DensePipelineConfig:
             return "ply" if (str(self.output_path).lower().endswith(".ply") and float(self.voxel_size) <= 0.0) else "f32"
         return rec
 
+    def launch_group(self, world: int = 1, previews: bool = False) -> int:
+        """The references per launch / fused call a run uses.  An explicit ``refs_per_launch`` is taken as it is.  Automatic (0): one reference at
+        a time - upstream's cadence - when somebody watches the run proceed (intermediate previews), on the host backend, with the host selection
+        stage in sampled mode, and in sharded runs (every rank has to derive the same number from the configuration alone); else
+        AUTO_REFS_PER_LAUNCH: the results are the same, the references' kernels run side by side instead of one after the other."""
+        n = int(self.refs_per_launch)
+        if n > 0:
+            return n
+        if previews or int(world) > 1 or self.backend != "device":
+            return 1
+        if self.triangulation_mode != "dense" and self.selection_backend != "device":
+            return 1
+        return AUTO_REFS_PER_LAUNCH
+
     def problem(self) -> Optional[str]:
         """Why this combination of settings cannot run, or None.  Every pair of settings either works together or is named here: nothing
         is silently ignored (tests/test_config_matrix.py generates the pairs)."""
         if self.triangulation_mode not in TRIANGULATION_MODES:
             return f"triangulation_mode must be one of {TRIANGULATION_MODES}, got {self.triangulation_mode!r}"
-        if int(self.refs_per_launch) < 1:
-            return "refs_per_launch must be >= 1"
+        if int(self.refs_per_launch) < 0:
+            return "refs_per_launch must be >= 1 (or 0: automatic)"
         if int(self.pairs_per_forward) < 1:
             return "pairs_per_forward must be >= 1"
         if self.selection_backend not in ("device", "host"):

@@ -257,7 +257,7 @@ def dense_init(args, progress_callback: Optional[Callable[[float, str], None]] =
         max_points=args.max_points, no_filter=args.no_filter, seed=args.seed, viz_interval=0,
         prefetch_packages=args.prefetch_packages, pack_workers=args.pack_workers,
         triangulation_mode=getattr(args, "triangulation_mode", "sampled"),
-        refs_per_launch=getattr(args, "refs_per_launch", 1), backend=getattr(args, "backend", "device"),
+        refs_per_launch=getattr(args, "refs_per_launch", 0), backend=getattr(args, "backend", "device"),
         stream_output=bool(getattr(args, "stream_output", False)), device_image_prep=bool(getattr(args, "device_image_prep", False)))
     try:
         result = run_dense_pipeline(records, refs_local, nn_table, config, progress_callback=progress_callback,
@@ -384,7 +384,7 @@ def build_argparser() -> argparse.ArgumentParser:
     ap.add_argument("--seed", type=int, default=0, help="Random seed")
     ap.add_argument("--triangulation_mode", type=str, default="sampled", choices=list(TRIANGULATION_MODES),
                     help="sampled = upstream behaviour; dense = every grid cell through the fused kernel")
-    ap.add_argument("--refs_per_launch", type=int, default=1, help="references per kernel launch (dense mode) or per fused call (sampled mode, device backend: same results, same RNG stream)")
+    ap.add_argument("--refs_per_launch", type=int, default=0, help="references per kernel launch (dense mode) or per fused call (sampled mode, device backend: same results, same RNG stream); 0 = automatic (16 where possible, 1 when intermediate previews are written)")
     ap.add_argument("--backend", type=str, default="device", choices=["device", "host"],
                     help="device = the HIP kernels (needs a GPU); host = the CPU twin of the C-ABI + the host sampling stage "
                          "(upstream's CPU-only configuration); never chosen automatically")

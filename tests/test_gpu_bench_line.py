@@ -38,6 +38,8 @@ def test_single_gpu_bench_line_contract():
     assert po["kernel"] == "lfd_dense_ply_kernel" and po["unordered"]["kernel"] == "lfd_dense_ply_segments_kernel" and po["unordered"]["survivors"] == po["survivors"] == u["survivors"]
     dm = d["default_mode"]                                   # the user-visible default beside the dense headline
     assert dm["ms_per_reference"] > 0 and abs(dm["refs_per_s"] - 1e3 / dm["ms_per_reference"]) < 1e-6 * dm["refs_per_s"] and dm["pairs_per_s"] > dm["refs_per_s"]
+    one = dm["one_reference_per_call"]                       # what a run with intermediate previews uses; the automatic default groups references on the one stream
+    assert "refs_per_launch=0" in dm["mode"] and one["ms_per_reference"] > dm["ms_per_reference"] > 0 and dm["ms_per_reference_device_sums"] > 0
     assert d["rccl_ranks"] == 0 and d["collective_backend"] is None
     rp = d["cpu_baseline"]["reference_python"]               # upstream's own code, timed in the development container (tests/golden/g11_reference_timing.json)
     assert rp["cores"] >= 1 and rp["ms_per_reference"] > 10 and rp["run_dense_pipeline"]["pack_workers_1"]["references"] > 100
@@ -45,6 +47,7 @@ def test_single_gpu_bench_line_contract():
     assert pl["scene"]["cameras"] == 8 and pl["sampled"]["device_prep"]["points"] > 0 and pl["dense"]["device_prep"]["d2h_bytes"] == 15 * pl["dense"]["device_prep"]["points"]
     s = d["sampled_mode"]
     assert s["ms_per_reference"] > 0 and s["pipelined_ms_per_reference"] > 0 and s["default_config_ms_per_reference"] > 0 and s["grouped"]["ms_per_reference"] > 0
+    assert s["chained"]["ms_per_reference"] > 0 and s["chained"]["default_config_ms_per_reference"] == dm["ms_per_reference"]
     assert d["end_to_end"] is None and "unmeasured" in d["end_to_end_note"]
     assert len(s["default_config_passes_ms_per_reference"]) == 5 and s["default_config_ms_per_reference"] == min(s["default_config_passes_ms_per_reference"])
     assert d["host"]["torch_threads"] >= 1 and d["host"]["cpus_visible"] >= d["host"]["torch_threads"]       # threads fitted to the container's quota (core/hostenv.py)

@@ -342,7 +342,8 @@ def test_launch_ahead_equals_the_synchronous_loop(g4, tmp_path, per_ref, monkeyp
     the counts come back behind an event): same points, same order, same per-reference counts as the one-at-a-time loop."""
     cams, refs, nn, table = _scene(g4, str(tmp_path))
     kw = dict(output_path=os.path.join(str(tmp_path), "o.ply"), nns_per_ref=2, seed=5, viz_interval=0, matches_per_ref=1200,
-              per_reference_rng=per_ref, upstream_normaliser=False)       # (upstream's normaliser needs the host between two references)
+              per_reference_rng=per_ref, upstream_normaliser=False,       # (upstream's normaliser needs the host between two references)
+              refs_per_launch=1)                                          # (one reference per fused call: the automatic default would group them)
     ahead = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(**kw), matcher=FakeMatcher(64, 64, table))
     calls = {"n": 0}
     orig = pl._HotPath.launch_sampled
