@@ -215,8 +215,66 @@ int main(int argc, char** argv) {
         fprintf(stderr, "a %s context was accepted by the other side's entry point\n", on_device ? "device" : "host");
         return 8;
     }
+    /* the device leg also drives upstream's whole per-reference stage (sampling on the context's MT19937 stream included) from C: one call per
+     * reference twice in a row, then the same two references in ONE call (lfd_triangulate_sampled_chain) on a re-seeded stream - the same counts,
+     * reference by reference, and the same first position */
+    long long chain_counts[2] = {-1, -1};
+    if (on_device) {
+        const int32_t M = 200, tiles = 24;
+        const int64_t cap2 = 2 * ((int64_t)M + tiles * tiles + 64);
+        lfd_points o2;
+        memset(&o2, 0, sizeof o2);
+        o2.xyz = (float*)to_device(calloc((size_t)cap2 * 3, sizeof(float)), (size_t)cap2 * 3 * sizeof(float), 1);
+        o2.rgb = (float*)to_device(calloc((size_t)cap2 * 3, sizeof(float)), (size_t)cap2 * 3 * sizeof(float), 1);
+        o2.err = (float*)to_device(calloc((size_t)cap2, sizeof(float)), (size_t)cap2 * sizeof(float), 1);
+        o2.capacity = cap2;
+        int64_t offs2_host[3] = {0, 0, 0};
+        int32_t info_host[5] = {0, 0, 0, 0, 0};
+        int64_t* offs2 = (int64_t*)to_device(offs2_host, sizeof offs2_host, 1);
+        int32_t* seg2 = (int32_t*)to_device(calloc((size_t)2 * k, sizeof(int32_t)), (size_t)2 * k * sizeof(int32_t), 1);
+        int32_t* order2 = (int32_t*)to_device(calloc((size_t)2 * k, sizeof(int32_t)), (size_t)2 * k * sizeof(int32_t), 1);
+        int32_t* info = (int32_t*)to_device(info_host, sizeof info_host, 1);
+        long long single_counts[2];
+        float first_single[3], first_chain[3];
+        if (lfd_rng_seed(ctx, 5u) != LFD_OK) return 9;
+        for (int r = 0; r < 2; ++r) {
+            rc = lfd_triangulate_sampled(ctx, &batch, &params, M, 0.9f, 2, tiles, 0.0f, &o2, offs2, seg2, order2, info, NULL);
+            if (rc != LFD_OK) { fprintf(stderr, "lfd_triangulate_sampled failed (%d): %s\n", rc, lfd_last_error(ctx)); return 9; }
+            hipDeviceSynchronize();
+            hipMemcpy(offs2_host, offs2, 2 * sizeof(int64_t), 2);
+            hipMemcpy(info_host, info, 3 * sizeof(int32_t), 2);
+            if (info_host[1] != 0 || info_host[2] != 0) { fprintf(stderr, "sampled call %d: selection status %d, launch status %d\n", r, info_host[1], info_host[2]); return 9; }
+            single_counts[r] = (long long)offs2_host[1];
+            if (r == 0) hipMemcpy(first_single, o2.xyz, sizeof first_single, 2);
+        }
+        /* the same reference twice in one batch */
+        const int32_t ref2[2] = {ref_cam, ref_cam}, slots2[2] = {k, k};
+        int32_t* nbr2 = (int32_t*)malloc((size_t)2 * k * sizeof(int32_t));
+        const float** cert2 = (const float**)malloc((size_t)2 * k * sizeof(float*));
+        const float** warp2 = (const float**)malloc((size_t)2 * k * sizeof(float*));
+        const uint8_t* image2[2] = {image_ptr, image_ptr};
+        for (int j = 0; j < 2 * k; ++j) { nbr2[j] = nbr_cam[j % k]; cert2[j] = cert_ptrs[j % k]; warp2[j] = warp_ptrs[j % k]; }
+        lfd_batch b2 = batch;
+        b2.n_refs = 2; b2.ref_cam = ref2; b2.n_slots = slots2; b2.nbr_cam = nbr2; b2.cert = cert2; b2.warp = warp2; b2.image = image2;
+        if (lfd_rng_seed(ctx, 5u) != LFD_OK) return 9;
+        rc = lfd_triangulate_sampled_chain(ctx, &b2, &params, M, 0.9f, 2, tiles, NULL, &o2, offs2, seg2, order2, info, NULL);
+        if (rc != LFD_OK) { fprintf(stderr, "lfd_triangulate_sampled_chain failed (%d): %s\n", rc, lfd_last_error(ctx)); return 9; }
+        hipDeviceSynchronize();
+        hipMemcpy(offs2_host, offs2, 3 * sizeof(int64_t), 2);
+        hipMemcpy(info_host, info, 5 * sizeof(int32_t), 2);
+        hipMemcpy(first_chain, o2.xyz, sizeof first_chain, 2);
+        chain_counts[0] = (long long)(offs2_host[1] - offs2_host[0]);
+        chain_counts[1] = (long long)(offs2_host[2] - offs2_host[1]);
+        if (info_host[1] != 0 || info_host[3] != 0 || info_host[4] != 0 || chain_counts[0] != single_counts[0] || chain_counts[1] != single_counts[1] ||
+            chain_counts[0] <= 0 || memcmp(first_single, first_chain, sizeof first_single) != 0) {
+            fprintf(stderr, "chained call: %lld + %lld survivors (status %d %d, launch %d), one call per reference: %lld + %lld\n", chain_counts[0], chain_counts[1],
+                    info_host[1], info_host[3], info_host[4], single_counts[0], single_counts[1]);
+            return 9;
+        }
+    }
     printf("OK %s: %lld survivors in upstream's groups, positions within %.2g of upstream's; bad argument -> status %d \"%s\"\n", argv[2],
            (long long)offs_host[1], worst, LFD_ERR_INVALID, msg);
+    if (on_device) printf("OK device: two references chained on one MT19937 stream from C: %lld + %lld survivors, as one call per reference\n", chain_counts[0], chain_counts[1]);
     lfd_destroy(ctx);
     return 0;
 }

@@ -77,6 +77,7 @@ def test_a_c_program_drives_the_device_entry_points_through_the_header_alone(cal
     res = subprocess.run([caller, str(tmp_path / "case.bin"), "device"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr + res.stdout
     assert res.stdout.startswith(f"OK device: {case['xyz'].shape[0]} survivors")
+    assert "two references chained on one MT19937 stream from C" in res.stdout           # lfd_rng_seed, lfd_triangulate_sampled, lfd_triangulate_sampled_chain
 
 
 def test_the_ctypes_mirror_is_the_compilers_layout():
