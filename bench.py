@@ -316,7 +316,7 @@ def sampled_mode_rate(args, dens, refs, dims, cfg, n_refs=16, cams_for_hot=None)
         t0 = time.perf_counter()
         ptsd, ready, fly = 0, [], []
         for _ in range(reps):          # (core/strategies.py::SampledLoop._launch_chain: a group's weight maps travel while the group before it computes)
-            b = hot.prepare_chain(todo, None)
+            b = bg                     # (the batch descriptor prebuilt, like the one-reference passes above)
             ready.append((b, hot.begin_chain_normalisers(b)))
             while len(ready) > 1:
                 b0, s0 = ready.pop(0)
