@@ -1052,8 +1052,9 @@ static int select_launch(lfd_context* ctx, bool topm, const float* best_cert, in
         if (several_wg) {
             A.coop = base + o_coop;
             A.n_wg = n_wg;
-            if (n_batch == 1) LFD_HIP(ctx, hipMemsetAsync(base + o_coop, 0, 64, ctx->stream));       // barrier words and flags
-            else LFD_HIP(ctx, hipMemset2DAsync(base + o_coop, total, 0, 64, (size_t)n_batch, ctx->stream));
+            // barrier words, flags and the coverage bins (everything in front of LFD_COOP_MT)
+            if (n_batch == 1) LFD_HIP(ctx, hipMemsetAsync(base + o_coop, 0, LFD_COOP_MT, ctx->stream));
+            else LFD_HIP(ctx, hipMemset2DAsync(base + o_coop, total, 0, LFD_COOP_MT, (size_t)n_batch, ctx->stream));
             hipLaunchKernelGGL(lfd_select_filter_mw_kernel, dim3((unsigned)n_wg + 1u, (unsigned)n_batch), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A, norms);
         } else {
             hipLaunchKernelGGL(lfd_select_filter_kernel, dim3(1, (unsigned)n_batch), dim3(LFD_SELECT_BLOCK), 0, ctx->stream, A);

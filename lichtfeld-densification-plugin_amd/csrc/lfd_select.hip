@@ -791,7 +791,12 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     const int gt = wg * kSelBlock + tid;
 
     // ---- weights, exact sum, NaN check ------------------------------------------------------------------------------
-    {
+    // A normaliser that was handed in (upstream's own torch sum: the pipeline's default) needs no sum of the weights: this pass and its barrier are
+    // skipped, the next one takes the certainties themselves (and looks for NaN)
+    const bool direct = s_handed_in > 0.0f;
+    for (int b = tid; b < nbins; b += kSelBlock) s_bin[b] = 0ull;
+    if (direct) __syncthreads();
+    else {
         double acc = 0.0;
         int bad = 0;
 #pragma unroll 4
@@ -822,17 +827,15 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         const double wsum = block_sum_f64(acc, s_d, tid);
         const int any_bad = block_sum_i32(bad, s_i, tid);
         if (tid == 0) { g_part[wg] = wsum; if (any_bad) atomicOr(&flags[3], 1); }
-        if (wg == 0) for (int b = tid; b < LFD_SELECT_MAX_BINS; b += kSelBlock) g_bins[b] = 0ull;
-        for (int b = tid; b < nbins; b += kSelBlock) s_bin[b] = 0ull;
+        LFD_MW_STAMP();
+        LFD_GRID_SYNC();
+        LFD_MW_STAMP();
     }
-    LFD_MW_STAMP();
-    LFD_GRID_SYNC();
-    LFD_MW_STAMP();
-
+    // (the coverage bins in memory were zeroed with the barrier words, before the launch)
     double s64 = 0.0;
-    for (int g = 0; g < G; ++g) s64 += g_part[g];                  // same order in every workgroup
-    const float s32 = (s_handed_in > 0.0f) ? s_handed_in : (float)s64;
-    if (__hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    if (!direct) for (int g = 0; g < G; ++g) s64 += g_part[g];     // same order in every workgroup
+    const float s32 = direct ? s_handed_in : (float)s64;
+    if (!direct && __hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         if (wg == 0 && tid == 0) *A.status = LFD_SELECT_NAN;
         LFD_CHAIN_PASS();
         return;
@@ -844,12 +847,31 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
 
     // ---- p = (weights / s) as f32; exactness precondition; non-zero count; span sums; marks initialised; coverage bins (best cell of every tile bin, by weight, ties: lower index) -----------------------------
     {
-        int nz = 0, inexact = 0, neg = 0;
+        int nz = 0, inexact = 0, neg = 0, nan_seen = 0;
         double part = 0.0;
 #pragma unroll 2
         for (int i = w_lo + 4 * lane; i < w_hi; i += 256) {
             float pf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (i + 3 < w_hi) {
+            if (direct) {
+                // weight = clamp(certainty, max = cap) * inside, as the skipped pass computes it
+                float cs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                const bool full = i + 3 < w_hi;
+                if (full && cert16) { const float4 c4 = *reinterpret_cast<const float4*>(cert + i); cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w; }
+                else { for (int e = 0; e < 4 && i + e < w_hi; ++e) cs[e] = cert[i + e]; }
+                int yy = i / W, xx = i - yy * W;
+#pragma unroll
+                for (int e = 0; e < 4; ++e, ++xx) {
+                    if (xx == W) { xx = 0; ++yy; }
+                    float c = cs[e];
+                    c = (c > A.cap) ? A.cap : c;
+                    const bool inside = xx >= A.border && xx <= W - 1 - A.border && yy >= A.border && yy <= H - 1 - A.border;
+                    const float w = (i + e < w_hi) ? c * (inside ? 1.0f : 0.0f) : 0.0f;
+                    if (w != w) nan_seen = 1;
+                    pf[e] = w / s32;
+                }
+                if (full) { *reinterpret_cast<float4*>(wbuf + i) = make_float4(pf[0], pf[1], pf[2], pf[3]); *reinterpret_cast<unsigned*>(mark + i) = 0u; }
+                else { for (int e = 0; e < 4 && i + e < w_hi; ++e) { wbuf[i + e] = pf[e]; mark[i + e] = 0; } }
+            } else if (i + 3 < w_hi) {
                 const float4 w4 = *reinterpret_cast<const float4*>(wbuf + i);
                 pf[0] = w4.x / s32; pf[1] = w4.y / s32; pf[2] = w4.z / s32; pf[3] = w4.w / s32;
                 *reinterpret_cast<float4*>(wbuf + i) = make_float4(pf[0], pf[1], pf[2], pf[3]);
@@ -886,7 +908,8 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         nz = block_sum_i32(nz, s_i, tid);
         inexact = block_sum_i32(inexact, s_i, tid);
         neg = block_sum_i32(neg, s_i, tid);                       // (its barriers also complete the LDS bins)
-        if (tid == 0) { atomicAdd(&flags[0], nz); if (inexact) atomicOr(&flags[1], 1); if (neg) atomicOr(&flags[2], 1); }
+        if (direct) nan_seen = block_sum_i32(nan_seen, s_i, tid);
+        if (tid == 0) { atomicAdd(&flags[0], nz); if (inexact) atomicOr(&flags[1], 1); if (neg) atomicOr(&flags[2], 1); if (nan_seen) atomicOr(&flags[3], 1); }
         for (int b = tid; b < nbins; b += kSelBlock) if (s_bin[b]) atomicMax(&g_bins[b], s_bin[b]);
     }
     LFD_MW_STAMP();
@@ -897,7 +920,8 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         const int inexact = __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int neg = __hip_atomic_load(&flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int st = LFD_SELECT_OK;
-        if (neg) st = LFD_SELECT_NEGATIVE; else if (nz < size) st = LFD_SELECT_FEWER_NONZERO; else if (inexact) st = LFD_SELECT_INEXACT;
+        if (direct && __hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) st = LFD_SELECT_NAN;
+        else if (neg) st = LFD_SELECT_NEGATIVE; else if (nz < size) st = LFD_SELECT_FEWER_NONZERO; else if (inexact) st = LFD_SELECT_INEXACT;
         if (st != LFD_SELECT_OK) {
             if (wg == 0 && tid == 0) *A.status = st;
             LFD_CHAIN_PASS();
