@@ -227,5 +227,6 @@ struct LfdSelectNorms {
 #define LFD_CHAIN_CURRENT 28          // u32: the reference of the launch that is drawing (the producer looks a whole first round ahead only while another follows)
 #define LFD_CHAIN_OFF 64              // [LFD_SELECT_BATCH_MAX + 1]: 1 + the absolute index of reference y's first draw; 0 = not known yet
 #define LFD_CHAIN_BROKEN (~0ull)      //   ... or this: a predecessor failed, nobody knows where the stream stands
-#define LFD_CHAIN_BYTES 512
+#define LFD_CHAIN_BEG 384             // [LFD_SELECT_BATCH_MAX + 1]: the same number, published by reference y ITSELF when it starts drawing (its follower looks a window behind that first round up in advance)
+#define LFD_CHAIN_BYTES 1024
 struct LfdSeedBatch { unsigned seed[LFD_SELECT_BATCH_MAX]; };

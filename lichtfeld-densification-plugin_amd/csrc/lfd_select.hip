@@ -29,6 +29,9 @@
 namespace {
 
 constexpr int kSelBlock = LFD_SELECT_BLOCK;
+#ifndef LFD_PRODUCER_PIECE
+#define LFD_PRODUCER_PIECE 4096
+#endif
 constexpr int kScanRoundDraws = 1024;     // multi-workgroup kernel: a later round with at most this many draws left searches the weights themselves
 
 // ---- MT19937 --------------------------------------------------------------------------------------
@@ -150,7 +153,9 @@ __device__ void mt_stream_fill(unsigned (*s_mt)[624], MtCursor& c, double* ring,
 // still to come (its first round needs exactly that many), by a later round's worth behind the launch's last reference - never more than the
 // ring holds beyond what has been released, in pieces short enough to notice soon that the last reference has said where it stopped; then it
 // commits the stream AT THAT POSITION: the key of the twist the position lies in, from `snaps`.
-__device__ void mt_stream_producer(const LfdSelectArgs& A, int n_refs, int look, int tid) {
+__device__ void mt_stream_producer(const LfdSelectArgs& A, int n_refs, int first_round, int tid) {
+    // while another reference follows it stays M doubles ahead of the first round of the one at work (the follower looks that window up in advance)
+    const int look = n_refs > 1 ? (A.M > first_round ? A.M : first_round) : first_round;
     __shared__ unsigned s_key[2][624];
     __shared__ unsigned long long s_tgt;
     __shared__ int s_cmd, s_pos0;
@@ -181,7 +186,10 @@ __device__ void mt_stream_producer(const LfdSelectArgs& A, int n_refs, int look,
                 const int ahead = (want == 0ull || (int)current + 1 < n_refs) ? look : (look < kScanRoundDraws ? look : kScanRoundDraws);
                 unsigned long long tgt = want + (unsigned long long)ahead;
                 if (tgt > rel + (unsigned long long)A.ring_cap) tgt = rel + (unsigned long long)A.ring_cap;
-                if (tgt > produced + 2048ull) tgt = produced + 2048ull;
+                // (pieces: short behind the launch's last reference - the commit waits for the piece at hand - longer while others follow, where
+                // every look at the chain's words costs the followers' lookups a microsecond)
+                const unsigned long long piece = ((int)current + 1 < n_refs) ? (unsigned long long)LFD_PRODUCER_PIECE : 2048ull;
+                if (tgt > produced + piece) tgt = produced + piece;
                 if (tgt > produced) { cmd = 1; s_tgt = tgt; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
@@ -939,6 +947,30 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     while (guide_K * 2 <= N / 4) guide_K *= 2;
     const double guide_Kd = (double)guide_K;
     int* guide = A.first;                                         // [N] scratch, K + 1 <= N entries used
+    // searchsorted(cdf, x, side="right") = how many entries are <= x (the cumulative sum never decreases): from the guide table's bracket
+    auto guided_search = [&](double x) -> int {
+        const int k = (int)(x * guide_Kd);                        // x < 1: k <= K - 1
+        int lo = guide[k];
+        int hi = (k + 1 < guide_K) ? guide[k + 1] : N;
+        while (hi - lo > 8) { const int half = (hi - lo) >> 1, mid = lo + half; if (cdf[mid] <= x) lo = mid + 1; else hi = mid; }
+        int below = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (lo + e < hi) below += (cdf[lo + e] <= x) ? 1 : 0;
+        return lo + below;
+    };
+    // A reference that is not the first of its chain looks its draws up BEFORE it knows which they are: they start somewhere behind its predecessor's
+    // first round - at that round's end if the predecessor needs no more, a few (the duplicates of that round) further otherwise - so it looks up a
+    // window of M doubles from there while the predecessor is still drawing; a lookup changes nothing.  What is left for the chain is to MARK the
+    // cells of the `size` draws the reference turns out to own.
+#ifdef LFD_CHAIN_STAMPS
+    unsigned long long st_[8] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0, 0, 0};
+#define LFD_CS(k) do { st_[k] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define LFD_CS(k) do { } while (0)
+#endif
+    unsigned long long pre_base = 0ull;          // absolute index of the first double looked up in advance
+    int pre_win = 0, pre_cell = -1;              // doubles looked up in advance (thread gt: the double pre_base + gt), this thread's cell
+    unsigned long long* ch_beg = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_BEG);
     int n_uniq = 0, guard = 0;
     unsigned long long my_begin = 0ull, consumed = 0ull;           // this reference's first double in the stream, doubles it has used
     while (n_uniq < size) {
@@ -1064,16 +1096,61 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             __syncthreads();
         }
     LFD_MW_STAMP();
+        if (guard == 1 && yref > 0) {
+            // the predecessor's first double, or this reference's own (the predecessor refused its input or is through already): whichever is known first
+            if (tid == 0) {
+                unsigned long long v = 0ull;
+                unsigned spins = 0;
+                while (true) {
+                    if (__hip_atomic_load(ch_off + yref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { v = 0ull; break; }
+                    v = __hip_atomic_load(ch_beg + yref - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v != 0ull) break;
+                    if (++spins > (1u << 23)) { v = 0ull; break; }          // (the wait for this reference's own first double below reports it)
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                s_msg = v;
+            }
+            __syncthreads();
+            const unsigned long long pb = s_msg;
+            __syncthreads();
+            LFD_CS(1);
+            if (pb != 0ull) {
+                pre_base = (pb - 1ull) + (unsigned long long)size;
+                pre_win = min(max(A.M, size), T);                            // (one double per thread)
+                // the producer is on its way there: it stays M doubles ahead of the predecessor's first round while another reference follows
+                if (tid == 0) {
+                    unsigned spins = 0;
+                    int ok = 1;
+                    // (this workgroup's share of the window only: the producer is busy with little else than this window while the predecessor
+                    // draws, the lookups follow it piece by piece)
+                    const int my_end = min(pre_win, (wg + 1) * kSelBlock);
+                    while (__hip_atomic_load(ch_produced, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pre_base + (unsigned long long)my_end) {
+                        if (__hip_atomic_load(ch_off + yref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == LFD_CHAIN_BROKEN || ++spins > (1u << 22)) { ok = 0; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    __threadfence();
+                    s_i[0] = ok;
+                }
+                __syncthreads();
+                const int ok = s_i[0];
+                __syncthreads();
+                if (!ok) pre_win = 0;                                       // (no lookup in advance: the ordinary path below, which also reports a broken chain)
+                else if (gt < pre_win) pre_cell = guided_search(A.ring[(pre_base + (unsigned long long)gt) & ring_mask]);
+            }
+            LFD_CS(2);
+        }
         // the draws of this round must be in place
         {
             if (guard == 1) {
                 // only now does anything here depend on the references before this one: where they left the stream
                 my_begin = chain_begin();
+                LFD_CS(3);
                 if (my_begin == LFD_CHAIN_BROKEN) { if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; chain_hand_on(LFD_CHAIN_BROKEN); } return; }
                 if (wg == 0 && tid == 0) {
                     __hip_atomic_store(reinterpret_cast<unsigned*>(A.chain + LFD_CHAIN_CURRENT), (unsigned)yref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(ch_released, my_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(ch_want, my_begin + (unsigned long long)need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ch_beg + yref, my_begin + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (after `want`: the successor waits for the producer)
                 }
             }
             if (tid == 0) {
@@ -1161,21 +1238,20 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
                 }
                 if (lane == 0 && found_now(c_lo + below)) ++cnt;
             }
+        } else if (guard == 1 && pre_win > 0) {
+            // the cells were looked up in advance: mark those of the draws this reference owns, [round_begin, round_begin + need); what the window
+            // did not reach (the predecessor's later rounds took more than M - size doubles: weights piled on a few cells) is looked up now
+            const unsigned long long mine = pre_base + (unsigned long long)gt;
+            if (gt < pre_win && mine >= round_begin && mine < round_begin + (unsigned long long)need && found_now(pre_cell)) ++cnt;
+            const unsigned long long reached = pre_base + (unsigned long long)pre_win, end = round_begin + (unsigned long long)need;
+            if (end > reached) {
+                const unsigned long long from = round_begin > reached ? round_begin : reached;
+                for (unsigned long long a = from + (unsigned long long)gt; a < end; a += (unsigned long long)T)
+                    if (found_now(guided_search(A.ring[a & ring_mask]))) ++cnt;
+            }
         } else
         for (int j = gt; j < need; j += T) {
-            const double x = A.ring[(round_begin + (unsigned long long)j) & ring_mask];
-            // searchsorted(cdf, x, side="right") = how many entries are <= x (the cumulative sum never decreases): from the guide table's bracket
-            const int k = (int)(x * guide_Kd);                  // x < 1: k <= K - 1
-            int lo = guide[k];
-            int hi = (k + 1 < guide_K) ? guide[k + 1] : N;
-            while (hi - lo > 8) { const int half = (hi - lo) >> 1, mid = lo + half; if (cdf[mid] <= x) lo = mid + 1; else hi = mid; }
-            {
-                int below = 0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (lo + e < hi) below += (cdf[lo + e] <= x) ? 1 : 0;
-                lo += below;
-            }
-            if (found_now(lo)) ++cnt;
+            if (found_now(guided_search(A.ring[(round_begin + (unsigned long long)j) & ring_mask]))) ++cnt;
         }
         // per-workgroup counts of this round, in a slot of their own per round parity (the `found` scratch, which nothing else uses any more): a
         // workgroup that is through the barrier below and already counting for the NEXT barrier - the next round's, or the final unique pass's, which
@@ -1191,6 +1267,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         {
             int appended = 0;
             for (int g = 0; g < G; ++g) appended += round_cnt[g];
+            if (guard == 1) LFD_CS(4);
             consumed += (unsigned long long)need;
             if (n_uniq + appended < size) {
                 if (wg == 0 && tid == 0) {
@@ -1205,6 +1282,12 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     if (wg == 0 && tid == 0) {                                     // the next reference starts where this one stopped (the producer commits behind the last)
         __hip_atomic_store(ch_released, my_begin + consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         chain_hand_on(my_begin + consumed);
+        LFD_CS(5);
+#ifdef LFD_CHAIN_STAMPS
+        printf("ref %d wg0: pred-begin seen +%.1f, lookup done +%.1f, own begin +%.1f, round 1 counted +%.1f, handed on +%.1f us (rounds %d)\n", yref,
+               (double)(long long)(st_[1] - st_[0]) * 0.01, (double)(long long)(st_[2] - st_[0]) * 0.01, (double)(long long)(st_[3] - st_[0]) * 0.01,
+               (double)(long long)(st_[4] - st_[0]) * 0.01, (double)(long long)(st_[5] - st_[0]) * 0.01, guard);
+#endif
     }
 
     // ---- np.unique(concat): marked cells in ascending order; thread (wg, wave, lane) owns span/64 consecutive cells ------------
