@@ -1,10 +1,10 @@
 """How the matched references of a run are triangulated: one strategy object per run, fed by the driver loop with ``submit(Matched)`` and
 closed with ``drain()``.
 
-  * ``SampledLoop``      - upstream's mode (core/pipeline.py:602-780 per reference): coverage sampling, then the selected cells.  Four
-                           schedules, picked per reference from what the configuration allows: several references per fused call (one RNG
-                           stream each - or, round 5, chained on upstream's one stream), upstream's normaliser pipelined over a side stream,
-                           launch-ahead, or one synchronous reference.
+  * ``SampledLoop``      - upstream's mode (core/pipeline.py:602-780 per reference): coverage sampling, then the selected cells.  Five
+                           schedules, picked per reference from what the configuration allows: several references per fused call chained on
+                           upstream's one RNG stream (the default where nobody waits for intermediate previews) or on one stream each,
+                           upstream's normaliser pipelined over a side stream, launch-ahead, or one synchronous reference.
   * ``DenseBatcher``     - every candidate cell of ``refs_per_launch`` references through one launch of the fused kernel.
   * ``DensePlyStreamer`` - dense mode whose only consumer is the streamed output file: the kernel writes the 15-byte PLY records itself,
                            the records cross PCIe on a side stream into pinned double buffers while the next launch computes, and a
@@ -61,7 +61,7 @@ class SampledLoop:
         self.chain_ready: List[tuple] = []    # ... groups whose weight maps are on their way to the host: (items, batch, normaliser slot or None)
         self.chain_fly: List[tuple] = []      # ... launched groups: (items, handle)
 
-    # -- the four schedules ---------------------------------------------------------------------------------------------------------
+    # -- the five schedules ---------------------------------------------------------------------------------------------------------
     def submit(self, m: Matched) -> None:
         hot, cfg = self.hot, self.config
         serial = bool(hot.clock.serialising)      # a stage-attribution run takes the unfused calls: `select` and `kernel` are then separate stages
