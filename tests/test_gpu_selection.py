@@ -389,7 +389,10 @@ def _chain_scene(dens, R, H, W, refuse=(), empty=()):
 
 
 @pytest.mark.parametrize("H,M,R,pos0,with_s", [(256, 2500, 40, None, False), (256, 2500, 7, 311, True), (512, 10000, 6, 623, True),
-                                               (512, 12000, 3, 624, False), (64, 900, 5, 17, True), (128, 3000, 33, 0, False)])
+                                               (512, 12000, 3, 624, False), (64, 900, 5, 17, True), (128, 3000, 33, 0, False),
+                                               # four compute workgroups (4 096 threads) for 5 100 draws per first round: the window a reference looks up in
+                                               # advance is shorter than what it owns
+                                               (192, 6000, 6, 5, True)])
 def test_chained_references_equal_successive_calls_on_one_stream(dens, H, M, R, pos0, with_s):
     """lfd_triangulate_sampled_chain: R references in one call on the context's single MT19937 stream give, bit for bit, the cells, the
     points and the final stream of R successive lfd_triangulate_sampled calls - with a refused reference (it consumes nothing) and an empty one
