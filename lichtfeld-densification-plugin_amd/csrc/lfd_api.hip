@@ -42,6 +42,7 @@ extern "C" __global__ void lfd_copy_segments_kernel(LfdCopyArgs A, const unsigne
 extern "C" __global__ void lfd_quantise_rgb_kernel(const float* rgb, long long n3, unsigned char* out);
 extern "C" __global__ void lfd_select_topm_kernel(LfdSelectArgs A);
 extern "C" __global__ void lfd_select_filter_mw_kernel(LfdSelectArgs A, LfdSelectNorms norms);
+extern "C" __global__ void lfd_select_begins_kernel(long long* pairs, long long stride, int n);
 extern "C" __global__ void lfd_mt_seed_kernel(unsigned* mt, unsigned seed);
 extern "C" __global__ void lfd_mt_seed_batch_kernel(unsigned* mt_base, LfdSeedBatch seeds);
 extern "C" __global__ void lfd_indexed_eval_kernel(LfdLaunch L, const long long* sel_idx, const long long* sel_offsets, float* scratch,
@@ -1139,10 +1140,10 @@ static int sampled_impl(lfd_context* ctx, const lfd_batch* batch, const lfd_para
     if (R == 1) {
         LFD_HIP(ctx, hipMemsetAsync(sel_pairs, 0, 16, ctx->stream));
     } else {
-        std::vector<long long> begins(2 * (size_t)R);
-        for (int r = 0; r < R; ++r) begins[2 * (size_t)r] = begins[2 * (size_t)r + 1] = (long long)r * cap_sel;
-        LFD_HIP(ctx, hipMemcpyAsync(sel_pairs, begins.data(), begins.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
-        LFD_HIP(ctx, hipStreamSynchronize(ctx->stream));       // the host vector goes out of scope
+        // (written on the device: a copy from a host vector had to be waited for - a drain of the stream inside every grouped call, which kept the
+        // caller from running ahead of the device)
+        hipLaunchKernelGGL(lfd_select_begins_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, ctx->stream, sel_pairs, (long long)cap_sel, R);
+        LFD_HIP(ctx, hipGetLastError());
     }
     if (!seeds && (topm || select_runs_on_several_workgroups(ctx, HW)) && R > 1) {
         // the context's stream, R references in ONE launch per LFD_SELECT_BATCH_MAX of them: everything that does not depend on the stream runs

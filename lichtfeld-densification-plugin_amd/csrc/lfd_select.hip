@@ -1485,6 +1485,12 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_topm_k
 }
 
 // seed exactly like np.random.seed(uint32): init_genrand
+// {begin, end} pairs of the references of a fused sampled call: reference r's cells start at r * stride, none selected yet
+extern "C" __global__ void lfd_select_begins_kernel(long long* pairs, long long stride, int n) {
+    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r < n) { pairs[2 * r] = (long long)r * stride; pairs[2 * r + 1] = (long long)r * stride; }
+}
+
 extern "C" __global__ void lfd_mt_seed_kernel(unsigned* mt, unsigned seed) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         mt[0] = seed;

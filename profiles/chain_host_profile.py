@@ -13,7 +13,7 @@ from lichtfeld_densification_plugin_amd.core import hip_backend as hb, hostenv  
 from lichtfeld_densification_plugin_amd.core.hotpath import HotPath                # noqa: E402
 
 
-def main(R=16, groups=12, H=512, W=512, k=3, M=10000):
+def main(R=16, groups=12, H=512, W=512, k=3, M=10000, depth_ready=1, depth_fly=1, prebuilt=False):
     hostenv.fit_threads_to_quota()
     dev = torch.device("cuda:0")
     dens = hb.HipDensifier(dev)
@@ -38,14 +38,15 @@ def main(R=16, groups=12, H=512, W=512, k=3, M=10000):
             r = fn()
             t[name] += time.perf_counter() - a
             return r
+        b_pre = hot.prepare_chain(refs, None)
         for _ in range(groups):
-            b = clock("prepare", lambda: hot.prepare_chain(refs, None))
+            b = b_pre if prebuilt else clock("prepare", lambda: hot.prepare_chain(refs, None))
             ready.append((b, clock("begin", lambda: hot.begin_chain_normalisers(b))))
-            while len(ready) > 1:
+            while len(ready) > depth_ready:
                 b0, s0 = ready.pop(0)
                 sums = clock("sums", lambda: hot.finish_chain_normalisers(s0))
                 fly.append(clock("launch", lambda: hot.launch_sampled_chain(b0, sums)))
-            while len(fly) > 1:
+            while len(fly) > depth_fly:
                 clock("collect", lambda: hot.finish_sampled(fly.pop(0), check_selection=False))
         while ready:
             b0, s0 = ready.pop(0)
@@ -55,7 +56,7 @@ def main(R=16, groups=12, H=512, W=512, k=3, M=10000):
             hot.finish_sampled(fly.pop(0), check_selection=False)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    print(f"{dt / (groups * R) * 1e3:.4f} ms per reference; host ms per group: " + ", ".join(f"{k_} {v / groups * 1e3:.3f}" for k_, v in t.items()))
+    print(f"ready {depth_ready} fly {depth_fly} prebuilt {prebuilt}: {dt / (groups * R) * 1e3:.4f} ms per reference; host ms per group: " + ", ".join(f"{k_} {v / groups * 1e3:.3f}" for k_, v in t.items()))
     # the sums alone
     x = torch.rand(R, H, W).pin_memory()
     a = time.perf_counter()
@@ -66,4 +67,5 @@ def main(R=16, groups=12, H=512, W=512, k=3, M=10000):
 
 
 if __name__ == "__main__":
-    main()
+    for dr, df in ((1, 1), (2, 1), (1, 2), (2, 2), (3, 3)):
+        main(groups=24, depth_ready=dr, depth_fly=df, prebuilt=True)
