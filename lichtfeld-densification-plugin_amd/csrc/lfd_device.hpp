@@ -228,5 +228,6 @@ struct LfdSelectNorms {
 #define LFD_CHAIN_OFF 64              // [LFD_SELECT_BATCH_MAX + 1]: 1 + the absolute index of reference y's first draw; 0 = not known yet
 #define LFD_CHAIN_BROKEN (~0ull)      //   ... or this: a predecessor failed, nobody knows where the stream stands
 #define LFD_CHAIN_BEG 384             // [LFD_SELECT_BATCH_MAX + 1]: the same number, published by reference y ITSELF when it starts drawing (its follower looks a window behind that first round up in advance)
+#define LFD_CHAIN_TENT 656            // [LFD_SELECT_BATCH_MAX + 1]: 1 + where reference y starts IF its predecessor's second round is its last (published when the predecessor's first round is counted)
 #define LFD_CHAIN_BYTES 1024
 struct LfdSeedBatch { unsigned seed[LFD_SELECT_BATCH_MAX]; };

@@ -155,7 +155,9 @@ __device__ void mt_stream_fill(unsigned (*s_mt)[624], MtCursor& c, double* ring,
 // commits the stream AT THAT POSITION: the key of the twist the position lies in, from `snaps`.
 __device__ void mt_stream_producer(const LfdSelectArgs& A, int n_refs, int first_round, int tid) {
     // while another reference follows it stays M doubles ahead of the first round of the one at work (the follower looks that window up in advance)
-    const int look = n_refs > 1 ? (A.M > first_round ? A.M : first_round) : first_round;
+    // (twice M: a follower marks the cells of its first round while the reference at work is in its second - the doubles of that round, which start
+    // up to M behind the ones asked for, have to be there already; the ring holds four first rounds)
+    const int look = n_refs > 1 ? 2 * (A.M > first_round ? A.M : first_round) : first_round;
     __shared__ unsigned s_key[2][624];
     __shared__ unsigned long long s_tgt;
     __shared__ int s_cmd, s_pos0;
@@ -776,6 +778,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         return v == LFD_CHAIN_BROKEN ? v : v - 1ull;
     };
     auto chain_hand_on = [&](unsigned long long next_begin) {    // one thread
+        __threadfence();                                           // (behind a tentative number, if one was said: see where the successor reads them)
         __hip_atomic_store(ch_off + yref + 1, next_begin == LFD_CHAIN_BROKEN ? next_begin : next_begin + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // a reference that leaves before it has drawn: the stream passes through it untouched
@@ -971,6 +974,7 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
     unsigned long long pre_base = 0ull;          // absolute index of the first double looked up in advance
     int pre_win = 0, pre_cell = -1;              // doubles looked up in advance (thread gt: the double pre_base + gt), this thread's cell
     unsigned long long* ch_beg = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_BEG);
+    unsigned long long* ch_tent = reinterpret_cast<unsigned long long*>(A.chain + LFD_CHAIN_TENT);
     int n_uniq = 0, guard = 0;
     unsigned long long my_begin = 0ull, consumed = 0ull;           // this reference's first double in the stream, doubles it has used
     while (n_uniq < size) {
@@ -1139,19 +1143,61 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             }
             LFD_CS(2);
         }
+        // A reference that is not the first of its chain marks the cells of its first round on a TENTATIVE first double: its predecessor says, as
+        // soon as ITS first round is counted, where the successor starts if the predecessor's next round is its last (it nearly always is: that round
+        // looks for the first round's ~140 duplicates and would have to draw a duplicate itself) - the successor's marking and counting then run
+        // beside the predecessor's second round.  When the predecessor is through, the number is confirmed - or the successor takes its marks back
+        // (exactly: every thread the cells it itself turned, the weights back into their spans), meets at a barrier and marks again.
+        bool speculative = false;
+        unsigned long long newbits = 0ull;           // which of this thread's draws of the round turned a cell (bit 0: the one looked up in advance)
+        int appended = 0;
+        auto publish_begin = [&]() {
+            if (wg == 0 && tid == 0) {
+                __hip_atomic_store(reinterpret_cast<unsigned*>(A.chain + LFD_CHAIN_CURRENT), (unsigned)yref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ch_released, my_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ch_want, my_begin + (unsigned long long)need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ch_beg + yref, my_begin + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (after `want`: the successor waits for the producer)
+            }
+        };
+        for (int attempt = 0; ; ++attempt) {
         // the draws of this round must be in place
         {
-            if (guard == 1) {
+            if (guard == 1 && attempt == 0) {
                 // only now does anything here depend on the references before this one: where they left the stream
-                my_begin = chain_begin();
+                if (yref > 0 && (need + T - 1) / T <= 60) {
+                    if (tid == 0) {
+                        unsigned long long v = 0ull;
+                        int fin = 1;
+                        unsigned spins = 0;
+                        // EVERY workgroup of the reference has to take the same way: tentative if the predecessor has said a tentative number at
+                        // all - even when the final one is known by now - and final only if it never will (it was through after one round, or
+                        // refused).  The predecessor writes the tentative number first and the final one behind a fence; read in the opposite
+                        // order, a final number without a tentative one means there is none.
+                        while (true) {
+                            const unsigned long long f = __hip_atomic_load(ch_off + yref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            unsigned long long t = __hip_atomic_load(ch_tent + yref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (f == LFD_CHAIN_BROKEN) { v = f; break; }
+                            if (t == 0ull && f != 0ull) {           // (the fence only here, not in every turn of the wait)
+                                __threadfence();
+                                t = __hip_atomic_load(ch_tent + yref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            if (t != 0ull) { v = t; fin = 0; break; }
+                            if (f != 0ull) { v = f; break; }
+                            if (++spins > (1u << 23)) { v = LFD_CHAIN_BROKEN; break; }
+                            __builtin_amdgcn_s_sleep(4);
+                        }
+                        s_msg = v;
+                        s_i[1] = fin;
+                    }
+                    __syncthreads();
+                    const unsigned long long v = s_msg;
+                    speculative = s_i[1] == 0;
+                    __syncthreads();
+                    my_begin = v == LFD_CHAIN_BROKEN ? v : v - 1ull;
+                } else my_begin = chain_begin();
                 LFD_CS(3);
                 if (my_begin == LFD_CHAIN_BROKEN) { if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; chain_hand_on(LFD_CHAIN_BROKEN); } return; }
-                if (wg == 0 && tid == 0) {
-                    __hip_atomic_store(reinterpret_cast<unsigned*>(A.chain + LFD_CHAIN_CURRENT), (unsigned)yref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(ch_released, my_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(ch_want, my_begin + (unsigned long long)need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(ch_beg + yref, my_begin + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (after `want`: the successor waits for the producer)
-                }
+                if (!speculative) publish_begin();
             }
             if (tid == 0) {
                 const unsigned long long end = my_begin + consumed + (unsigned long long)need;
@@ -1242,16 +1288,18 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
             // the cells were looked up in advance: mark those of the draws this reference owns, [round_begin, round_begin + need); what the window
             // did not reach (the predecessor's later rounds took more than M - size doubles: weights piled on a few cells) is looked up now
             const unsigned long long mine = pre_base + (unsigned long long)gt;
-            if (gt < pre_win && mine >= round_begin && mine < round_begin + (unsigned long long)need && found_now(pre_cell)) ++cnt;
+            if (gt < pre_win && mine >= round_begin && mine < round_begin + (unsigned long long)need && found_now(pre_cell)) { ++cnt; newbits |= 1ull; }
             const unsigned long long reached = pre_base + (unsigned long long)pre_win, end = round_begin + (unsigned long long)need;
             if (end > reached) {
                 const unsigned long long from = round_begin > reached ? round_begin : reached;
-                for (unsigned long long a = from + (unsigned long long)gt; a < end; a += (unsigned long long)T)
-                    if (found_now(guided_search(A.ring[a & ring_mask]))) ++cnt;
+                int it = 1;
+                for (unsigned long long a = from + (unsigned long long)gt; a < end; a += (unsigned long long)T, ++it)
+                    if (found_now(guided_search(A.ring[a & ring_mask]))) { ++cnt; newbits |= 1ull << it; }
             }
-        } else
-        for (int j = gt; j < need; j += T) {
-            if (found_now(guided_search(A.ring[(round_begin + (unsigned long long)j) & ring_mask]))) ++cnt;
+        } else {
+            int it = 1;
+            for (int j = gt; j < need; j += T, ++it)
+                if (found_now(guided_search(A.ring[(round_begin + (unsigned long long)j) & ring_mask]))) { ++cnt; if (it < 64) newbits |= 1ull << it; }
         }
         // per-workgroup counts of this round, in a slot of their own per round parity (the `found` scratch, which nothing else uses any more): a
         // workgroup that is through the barrier below and already counting for the NEXT barrier - the next round's, or the final unique pass's, which
@@ -1264,13 +1312,51 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         LFD_MW_STAMP();
         LFD_GRID_SYNC();
         LFD_MW_STAMP();
+        appended = 0;
+        for (int g = 0; g < G; ++g) appended += round_cnt[g];
+        if (!speculative) break;
         {
-            int appended = 0;
-            for (int g = 0; g < G; ++g) appended += round_cnt[g];
+            // marked and counted on a tentative first double: confirmed ...
+            const unsigned long long final_begin = chain_begin();
+            if (final_begin == LFD_CHAIN_BROKEN) { if (wg == 0 && tid == 0) { *A.status = LFD_SELECT_NO_PROGRESS; chain_hand_on(LFD_CHAIN_BROKEN); } return; }
+            speculative = false;
+#ifdef LFD_CHAIN_STAMPS
+            st_[6] = my_begin; st_[7] = final_begin;
+#endif
+            if (final_begin == my_begin) { publish_begin(); break; }
+            // ... or taken back: every thread the cells its own draws turned (found again by the same walk), their weights back into the span sums
+            auto take_back = [&](int cell) {
+                const unsigned sh = 8u * ((unsigned)cell & 3u);
+                atomicAnd(mark32 + (cell >> 2), ~(0xfdu << sh));                      // (bit 1, a coverage pick, stays)
+                atomicAdd(&g_span[cell / span], (double)wbuf[cell]);
+            };
+            if (pre_win > 0) {
+                if (newbits & 1ull) take_back(pre_cell);
+                const unsigned long long reached = pre_base + (unsigned long long)pre_win, end = round_begin + (unsigned long long)need;
+                if (end > reached) {
+                    const unsigned long long from = round_begin > reached ? round_begin : reached;
+                    int it = 1;
+                    for (unsigned long long a = from + (unsigned long long)gt; a < end; a += (unsigned long long)T, ++it)
+                        if ((newbits >> it) & 1ull) take_back(guided_search(A.ring[a & ring_mask]));
+                }
+            } else {
+                int it = 1;
+                for (int j = gt; j < need; j += T, ++it)
+                    if ((newbits >> it) & 1ull) take_back(guided_search(A.ring[(round_begin + (unsigned long long)j) & ring_mask]));
+            }
+            newbits = 0ull;
+            my_begin = final_begin;
+            publish_begin();
+            LFD_GRID_SYNC();
+        }
+        }      // (attempt)
+        {
             if (guard == 1) LFD_CS(4);
             consumed += (unsigned long long)need;
             if (n_uniq + appended < size) {
                 if (wg == 0 && tid == 0) {
+                    // a successor may start marking now: this is where it starts if the round to come is this reference's last
+                    if (guard == 1) __hip_atomic_store(ch_tent + yref + 1, my_begin + consumed + (unsigned long long)(size - n_uniq - appended) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // (everybody is through with this round's draws: they are behind the barrier above)
                     __hip_atomic_store(ch_released, my_begin + consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(ch_want, my_begin + consumed + (unsigned long long)(size - n_uniq - appended), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1284,9 +1370,9 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
         chain_hand_on(my_begin + consumed);
         LFD_CS(5);
 #ifdef LFD_CHAIN_STAMPS
-        printf("ref %d wg0: pred-begin seen +%.1f, lookup done +%.1f, own begin +%.1f, round 1 counted +%.1f, handed on +%.1f us (rounds %d)\n", yref,
+        printf("ref %d wg0: pred-begin seen +%.1f, lookup done +%.1f, own begin +%.1f, round 1 counted +%.1f, handed on +%.1f us (rounds %d; tentative first double %llu, final %llu)\n", yref,
                (double)(long long)(st_[1] - st_[0]) * 0.01, (double)(long long)(st_[2] - st_[0]) * 0.01, (double)(long long)(st_[3] - st_[0]) * 0.01,
-               (double)(long long)(st_[4] - st_[0]) * 0.01, (double)(long long)(st_[5] - st_[0]) * 0.01, guard);
+               (double)(long long)(st_[4] - st_[0]) * 0.01, (double)(long long)(st_[5] - st_[0]) * 0.01, guard, st_[6], st_[7]);
 #endif
     }
 
