@@ -2,9 +2,11 @@
 // (upstream core/sampling.py:8-53 = torch clamp/sum + legacy numpy.random.choice + argsort walk).
 //
 // Two kernels with identical results: lfd_select_filter_kernel runs the whole selection in one 1024-thread workgroup
-// (small maps, profiling); lfd_select_filter_mw_kernel shares the streaming passes, the searches and the ordered compactions
-// out over several workgroups that meet at grid barriers, with one more workgroup on the (sequential) MT19937 stream.  The
-// problem is ~260k weights and ~9k draws: latency and one CU's memory pipeline bound it, not the chip's bandwidth.
+// (small maps, profiling); lfd_select_filter_mw_kernel shares the streaming passes and the searches out over several workgroups
+// that meet at grid barriers, with one more workgroup that PRODUCES the (sequential) MT19937 stream as an array of doubles.  A launch
+// of the second kernel may cover several references ON ONE STREAM (lfd_triangulate_sampled_chain): every reference draws from where
+// the one before it stopped, everything else of their selections runs side by side.  The problem is ~260k weights
+// and ~9k draws per reference: latency and one CU's memory pipeline bound it, not the chip's bandwidth.
 //
 // Restated third-party algorithms (absent from /root/reference; NumPy 2.2.6 numpy/random/mtrand.pyx
 // `RandomState.choice(a, size, replace=False, p)` and `_legacy_seeding`, randomkit's MT19937):
@@ -678,12 +680,12 @@ extern "C" __global__ void __launch_bounds__(LFD_SELECT_BLOCK) lfd_select_filter
 }
 
 // =================================================================================================
-// The same selection on several workgroups (one per CU): the streaming passes, the searches and the compactions are
-// split over n_wg workgroups that meet at grid barriers; one extra workgroup runs the MT19937 stream (sequential by
-// nature: the first round's draws are generated while the others stream the map, on a copy of the state that is
-// committed only once upstream's argument checks have passed).  Results are bit-identical to the single-workgroup
-// kernel: every sum involved is exact (see the header), so the partition does not change it, and the ordered
-// compactions keep (workgroup, thread) order = cell / draw order.
+// The same selection on several workgroups (one per CU): the streaming passes and the searches are split over n_wg
+// workgroups that meet at grid barriers; one extra workgroup produces the MT19937 stream (sequential by nature) ahead of
+// what is asked for and commits it - at the position the launch's last reference stopped at - only when that reference
+// says so: a reference whose input upstream would refuse (its argument checks) draws nothing.  Results are bit-identical
+// to the single-workgroup kernel: every sum involved is exact (see the header), so neither the partition nor the order of
+// the atomic updates changes it; the cells found are a SET (upstream returns np.unique of them).
 // =================================================================================================
 namespace {
 
