@@ -185,3 +185,20 @@ def test_pairs_with_a_device_only_setting_on_the_device(scene):
     # (round 5: several references per fused call ALSO on upstream's one stream - lfd_triangulate_sampled_chain - and it has to give the plain sequence)
     assert outcomes[("launch2", "per_ref_rng")] == "ran" and outcomes[("launch2", "launch2")] == "ran" and outcomes[("launch2", "select_host")] == "refused"
     assert outcomes[("dense", "stream")] == "ran"            # DensePlyStreamer
+
+
+def test_automatic_references_per_launch():
+    """refs_per_launch = 0 (the default) is resolved by the run: sixteen where the results do not depend on it and nobody waits for intermediate
+    results, one otherwise; an explicit number is taken as it is."""
+    from lichtfeld_densification_plugin_amd.core.types import AUTO_REFS_PER_LAUNCH
+    cfg = lfd.DensePipelineConfig(output_path="a.ply")
+    assert cfg.refs_per_launch == 0 and AUTO_REFS_PER_LAUNCH == 16
+    assert cfg.launch_group() == 16 and cfg.launch_group(world=1, previews=False) == 16
+    assert cfg.launch_group(previews=True) == 1                         # the GUI's previews keep upstream's cadence
+    assert cfg.launch_group(world=2) == 1                               # every rank has to derive the same number from the configuration alone
+    assert lfd.DensePipelineConfig(output_path="a.ply", backend="host").launch_group() == 1
+    assert lfd.DensePipelineConfig(output_path="a.ply", selection_backend="host").launch_group() == 1
+    assert lfd.DensePipelineConfig(output_path="a.ply", triangulation_mode="dense").launch_group() == 16
+    assert lfd.DensePipelineConfig(output_path="a.ply", refs_per_launch=3).launch_group(previews=True) == 3
+    with pytest.raises(ValueError, match="refs_per_launch"):
+        lfd.DensePipelineConfig(output_path="a.ply", refs_per_launch=-1)
