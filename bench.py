@@ -1273,10 +1273,14 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         backend = "gloo" if shared_gpu else "nccl"
+        # (a collective that never completes - the first run on real multi-GPU hardware is still ahead - becomes an error after five minutes, not a
+        # silent wait until the backend's own half-hour default)
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("LFD_BENCH_COLLECTIVE_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
 
     if dist is not None:
         return run_sharded(args, world, rank, dev, dist, backend)
