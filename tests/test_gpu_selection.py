@@ -544,12 +544,14 @@ def test_chained_selections_stress_against_numpy(dens):
     n_cams = 24
     cams = synthetic.ring_cameras(n_cams, seed=0)
     dens.upload_cameras(cams)
-    rs = np.random.RandomState(2026)
+    import os
+    n_calls = int(os.environ.get("LFD_CHAIN_STRESS_CALLS", "30"))          # (a longer one-off: LFD_CHAIN_STRESS_CALLS=250 LFD_CHAIN_STRESS_SEED=1 ... -k stress)
+    rs = np.random.RandomState(int(os.environ.get("LFD_CHAIN_STRESS_SEED", "2026")))
     host_rng = np.random.RandomState(777)
     dens.seed_rng(777)
     warps = {}
     total_refs = peaked_refs = 0
-    for call in range(30):
+    for call in range(n_calls):
         H, W = [(128, 128), (192, 160), (256, 256), (320, 320), (512, 384)][int(rs.randint(0, 5))]
         R = int(rs.randint(1, 13))
         M = int(rs.choice([400, 1500, 3000, 6000, 12000]))
@@ -596,4 +598,4 @@ def test_chained_selections_stress_against_numpy(dens):
             np.testing.assert_array_equal(cells[r * cap:r * cap + n], ref)
         assert dens.rng_state()[1] == int(host_rng.get_state()[2]), call
         total_refs += R
-    assert total_refs > 120 and peaked_refs > 20
+    assert total_refs > 4 * n_calls and peaked_refs > n_calls // 2
