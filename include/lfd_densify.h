@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LFD_ABI_VERSION 8
+#define LFD_ABI_VERSION 9
 #define LFD_MAX_SLOTS 16 /* neighbours per reference handled by one launch */
 
 enum lfd_status {
@@ -258,6 +258,14 @@ int lfd_triangulate_sampled_chain(lfd_context* ctx, const lfd_batch* batch, cons
 int lfd_rng_seed(lfd_context* ctx, uint32_t seed);
 int lfd_rng_get_state(lfd_context* ctx, uint32_t* key624_host, int32_t* pos_host);
 int lfd_rng_set_state(lfd_context* ctx, const uint32_t* key624_host, int32_t pos);
+/* The stream put aside and taken back ON THE DEVICE, in stream order, without a host wait: lfd_rng_checkpoint copies the context's MT19937
+ * state (key + position) into one of LFD_RNG_CHECKPOINTS places, lfd_rng_rollback copies it back.  A caller that launches fused calls AHEAD
+ * of reading their status (lfd_triangulate_sampled_chain: a chain whose bounded spins expire commits nothing, a reference refused for
+ * inexactness draws nothing although upstream would have) takes a checkpoint before every call and, on such a status, rolls back to the
+ * first affected call's checkpoint and redoes the references one at a time - the stream then continues exactly where upstream's would. */
+#define LFD_RNG_CHECKPOINTS 4
+int lfd_rng_checkpoint(lfd_context* ctx, int32_t place);
+int lfd_rng_rollback(lfd_context* ctx, int32_t place);
 int lfd_select_samples(lfd_context* ctx, const float* best_cert, int32_t H, int32_t W, int32_t M, float cap,
                        int32_t border, int32_t tiles, float s_override, int64_t* sel_out, int64_t capacity,
                        int32_t* n_sel_host, int32_t* status_host);

@@ -18,7 +18,7 @@ import torch
 from .types import CameraRecord, DensePipelineConfig
 
 LFD_MAX_SLOTS = 16
-LFD_ABI_VERSION = 8
+LFD_ABI_VERSION = 9
 LFD_FLAG_EXACT_COLOUR = 1     # lfd_params.flags: dense mode blends colours with upstream's f64 arithmetic (bit-identical rgb)
 LFD_FLAG_TILE_SEGMENTS = 2    # informational: the caller takes the unordered-retirement route (lfd_triangulate_dense_segments)
 _LIB_NAME = "liblfd_densify.so"
@@ -172,6 +172,8 @@ def load_library() -> C.CDLL:
     lib.lfd_rng_seed.argtypes = [ctxp, C.c_uint32]
     lib.lfd_rng_get_state.argtypes = [ctxp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
     lib.lfd_rng_set_state.argtypes = [ctxp, C.POINTER(C.c_uint32), C.c_int32]
+    lib.lfd_rng_checkpoint.argtypes = [ctxp, C.c_int32]
+    lib.lfd_rng_rollback.argtypes = [ctxp, C.c_int32]
     lib.lfd_select_samples.argtypes = [ctxp, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32,
                                        C.c_float, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.lfd_create_host.argtypes = [C.c_int32, C.POINTER(ctxp)]
@@ -197,6 +199,7 @@ def load_library() -> C.CDLL:
     for name in ("lfd_create", "lfd_set_stream", "lfd_reload_env", "lfd_kernel_timing", "lfd_kernel_timing_read", "lfd_upload_cameras", "lfd_prepare_batch", "lfd_aggregate", "lfd_triangulate_dense",
                  "lfd_triangulate_dense_ply", "lfd_triangulate_dense_ply_segments", "lfd_dense_tiles_per_ref", "lfd_triangulate_dense_segments", "lfd_order_segments", "lfd_pack_ply_segments", "lfd_pack_points3d_segments",
                  "lfd_triangulate_indexed", "lfd_triangulate_sampled", "lfd_triangulate_sampled_multi", "lfd_triangulate_sampled_chain", "lfd_launch_status", "lfd_rng_seed", "lfd_rng_get_state", "lfd_rng_set_state",
+                 "lfd_rng_checkpoint", "lfd_rng_rollback",
                  "lfd_select_samples", "lfd_select_top_m", "lfd_pack_ply", "lfd_pack_points3d", "lfd_quantise_rgb", "lfd_copy_segments", "lfd_identity_axis",
                  "lfd_host_fundamental", "lfd_get_pair_fundamental", "lfd_create_host", "lfd_aggregate_host",
                  "lfd_triangulate_dense_host", "lfd_triangulate_indexed_host", "lfd_prepare_image", "lfd_prepare_mask",
@@ -493,7 +496,16 @@ class PreparedBatch:
 
 
 _tls = threading.local()
-_SELECT_ERRORS = {1: "probabilities contain NaN", 2: "probabilities are not non-negative", 3: "Fewer non-zero entries in p than size"}
+# 1-3: what upstream's np.random.choice raises for (the reference drew nothing, there as here).  4-7: this implementation's own refusals -
+# the reference did NOT do what upstream would have done with the stream, so a fused call of several references that reports one of them
+# is void from that reference on (SELECT_VOIDS_STREAM; core/strategies.py::SampledLoop rolls the stream back and redoes the references).
+_SELECT_ERRORS = {1: "probabilities contain NaN", 2: "probabilities are not non-negative", 3: "Fewer non-zero entries in p than size",
+                  4: "selection: a weight is below 2^-29 (exact parallel cumsum not guaranteed)",
+                  5: "selection made no progress (a bounded wait between its workgroups expired; nothing was committed to the random stream)",
+                  6: "selection: too many coverage bins for the device stage",
+                  7: "selection: more cells than the output has room for"}
+SELECT_VOIDS_STREAM = frozenset((4, 5, 6, 7))
+RNG_CHECKPOINTS = 4            # LFD_RNG_CHECKPOINTS of the header
 
 
 def selection_error(status: int) -> str:
@@ -585,9 +597,9 @@ class OutputBuffers:
             if st in (1, 2, 3):
                 raise ValueError(_SELECT_ERRORS[st])
             if st == 4:
-                raise SelectionInexact("selection: a weight is below 2^-29 (exact parallel cumsum not guaranteed)")
+                raise SelectionInexact(_SELECT_ERRORS[4])
             if st != 0:
-                raise HipBackendError(f"selection failed with status {st}")
+                raise HipBackendError(selection_error(st))
         n_off, n_seg = 2 * (self._n_refs + 1), self._n_refs * self._k
         offs = meta[:n_off].view(np.int64).copy()
         n = int(offs[-1])
@@ -769,6 +781,14 @@ class HipDensifier:
         k = np.ascontiguousarray(key, dtype=np.uint32)
         self._check(self._lib.lfd_rng_set_state(self._ctx, k.ctypes.data_as(C.POINTER(C.c_uint32)), int(pos)),
                     "lfd_rng_set_state")
+
+    def checkpoint_rng(self, place: int) -> None:
+        """The stream put aside on the device, in stream order (no host wait): lfd_rng_checkpoint."""
+        self._check(self._lib.lfd_rng_checkpoint(self._ctx, int(place)), "lfd_rng_checkpoint")
+
+    def rollback_rng(self, place: int) -> None:
+        """... and taken back: the stream continues from where ``checkpoint_rng(place)`` saw it."""
+        self._check(self._lib.lfd_rng_rollback(self._ctx, int(place)), "lfd_rng_rollback")
 
     def select_samples(self, best_cert: torch.Tensor, M: int, cap: float = 0.9, border: int = 2, tiles: int = 24,
                        s_override: float = 0.0) -> torch.Tensor:

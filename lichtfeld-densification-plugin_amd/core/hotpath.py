@@ -59,6 +59,7 @@ class HotPath:
         self._buf_pool: dict = {}              # recycled survivor buffers of the fused sampled calls
         self._norm_side = None                 # upstream's normaliser: side stream, free slots, border masks (begin_normaliser)
         self._norm_free: list = []
+        self._norm_group, self._norm_grid = 1, None
         self._norm_masks: dict = {}
         self.dens.upload_cameras(cams)
         self.cams = list(cams) if bool(config.exp("upstream_fundamental")) else None
@@ -249,51 +250,63 @@ class HotPath:
             return False
         return float(cfg.certainty_thresh) >= 2.0 ** -29 * H * W * max(self.sample_cap, 1e-6)
 
-    def begin_normaliser(self, ref: hb.ReferenceInputs, axes):
-        """Aggregate on the launch stream; the capped, border-masked WEIGHTS (upstream's ``clamp(max=cap) * inside.float()``: exactly rounded
-        element by element, so the device gives the host's values) right behind it; then the 1 MB weight map to pinned host memory on the side
-        stream, an event behind it.  What is left for the host is upstream's one library-dependent step: torch's f32 ``sum``."""
-        batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes, cameras=self.cams)
-        if self._norm_side is None:
-            self._norm_side = torch.cuda.Stream(device=self.dev)
-        H, W = batch.H, batch.W
+    def _normaliser_slot(self, R: int, H: int, W: int) -> dict:
+        """Buffers of a group's weight maps on their way to the host: aggregated map, weights, pinned landing area, two events.  A slot is
+        allocated for the run's group size and SLICED for whatever is smaller (a last short group, a single reference between groups): a run
+        allocates two of them - hipHostMalloc of tens of MB costs milliseconds - and a slot of another grid is dropped, not kept."""
+        for i, cand in enumerate(self._norm_free):
+            if cand["grid"] == (H, W) and cand["cap"] >= R:
+                slot = self._norm_free.pop(i)
+                break
+        else:
+            self._norm_free.clear()            # a stale grid's - or too small - slots go back to the driver
+            cap = self._norm_group = max(int(R), self._norm_group if self._norm_grid == (H, W) else 1)       # the largest group this grid has seen
+            self._norm_grid = (H, W)
+            slot = {"grid": (H, W), "cap": cap,
+                    "best": torch.empty((cap, H, W), dtype=torch.float32, device=self.dev), "w": torch.empty((cap, H, W), dtype=torch.float32, device=self.dev),
+                    "host": torch.empty((cap, H, W), dtype=torch.float32).pin_memory(), "agg_done": torch.cuda.Event(), "copied": torch.cuda.Event()}
+        slot["n"] = int(R)
+        return slot
+
+    def _border_mask(self, H: int, W: int) -> torch.Tensor:
         mask = self._norm_masks.get((H, W))
         if mask is None:
             ys = torch.arange(H, device=self.dev).view(H, 1)
             xs = torch.arange(W, device=self.dev).view(1, W)
             mask = ((xs >= 2) & (xs <= W - 1 - 2) & (ys >= 2) & (ys <= H - 1 - 2)).to(torch.float32)          # border = 2 (core/pipeline.py:642-649 upstream)
-            self._norm_masks[(H, W)] = mask
-        slot = None
-        for i, cand in enumerate(self._norm_free):
-            if tuple(cand["best"].shape) == (1, H, W) and cand["w"].dim() == 2:
-                slot = self._norm_free.pop(i)
-                break
-        if slot is None:
-            slot = {"best": torch.empty((1, H, W), dtype=torch.float32, device=self.dev), "w": torch.empty((H, W), dtype=torch.float32, device=self.dev),
-                    "host": torch.empty((H, W), dtype=torch.float32).pin_memory(), "agg_done": torch.cuda.Event(), "copied": torch.cuda.Event()}
-        with self.clock.stage("select", sync=False):
-            self._begin_normaliser(batch, slot, mask)
-        return batch, slot
+            self._norm_masks = {(H, W): mask}
+        return mask
 
-    def _begin_normaliser(self, batch, slot, mask) -> None:
-        self.dens.launch_aggregate(batch, self.params, slot["best"], None)
+    def _start_normalisers(self, batch: hb.PreparedBatch, slot: dict) -> None:
+        """Aggregate on the launch stream; the capped, border-masked WEIGHTS (upstream's ``clamp(max=cap) * inside.float()``: exactly rounded
+        element by element, so the device gives the host's values) right behind it; then the weight maps to pinned host memory on the side
+        stream, an event behind them.  What is left for the host is upstream's one library-dependent step: torch's f32 ``sum``."""
+        if self._norm_side is None:
+            self._norm_side = torch.cuda.Stream(device=self.dev)
+        n = slot["n"]
+        best, w, host = slot["best"][:n], slot["w"][:n], slot["host"][:n]
+        self.dens.launch_aggregate(batch, self.params, best, None)
         with torch.cuda.stream(self.dens.stream):
-            torch.clamp(slot["best"][0], max=self.sample_cap, out=slot["w"])
-            slot["w"].mul_(mask)
+            torch.clamp(best, max=self.sample_cap, out=w)
+            w.mul_(self._border_mask(batch.H, batch.W))
             slot["agg_done"].record(self.dens.stream)
         with torch.cuda.stream(self._norm_side):
             self._norm_side.wait_event(slot["agg_done"])
-            slot["host"].copy_(slot["w"], non_blocking=True)
+            host.copy_(w, non_blocking=True)
             slot["copied"].record(self._norm_side)
+
+    def begin_normaliser(self, ref: hb.ReferenceInputs, axes):
+        """One reference's weight map on its way to the host (``_start_normalisers``); returns what ``finish_normaliser`` needs."""
+        batch = hb.PreparedBatch([ref], self.w_match, self.h_match, axes=axes, cameras=self.cams)
+        slot = self._normaliser_slot(1, batch.H, batch.W)
+        with self.clock.stage("select", sync=False):
+            self._start_normalisers(batch, slot)
+        return batch, slot
 
     def finish_normaliser(self, handle) -> float:
         """upstream's torch f32 sum (core/sampling.py:27 there) of the weight map that has arrived; the slot goes back to the pool"""
         _batch, slot = handle
-        with self.clock.stage("select", sync=False):
-            slot["copied"].synchronize()
-            s_up = float(slot["host"].reshape(-1).sum())
-        self._norm_free.append(slot)
-        return s_up if s_up > 0.0 else 0.0      # (a sum <= 0 is upstream's "nothing to sample" case, which the device stage reports from its exact sum)
+        return self.finish_chain_normalisers(slot)[0]
 
     def launch_sampled_multi(self, refs: List[hb.ReferenceInputs], axes, seeds: List[int]):
         """``refs_per_launch`` references through ONE fused call, each on its own stream (per_reference_rng)."""
@@ -328,42 +341,28 @@ class HotPath:
         """``begin_normaliser`` for a whole group: ONE aggregate launch, the capped, border-masked weights of all its references in one pass, one
         copy to pinned host memory on the side stream.  The caller launches the group BEFORE this one next (its sums have long arrived), so that
         the copy and torch's sums of this group hide under that group's kernels."""
-        if self._norm_side is None:
-            self._norm_side = torch.cuda.Stream(device=self.dev)
-        R, H, W = batch.n_refs, batch.H, batch.W
-        mask = self._norm_masks.get((H, W))
-        if mask is None:
-            ys = torch.arange(H, device=self.dev).view(H, 1)
-            xs = torch.arange(W, device=self.dev).view(1, W)
-            mask = ((xs >= 2) & (xs <= W - 1 - 2) & (ys >= 2) & (ys <= H - 1 - 2)).to(torch.float32)          # border = 2 (core/pipeline.py:642-649 upstream)
-            self._norm_masks[(H, W)] = mask
-        slot = None
-        for i, cand in enumerate(self._norm_free):
-            if tuple(cand["best"].shape) == (R, H, W) and cand["w"].dim() == 3:
-                slot = self._norm_free.pop(i)
-                break
-        if slot is None:
-            slot = {"best": torch.empty((R, H, W), dtype=torch.float32, device=self.dev), "w": torch.empty((R, H, W), dtype=torch.float32, device=self.dev),
-                    "host": torch.empty((R, H, W), dtype=torch.float32).pin_memory(), "agg_done": torch.cuda.Event(), "copied": torch.cuda.Event()}
+        slot = self._normaliser_slot(batch.n_refs, batch.H, batch.W)
         with self.clock.stage("select", sync=False):
-            self.dens.launch_aggregate(batch, self.params, slot["best"], None)
-            with torch.cuda.stream(self.dens.stream):
-                torch.clamp(slot["best"], max=self.sample_cap, out=slot["w"])
-                slot["w"].mul_(mask)
-                slot["agg_done"].record(self.dens.stream)
-            with torch.cuda.stream(self._norm_side):
-                self._norm_side.wait_event(slot["agg_done"])
-                slot["host"].copy_(slot["w"], non_blocking=True)
-                slot["copied"].record(self._norm_side)
+            self._start_normalisers(batch, slot)
         return slot
 
     def finish_chain_normalisers(self, slot) -> List[float]:
         """upstream's torch f32 sum (core/sampling.py:27 there) of every reference's weight map, each over its own contiguous (H, W) block"""
-        with self.clock.stage("select", sync=False):
-            slot["copied"].synchronize()
-            sums = [float(slot["host"][r].reshape(-1).sum()) for r in range(int(slot["host"].shape[0]))]
-        self._norm_free.append(slot)
+        try:
+            with self.clock.stage("select", sync=False):
+                slot["copied"].synchronize()
+                sums = [float(slot["host"][r].reshape(-1).sum()) for r in range(slot["n"])]
+        finally:
+            self._norm_free.append(slot)
+        # (a sum <= 0 is upstream's "nothing to sample" case, which the device stage reports itself from its exact sum)
         return [v if v > 0.0 else 0.0 for v in sums]
+
+    def checkpoint_rng(self, place: int) -> None:
+        """The device's random stream put aside in stream order, before a fused call of several references (core/strategies.py::SampledLoop)."""
+        self.dens.checkpoint_rng(place)
+
+    def rollback_rng(self, place: int) -> None:
+        self.dens.rollback_rng(place)
 
     def launch_sampled_chain(self, batch: hb.PreparedBatch, s_overrides: Optional[List[float]]):
         M = self.config.matches_per_ref

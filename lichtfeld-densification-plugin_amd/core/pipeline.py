@@ -136,13 +136,14 @@ def _as_device_map(t, dev) -> torch.Tensor:
     return torch.as_tensor(t).detach().to(dev, torch.float32).contiguous()
 
 
-def _make_strategy(config, plan: ShardPlan, hot: HotPath, outputs: RunOutputs, per_ref_rng: bool, debug_state):
+def _make_strategy(config, plan: ShardPlan, hot: HotPath, outputs: RunOutputs, per_ref_rng: bool, debug_state, auto_group: bool = False):
+    """``auto_group``: refs_per_launch was 0 - the strategy bounds the automatic group by the bytes its buffers take at the run's grid."""
     debug_on = debug_state is not None and debug_state.is_enabled()
     if DensePlyStreamer.applies(config, plan, hot.on_host, outputs, debug_on):
-        return DensePlyStreamer(hot, outputs, config)
+        return DensePlyStreamer(hot, outputs, config, auto_group)
     if config.triangulation_mode == "dense":
-        return DenseBatcher(hot, outputs, config)
-    return SampledLoop(hot, outputs, config, per_ref_rng)
+        return DenseBatcher(hot, outputs, config, auto_group)
+    return SampledLoop(hot, outputs, config, per_ref_rng, auto_group)
 
 
 def run_dense_pipeline(
@@ -175,6 +176,7 @@ def run_dense_pipeline(
     per_ref_rng = bool(config.per_reference_rng) or world > 1
     # refs_per_launch = 0 (the default): several references per launch where the results do not depend on it and nobody watches the run proceed
     previews = (on_sequential_viz is not None and int(config.viz_interval) > 0) or debug_state is not None
+    auto_group = int(config.refs_per_launch) == 0
     if int(config.refs_per_launch) != config.launch_group(world, previews):
         config = dataclasses.replace(config, refs_per_launch=config.launch_group(world, previews))
     clock = stage_clock if stage_clock is not None else NULL_CLOCK
@@ -213,7 +215,7 @@ def run_dense_pipeline(
         # least one package per worker, so that none of them idles)
         prefetch = OrderedPrefetcher(jobs, workers=int(config.pack_workers), window=max(int(config.prefetch_packages), int(config.pack_workers)), clock=clock)
         outputs.open()
-        strategy = _make_strategy(config, plan, hot, outputs, per_ref_rng, debug_state)
+        strategy = _make_strategy(config, plan, hot, outputs, per_ref_rng, debug_state, auto_group)
         total_refs = len(plan.my_positions)
         for local_i, packed in enumerate(prefetch):
             raise_if_cancelled(cancel_requested)

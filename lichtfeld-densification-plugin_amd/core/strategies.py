@@ -41,6 +41,22 @@ class Matched:
     want_debug: bool = False
 
 
+# refs_per_launch = 0 (automatic): the group is AUTO_REFS_PER_LAUNCH references unless their buffers would be large - what ONE launch / fused call
+# may hold on the device (survivor rows, weight maps) and in one pinned landing area on the host (hipHostMalloc'ed, page-locked memory)
+AUTO_DEVICE_BYTES = 1 << 30
+AUTO_PINNED_BYTES = 256 << 20
+
+
+def bounded_group(n: int, cells: int, device_bytes_per_cell: int, pinned_bytes_per_cell: int) -> int:
+    """The automatic group of a grid of ``cells`` cells: ``n`` references, fewer where n of them would exceed the budgets above (a 1280^2 grid
+    in dense mode: 45 MB of survivor rows per reference), never less than one.  An explicit ``refs_per_launch`` is not touched."""
+    if device_bytes_per_cell:
+        n = min(n, AUTO_DEVICE_BYTES // max(1, cells * device_bytes_per_cell))
+    if pinned_bytes_per_cell:
+        n = min(n, AUTO_PINNED_BYTES // max(1, cells * pinned_bytes_per_cell))
+    return max(1, int(n))
+
+
 def reference_seed(seed: int, uid: int) -> int:
     return (int(seed) * 1000003 + int(uid) * 7919 + 12345) & 0xFFFFFFFF
 
@@ -51,30 +67,34 @@ def _trimmed(res: hb.TriangulationOutput, lo: int, hi: int):
 
 
 class SampledLoop:
-    def __init__(self, hot: HotPath, outputs: RunOutputs, config, per_ref_rng: bool):
+    def __init__(self, hot: HotPath, outputs: RunOutputs, config, per_ref_rng: bool, auto_group: bool = False):
         self.hot, self.out, self.config, self.per_ref_rng = hot, outputs, config, bool(per_ref_rng)
+        self.auto_group = bool(auto_group)    # refs_per_launch was 0: the group is bounded by bytes (``bounded_group``)
         self.stream_rng = np.random.RandomState(int(config.seed))     # upstream: np.random.seed(config.seed), global stream
         self.group: List[tuple] = []          # several references per fused call: (Matched, seed)
         self.pend_norm: List[tuple] = []      # default mode: aggregated map on its way to the host: (Matched, handle)
         self.inflight: List[tuple] = []       # launched, not yet read back: (Matched, handle)
         self.chain: List[Matched] = []        # single stream, several references per fused call: the group that is filling up
         self.chain_ready: List[tuple] = []    # ... groups whose weight maps are on their way to the host: (items, batch, normaliser slot or None)
-        self.chain_fly: List[tuple] = []      # ... launched groups: (items, handle)
+        self.chain_fly: List[tuple] = []      # ... launched groups: (items, handle, (checkpoint place, epoch))
+        self._ckpt, self._epoch = 0, 0        # next checkpoint place of the device's stream; recoveries so far (a checkpoint older than one is stale)
 
     # -- the five schedules ---------------------------------------------------------------------------------------------------------
     def submit(self, m: Matched) -> None:
         hot, cfg = self.hot, self.config
+        # (a group's aggregated maps and weights on the device, its weights in one pinned landing area: 8 and 4 bytes per cell and reference)
+        n_group = bounded_group(int(cfg.refs_per_launch), m.H * m.W, 8, 4) if self.auto_group else int(cfg.refs_per_launch)
         serial = bool(hot.clock.serialising)      # a stage-attribution run takes the unfused calls: `select` and `kernel` are then separate stages
         need_best = m.want_debug or serial
         dseed = reference_seed(cfg.seed, m.packed.ref_uid) if self.per_ref_rng else None
-        if self.per_ref_rng and int(cfg.refs_per_launch) > 1 and hot.can_launch_ahead(need_best, True, m.H, m.W):
+        if self.per_ref_rng and n_group > 1 and hot.can_launch_ahead(need_best, True, m.H, m.W):
             # every reference has its own stream: refs_per_launch of them share one fused call (lfd_triangulate_sampled_multi)
             self.group.append((m, dseed))
-            if len(self.group) >= int(cfg.refs_per_launch):
+            if len(self.group) >= n_group:
                 self._flush_group()
             return
         self._flush_group()
-        if not self.per_ref_rng and int(cfg.refs_per_launch) > 1 and hot.can_chain(need_best, m.H, m.W):
+        if not self.per_ref_rng and n_group > 1 and hot.can_chain(need_best, m.H, m.W):
             # upstream's ONE stream, refs_per_launch references per fused call (lfd_triangulate_sampled_chain): they draw one after the other, in
             # this order, everything else of their selections runs side by side
             while self.pend_norm:
@@ -84,7 +104,7 @@ class SampledLoop:
             if self.chain and (self.chain[0].H, self.chain[0].W) != (m.H, m.W):
                 self._launch_chain()
             self.chain.append(m)
-            if len(self.chain) >= int(cfg.refs_per_launch):
+            if len(self.chain) >= n_group:
                 self._launch_chain()
             return
         self._drain_chain()
@@ -188,13 +208,20 @@ class SampledLoop:
             self._promote_chain()
 
     def _promote_chain(self) -> None:
+        """The oldest group whose weight maps are on their way: its sums, a checkpoint of the stream as it finds it, its fused call."""
         items, batch, slot = self.chain_ready.pop(0)
+        place = None
         try:
             sums = self.hot.finish_chain_normalisers(slot) if slot is not None else None
-            self.chain_fly.append((items, self.hot.launch_sampled_chain(batch, sums)))
+            self.hot.checkpoint_rng(self._ckpt)
+            place, self._ckpt = (self._ckpt, self._epoch), (self._ckpt + 1) % hb.RNG_CHECKPOINTS
+            self.chain_fly.append((items, self.hot.launch_sampled_chain(batch, sums), place))
         except Exception as ex:
-            for m in items:
-                log.error(f"Triangulation error for ref {m.packed.ref_uid}: {ex}")
+            # the call may have been enqueued in part: the groups before it are collected first (in order), then the stream goes back to where
+            # this group found it and its references are redone one at a time - upstream isolates failures per reference (core/pipeline.py:874-879)
+            while self.chain_fly:
+                self._finish_chain()
+            self._recover(items, place, ex)
         while len(self.chain_fly) > 1:
             self._finish_chain()
 
@@ -205,12 +232,19 @@ class SampledLoop:
             self._finish_chain()
 
     def _finish_chain(self) -> None:
-        items, handle = self.chain_fly.pop(0)
+        items, handle, place = self.chain_fly.pop(0)
         try:
             res = self.hot.finish_sampled(handle, check_selection=False)
         except Exception as ex:
-            for m in items:
-                log.error(f"Triangulation error for ref {m.packed.ref_uid}: {ex}")
+            self._recover(items, place, ex)
+            return
+        # 1-3 are upstream's own refusals (np.random.choice raises before it draws: that reference's error, the stream untouched, there as here).
+        # Anything else is THIS implementation's: a chain whose bounded waits expired commits nothing although its first references have drawn,
+        # a reference refused for inexactness draws nothing although upstream would have - the stream of the whole call, and of every call
+        # launched behind it, is not upstream's any more.
+        void = [int(st) for st in res.sel_status[:len(items)] if int(st) in hb.SELECT_VOIDS_STREAM]
+        if void:
+            self._recover(items, place, hb.selection_error(void[0]))
             return
         for bi, m in enumerate(items):
             st = int(res.sel_status[bi])
@@ -220,6 +254,33 @@ class SampledLoop:
             lo, hi = int(res.ref_offsets[bi]), int(res.ref_offsets[bi + 1])
             if hi > lo:
                 self.out.emit(Emission(m.local_i, m.packed, _trimmed(res, lo, hi)), self.hot)
+
+    def _recover(self, items: List[Matched], place, why) -> None:
+        """A fused call of several references failed as a whole.  Nothing of it has been emitted; whatever was launched behind it drew from a
+        stream that is void, so those calls are collected and discarded too.  The stream is rolled back to the checkpoint taken before the call
+        (on the device, in stream order) and every reference concerned is redone alone, in order: the cloud and the stream afterwards are what
+        the one-reference schedule gives.  If the stream cannot be restored the run fails - a wrong stream would silently change every later
+        selection."""
+        todo = list(items)
+        while self.chain_fly:
+            later, handle, _place = self.chain_fly.pop(0)
+            try:
+                self.hot.finish_sampled(handle, check_selection=False)       # waited for, its buffers back in the pool, its results dropped
+            except Exception:
+                pass
+            todo += later
+        log.warn(f"Grouped triangulation of refs {[m.packed.ref_uid for m in items]} failed ({why}); redoing refs "
+                 f"{[m.packed.ref_uid for m in todo]} one by one")
+        # (a checkpoint taken before an EARLIER recovery is stale - and not needed: that recovery's own rollback, later in stream order than
+        # anything this call enqueued, has already put the stream right)
+        if place is not None and place[1] == self._epoch:
+            try:
+                self.hot.rollback_rng(place[0])
+            except Exception as ex:
+                raise RuntimeError(f"the random stream could not be restored after a failed grouped call ({why}): {ex}") from ex
+        self._epoch += 1
+        for m in todo:
+            self._one_synchronously(m, None, False)
 
     def _drain_chain(self) -> None:
         self._launch_chain()
@@ -253,13 +314,18 @@ class SampledLoop:
 
 
 class DenseBatcher:
-    def __init__(self, hot: HotPath, outputs: RunOutputs, config):
-        self.hot, self.out, self.config = hot, outputs, config
+    def __init__(self, hot: HotPath, outputs: RunOutputs, config, auto_group: bool = False):
+        self.hot, self.out, self.config, self.auto_group = hot, outputs, config, bool(auto_group)
         self.pending: List[Matched] = []
 
     def submit(self, m: Matched) -> None:
+        if self.pending and (self.pending[0].H, self.pending[0].W) != (m.H, m.W):
+            self.drain()                  # one launch, one grid
         self.pending.append(m)
-        if len(self.pending) >= int(self.config.refs_per_launch):
+        n = int(self.config.refs_per_launch)
+        if self.auto_group:               # 33 bytes per cell: xyz, rgb, err + the cell and slot columns of the C-ABI
+            n = bounded_group(n, m.H * m.W, 33, 0)
+        if len(self.pending) >= n:
             self.drain()
 
     def drain(self) -> None:
@@ -313,8 +379,8 @@ class DensePlyStreamer:
 
     Replaces upstream core/pipeline.py:753-780,880-884,917-919 + core/writers.py:29-46 for that consumer."""
 
-    def __init__(self, hot: HotPath, outputs: RunOutputs, config):
-        self.hot, self.out, self.config = hot, outputs, config
+    def __init__(self, hot: HotPath, outputs: RunOutputs, config, auto_group: bool = False):
+        self.hot, self.out, self.config, self.auto_group = hot, outputs, config, bool(auto_group)
         self.unordered = bool(config.exp("dense_tile_segments"))
         self.pending: List[Matched] = []
         self.launched: List[tuple] = []
@@ -331,9 +397,15 @@ class DensePlyStreamer:
         return (config.triangulation_mode == "dense" and bool(config.stream_output) and plan.world == 1 and not on_host
                 and outputs.intermediate_base is None and not debug_enabled)
 
+    def _group(self, cells: int) -> int:
+        n = int(self.config.refs_per_launch)         # 15-byte records: once on the device, once in the pinned landing area of a buffer pair
+        return bounded_group(n, cells, 15, 15) if self.auto_group else n
+
     def submit(self, m: Matched) -> None:
+        if self.pending and (self.pending[0].H, self.pending[0].W) != (m.H, m.W):
+            self._launch()                # one launch, one grid
         self.pending.append(m)
-        if len(self.pending) >= int(self.config.refs_per_launch):
+        if len(self.pending) >= self._group(m.H * m.W):
             self._launch()
 
     def _slot(self, n_refs: int, cells: int) -> _Slot:
@@ -344,7 +416,7 @@ class DensePlyStreamer:
                 return s
         if len(fits) < 2:
             tpr = self.hot.dens.tiles_per_ref(cells, 1) if self.unordered else 0
-            self.slots.append(_Slot(max(n_refs, int(self.config.refs_per_launch)), cells, self.hot.dev, tpr))
+            self.slots.append(_Slot(max(n_refs, self._group(cells)), cells, self.hot.dev, tpr))
             return self.slots[-1]
         # Both pairs are busy.  One of them may belong to a launch that is still in flight: its records reach the writer - and the pair comes back -
         # only after that launch has been COLLECTED, so everything in flight is collected first (waiting for such a pair without doing so would

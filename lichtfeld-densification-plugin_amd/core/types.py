@@ -210,6 +210,37 @@ class DensePipelineConfig:
             raise ValueError(msg)
 
 
+# Settings that were dataclass fields of this package before its round-5 layout and live in ``experimental`` now: still accepted as keywords and
+# still readable as attributes (both with a DeprecationWarning), so that a caller written against the older surface keeps running.
+_MOVED_TO_EXPERIMENTAL = ("exchange_overlap", "exchange_round", "exchange_records", "exchange_replicate", "stream_shared_file",
+                          "dense_tile_segments", "upstream_fundamental")
+
+
+def _accept_moved_settings(cls):
+    import functools
+    import warnings
+    plain_init = cls.__init__
+
+    @functools.wraps(plain_init)
+    def __init__(self, *args, **kwargs):
+        moved = {k: kwargs.pop(k) for k in _MOVED_TO_EXPERIMENTAL if k in kwargs}
+        if moved:
+            warnings.warn(f"DensePipelineConfig({', '.join(moved)}=...) moved to experimental={{...}}", DeprecationWarning, stacklevel=2)
+            kwargs["experimental"] = {**moved, **dict(kwargs.get("experimental") or {})}
+        plain_init(self, *args, **kwargs)
+
+    cls.__init__ = __init__
+    for name in _MOVED_TO_EXPERIMENTAL:
+        def getter(self, _n=name):
+            warnings.warn(f"DensePipelineConfig.{_n} moved to experimental[{_n!r}] (config.exp({_n!r}))", DeprecationWarning, stacklevel=2)
+            return self.exp(_n)
+        setattr(cls, name, property(getter))
+    return cls
+
+
+DensePipelineConfig = _accept_moved_settings(DensePipelineConfig)
+
+
 @dataclasses.dataclass
 class CameraRecord:
     uid: int

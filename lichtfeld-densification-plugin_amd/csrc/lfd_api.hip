@@ -514,7 +514,7 @@ void lfd_destroy(lfd_context* ctx) {
     }
     for (hipEvent_t ev : ctx->kt_start) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->kt_stop) (void)hipEventDestroy(ev);
-    for (DeviceBuffer* b : {&ctx->cams, &ctx->ws, &ctx->axes, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->colour_tab, &ctx->mt, &ctx->mt_batch, &ctx->sel_scratch, &ctx->sel_chain, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab, &ctx->seg_scan})
+    for (DeviceBuffer* b : {&ctx->cams, &ctx->ws, &ctx->axes, &ctx->scratch, &ctx->codes, &ctx->idx_tab, &ctx->agg, &ctx->sel_buf, &ctx->colour_tab, &ctx->mt, &ctx->mt_ckpt, &ctx->mt_batch, &ctx->sel_scratch, &ctx->sel_chain, &ctx->stamps, &ctx->img_tab, &ctx->msk_tab, &ctx->seg_scan})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
     delete ctx;
@@ -926,6 +926,26 @@ int lfd_rng_set_state(lfd_context* ctx, const uint32_t* key624, int32_t pos) {
     ctx->mt_seeded = true;
     return LFD_OK;
 }
+
+// The stream put aside / taken back in stream order (device-to-device, 2.5 KB): see the header.
+static int rng_checkpoint_copy(lfd_context* ctx, int32_t place, bool take_back) {
+    if (!ctx) return fail(nullptr, LFD_ERR_INVALID, "null context");
+    if (ctx->is_host) return fail(ctx, LFD_ERR_STATE, "device entry point called on a host context");
+    if (place < 0 || place >= LFD_RNG_CHECKPOINTS) return fail(ctx, LFD_ERR_INVALID, "checkpoint place out of range");
+    if (!ctx->mt_seeded) return fail(ctx, LFD_ERR_STATE, "lfd_rng_seed / lfd_rng_set_state must be called first");
+    if (take_back && !(ctx->mt_ckpt_taken & (1u << place))) return fail(ctx, LFD_ERR_STATE, "no checkpoint was taken at this place");
+    LFD_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, ctx->mt_ckpt, (size_t)LFD_RNG_CHECKPOINTS * 640 * sizeof(unsigned));
+    if (rc != LFD_OK) return rc;
+    unsigned* slot = static_cast<unsigned*>(ctx->mt_ckpt.ptr) + (size_t)place * 640;
+    if (take_back) LFD_HIP(ctx, hipMemcpyAsync(ctx->mt.ptr, slot, 625 * sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
+    else LFD_HIP(ctx, hipMemcpyAsync(slot, ctx->mt.ptr, 625 * sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
+    if (!take_back) ctx->mt_ckpt_taken |= 1u << place;
+    return LFD_OK;
+}
+
+int lfd_rng_checkpoint(lfd_context* ctx, int32_t place) { return rng_checkpoint_copy(ctx, place, false); }
+int lfd_rng_rollback(lfd_context* ctx, int32_t place) { return rng_checkpoint_copy(ctx, place, true); }
 
 // whether a filtered selection of an N-cell map runs on the multi-workgroup kernel (the only one that can chain references on one stream)
 static bool select_runs_on_several_workgroups(lfd_context* ctx, long long N) {

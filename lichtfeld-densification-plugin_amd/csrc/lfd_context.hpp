@@ -86,6 +86,8 @@ struct lfd_context {
     DeviceBuffer scratch, codes, idx_tab, agg, sel_buf;
     // selection stage: legacy MT19937 stream (625 words) + scratch
     DeviceBuffer mt, sel_scratch, mt_batch;      // mt_batch: per-reference MT19937 states of lfd_triangulate_sampled_multi
+    DeviceBuffer mt_ckpt;                        // lfd_rng_checkpoint: LFD_RNG_CHECKPOINTS copies of `mt` (640 words apart)
+    unsigned mt_ckpt_taken = 0;                  // ... which of them hold a state
     DeviceBuffer sel_chain;                      // lfd_triangulate_sampled_chain: chain block, the stream's ring of doubles, the keys of its twists
     DeviceBuffer stamps;           // profiling builds: phase stamps of the dense kernel
     DeviceBuffer seg_scan;         // tile segments: exclusive prefix of the last table handed to lfd_order_segments / lfd_pack_*_segments

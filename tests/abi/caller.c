@@ -271,6 +271,19 @@ int main(int argc, char** argv) {
                     info_host[1], info_host[3], info_host[4], single_counts[0], single_counts[1]);
             return 9;
         }
+        /* the stream put aside before a call and taken back after it: the second reference alone, from the checkpoint between the two, is the chain's second */
+        if (lfd_rng_seed(ctx, 5u) != LFD_OK) return 9;
+        rc = lfd_triangulate_sampled(ctx, &batch, &params, M, 0.9f, 2, tiles, 0.0f, &o2, offs2, seg2, order2, info, NULL);
+        if (rc != LFD_OK || lfd_rng_checkpoint(ctx, 2) != LFD_OK) { fprintf(stderr, "checkpoint: %s\n", lfd_last_error(ctx)); return 9; }
+        for (int again = 0; again < 2; ++again) {
+            rc = lfd_triangulate_sampled(ctx, &batch, &params, M, 0.9f, 2, tiles, 0.0f, &o2, offs2, seg2, order2, info, NULL);
+            if (rc != LFD_OK) return 9;
+            hipDeviceSynchronize();
+            hipMemcpy(offs2_host, offs2, 2 * sizeof(int64_t), 2);
+            if ((long long)offs2_host[1] != single_counts[1]) { fprintf(stderr, "after a rollback: %lld survivors, expected %lld\n", (long long)offs2_host[1], single_counts[1]); return 9; }
+            if (lfd_rng_rollback(ctx, 2) != LFD_OK) { fprintf(stderr, "rollback: %s\n", lfd_last_error(ctx)); return 9; }
+        }
+        if (lfd_rng_rollback(ctx, 1) == LFD_OK || lfd_rng_checkpoint(ctx, LFD_RNG_CHECKPOINTS) == LFD_OK) { fprintf(stderr, "a place without a checkpoint / out of range was accepted\n"); return 9; }
     }
     printf("OK %s: %lld survivors in upstream's groups, positions within %.2g of upstream's; bad argument -> status %d \"%s\"\n", argv[2],
            (long long)offs_host[1], worst, LFD_ERR_INVALID, msg);

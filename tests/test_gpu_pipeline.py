@@ -898,3 +898,36 @@ def test_chained_groups_with_previews_and_a_debug_reference_in_between(tmp_path)
     for (_, a), (_, b) in zip(gv, pv):
         assert a == b
     assert gs == ps
+
+
+@pytest.mark.parametrize("status,group", [(5, 2), (4, 3), (5, 16)])
+def test_a_void_grouped_call_is_redone_on_the_restored_stream(tmp_path, monkeypatch, status, group):
+    """What the selection kernels report when a chain's bounded waits expire (5: nothing committed) or a reference is refused for inexactness (4: it
+    drew nothing although upstream would have) cannot be provoked on a healthy device, so the status of ONE collected call is falsified here - the
+    call itself, and the call launched behind it, have really run and really moved the device's stream.  The driver has to drop both, take the
+    stream back to the checkpoint lfd_rng_checkpoint made before the first of them, and redo their references one at a time: the cloud is the
+    plain run's, bit for bit - which it can only be if the stream was restored exactly."""
+    from fuzz_scenes import Table
+    from lichtfeld_densification_plugin_amd.core import hotpath
+    d = str(tmp_path)
+    cams, refs, nn, table, size = _chain_scene(d)
+    kw = dict(output_path=os.path.join(d, "o.ply"), nns_per_ref=2, seed=11, viz_interval=0, matches_per_ref=3000, use_masks=True)
+    plain = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(refs_per_launch=1, **kw), matcher=Table(size[0], size[1], table))
+    real, seen, rolled = hotpath.HotPath.finish_sampled, [], []
+
+    def falsified(self, handle, check_selection=True):
+        res = real(self, handle, check_selection)
+        if not check_selection:
+            seen.append(len(res.sel_status))
+            if len(seen) == 1:                          # the run's first grouped call
+                res.sel_status[min(1, len(res.sel_status) - 1)] = status
+        return res
+    real_rollback = hotpath.HotPath.rollback_rng
+    monkeypatch.setattr(hotpath.HotPath, "finish_sampled", falsified)
+    monkeypatch.setattr(hotpath.HotPath, "rollback_rng", lambda self, place: (rolled.append(place), real_rollback(self, place))[1])
+    got = pl.run_dense_pipeline(cams, refs, nn, lfd.DensePipelineConfig(refs_per_launch=group, **kw), matcher=Table(size[0], size[1], table))
+    assert rolled == [0] and seen[0] == min(group, 7)
+    np.testing.assert_array_equal(got.points_per_reference, plain.points_per_reference)
+    np.testing.assert_array_equal(got.xyz, plain.xyz)
+    np.testing.assert_array_equal(got.rgb, plain.rgb)
+    np.testing.assert_array_equal(got.err, plain.err)

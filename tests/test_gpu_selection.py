@@ -84,6 +84,37 @@ def test_stream_continues_across_references(dens):
     assert dens.rng_state()[1] == pos
 
 
+def test_checkpoints_of_the_stream_are_taken_and_rolled_back_on_the_device(dens):
+    """lfd_rng_checkpoint / lfd_rng_rollback: the stream put aside and taken back in stream order, several places side by side; a place nobody
+    checkpointed, or one out of range, is refused."""
+    a = torch.from_numpy(_tiefree(96, 96, 5)).to(dens.device)
+    dens.seed_rng(21)
+    k0, p0 = dens.rng_state()
+    dens.checkpoint_rng(0)
+    s1 = dens.select_samples(a, 2000)
+    k1, p1 = dens.rng_state()
+    dens.checkpoint_rng(3)
+    s2 = dens.select_samples(a, 2000)
+    assert (p1, k1.tobytes()) != (p0, k0.tobytes()) and not torch.equal(s1, s2)
+    dens.rollback_rng(3)
+    k, p = dens.rng_state()
+    assert p == p1 and np.array_equal(k, k1)
+    assert torch.equal(dens.select_samples(a, 2000), s2)                     # the stream continues as it did from there
+    dens.rollback_rng(0)
+    k, p = dens.rng_state()
+    assert p == p0 and np.array_equal(k, k0)
+    assert torch.equal(dens.select_samples(a, 2000), s1)
+    fresh = hb.HipDensifier(dens.device)
+    try:
+        fresh.seed_rng(1)
+        with pytest.raises(hb.HipBackendError, match="no checkpoint"):
+            fresh.rollback_rng(1)
+        with pytest.raises(hb.HipBackendError, match="out of range"):
+            fresh.checkpoint_rng(hb.RNG_CHECKPOINTS)
+    finally:
+        fresh.close()
+
+
 def test_edge_cases_follow_upstream(dens, g2):
     dev = dens.device
     dens.seed_rng(0)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert len(names) >= 12
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/lfd_densify.h but not exported"
-    assert lib.lfd_abi_version() == hb.LFD_ABI_VERSION == 8
+    assert lib.lfd_abi_version() == hb.LFD_ABI_VERSION == 9
     assert ctypes.sizeof(hb.lfd_params) == 32
 
 

@@ -314,3 +314,26 @@ def test_visibility_selection_is_upstreams_greedy_loop_at_scene_size():
     rec2.images = {i: Img(im) for i, im in list(rec.images.items())[:12]}
     rec.images = dict(list(rec.images.items())[:12])
     assert selection.select_cameras_by_visibility(rec2, 9) == upstream_loop(9)
+
+
+def test_settings_that_moved_to_experimental_are_still_accepted_and_readable():
+    """Seven settings were dataclass fields before the configuration surface was collapsed: a caller written against that surface keeps
+    running (keyword and attribute both forward to ``experimental``, each with a DeprecationWarning); an unknown keyword is still a TypeError."""
+    import dataclasses
+    import warnings
+    import lichtfeld_densification_plugin_amd as lfd
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                         # the plain surface warns about nothing
+        cfg = lfd.DensePipelineConfig("a.ply", triangulation_mode="dense", experimental={"dense_tile_segments": True})
+        assert dataclasses.replace(cfg, seed=3).exp("dense_tile_segments") is True
+    with pytest.warns(DeprecationWarning, match="moved to experimental"):
+        old = lfd.DensePipelineConfig("a.ply", triangulation_mode="dense", dense_tile_segments=True, exchange_round=8, experimental={"exchange_round": 4})
+    assert old.experimental == {"dense_tile_segments": True, "exchange_round": 4}                      # an explicit experimental entry wins
+    with pytest.warns(DeprecationWarning, match=r"experimental\['upstream_fundamental'\]"):
+        assert old.upstream_fundamental is True
+    assert "dense_tile_segments" not in {f.name for f in dataclasses.fields(old)}
+    with pytest.raises(ValueError, match="needs triangulation_mode='dense'"), warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        lfd.DensePipelineConfig("a.ply", dense_tile_segments=True)                                      # the moved keyword is validated like the dict entry
+    with pytest.raises(TypeError):
+        lfd.DensePipelineConfig("a.ply", no_such_setting=1)
