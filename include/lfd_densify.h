@@ -234,7 +234,11 @@ int lfd_triangulate_sampled_multi(lfd_context* ctx, const lfd_batch* batch, cons
  * batch order: the points, the cells selected and the position the stream is left at are those of n_refs successive
  * lfd_triangulate_sampled calls, bit for bit.  What does not depend on the stream (weights, probabilities, the first cumulative sum of every
  * reference) runs side by side; a reference starts drawing where the one before it stopped.  A reference whose selection refuses its input
- * (selection status != 0: upstream raises before it draws) consumes nothing and emits nothing, the others are not affected.
+ * (selection status 1-3: upstream raises before it draws) consumes nothing and emits nothing, the others are not affected.  A status of 4-7 on
+ * any reference is THIS implementation's refusal, not upstream's: the call is VOID as a whole (a chain whose bounded waits expire - 5 - commits
+ * nothing to the stream although its first references have drawn; a reference refused for inexactness - 4 - draws nothing although upstream would
+ * have).  Callers that read the status behind further launches take lfd_rng_checkpoint before the call and, on such a status, roll back and redo
+ * the references with lfd_triangulate_sampled one at a time (core/strategies.py::SampledLoop._recover does).
  * s_overrides: host f32 [n_refs] or NULL - the normaliser of reference r (> 0: upstream's own torch sum, handed in; else the exact device sum).
  * out->capacity, sel_info, sel_cells: as lfd_triangulate_sampled_multi.  lfd_rng_seed / lfd_rng_set_state first. */
 int lfd_triangulate_sampled_chain(lfd_context* ctx, const lfd_batch* batch, const lfd_params* params, int32_t M, float cap,
