@@ -103,8 +103,82 @@ def run_once(scene_root: str, matcher, *, mode: str, device_prep: bool, backend:
     return res
 
 
+class _SceneNode:
+    """What ``densify.extract_cameras_from_lfs`` reads of a LichtFeld Studio camera node (upstream densify.py:215-245): the GUI entry point's input."""
+
+    def __init__(self, rec):
+        self.has_camera, self.camera_uid = True, int(rec.uid)
+        self.camera_width, self.camera_height = int(rec.width), int(rec.height)
+        self.camera_focal_x, self.camera_focal_y = float(rec.K[0, 0]), float(rec.K[1, 1])
+        self.camera_R, self.camera_T = np.asarray(rec.R, np.float32), np.asarray(rec.t, np.float32).reshape(3)
+        self.image_path, self.mask_path, self.has_mask = rec.image_path, rec.mask_path, rec.mask_path is not None
+
+
+def run_gui_once(nodes, matcher, out_dir: str, *, viz_interval: int, device_prep: bool, pack_workers: int, roma_setting: str = "fast", num_refs: float = 0.8,
+                 nns: int = 3, matches: int = 10000) -> dict:
+    """One ``dense_init_from_lfs`` - the entry point LichtFeld Studio's panel calls (upstream densify.py:248-315, panels/densification.py:278-285) - with
+    the GUI's defaults: intermediate previews every ``viz_interval`` references that produced points (a cumulative PLY each, handed to
+    ``on_sequential_viz``; the panel loads it into the scene - here its size is read), one reference per fused call while somebody watches
+    (``DensePipelineConfig.launch_group``), progress callbacks, the final PLY.  ``viz_interval = 0``: the same run without previews."""
+    import lichtfeld_densification_plugin_amd as lfd
+    from lichtfeld_densification_plugin_amd import densify
+    from lichtfeld_densification_plugin_amd.core.stages import StageClock
+    out_path = os.path.join(out_dir, "gui_dense.ply")
+    cfg = lfd.DensePipelineConfig(output_path=out_path, roma_setting=roma_setting, num_refs=num_refs, nns_per_ref=nns, matches_per_ref=matches,
+                                  viz_interval=int(viz_interval), pack_workers=int(pack_workers), device_image_prep=bool(device_prep))
+    _clear_image_caches()
+    clock = StageClock()
+    seen = {"previews": 0, "preview_bytes": 0, "progress": 0}
+
+    def on_viz(path):
+        seen["previews"] += 1
+        seen["preview_bytes"] += os.path.getsize(path)
+        os.remove(path)                 # (the panel replaces its preview node by the new file; the old one is of no further use)
+
+    def on_progress(_pct, _msg):
+        seen["progress"] += 1
+    matcher.calls = matcher.pairs = 0
+    matcher.seconds = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    code, info = densify.dense_init_from_lfs(nodes, cfg, progress_callback=on_progress, on_sequential_viz=(on_viz if viz_interval > 0 else None),
+                                             matcher=matcher, stage_clock=clock)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if code != 0:
+        raise RuntimeError(f"dense_init_from_lfs returned {code}: {info}")
+    n = _ply_vertices(out_path)
+    rep = clock.report()
+    res = {"seconds": dt, "references": matcher.calls, "pairs": matcher.pairs, "points": n, "refs_per_s": matcher.calls / dt, "pairs_per_s": matcher.pairs / dt,
+           "points_per_s": n / dt, "previews": seen["previews"], "preview_bytes": seen["preview_bytes"], "progress_callbacks": seen["progress"],
+           "file_bytes": os.path.getsize(out_path), "stage_seconds": {k: v["seconds"] for k, v in rep.items() if isinstance(v, dict)}}
+    os.remove(out_path)
+    return res
+
+
+def gui_leg(dev, records, *, roma_setting: str, num_refs: float, nns: int, pack_workers: int, out_dir: str) -> dict:
+    """The GUI entry point on the scene's cameras as scene nodes: with the panel's previews (every third reference) and without."""
+    from lichtfeld_densification_plugin_amd import densify, synthetic
+    from lichtfeld_densification_plugin_amd.core.selection import nearest_neighbors, select_cameras_kcenters
+    nodes = [_SceneNode(r) for r in records]
+    recs = densify.extract_cameras_from_lfs(nodes)              # (principal point at the image centre: the GUI path's assumption)
+    flat = np.stack([c.flat_pose() for c in recs], axis=0)
+    refs = select_cameras_kcenters(flat, max(1, int(round(num_refs * len(recs))) if num_refs <= 1.0 else int(num_refs)))
+    nn_table = nearest_neighbors(flat, max(1, min(int(nns), len(recs) - 1)))
+    matcher = synthetic.SyntheticMatcher(recs, setting=roma_setting, device=dev, noise_px=0.5, outlier_frac=0.05, channels=2, seed=0)
+    matcher.precompute(refs, nn_table, nns)
+    kw = dict(device_prep=True, pack_workers=pack_workers, roma_setting=roma_setting, num_refs=num_refs, nns=nns)
+    run_gui_once(nodes, matcher, out_dir, viz_interval=0, **kw)                      # untimed: the new matcher's table is touched once
+    out = {"what": "densify.dense_init_from_lfs (the panel's entry point: k-centres references, principal point at the image centre) on the same cameras as scene "
+                   "nodes, sampled mode, device image preparation; `previews_every_3`: the GUI's default viz_interval = 3 - a cumulative PLY after every third "
+                   "reference, handed to on_sequential_viz (its size is read, the file removed), one reference per fused call while previews are watched",
+           "previews_every_3": run_gui_once(nodes, matcher, out_dir, viz_interval=3, **kw),
+           "no_previews": run_gui_once(nodes, matcher, out_dir, viz_interval=0, **kw)}
+    return out
+
+
 def pipeline_leg(dev, *, n_cams: int = 185, latency_ms: float = 20.0, scene_root: str = None, backend: str = "device", roma_setting: str = "fast",
-                 width: int = 1297, height: int = 840, refs_per_launch: int = 16, runs=("zero", "latency", "stages"), num_refs: float = 0.8,
+                 width: int = 1297, height: int = 840, refs_per_launch: int = 16, runs=("zero", "latency", "stages", "gui"), num_refs: float = 0.8,
                  nns: int = 3) -> dict:
     """The `pipeline` object of the bench line: {"scene", "sampled": {...}, "dense": {...}, "pcie"}."""
     from lichtfeld_densification_plugin_amd import densify, synthetic
@@ -162,6 +236,9 @@ def pipeline_leg(dev, *, n_cams: int = 185, latency_ms: float = 20.0, scene_root
             m["stages"] = {"seconds_per_stage": st["stage_seconds"], "run_seconds": st["seconds"],
                            "ms_per_reference": {k: round(v / max(1, st["references"]) * 1e3, 4) for k, v in st["stage_seconds"].items()}}
         leg[mode] = m
+    if on_gpu and "gui" in runs:
+        from lichtfeld_densification_plugin_amd.core import hostenv
+        leg["gui"] = gui_leg(dev, records, roma_setting=roma_setting, num_refs=num_refs, nns=nns, pack_workers=max(4, hostenv.usable_cores()), out_dir=scene_root)
     if on_gpu:
         ceiling = pinned_d2h_GBps(dev)
         best = max((r.get("d2h_GBps", 0.0) for r in leg["dense"].values() if isinstance(r, dict)), default=0.0)

@@ -333,7 +333,8 @@ class RunOutputs:
         if em.dbg is not None and self.debug_state is not None:
             self._debug_previews(em)
         if self.intermediate_base and self.refs_with_points % self.config.viz_interval == 0:
-            self._snapshot()
+            with hot.clock.stage("write", sync=False):       # the cumulative preview file + whatever the caller's on_sequential_viz does with it
+                self._snapshot()
 
     def _debug_previews(self, em: Emission) -> None:
         total_val = self.total_pairs_est if self.total_pairs_est > 0 else max(self.pair_counter, 1)

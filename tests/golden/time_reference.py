@@ -12,7 +12,7 @@ SURVEY 8d: "the reference's Python is timed here ... on identical fixtures; repo
   B  ``run_dense_pipeline`` (core/pipeline.py:783-928: threaded loader, PIL resize, matcher call, `_collect_reference_matches`, `_triangulate_ref`,
      accumulation) + ``write_ply`` (core/writers.py:29-46) on the on-disk scene of bench.py's `pipeline` leg (synthetic.write_colmap_scene, the same
      cameras / images / reference plan / matcher fields), with ``pack_workers`` 1 and 4 - seconds, references/s, pairs/s, points/s, and the
-     matcher's own share of the wall time.  Upstream's loader hands packages over in completion order, so the stand-in matcher recognises the
+     matcher's own share of the wall time - and once more with the GUI's intermediate previews (viz_interval = 3: 49 cumulative PLYs).  Upstream's loader hands packages over in completion order, so the stand-in matcher recognises the
      images it is handed by a fingerprint (synthetic.SyntheticMatcher.register_image) instead of counting calls.
 
 ``--write`` stores the record as tests/golden/g11_reference_timing.json; bench.py quotes it as ``cpu_baseline.reference_python``."""
@@ -96,8 +96,10 @@ def make_scene(scene_root: str, n_cams: int, width: int, height: int):
     return densify.plan_scene(args)
 
 
-def leg_pipeline(ns, plan, n_cams: int, width: int, height: int, workers: int, setting: str = "fast") -> dict:
-    """upstream's run_dense_pipeline + write_ply on the pipeline leg's scene"""
+def leg_pipeline(ns, plan, n_cams: int, width: int, height: int, workers: int, setting: str = "fast", viz_interval: int = 0) -> dict:
+    """upstream's run_dense_pipeline + write_ply on the pipeline leg's scene.  ``viz_interval`` > 0: with the GUI's intermediate previews
+    (core/pipeline.py:508-532 upstream: the cloud so far re-concatenated and written by write_ply after every viz_interval-th reference that produced
+    points, the path handed to on_sequential_viz - here a callback that reads the file's size and removes it, as bench_pipeline.py's GUI leg does)"""
     P = ns.pipeline
     records, refs_local, nn_table, sparse = plan
     matcher = synthetic.SyntheticMatcher(records, setting=setting, device="cpu", noise_px=0.5, outlier_frac=0.05, channels=4, seed=0)
@@ -112,12 +114,18 @@ def leg_pipeline(ns, plan, n_cams: int, width: int, height: int, workers: int, s
     P.has_cached_romav2_weights = lambda: True
     out_path = os.path.join(sparse, "reference_timing.ply")
     cfg = ns.config.DensePipelineConfig(output_path=out_path, roma_setting=setting, num_refs=0.8, nns_per_ref=3, matches_per_ref=10000, reproj_thresh=0.8,
-                                        viz_interval=0, pack_workers=workers, seed=0)
+                                        viz_interval=int(viz_interval), pack_workers=workers, seed=0)
     matcher.calls = matcher.pairs = 0
     matcher.seconds = 0.0
+    seen = {"previews": 0, "preview_bytes": 0, "seconds": 0.0, "last": None}
+
+    def on_viz(path):
+        seen["previews"] += 1
+        seen["preview_bytes"] += os.path.getsize(path)
+        os.remove(path)
     t0 = time.perf_counter()
     with np.errstate(all="ignore"):
-        res = P.run_dense_pipeline(records, refs_local, nn_table, cfg)
+        res = P.run_dense_pipeline(records, refs_local, nn_table, cfg, on_sequential_viz=(on_viz if viz_interval > 0 else None))
     t1 = time.perf_counter()
     ns.writers.write_ply(out_path, res.xyz, ns.image_utils.to_uint8_rgb(res.rgb))
     t2 = time.perf_counter()
@@ -127,7 +135,8 @@ def leg_pipeline(ns, plan, n_cams: int, width: int, height: int, workers: int, s
     return {"pack_workers": workers, "cameras": n_cams, "image_size": [width, height], "references": matcher.calls, "pairs": matcher.pairs, "points": n,
             "seconds": dt, "pipeline_seconds": t1 - t0, "write_ply_seconds": t2 - t1, "matcher_seconds": matcher.seconds,
             "refs_per_s": matcher.calls / dt, "pairs_per_s": matcher.pairs / dt, "points_per_s": n / dt,
-            "seconds_per_reference_without_matcher": (dt - matcher.seconds) / max(1, matcher.calls)}
+            "seconds_per_reference_without_matcher": (dt - matcher.seconds) / max(1, matcher.calls),
+            "viz_interval": int(viz_interval), "previews": seen["previews"], "preview_bytes": seen["preview_bytes"]}
 
 
 def main():
@@ -136,6 +145,7 @@ def main():
     ap.add_argument("--cams", type=int, default=185)
     ap.add_argument("--refs", type=int, default=6, help="references of leg A per configuration")
     ap.add_argument("--quick", action="store_true", help="a small scene (16 cameras) for leg B: a smoke run of this script")
+    ap.add_argument("--no-previews", action="store_true", help="skip the run with the GUI's intermediate previews (minutes: upstream writes every preview point by point)")
     a = ap.parse_args()
     threads = hostenv.fit_threads_to_quota()
     n_cams = 16 if a.quick else a.cams
@@ -152,6 +162,10 @@ def main():
     for workers in (1, 4):
         rec["run_dense_pipeline"][f"pack_workers_{workers}"] = leg_pipeline(ns, plan, n_cams, 1297, 840, workers)
         print(json.dumps(rec["run_dense_pipeline"][f"pack_workers_{workers}"]), flush=True)
+    if not a.no_previews:
+        # the GUI's default (DensePipelineConfig.viz_interval = 3, panels/densification.py hands on_sequential_viz in): what bench_pipeline.py's `gui` leg runs
+        rec["run_dense_pipeline"]["pack_workers_4_previews_every_3"] = leg_pipeline(ns, plan, n_cams, 1297, 840, 4, viz_interval=3)
+        print(json.dumps(rec["run_dense_pipeline"]["pack_workers_4_previews_every_3"]), flush=True)
     tmp.cleanup()
     if a.write:
         with open(os.path.join(HERE, "g11_reference_timing.json"), "w") as fh:

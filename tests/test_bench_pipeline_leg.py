@@ -86,3 +86,8 @@ def test_pipeline_leg_contract_on_the_device(tmp_path):
     assert d["d2h_bytes"] == 15 * d["points"] and d["d2h_GBps"] > 0 and "write" in d["stage_seconds"]      # records only: 15 B per survivor crossed PCIe
     p = leg["pcie"]
     assert p["d2h_pinned_copy_GBps"] > 1 and 0 < p["frac_of_measured_copy"] <= 1.5 and p["nominal_gen5_x16_GBps"] == 64.0
+    # the GUI entry point on the same cameras as scene nodes: previews after every third reference that produced points, the same cloud without them
+    g = leg["gui"]
+    a, b = g["previews_every_3"], g["no_previews"]
+    assert a["references"] == b["references"] == 6 and a["points"] == b["points"] > 0 and a["file_bytes"] == b["file_bytes"]
+    assert a["previews"] == a["references"] // 3 and b["previews"] == 0 and a["preview_bytes"] > a["file_bytes"] // 2 and a["progress_callbacks"] > a["references"]
