@@ -601,9 +601,11 @@ def reference_python_record():
                                        "matches_per_ref": r["matches_per_ref"]} for name, r in g["triangulate_ref"].items()},
             "ms_per_reference": tri["seconds_per_reference"]["mean"] * 1e3, "points_per_s": tri["points_per_s"],
             "run_dense_pipeline": {name: {k_: r[k_] for k_ in ("pack_workers", "cameras", "references", "pairs", "points", "seconds", "matcher_seconds", "refs_per_s",
-                                                              "pairs_per_s", "points_per_s", "write_ply_seconds")} for name, r in pipe.items()},
+                                                              "pairs_per_s", "points_per_s", "write_ply_seconds", "viz_interval", "previews", "preview_bytes") if k_ in r}
+                                   for name, r in pipe.items()},
             "note": "upstream core/pipeline.py::_triangulate_ref (sampled mode, 512^2, GUI k = 3 / M = 10000 and CLI k = 4 / M = 12000) on references of this "
-                    "workload, and upstream's run_dense_pipeline + write_ply on the pipeline leg's scene (same images, plan and matcher fields)"}
+                    "workload, and upstream's run_dense_pipeline + write_ply on the pipeline leg's scene (same images, plan and matcher fields; "
+                    "`pack_workers_4_previews_every_3`: with the GUI's intermediate previews, what the pipeline leg's `gui.previews_every_3` runs)"}
 
 
 def parity_report(args, dens, cams, refs, srefs, dims, cfg):
