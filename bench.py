@@ -51,6 +51,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.m
 WORKLOADS = {
     "config2": dict(refs=64, k=3, preset="fast", n_cams=185, arc=None,
                     what="config[1]: garden @fast, GUI default thresholds, 64 reference views x 3 neighbours resident"),
+    "config3": dict(refs=32, k=3, preset="high", n_cams=194, arc=None, width=1237, height=822,
+                    what="config[2]: bicycle (194 cameras 1237x822) @high (960x960 grid over 640-px match images), full filter stack, 32 reference views x 3 neighbours resident"),
     "config4": dict(refs=56, k=8, preset="fast", n_cams=185, arc=None,
                     what="config[3]: garden, all cameras, ref-fraction 0.3 -> 56 reference views x 8 neighbours = 448 pairs, sharded"),
     "config5": dict(refs=12, k=8, preset="precise", n_cams=12, arc=0.6,
@@ -169,7 +171,8 @@ def build_workload(args, rank, world, dev, positions=None):
     h_lr, w_lr, H, W = synthetic.ROMA_PRESETS[args.preset]
     wl = WORKLOADS[args.workload]
     n_cams = wl["n_cams"]
-    cams = synthetic.ring_cameras(n_cams, seed=0, **({"arc": wl["arc"]} if wl["arc"] else {}))
+    cams = synthetic.ring_cameras(n_cams, seed=0, **({"arc": wl["arc"]} if wl["arc"] else {}),
+                                  **({"width": wl["width"], "height": wl["height"]} if "width" in wl else {}))
     total_refs = args.refs * world if args.scaling == "weak" else args.refs
     step = 3 if n_cams >= 3 * total_refs or n_cams % 3 else 1
     ref_ids = [(i * step) % n_cams for i in range(total_refs)]          # spread over the ring
@@ -1055,7 +1058,7 @@ def run_sharded(args, world, rank, dev, dist, backend):
             "value_includes": (f"every point of the scene ONCE: compute + the {args.exchange} of the survivors ({rec_bytes}-byte records) of {n_sh} sharded "
                                f"references in {sched.n_rounds} round(s) beside the compute; {n_rep} references replicated (computed by every rank that "
                                "receives the cloud instead of travelling); the ordered cloud ends up contiguous where the collective delivers it"),
-            "config": {"workload": f"{WORKLOADS[args.workload]['what']}: ring of {WORKLOADS[args.workload]['n_cams']} cameras 1297x840, `{args.preset}` grid {H}x{W}, "
+            "config": {"workload": f"{WORKLOADS[args.workload]['what']}: ring of {WORKLOADS[args.workload]['n_cams']} cameras {WORKLOADS[args.workload].get('width', 1297)}x{WORKLOADS[args.workload].get('height', 840)}, `{args.preset}` grid {H}x{W}, "
                                    f"{args.refs} reference views x {args.k} neighbours {'per GPU' if args.scaling == 'weak' else 'in total, dealt over the ranks'}, "
                                    f"default thresholds (certainty 0.2 / sampson 5.0 / reproj 0.8 / parallax 0.5 deg), noise {args.noise_px} px, {args.outliers:.0%} outliers",
                        "kernel": f"fused dense filter+triangulate kernel ({kname})", "mode": "dense", "refs_per_gpu": n_rank_refs, "refs_total": total_refs,
@@ -1387,7 +1390,7 @@ def main():
             "value": value, "unit": "points/s", "n_gpus": world, "rccl_ranks": rccl, "collective_backend": backend, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32 (+f64 Sampson/DLT solve)", "data": "synthetic",
-            "config": {"workload": f"{WORKLOADS[args.workload]['what']}: ring of {WORKLOADS[args.workload]['n_cams']} cameras 1297x840, `{args.preset}` grid {H}x{W}, "
+            "config": {"workload": f"{WORKLOADS[args.workload]['what']}: ring of {WORKLOADS[args.workload]['n_cams']} cameras {WORKLOADS[args.workload].get('width', 1297)}x{WORKLOADS[args.workload].get('height', 840)}, `{args.preset}` grid {H}x{W}, "
                                    f"{args.refs} reference views x {args.k} neighbours {'resident per GPU' if args.scaling == 'weak' else 'in total, dealt over the ranks'}, "
                                    f"default thresholds (certainty 0.2 / sampson 5.0 / reproj 0.8 / parallax 0.5 deg), "
                                    f"noise {args.noise_px} px, {args.outliers:.0%} outliers",

@@ -17,3 +17,8 @@ run --preset fast --k 4 --refs 64
 run --preset fast --k 8 --refs 56
 run --preset high --k 3 --refs 32
 run --preset precise --k 8 --refs 12
+# the BASELINE configurations by name (round 6: config3 = bicycle's 194 cameras 1237x822 @high added as a workload)
+run --workload config2
+run --workload config3
+run --workload config4
+run --workload config5
