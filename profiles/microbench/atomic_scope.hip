@@ -6,6 +6,7 @@
 
 template <int kScope>
 __global__ void chain(unsigned long long* ctr, int n, long long* ticks) {
+    if (threadIdx.x != 0) return;          // ONE lane: 64 lanes on one address would be 64 serialised atomics per instruction
     long long t0 = wall_clock64();
     unsigned long long v = 0;
     for (int i = 0; i < n; ++i) v += __hip_atomic_fetch_add(ctr, 1ull + (v & 1ull), __ATOMIC_RELAXED, kScope);
