@@ -55,6 +55,9 @@
 #ifndef LFD_LOOKBACK_LANES
 #define LFD_LOOKBACK_LANES 16      // lanes of the look-back wave that read a tile-state word per round trip (the window).  The words are read past the caches: 16 per round measured 0.306 ms, 32 0.308, 64 0.311, 8 0.316; 128 ... 1024 (several words per lane) 0.32 ... 0.56
 #endif
+#ifndef LFD_WARP_BY_LANE
+#define LFD_WARP_BY_LANE 1         // dense kernel: the winner's warp fetched by consecutive lanes for consecutive cells (slots exchanged through LDS inside the wave)
+#endif
 #ifndef LFD_LOOKBACK_WATCH_ONE
 #define LFD_LOOKBACK_WATCH_ONE 1     // look-back: one lane watches the nearest predecessor's word until it is published, then the window is read
 #endif

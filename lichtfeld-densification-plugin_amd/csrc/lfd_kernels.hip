@@ -711,6 +711,77 @@ __device__ __forceinline__ void lfd_dense_body(const LfdLaunch& L) {
         //      coordinates are parked in this thread's own LDS slots (the slots later receive the cell's
         //      outputs), so the geometry loop below carries no per-cell register arrays ------------------
         unsigned bj_packed = 0;                   // 4 x 8 bits: the winning slot of each of this thread's cells
+#if LFD_WARP_BY_LANE
+        // A thread's four cells are CONSECUTIVE (the certainty planes want 16-byte loads), so the winner's warp read cell by cell is a wave-wide
+        // load of 8 bytes at a 32-byte stride - sixteen 128-byte lines per plane and load, up to 48 with three planes, four loads per wave - in a
+        // memory pipeline whose queue is what a tile's round trips wait in (MI355X_MICROARCH: the price of a hop sits in the CU's own queue).  Here the
+        // winners' slots go through LDS to the lanes of the SAME wave and lane l fetches the cells l, l + 64, l + 128, l + 192 of the wave's 256:
+        // consecutive lanes, consecutive cells - four lines per plane and load - and parks the coordinates in THOSE cells' slots (word stride 3 and 1
+        // instead of 12 and 4).  LDS operations of one wave complete in order: no barrier.  Same bits.
+        const bool wave_whole = kCpt == 4 && (L.W & 3) == 0 && tile_cell0 + (wave + 1) * 64 * kCpt <= HW;
+#if LFD_DENSE_ALL_WARPS
+        const bool by_lane = wave_whole && !have_warps;
+#else
+        const bool by_lane = wave_whole;
+#endif
+        if (by_lane) {
+            // (thread index, lane and wave taken from the hardware register again, as values of their own: copies of the kernel's `tid` / `lane` used here
+            // would stay in registers across the geometry loop, which has none to spare)
+            int t2 = (int)threadIdx.x;
+            asm volatile("" : "+v"(t2));
+            const int ln = t2 & 63, wv = t2 >> 6;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bj_packed |= (unsigned)bj[e] << (8 * e);
+            *reinterpret_cast<unsigned*>(&stage.slot[t2 * kCpt]) = bj_packed;
+            if (L.warp_channels != 4) {          // the A-grid coordinates of the thread's own cells: computed (or two small loads), parked at once
+                int dy, x0;
+                lfd_divmod_local(tile_x0 + t2 * kCpt, L.W, L.inv_w, L.w_log2, dy, x0);
+                const int y0 = tile_y0 + dy;
+                float xa[4], ya;
+                if (L.axis_identity) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xa[e] = lfd_axis_value(L.ax, x0 + e);
+                    ya = lfd_axis_value(L.ay, y0);
+                } else {
+                    const float4 ax = load_f32x4(L.axis_x + x0);
+                    xa[0] = ax.x; xa[1] = ax.y; xa[2] = ax.z; xa[3] = ax.w;
+                    ya = lfd_global(L.axis_y)[y0];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { stage.xyz[3 * (t2 * kCpt + e) + 0] = xa[e]; stage.xyz[3 * (t2 * kCpt + e) + 1] = ya; }
+            }
+            // (what one lane wrote another lane of the wave reads: in order in the hardware, and kept in order by the compiler)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int wbase = wv * 64 * kCpt + ln;
+            int sj[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sj[e] = (int)stage.slot[wbase + 64 * e];
+            if (L.warp_channels == 4) {          // upstream's concatenated [xA, yA, xB, yB]: 16 bytes per cell, consecutive lanes read one contiguous KB per plane
+                float4 v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = load_f32x4(S.slot[sj[e]].warp + (size_t)(unsigned)(tile_cell0 + wbase + 64 * e) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int sl = wbase + 64 * e;
+                    stage.xyz[3 * sl + 0] = v[e].x; stage.xyz[3 * sl + 1] = v[e].y; stage.xyz[3 * sl + 2] = v[e].z;
+                    stage.err[sl] = v[e].w;
+                }
+            } else {
+                float2 v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = load_f32x2(S.slot[sj[e]].warp + (size_t)(unsigned)(tile_cell0 + wbase + 64 * e) * 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int sl = wbase + 64 * e;
+                    stage.xyz[3 * sl + 2] = v[e].x;
+                    stage.err[sl] = v[e].y;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else
+#endif
         if (kCpt == 4 && (L.W & 3) == 0 && cell0 + 3 < HW) {
             // W % 4 == 0: the four cells share a row, so one cell -> (row, column) conversion serves all
             float xa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ya = 0.0f;
