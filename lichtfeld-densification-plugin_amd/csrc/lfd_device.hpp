@@ -24,10 +24,12 @@
                                          // nothing constant is kept in vector registers across it any more, and the tile's LDS block is 20.4 KB: eight workgroups per CU (7: 0.2819, 8: see profiles/history.md (r3/ablation.txt))
 #endif
 #ifndef LFD_DENSE_ALL_WARPS
-#define LFD_DENSE_ALL_WARPS 2   // dense kernel, references with at most this many neighbours (two-channel warps, no masks): the warps of ALL slots ride
+#define LFD_DENSE_ALL_WARPS 0   // dense kernel, references with at most this many neighbours (two-channel warps, no masks): the warps of ALL slots ride
                                 // along with the certainty planes - one dependent memory round trip less for 8 (k-1) B per cell more traffic.
-                                // Measured (profiles/history.md (r2/ablation.txt)): k = 1 0.118 -> 0.116 ms, k = 2 0.307 -> 0.290, k = 3 0.317 -> 0.307 (but 1.44 x
-                                // the algorithmic bytes instead of 1.10 x), k = 4 slower.  On up to two neighbours; 0 = never.
+                                // Measured in round 2 (profiles/history.md (r2/ablation.txt)): k = 1 0.118 -> 0.116 ms, k = 2 0.307 -> 0.290, k = 3 0.317 -> 0.307 (but
+                                // 1.44 x the algorithmic bytes instead of 1.10 x), k = 4 slower: it was on for up to two neighbours until round 6.  With the winner's
+                                // warp fetched by consecutive lanes (LFD_WARP_BY_LANE) the dependent round trip is cheap enough: 0 (never) now measures -2.0 % at
+                                // k = 2 and -0.5 % at k = 1 against 2 (profiles/r6/ab_warp_by_lane.txt).
 #endif
 #ifndef LFD_FRONT_PRIO
 #define LFD_FRONT_PRIO 1        // s_setprio of a dense-kernel wave until its geometry loop starts (0 = off): the handful of instructions between the
