@@ -165,6 +165,76 @@ def valu_roofline(args, kernel_ms):
             "valu_busy_frac": v.get("valu_busy_frac"), "source": v.get("source")}
 
 
+def _hwmon_of(dev):
+    """The hwmon directory of THIS GPU (sysfs: package power in microwatts, shader clock in Hz), found through the device's PCI address - the box shows the
+    cards of other tenants too.  None where sysfs does not say (another driver layout, no permission)."""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        want = f"{int(pr.pci_domain_id):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}"
+    except Exception:
+        return None
+    for card in glob.glob("/sys/class/drm/card*/device"):
+        try:
+            if os.path.basename(os.path.realpath(card)).lower().startswith(want):
+                mons = glob.glob(os.path.join(card, "hwmon", "hwmon*"))
+                return mons[0] if mons else None
+        except OSError:
+            continue
+    return None
+
+
+def power_under_kernel(dens, batches, params, out, dev, seconds=1.5):
+    """What the third bound of the fused kernel looks like on THIS box while THIS process runs it: the package's power against its cap and the shader clock,
+    read from sysfs every ~10 ms beside `seconds` of back-to-back launches (the timed loop's step, outside the timed region).  profiles/r6/clock_power.txt is
+    the same measurement with rocm-smi."""
+    import threading
+    mon = _hwmon_of(dev)
+    if mon is None:
+        return {"note": "hwmon of this GPU not found in sysfs"}
+
+    def read(name):
+        with open(os.path.join(mon, name)) as fh:
+            return float(fh.read().strip())
+    try:
+        cap_w = read("power1_cap") * 1e-6
+        read("power1_input"), read("freq1_input")
+    except Exception as exc:
+        return {"note": f"hwmon not readable ({exc})"}
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                samples.append((time.perf_counter(), read("power1_input") * 1e-6, read("freq1_input") * 1e-6))
+            except Exception:
+                pass
+            time.sleep(0.01)
+    th = threading.Thread(target=sampler, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(64):
+            b = batches[n % len(batches)]
+            dens.prepare(b, params)
+            dens.launch_dense(b, params, out)
+            n += 1
+        torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    stop.set()
+    th.join()
+    use = [(w, f) for (t, w, f) in samples if t0 + 0.5 * seconds <= t <= t1]      # the second half: the firmware's averaging window has filled
+    if not use:
+        return {"note": "no samples"}
+    w = float(np.mean([u[0] for u in use]))
+    return {"package_W": w, "cap_W": cap_w, "frac_of_cap": w / cap_w if cap_w else None, "sclk_MHz": float(np.mean([u[1] for u in use])), "samples": len(use),
+            "launches": n, "ms_per_launch": (t1 - t0) / n * 1e3,
+            "source": "sysfs hwmon of this GPU (power1_input, freq1_input, power1_cap), sampled every ~10 ms beside back-to-back launches of the timed loop's step; "
+                      "second half of the window",
+            "note": "the fused kernel runs at the package's power cap: its speed is energy per cell (DESIGN 4.2)"}
+
+
 def build_workload(args, rank, world, dev, positions=None):
     """Global reference list dealt round-robin; this rank generates and keeps only its share (``positions``: these positions of the global
     list instead).  weak scaling: --refs references per rank; strong scaling: --refs in total (BASELINE's metric is ONE scene at 1/2/4/8 GPUs)."""
@@ -1428,6 +1498,7 @@ def main():
                 line["end_to_end_note"] = why
             else:
                 line.pop("end_to_end_note", None)
+            line["roofline"]["power"] = power_under_kernel(dens, batches, params, out, dev)      # the bound that binds: the package's power cap
             line["unordered_retirement"] = unordered_rate(args, dens, batch, params, out, H, W, algo_bytes)
             line["ply_output"] = ply_output_rate(args, dens, batch, params, H, W, cells, s_frac)
         if not args.light and world == 1:     # the side legs (and the CPU baseline) belong to the N = 1 line; at N > 1 the other ranks are waiting

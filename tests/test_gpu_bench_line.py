@@ -29,6 +29,8 @@ def test_single_gpu_bench_line_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["kernel"] == "lfd_dense_kernel" and r["kernel_ms"] > 0 and "traffic" in r and "valu" in r and "valu_busy_frac" in r
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    pw = r["power"]          # the package's power and the shader clock beside back-to-back launches (sysfs), or the reason they could not be read
+    assert ("note" in pw) and (("package_W" not in pw) or (pw["package_W"] > 50 and pw["cap_W"] >= pw["package_W"] * 0.5 and pw["sclk_MHz"] > 100 and pw["samples"] > 5))
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "points/s" and "sample" in c
     assert d["parity"]["flipped_out_of_band"] == 0 and d["parity"]["cells"] == 320 * 320
