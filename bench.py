@@ -232,7 +232,8 @@ def power_under_kernel(dens, batches, params, out, dev, seconds=1.5):
             "launches": n, "ms_per_launch": (t1 - t0) / n * 1e3,
             "source": "sysfs hwmon of this GPU (power1_input, freq1_input, power1_cap), sampled every ~10 ms beside back-to-back launches of the timed loop's step; "
                       "second half of the window",
-            "note": "the fused kernel runs at the package's power cap: its speed is energy per cell (DESIGN 4.2)"}
+            "note": "the fused kernel draws the package's power cap or close to it and runs at the shader clock the firmware grants under it (2.4 GHz nominal): its "
+                    "speed is energy per cell (DESIGN 4.2; rocm-smi beside 30 000 launches: profiles/r6/clock_power.txt)"}
 
 
 def build_workload(args, rank, world, dev, positions=None):
