@@ -52,3 +52,14 @@ def test_gather_to_root_replication_and_weak_scaling():
     assert root["sharded_positions"] == list(range(0, 48, 4)) and root["launches_per_step"] == 3 + 1
     w = _plan("--gpus", "2", "--scaling", "weak", "--refs", "5", "--workload", "config2")
     assert w["refs_total"] == 10 and w["neighbours"] == 3 and [len(r["sharded_positions"]) for r in w["ranks"]] == [5, 5]
+
+
+def test_every_baseline_configuration_is_a_workload():
+    """BASELINE.json's configurations 2-5 by name (config[0], the two-view CPU case, is a parity test, not a bench line): the plan names the
+    configuration's cameras, grid and pair count."""
+    want = {"config2": (64, 3, [512, 512], "config[1]"), "config3": (32, 3, [960, 960], "config[2]"),
+            "config4": (56, 8, [512, 512], "config[3]"), "config5": (12, 8, [1280, 1280], "config[4]")}
+    for name, (refs, k, grid, label) in want.items():
+        d = _plan("--gpus", "2", "--workload", name)
+        assert (d["refs_total"], d["neighbours"], d["grid"]) == (refs, k, grid) and label in d["workload"], (name, d["workload"])
+    assert "194 cameras 1237x822" in _plan("--gpus", "2", "--workload", "config3")["workload"]        # bicycle's image set
